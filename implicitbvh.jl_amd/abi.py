@@ -1,0 +1,141 @@
+"""ctypes mirror of include/ibvh.h: enums, POD descriptors, record dtypes, status -> exception.
+
+Record layouts follow Julia's isbits struct layout (= C layout), see include/ibvh.h:
+BSphere{T} (bsphere.jl:26-29), BBox{T} (bbox.jl:35-38), BoundingVolume{V,I,M}
+(bounding_volumes.jl:55-59), IndexPair{I} (traverse.jl:6).
+"""
+import ctypes as C
+
+import numpy as np
+
+# enums ---------------------------------------------------------------------------------------
+BSPHERE, BBOX = 0, 1
+F32, F64 = 0, 1
+I32, I64 = 0, 1
+U16, U32, U64 = 0, 1, 2
+NARROW_NONE, NARROW_MORTON_LT, NARROW_INDEX_LT = 0, 1, 2
+
+OK, ERR_INVALID_ARG, ERR_DOMAIN, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_OVERFLOW, ERR_HIP, ERR_SCRATCH = range(8)
+
+FLOAT_DTYPES = {F32: np.float32, F64: np.float64}
+INDEX_DTYPES = {I32: np.int32, I64: np.int64}
+MORTON_DTYPES = {U16: np.uint16, U32: np.uint32, U64: np.uint64}
+MORTON_BITS = {U16: 15, U32: 30, U64: 63}  # 3 x (5, 10, 21), morton/default.jl:167-169
+
+
+class DomainError(ValueError):
+    """Julia's DomainError (implicit_tree.jl:78-80)."""
+
+
+class CapacityError(RuntimeError):
+    def __init__(self, msg, required):
+        super().__init__(msg)
+        self.required = required
+
+
+class Types(C.Structure):
+    _fields_ = [("leaf_kind", C.c_int32), ("leaf_float", C.c_int32), ("node_kind", C.c_int32),
+                ("node_float", C.c_int32), ("index_type", C.c_int32), ("morton_type", C.c_int32)]
+
+    def key(self):
+        return (self.leaf_kind, self.leaf_float, self.node_kind, self.node_float, self.index_type,
+                self.morton_type)
+
+
+class Tree(C.Structure):
+    _fields_ = [("levels", C.c_int64), ("real_leaves", C.c_int64), ("real_nodes", C.c_int64),
+                ("virtual_leaves", C.c_int64), ("virtual_nodes", C.c_int64)]
+
+    def astuple(self):
+        return (self.levels, self.real_leaves, self.real_nodes, self.virtual_leaves, self.virtual_nodes)
+
+
+class Layout(C.Structure):
+    _fields_ = [("volume_bytes", C.c_int64), ("node_bytes", C.c_int64), ("index_off", C.c_int64),
+                ("morton_off", C.c_int64), ("leaf_bytes", C.c_int64), ("pair_bytes", C.c_int64)]
+
+
+class Bvh(C.Structure):
+    _fields_ = [("types", Types), ("tree", Tree), ("built_level", C.c_int64), ("leaves", C.c_void_p),
+                ("nodes", C.c_void_p), ("skips", C.c_void_p)]
+
+
+class BuildDesc(C.Structure):
+    _fields_ = [("types", Types), ("n", C.c_int64), ("built_level", C.c_int64),
+                ("already_wrapped", C.c_int32), ("compute_extrema", C.c_int32),
+                ("mins", C.c_double * 3), ("maxs", C.c_double * 3)]
+
+
+class BfsResult(C.Structure):
+    _fields_ = [("num_contacts", C.c_int64), ("num_checks", C.c_int64), ("contacts_in", C.c_int64),
+                ("required_capacity", C.c_int64)]
+
+
+def volume_dtype(kind, flt):
+    t = FLOAT_DTYPES[flt]
+    if kind == BSPHERE:
+        return np.dtype([("x", t, (3,)), ("r", t)], align=True)
+    return np.dtype([("lo", t, (3,)), ("up", t, (3,))], align=True)
+
+
+def volume_width(kind):
+    """Number of scalars in a volume: BSphere 4 (x, r), BBox 6 (lo, up)."""
+    return 4 if kind == BSPHERE else 6
+
+
+def leaf_dtype(types):
+    return np.dtype([("volume", volume_dtype(types.leaf_kind, types.leaf_float)),
+                     ("index", INDEX_DTYPES[types.index_type]),
+                     ("morton", MORTON_DTYPES[types.morton_type])], align=True)
+
+
+def node_dtype(types):
+    return volume_dtype(types.node_kind, types.node_float)
+
+
+def pair_dtype(types):
+    t = INDEX_DTYPES[types.index_type]
+    return np.dtype([("a", t), ("b", t)], align=True)
+
+
+def key_dtype(types):
+    return np.uint64 if types.morton_type == U64 else np.uint32
+
+
+def make_types(leaf_kind=BSPHERE, leaf_float=F32, node_kind=BBOX, node_float=F32, index_type=I32,
+               morton_type=U32):
+    return Types(leaf_kind, leaf_float, node_kind, node_float, index_type, morton_type)
+
+
+def combo_supported(t):
+    """NodeType(leaf) must exist in the reference (merge.jl) and the node float is never wider."""
+    if t.node_kind == BSPHERE and t.leaf_kind != BSPHERE:
+        return False
+    if t.node_float == F64 and t.leaf_float != F64:
+        return False
+    return True
+
+
+_STATUS_TEXT = {
+    ERR_INVALID_ARG: "invalid argument (ArgumentError in the reference)",
+    ERR_DOMAIN: "must have at least one geometry! (DomainError)",
+    ERR_UNSUPPORTED: "type combination not supported by libibvh",
+    ERR_CAPACITY: "caller buffer too small",
+    ERR_OVERFLOW: "count does not fit the index type",
+    ERR_HIP: "HIP runtime error",
+    ERR_SCRATCH: "scratch buffer too small",
+}
+
+
+def check(status, what="ibvh"):
+    """Map an ibvh_status to the exception the Julia shim raises for it."""
+    if status == OK:
+        return
+    msg = f"{what}: {_STATUS_TEXT.get(status, 'status %d' % status)}"
+    if status == ERR_DOMAIN:
+        raise DomainError(msg)
+    if status in (ERR_INVALID_ARG, ERR_UNSUPPORTED):
+        raise ValueError(msg)
+    if status == ERR_OVERFLOW:
+        raise OverflowError(msg)
+    raise RuntimeError(msg)

@@ -1,0 +1,287 @@
+/*
+ * ibvh.h — C ABI of libibvh, the MI355X (gfx950) implicit-BVH engine.
+ *
+ * This is the drop-in boundary for ImplicitBVH.jl's hot path (Morton encode ->
+ * stable LSB radix sort -> bottom-up ImplicitTree merge -> LVT / BFS traversal
+ * of one BVH, two BVHs, or rays).  The reference has no FFI: its back-end seam is
+ * Julia method dispatch on the array type (src/build.jl:198, src/traverse/
+ * leaf_vs_tree/traverse_single.jl:1, src/raytrace/raytrace.jl:71).  A package
+ * extension for AMDGPU.jl's ROCArray `ccall`s the entry points below (see
+ * INTEGRATION.md); every one cites the reference function it replaces.
+ *
+ * Conventions
+ *   - plain C, no HIP/torch types: `void *stream` is a hipStream_t (NULL = default
+ *     stream); all buffer pointers are DEVICE pointers owned by the caller;
+ *   - record layouts are the C layouts Julia gives its isbits structs:
+ *       BSphere{T}            { T x[3]; T r; }                  (bsphere.jl:26-29)
+ *       BBox{T}               { T lo[3]; T up[3]; }             (bbox.jl:35-38)
+ *       BoundingVolume{V,I,M} { V volume; I index; M morton; }  (bounding_volumes.jl:55-59)
+ *       IndexPair{I}          { I first; I second; }            (traverse.jl:6)
+ *   - indices are 1-based exactly as in the reference;
+ *   - every function returns an ibvh_status; nothing is allocated or freed by the
+ *     library; calls are asynchronous on `stream` unless stated otherwise.
+ */
+#ifndef IBVH_H
+#define IBVH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ----------------------------------------------------------------------------------- */
+/* status codes -> exceptions the Julia shim raises                                      */
+/* ----------------------------------------------------------------------------------- */
+typedef enum ibvh_status {
+    IBVH_OK = 0,
+    IBVH_ERR_INVALID_ARG = 1, /* ArgumentError (@argcheck in build.jl:207,235,260; lvt/traverse_single.jl:10) */
+    IBVH_ERR_DOMAIN = 2,      /* DomainError: fewer than one leaf (implicit_tree.jl:78-80)                    */
+    IBVH_ERR_UNSUPPORTED = 3, /* a type combination this library does not instantiate                        */
+    IBVH_ERR_CAPACITY = 4,    /* caller buffer too small; the required size is reported                      */
+    IBVH_ERR_OVERFLOW = 5,    /* a count does not fit the index type I                                       */
+    IBVH_ERR_HIP = 6,         /* a HIP runtime call failed                                                    */
+    IBVH_ERR_SCRATCH = 7      /* scratch buffer smaller than ibvh_build_scratch_bytes()                      */
+} ibvh_status;
+
+/* ----------------------------------------------------------------------------------- */
+/* type descriptors                                                                     */
+/* ----------------------------------------------------------------------------------- */
+enum { IBVH_BSPHERE = 0, IBVH_BBOX = 1 };       /* volume kinds                       */
+enum { IBVH_F32 = 0, IBVH_F64 = 1 };            /* float types                        */
+enum { IBVH_I32 = 0, IBVH_I64 = 1 };            /* index types (BVHOptions.index)     */
+enum { IBVH_U16 = 0, IBVH_U32 = 1, IBVH_U64 = 2 }; /* Morton types (morton/default.jl:21) */
+
+/* narrow-phase menu.  The reference takes an arbitrary Julia closure that is only ever
+ * evaluated as `iscontact(...) && narrow(a, b)` at leaf level
+ * (lvt/traverse_single.jl:170); closures cannot cross a C ABI, so a fixed menu is offered. */
+enum {
+    IBVH_NARROW_NONE = 0,      /* (a, b) -> true  (the reference default)                 */
+    IBVH_NARROW_MORTON_LT = 1, /* (a, b) -> a.morton < b.morton (runtests.jl:1239)        */
+    IBVH_NARROW_INDEX_LT = 2   /* (a, b) -> a.index < b.index                             */
+};
+
+typedef struct ibvh_types {
+    int32_t leaf_kind;   /* IBVH_BSPHERE | IBVH_BBOX */
+    int32_t leaf_float;  /* IBVH_F32 | IBVH_F64      */
+    int32_t node_kind;
+    int32_t node_float;
+    int32_t index_type;  /* IBVH_I32 | IBVH_I64      */
+    int32_t morton_type; /* IBVH_U16 | IBVH_U32 | IBVH_U64 */
+} ibvh_types;
+
+/* ImplicitTree{I} (implicit_tree.jl:52-67), widened to int64 at the boundary. */
+typedef struct ibvh_tree {
+    int64_t levels;
+    int64_t real_leaves;
+    int64_t real_nodes;
+    int64_t virtual_leaves;
+    int64_t virtual_nodes;
+} ibvh_tree;
+
+/* Byte layout of one BoundingVolume{V,I,M} record. */
+typedef struct ibvh_layout {
+    int64_t volume_bytes; /* sizeof(V)                       */
+    int64_t node_bytes;   /* sizeof(N), the node volume type */
+    int64_t index_off;
+    int64_t morton_off;
+    int64_t leaf_bytes;   /* sizeof(BoundingVolume{V,I,M})   */
+    int64_t pair_bytes;   /* sizeof(IndexPair{I})            */
+} ibvh_layout;
+
+/* A built BVH as the traversals see it: struct BVH (build.jl:155-166). */
+typedef struct ibvh_bvh {
+    ibvh_types types;
+    ibvh_tree tree;
+    int64_t built_level;
+    const void *leaves; /* real_leaves x BoundingVolume records, Morton-sorted    */
+    const void *nodes;  /* (real_nodes - real_leaves) x node volumes              */
+    const void *skips;  /* levels x I, see ibvh_compute_skips                     */
+} ibvh_bvh;
+
+/* Inputs of one BVH construction: BVH(bounding_volumes, node_type; built_level, options)
+ * (build.jl:198-271) with options.morton = DefaultMortonAlgorithm (morton/default.jl:21-40). */
+typedef struct ibvh_build_desc {
+    ibvh_types types;
+    int64_t n;               /* number of bounding volumes (>= 1)                              */
+    int64_t built_level;     /* integer level 1..levels (use ibvh_compute_build_level)         */
+    int32_t already_wrapped; /* 1: `leaves` already holds BoundingVolume records whose .index
+                                is kept (build.jl:220-222); 0: wrap `volumes`, index = 1..n  */
+    int32_t compute_extrema; /* 1: derive mins/maxs from the centres (morton/default.jl:53)    */
+    double mins[3];          /* used when compute_extrema == 0 (alg.mins / alg.maxs)           */
+    double maxs[3];
+} ibvh_build_desc;
+
+/* ----------------------------------------------------------------------------------- */
+/* host-side shape math (no GPU needed)                                                 */
+/* ----------------------------------------------------------------------------------- */
+
+/* ImplicitTree{I}(num_leaves) — implicit_tree.jl:77-90.  IBVH_ERR_DOMAIN when n < 1. */
+ibvh_status ibvh_tree_shape(int64_t num_leaves, ibvh_tree *out);
+
+/* compute_skips! — implicit_tree.jl:100-113; writes tree->levels int64 values (host). */
+ibvh_status ibvh_compute_skips(const ibvh_tree *tree, int64_t *skips_out);
+
+/* memory_index / level_indices / isvirtual — implicit_tree.jl:128-199 (host helpers). */
+ibvh_status ibvh_memory_index(const ibvh_tree *tree, int64_t implicit_index, int64_t *out);
+ibvh_status ibvh_level_indices(const ibvh_tree *tree, int64_t level, int64_t *start, int64_t *stop);
+ibvh_status ibvh_isvirtual(const ibvh_tree *tree, int64_t implicit_index, int32_t *out);
+
+/* compute_build_level for a fractional argument — build.jl:309-325:
+ * round(I, levels + (1 - levels) * frac), ties to even like Julia's round. */
+ibvh_status ibvh_compute_build_level(const ibvh_tree *tree, double frac, int64_t *out);
+
+/* Record layout of the given type combination; IBVH_ERR_UNSUPPORTED if not instantiated. */
+ibvh_status ibvh_layout_of(const ibvh_types *types, ibvh_layout *out);
+
+/* ----------------------------------------------------------------------------------- */
+/* build                                                                                */
+/* ----------------------------------------------------------------------------------- */
+
+/* Scratch bytes ibvh_build needs for n leaves of the given types. */
+ibvh_status ibvh_build_scratch_bytes(const ibvh_types *types, int64_t n, size_t *bytes_out);
+
+/* The whole of BVH(...) on device — build.jl:198-271:
+ *   wrap (build.jl:328-352) -> extrema (morton/utils.jl:1-72) -> Morton encode
+ *   (morton/default.jl:63-157) -> stable ascending sort by .morton (build.jl:248-253)
+ *   -> compute_skips! -> aggregate_oibvh! down to built_level (build.jl:366-523).
+ * volumes : n x V raw volumes (ignored when desc->already_wrapped)
+ * leaves  : n x BoundingVolume records, written (or sorted in place when already_wrapped)
+ * nodes   : (real_nodes - real_leaves) x N
+ * skips   : levels x I
+ * extrema_out : optional 6 x double device->host copy target is NOT provided; pass NULL or a
+ *           DEVICE pointer to 6 values of the leaf float type (mins then maxs, expanded).
+ */
+ibvh_status ibvh_build(const ibvh_build_desc *desc, const void *volumes, void *leaves, void *nodes,
+                       void *skips, void *extrema_out, void *scratch, size_t scratch_bytes,
+                       void *stream);
+
+/* Stand-alone pieces of the build, exposed for tests, profiling and the multi-GPU driver. */
+
+/* bounding_volumes_extrema (morton/utils.jl:55-72): 6 values of the leaf float type
+ * (xmin,ymin,zmin,xmax,ymax,zmax), epsilon-expanded when `expand` != 0, written to DEVICE
+ * memory `extrema_out`.  `records` are raw volumes (stride volume_bytes) when wrapped == 0. */
+ibvh_status ibvh_extrema(const ibvh_types *types, const void *records, int32_t wrapped, int64_t n,
+                         int32_t expand, void *extrema_out, void *scratch, size_t scratch_bytes,
+                         void *stream);
+
+/* _morton_encode! (morton/default.jl:63-108) into a separate key array (uint32 for U16/U32,
+ * uint64 for U64) using DEVICE extrema (6 x leaf float, already expanded). */
+ibvh_status ibvh_morton_keys(const ibvh_types *types, const void *records, int32_t wrapped,
+                             int64_t n, const void *extrema, void *keys_out, void *stream);
+
+/* Stable LSB radix sort of (key, value=uint32) pairs; key_bits = significant low bits.
+ * keys/vals are sorted into keys_out/vals_out (may alias the alt buffers as documented in
+ * DESIGN.md); key_bytes is 4 or 8. */
+ibvh_status ibvh_sort_pairs(int32_t key_bytes, int32_t key_bits, int64_t n, void *keys, void *vals,
+                            void *keys_alt, void *vals_alt, int32_t *result_in_alt, void *scratch,
+                            size_t scratch_bytes, void *stream);
+ibvh_status ibvh_sort_scratch_bytes(int32_t key_bytes, int64_t n, size_t *bytes_out);
+
+/* aggregate_oibvh! alone (build.jl:366-523) over already-sorted leaves. */
+ibvh_status ibvh_aggregate(const ibvh_types *types, const ibvh_tree *tree, int64_t built_level,
+                           const void *leaves, void *nodes, void *stream);
+
+/* ----------------------------------------------------------------------------------- */
+/* leaf-vs-tree traversal (LVTTraversal, the reference default)                          */
+/* ----------------------------------------------------------------------------------- */
+/* The reference's own two-pass protocol (lvt/traverse_single.jl:53-75):
+ *   _count : pass 1 + inclusive scan of the per-work-item counts; SYNCHRONISES the stream and
+ *            returns the total (the reference's `@allowscalar thread_ncontacts[end]`, :60);
+ *   _write : pass 2, contact k of work item i lands at counts[i-1] + k (1-based), which makes
+ *            the contact list order deterministic and identical to the reference's.
+ * counts : one I per work item (cache2 of BVHTraversal on the GPU path, :31-32).
+ */
+ibvh_status ibvh_traverse_lvt_count(const ibvh_bvh *bvh, int64_t start_level, int32_t narrow,
+                                    void *counts, int64_t *total_out, void *stream);
+ibvh_status ibvh_traverse_lvt_write(const ibvh_bvh *bvh, int64_t start_level, int32_t narrow,
+                                    const void *counts, void *contacts, void *stream);
+
+/* traverse(bvh1, bvh2, LVTTraversal()) — lvt/traverse_pair.jl:1-244.  The BVH with more leaves
+ * supplies the work items (:15-36); contacts are always (index in bvh1, index in bvh2).
+ * counts needs max(n1, n2) entries. */
+ibvh_status ibvh_traverse_pair_lvt_count(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2,
+                                         int64_t start_level1, int64_t start_level2,
+                                         int32_t narrow, void *counts, int64_t *total_out,
+                                         void *stream);
+ibvh_status ibvh_traverse_pair_lvt_write(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2,
+                                         int64_t start_level1, int64_t start_level2,
+                                         int32_t narrow, const void *counts, void *contacts,
+                                         void *stream);
+
+/* traverse_rays(bvh, points, directions, LVTTraversal()) — raytrace/leaf_vs_tree/
+ * leaf_vs_tree.jl:1-228.  points/directions: (3, num_rays) column-major arrays of the leaf
+ * float type; contacts are (leaf.index, iray). */
+ibvh_status ibvh_traverse_rays_lvt_count(const ibvh_bvh *bvh, const void *points,
+                                         const void *directions, int64_t num_rays,
+                                         int64_t start_level, void *counts, int64_t *total_out,
+                                         void *stream);
+ibvh_status ibvh_traverse_rays_lvt_write(const ibvh_bvh *bvh, const void *points,
+                                         const void *directions, int64_t num_rays,
+                                         int64_t start_level, const void *counts, void *contacts,
+                                         void *stream);
+
+/* ----------------------------------------------------------------------------------- */
+/* breadth-first traversal (BFSTraversal): level-synchronous pair queues                 */
+/* ----------------------------------------------------------------------------------- */
+typedef struct ibvh_bfs_result {
+    int64_t num_contacts;
+    int64_t num_checks;        /* BVHTraversal.num_checks (bfs/traverse_single.jl:25,48)          */
+    int64_t contacts_in;       /* 1: contacts are in bvtt1, 2: in bvtt2                            */
+    int64_t required_capacity; /* pairs each queue must hold; set when IBVH_ERR_CAPACITY          */
+} ibvh_bfs_result;
+
+/* Pairs the initial queue needs: initial_bvtt (bfs/traverse_single.jl:64-99). */
+ibvh_status ibvh_bfs_initial_capacity(const ibvh_bvh *bvh, int64_t start_level, int64_t *pairs_out);
+ibvh_status ibvh_bfs_pair_initial_capacity(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2,
+                                           int64_t start_level1, int64_t start_level2,
+                                           int64_t *pairs_out);
+ibvh_status ibvh_bfs_rays_initial_capacity(const ibvh_bvh *bvh, int64_t num_rays,
+                                           int64_t start_level, int64_t *pairs_out);
+
+/* traverse(bvh, BFSTraversal()) — bfs/traverse_single.jl:1-61.  bvtt1/bvtt2: two queues of
+ * `capacity` IndexPair{I} each (cache1/cache2).  counters: DEVICE scratch of at least
+ * 4 * (levels + 2) int64.  Synchronises the stream (one read per level, as the reference,
+ * bfs/traverse_single_gpu.jl:24).  On IBVH_ERR_CAPACITY grow both queues to
+ * result->required_capacity and call again (the reference's resize!, bfs/traverse_single.jl:40). */
+ibvh_status ibvh_traverse_bfs(const ibvh_bvh *bvh, int64_t start_level, int32_t narrow, void *bvtt1,
+                              void *bvtt2, int64_t capacity, void *counters,
+                              ibvh_bfs_result *result, void *stream);
+
+/* traverse(bvh1, bvh2, BFSTraversal()) — bfs/traverse_pair.jl:1-151 (six-phase descent). */
+ibvh_status ibvh_traverse_pair_bfs(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, int64_t start_level1,
+                                   int64_t start_level2, int32_t narrow, void *bvtt1, void *bvtt2,
+                                   int64_t capacity, void *counters, ibvh_bfs_result *result,
+                                   void *stream);
+
+/* traverse_rays(bvh, points, directions, BFSTraversal()) — raytrace/breadth_first/
+ * breadth_first.jl:1-66. */
+ibvh_status ibvh_traverse_rays_bfs(const ibvh_bvh *bvh, const void *points, const void *directions,
+                                   int64_t num_rays, int64_t start_level, void *bvtt1, void *bvtt2,
+                                   int64_t capacity, void *counters, ibvh_bfs_result *result,
+                                   void *stream);
+
+/* ----------------------------------------------------------------------------------- */
+/* input preparation adjacent to the path                                               */
+/* ----------------------------------------------------------------------------------- */
+/* BSphere{T}(p1,p2,p3) (bsphere.jl:43-112) / BBox{T}(p1,p2,p3) (bbox.jl:59-70) for n triangles
+ * stored as n x 9 values (p1 p2 p3) of float type `flt`; writes n volumes of `kind`. */
+ibvh_status ibvh_volumes_from_triangles(int32_t kind, int32_t flt, const void *triangles, int64_t n,
+                                        void *volumes_out, void *stream);
+
+/* Deterministic synthetic inputs shared by bench, tests and the oracle (SplitMix64 counter
+ * based).  Writes n BSphere{F32} with centres uniform in
+ * [origin, origin+extent)^3 and radius r0*(0.5+0.5u). */
+ibvh_status ibvh_generate_spheres_f32(int64_t n, uint64_t seed, int64_t first_index,
+                                      const float origin[3], const float extent[3], float r0,
+                                      void *volumes_out, void *stream);
+
+/* Library / device introspection. */
+const char *ibvh_version(void);
+const char *ibvh_status_string(int32_t status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IBVH_H */
