@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py — BVH build + self-traverse throughput on MI355X (BASELINE.json metric).
+
+A step = one pass of the hot path over one batch of synthetic leaves that already sit in HBM:
+    BVH(volumes, BBox{Float32}; cache=previous)  ->  traverse(bvh, LVTTraversal(); cache=previous)
+on `--n` BSphere{Float32} leaves (default 1e6: BASELINE.json configs[1]), UInt32 Morton, Int32
+indices.  Protocol follows the reference's benchmark scripts (benchmark/bvh_build.jl:38-45,
+bvh_contact.jl:40-45): warm-up, then timed repetitions on resident data with buffer reuse.
+
+N > 1 (launched by torch.distributed.run): the leaves are sharded over the ranks; the build's
+global centre AABB is an RCCL all-reduce and the Morton sort a distributed radix-sort exchange
+(implicitbvh_amd.dist); each rank then builds and self-traverses its slice.  Weak scaling: --n is the
+per-GPU leaf count, value = all ranks' leaves / max-over-ranks time.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed inside the library)
+and `cpu_baseline` (the CPU oracle's multi-threaded restatement, timed on this box's host cores).
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+# Algorithmic bytes per LEAF and launch for the kernels of one step, for
+# BSphere{F32} leaves / BBox{F32} nodes / U32 / I32; C = contacts per leaf.
+def algorithmic_bytes(kernel, n, contacts):
+    c = contacts / max(n, 1)
+    table = {
+        "extrema_partial_kernel": 16.0,            # read raw volumes
+        "encode_kernel": 16.0 + 4.0,               # read volumes, write keys (positions are implicit)
+        "hist_kernel": 4.0,                        # read keys
+        "scatter_kernel": 8.0 + 8.0,               # read + write (key, position)
+        "gather_kernel": 4.0 + 4.0 + 16.0 + 24.0,  # perm + key + volume -> record
+        "aggregate_kernel": 16.0 + 24.0 + 24.0,    # leaves' volumes + every node read once + written once
+        "lvt_kernel_count": 24.0 + 24.0 + 4.0,     # leaves + nodes once + counts
+        "lvt_kernel_write": 24.0 + 24.0 + 4.0 + 8.0 * c,  # + prefix read, contacts written
+        "scan_reduce_kernel": 4.0, "scan_apply_kernel": 8.0,
+    }
+    return table.get(kernel, 0.0) * n
+
+
+def kernel_key(name):
+    """'(lvt_kernel<L, N, I, MODE, true>)' -> 'lvt_kernel_write'."""
+    base = name.strip("() ").split("<")[0].split("::")[-1].strip()
+    if base == "lvt_kernel":
+        return "lvt_kernel_write" if "true>" in name.replace(" ", "") else "lvt_kernel_count"
+    return base
+
+
+def collect_profile(lib):
+    cnt = C.c_int64()
+    lib.call("ibvh_profile_count", C.byref(cnt))
+    out = {}
+    for i in range(cnt.value):
+        name, ms = C.c_char_p(), C.c_float()
+        lib.call("ibvh_profile_get", i, C.byref(name), C.byref(ms))
+        k = kernel_key(name.value.decode())
+        tot, num = out.get(k, (0.0, 0))
+        out[k] = (tot + ms.value, num + 1)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=1_000_000, help="leaves per GPU")
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-n", type=int, default=0, help="leaves of the CPU baseline sample (0 = same as --n, capped)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import implicitbvh_amd as ibvh
+    from implicitbvh_amd import lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    lib.load()
+
+    n = args.n
+    n_global = n * world
+    # SURVEY.md §8(d) config 2 law: r = r0*(0.5+0.5u), r0 = 0.5*(3k/(4 pi N))^(1/3), k = 8 -> ~1.8 contacts / leaf
+    r0 = 0.5 * (3 * 8 / (4 * math.pi * n_global)) ** (1 / 3)
+    vols = ibvh.generate_spheres(n, args.seed, first_index=rank * n, r0=r0)
+
+    if world > 1:
+        from implicitbvh_amd import dist as ibvh_dist
+        builder = ibvh_dist.DistributedBuilder(dist.group.WORLD)
+
+        def one_step(state):
+            bvh = builder.build(vols, cache=state[0])
+            trav = ibvh.traverse(bvh, cache=state[1])
+            return bvh, trav
+    else:
+        def one_step(state):
+            bvh = ibvh.BVH(vols, cache=state[0])
+            trav = ibvh.traverse(bvh, cache=state[1])
+            return bvh, trav
+
+    state = (None, None)
+    for _ in range(args.warmup):
+        state = one_step(state)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        state = one_step(state)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    contacts = state[1].num_contacts
+    leaves_here = len(state[0].leaves)
+    if dist is not None:
+        c = torch.tensor([contacts, leaves_here], dtype=torch.int64, device="cuda")
+        dist.all_reduce(c)
+        contacts_total, leaves_total = int(c[0]), int(c[1])
+    else:
+        contacts_total, leaves_total = contacts, leaves_here
+    ms_per_step = elapsed / args.steps * 1e3
+    value = leaves_total * args.steps / elapsed / 1e6
+
+    # ---- per-kernel timing pass (HIP events inside the library, on the launch stream) -------------
+    prof_steps = max(3, min(10, args.steps))
+    lib.call("ibvh_profile_enable", 1)
+    torch.cuda.synchronize()
+    tp0 = time.perf_counter()
+    for _ in range(prof_steps):
+        state = one_step(state)
+    torch.cuda.synchronize()
+    tp = time.perf_counter() - tp0
+    prof = collect_profile(lib)
+    lib.call("ibvh_profile_enable", 0)
+
+    roofline, kernels = None, {}
+    if prof:
+        for k, (tot, num) in prof.items():
+            avg_ms = tot / num
+            ab = algorithmic_bytes(k, leaves_here, contacts)
+            kernels[k] = {"avg_ms": round(avg_ms, 5), "launches_per_step": round(num / prof_steps, 2),
+                          "ms_per_step": round(tot / prof_steps, 5),
+                          "algorithmic_GBps": round(ab / (avg_ms * 1e-3) / 1e9, 1) if ab else None}
+        dom = max(prof, key=lambda k: prof[k][0])
+        avg_s = prof[dom][0] / prof[dom][1] * 1e-3
+        ab = algorithmic_bytes(dom, leaves_here, contacts)
+        achieved = ab / avg_s / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes_per_launch": int(ab), "avg_launch_ms": round(avg_s * 1e3, 5)}
+        # Morton+sort phase (north star: >= 40 % of the HBM roofline on 152 B/leaf)
+        ms_phase = sum(v["ms_per_step"] for k, v in kernels.items()
+                       if k in ("extrema_partial_kernel", "extrema_final_kernel", "encode_kernel", "hist_kernel",
+                                "scan_kernel", "scatter_kernel", "gather_kernel"))
+        if ms_phase > 0:
+            gbps = 152.0 * leaves_here / (ms_phase * 1e-3) / 1e9
+            roofline["morton_sort_phase"] = {"ms": round(ms_phase, 4), "algorithmic_GBps": round(gbps, 1),
+                                             "frac": round(gbps / HBM_PEAK_GBS, 4), "bytes_per_leaf": 152}
+
+    # ---- CPU baseline: the oracle's multi-threaded restatement, rank 0 only, bounded sample --------
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as orc  # the checker, here only as the timed CPU baseline
+        cores = os.cpu_count() or 1
+        cpu_n = args.cpu_n or min(n, 2_000_000)
+        host = orc.generate_spheres_f32(cpu_n, args.seed, r0=0.5 * (3 * 8 / (4 * math.pi * cpu_n)) ** (1 / 3))
+        best = None
+        t_budget = time.perf_counter()
+        for _ in range(3):
+            _, cc, tb, tt = orc.bench_build_traverse_f32(host, cores)
+            if best is None or tb + tt < best[0] + best[1]:
+                best = (tb, tt, len(cc))
+            if time.perf_counter() - t_budget > 25:
+                break
+        cpu_baseline = {"value": round(cpu_n / (best[0] + best[1]) / 1e6, 4), "unit": "Mleaves/s", "cores": cores,
+                        "kind": "port",
+                        "sample": f"{cpu_n} BSphere{{Float32}} leaves, same generator/law as the GPU workload, "
+                                  f"build {best[0]*1e3:.1f} ms + LVT traverse {best[1]*1e3:.1f} ms, {best[2]} contacts, "
+                                  f"best of <=3 runs, {cores} threads",
+                        "build_ms": round(best[0] * 1e3, 3), "traverse_ms": round(best[1] * 1e3, 3)}
+
+    if rank == 0:
+        t_trav = sum(v["ms_per_step"] for k, v in kernels.items() if k.startswith(("lvt_", "scan_"))) if kernels else None
+        line = {
+            "metric": "BVH build+traverse throughput", "value": round(value, 3), "unit": "Mleaves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{n} random BSphere{{Float32}} leaves per GPU, BBox{{Float32}} nodes, UInt32 Morton, "
+                                   f"Int32 index, build + LVT self-traverse (BASELINE.json configs[1])",
+                       "leaves_per_gpu": n, "leaves_total": leaves_total, "contacts_total": contacts_total,
+                       "parallelism": "single GPU" if world == 1 else f"leaves sharded over {world} GPUs (RCCL build), per-GPU traversal"},
+            "mcontacts_per_s": round(contacts_total * args.steps / elapsed / 1e6, 3),
+            "mcontacts_per_s_traverse_only": round(contacts / (t_trav * 1e-3) / 1e6, 3) if t_trav else None,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+            "profiled_ms_per_step": round(tp / prof_steps * 1e3, 4),
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

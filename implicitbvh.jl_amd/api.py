@@ -1,1 +1,642 @@
-__all__ = []
+"""Host-side mirror of ImplicitBVH.jl's hot-path API over libibvh (HIP, gfx950).
+
+Same names, argument meaning and error behaviour as the reference:
+    BVH(bounding_volumes, node_type; built_level, cache, options)      src/build.jl:198-271
+    traverse(bvh[, bvh2], alg; start_level..., narrow, cache, options)  src/traverse/traverse.jl:210-233
+    traverse_rays(bvh, points, directions, alg; ...)                    src/raytrace/raytrace.jl:71-80
+    BVHOptions, DefaultMortonAlgorithm, LVTTraversal, BFSTraversal, BVHTraversal, ImplicitTree,
+    default_start_level, memory_index, level_indices, isvirtual.
+Device memory is torch tensors on the current CUDA(HIP) device; this module allocates buffers, fills
+the POD descriptors of include/ibvh.h and calls the C entry points.  Nothing is computed on the host
+and there is no CPU fallback.
+
+Python renderings of Julia types:
+    BSphere{T} arrays  -> float tensor of shape (n, 4): x, y, z, r
+    BBox{T} arrays     -> float tensor of shape (n, 6): lo, up
+    node_type          -> BSphere(dtype) / BBox(dtype) tokens, e.g. BBox(torch.float32)
+    Vector{BoundingVolume{V,I,M}} -> BoundingVolumes (byte buffer with the Julia record layout)
+    Vector{IndexPair{I}}          -> integer tensor of shape (n, 2)
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+from . import abi, lib
+
+__all__ = [
+    "BSphere", "BBox", "BoundingVolumes", "BVHOptions", "DefaultMortonAlgorithm", "ImplicitTree", "BVH",
+    "BVHTraversal", "LVTTraversal", "BFSTraversal", "traverse", "traverse_rays", "default_start_level",
+    "memory_index", "level_indices", "isvirtual", "bounding_volumes_from_triangles", "generate_spheres",
+    "NARROW_MORTON_LT", "NARROW_INDEX_LT",
+]
+
+NARROW_MORTON_LT = abi.NARROW_MORTON_LT
+NARROW_INDEX_LT = abi.NARROW_INDEX_LT
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _require_gpu():
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise RuntimeError("implicitbvh_amd needs an AMD GPU (MI355X / gfx950); there is no CPU fallback")
+    lib.load()
+    return torch
+
+
+def _stream():
+    return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr() if t is not None and t.numel() > 0 else 0)
+
+
+def _float_code(dtype):
+    torch = _torch()
+    if dtype in (torch.float32, np.float32, "float32", float.__name__ + "32"):
+        return abi.F32
+    if dtype in (torch.float64, np.float64, "float64", float):
+        return abi.F64
+    raise ValueError(f"unsupported float type {dtype} (Float32 and Float64 are instantiated)")
+
+
+def _torch_float(code):
+    torch = _torch()
+    return torch.float32 if code == abi.F32 else torch.float64
+
+
+def _index_code(x):
+    torch = _torch()
+    if x in (torch.int32, np.int32, "int32") or isinstance(x, np.int32):
+        return abi.I32
+    if x in (torch.int64, np.int64, "int64", int) or isinstance(x, (np.int64, int)):
+        return abi.I64
+    raise ValueError(f"unsupported index type {x} (Int32 and Int64 are instantiated)")
+
+
+def _torch_index(code):
+    torch = _torch()
+    return torch.int32 if code == abi.I32 else torch.int64
+
+
+def _morton_code(x):
+    for code, dt in abi.MORTON_DTYPES.items():
+        if x is dt or x == dt or isinstance(x, dt) or x == np.dtype(dt).name:
+            return code
+    raise ValueError(f"unsupported Morton type {x} (UInt16, UInt32, UInt64)")
+
+
+# ---------------------------------------------------------------------------------------------
+# type tokens
+# ---------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class _VolumeType:
+    kind: int
+    flt: int
+
+    def __repr__(self):
+        return f"{'BSphere' if self.kind == abi.BSPHERE else 'BBox'}{{{'Float32' if self.flt == abi.F32 else 'Float64'}}}"
+
+
+def BSphere(dtype=None):
+    """Type token BSphere{T} (bsphere.jl:26-29)."""
+    return _VolumeType(abi.BSPHERE, _float_code(dtype if dtype is not None else _torch().float32))
+
+
+def BBox(dtype=None):
+    """Type token BBox{T} (bbox.jl:35-38)."""
+    return _VolumeType(abi.BBOX, _float_code(dtype if dtype is not None else _torch().float32))
+
+
+@dataclass(frozen=True)
+class DefaultMortonAlgorithm:
+    """morton/default.jl:21-40.  `exemplar` is a numpy unsigned type (np.uint16/32/64)."""
+    exemplar: type = np.uint32
+    compute_extrema: bool = True
+    mins: tuple = (float("nan"),) * 3
+    maxs: tuple = (float("nan"),) * 3
+
+    def __post_init__(self):
+        _morton_code(self.exemplar)
+
+
+@dataclass(frozen=True)
+class BVHOptions:
+    """utils.jl:34-93.  CPU threading knobs are kept for signature parity; only `index`, `morton` and
+    `block_size` influence the GPU path (block_size is advisory: kernels pick their own geometry)."""
+    index: object = np.int32
+    morton: DefaultMortonAlgorithm = field(default_factory=DefaultMortonAlgorithm)
+    num_threads: int = 1
+    min_mortons_per_thread: int = 100
+    min_sorts_per_thread: int = 100
+    min_boundings_per_thread: int = 100
+    min_traversals_per_thread: int = 100
+    block_size: int = 256
+
+    def __post_init__(self):
+        for name in ("num_threads", "min_mortons_per_thread", "min_sorts_per_thread", "min_boundings_per_thread",
+                     "min_traversals_per_thread", "block_size"):
+            if not getattr(self, name) > 0:  # @argcheck ... > 0 (utils.jl:73-78)
+                raise ValueError(f"BVHOptions: {name} > 0 must hold")
+        _index_code(self.index)
+
+    @property
+    def index_code(self):
+        return _index_code(self.index)
+
+    @property
+    def morton_code(self):
+        return _morton_code(self.morton.exemplar)
+
+
+class LVTTraversal:
+    """Leaf-vs-tree traversal (traverse/leaf_vs_tree/leaf_vs_tree.jl:1), the default."""
+
+
+class BFSTraversal:
+    """Breadth-first BVTT traversal (traverse/breadth_first/breadth_first.jl:1)."""
+
+
+# ---------------------------------------------------------------------------------------------
+# ImplicitTree
+# ---------------------------------------------------------------------------------------------
+class ImplicitTree:
+    """implicit_tree.jl:52-90."""
+
+    def __init__(self, num_leaves):
+        self._t = abi.Tree()
+        lib.call("ibvh_tree_shape", int(num_leaves), C.byref(self._t))
+
+    levels = property(lambda s: s._t.levels)
+    real_leaves = property(lambda s: s._t.real_leaves)
+    real_nodes = property(lambda s: s._t.real_nodes)
+    virtual_leaves = property(lambda s: s._t.virtual_leaves)
+    virtual_nodes = property(lambda s: s._t.virtual_nodes)
+
+    def __repr__(self):
+        return f"ImplicitTree(levels: {self.levels}, real_leaves: {self.real_leaves})"
+
+
+def memory_index(tree, implicit_index):
+    out = C.c_int64()
+    try:
+        lib.call("ibvh_memory_index", C.byref(tree._t), int(implicit_index), C.byref(out))
+    except ValueError as e:
+        raise IndexError(str(e))  # BoundsError (implicit_tree.jl:131-135)
+    return out.value
+
+
+def level_indices(tree, level):
+    a, b = C.c_int64(), C.c_int64()
+    try:
+        lib.call("ibvh_level_indices", C.byref(tree._t), int(level), C.byref(a), C.byref(b))
+    except ValueError as e:
+        raise IndexError(str(e))
+    return a.value, b.value
+
+
+def isvirtual(tree, implicit_index):
+    out = C.c_int32()
+    try:
+        lib.call("ibvh_isvirtual", C.byref(tree._t), int(implicit_index), C.byref(out))
+    except ValueError as e:
+        raise IndexError(str(e))
+    return bool(out.value)
+
+
+# ---------------------------------------------------------------------------------------------
+# BoundingVolumes: Vector{BoundingVolume{V,I,M}} in device memory
+# ---------------------------------------------------------------------------------------------
+class BoundingVolumes:
+    """Device array of BoundingVolume{V,I,M} records (bounding_volumes.jl:55-59) with the Julia layout."""
+
+    def __init__(self, types, n, buf=None):
+        torch = _torch()
+        self.types = types
+        self.n = int(n)
+        lay = abi.Layout()
+        lib.call("ibvh_layout_of", C.byref(types), C.byref(lay))
+        self.layout = lay
+        if buf is None:
+            buf = torch.zeros(self.n * lay.leaf_bytes, dtype=torch.uint8, device="cuda")
+        self.buf = buf
+
+    def __len__(self):
+        return self.n
+
+    @classmethod
+    def wrap(cls, volumes, indices, options=None):
+        """Manually wrapped volumes with user indices (build.jl:128-153); morton = 0."""
+        torch = _require_gpu()
+        options = options or BVHOptions()
+        kind, flt = _volume_kind(volumes)
+        types = abi.make_types(kind, flt, abi.BBOX, abi.F32, options.index_code, options.morton_code)
+        out = cls(types, volumes.shape[0])
+        out.volume.copy_(volumes)
+        out.index.copy_(torch.as_tensor(indices, device="cuda").to(_torch_index(types.index_type)))
+        return out
+
+    def _strided(self, dtype, offset, width):
+        torch = _torch()
+        esz = torch.empty((), dtype=dtype).element_size()
+        lb = self.layout.leaf_bytes
+        assert lb % esz == 0 and offset % esz == 0
+        flat = self.buf.view(dtype)
+        return flat.as_strided((self.n, width), (lb // esz, 1), offset // esz)
+
+    @property
+    def volume(self):
+        """(n, 4|6) strided float view of the .volume fields."""
+        return self._strided(_torch_float(self.types.leaf_float), 0, abi.volume_width(self.types.leaf_kind))
+
+    @property
+    def index(self):
+        return self._strided(_torch_index(self.types.index_type), self.layout.index_off, 1)[:, 0]
+
+    @property
+    def morton(self):
+        """Morton codes as int64 (torch has no unsigned 32/64-bit arithmetic); values are exact for U16/U32
+        and the two's-complement image for U64 (bit 63 is never set: 63 significant bits)."""
+        torch = _torch()
+        m = self.to_numpy()["morton"].astype(np.int64)
+        return torch.from_numpy(m)
+
+    def to_numpy(self):
+        """Host copy as a numpy structured array (volume, index, morton)."""
+        dt = abi.leaf_dtype(self.types)
+        assert dt.itemsize == self.layout.leaf_bytes
+        return self.buf.cpu().numpy().view(dt)
+
+
+def _volume_kind(volumes):
+    if volumes.dim() != 2 or volumes.shape[1] not in (4, 6):
+        raise ValueError("bounding volumes must be an (n, 4) BSphere or (n, 6) BBox float tensor")
+    if not volumes.is_cuda:
+        raise ValueError("bounding volumes must live on the GPU (device='cuda')")
+    return (abi.BSPHERE if volumes.shape[1] == 4 else abi.BBOX), _float_code(volumes.dtype)
+
+
+# ---------------------------------------------------------------------------------------------
+# BVH
+# ---------------------------------------------------------------------------------------------
+class BVH:
+    """struct BVH + constructor (build.jl:155-271).
+
+        bvh = BVH(bounding_volumes, BBox(torch.float32), built_level=1, cache=None, options=BVHOptions())
+
+    bounding_volumes: (n,4)/(n,6) CUDA float tensor, or a BoundingVolumes (kept indices, sorted IN PLACE,
+    build.jl:128-153).  built_level: int level or float fraction (build.jl:309-325).  cache: a previous BVH
+    whose nodes / skips / scratch buffers are reused (build.jl:232-238, 257-263).
+    Fields: built_level, tree, skips, nodes, leaves (+ extrema: the expanded Morton bounds, device tensor).
+    """
+
+    def __init__(self, bounding_volumes, node_type=None, built_level=1, cache: Optional["BVH"] = None, options=None):
+        torch = _require_gpu()
+        options = options or BVHOptions()
+        node_type = node_type or BBox(torch.float32)  # default BBox{Float32} (build.jl:200)
+        wrapped = isinstance(bounding_volumes, BoundingVolumes)
+        if wrapped:
+            src = bounding_volumes
+            # check_bounding_volume_types (build.jl:355-361)
+            if src.types.index_type != options.index_code:
+                raise ValueError("BoundingVolume index type does not match BVHOptions index_exemplar type")
+            if src.types.morton_type != options.morton_code:
+                raise ValueError("BoundingVolume morton type does not match BVHOptions morton type")
+            kind, flt, n = src.types.leaf_kind, src.types.leaf_float, len(src)
+        else:
+            kind, flt = _volume_kind(bounding_volumes)
+            n = bounding_volumes.shape[0]
+        types = abi.make_types(kind, flt, node_type.kind, node_type.flt, options.index_code, options.morton_code)
+        if not abi.combo_supported(types):
+            raise ValueError(f"no conversion from {'BSphere' if kind == abi.BSPHERE else 'BBox'} leaves to {node_type!r}")
+        self.tree = ImplicitTree(n)  # DomainError for n < 1
+        tree = self.tree
+        # compute_build_level (build.jl:309-325)
+        if isinstance(built_level, (int, np.integer)):
+            if not 1 <= built_level <= tree.levels:
+                raise ValueError("1 <= built_level <= tree.levels must hold")
+            built_ilevel = int(built_level)
+        elif isinstance(built_level, float):
+            out = C.c_int64()
+            lib.call("ibvh_compute_build_level", C.byref(tree._t), float(built_level), C.byref(out))
+            built_ilevel = out.value
+        else:
+            raise TypeError("built_level (the level to build BVH up to) must be an Integer or AbstractFloat")
+        self.built_level = built_ilevel
+        self.types = types
+        idt, ndt = _torch_index(types.index_type), _torch_float(types.node_float)
+        nw = abi.volume_width(types.node_kind)
+        num_nodes = tree.real_nodes - tree.real_leaves
+        # buffers, honouring cache= (type checks as build.jl:235,260)
+        if cache is None:
+            self.skips = torch.empty(tree.levels, dtype=idt, device="cuda")
+            self.nodes = torch.empty((num_nodes, nw), dtype=ndt, device="cuda")
+            self._scratch = None
+        else:
+            if cache.skips.dtype != idt:
+                raise ValueError("eltype(cache.skips) === I must hold")
+            if cache.nodes.dtype != ndt or cache.nodes.shape[1] != nw:
+                raise ValueError("eltype(cache.nodes) === N must hold")
+            self.skips = cache.skips if cache.skips.numel() == tree.levels else torch.empty(tree.levels, dtype=idt, device="cuda")
+            self.nodes = cache.nodes if cache.nodes.shape[0] == num_nodes else torch.empty((num_nodes, nw), dtype=ndt, device="cuda")
+            self._scratch = cache._scratch
+        need = C.c_size_t()
+        lib.call("ibvh_build_scratch_bytes", C.byref(types), n, C.byref(need))
+        if self._scratch is None or self._scratch.numel() < need.value:
+            self._scratch = torch.empty(need.value, dtype=torch.uint8, device="cuda")
+        if wrapped:
+            self.leaves = bounding_volumes
+            self.leaves.types = types  # node type is not part of the record layout
+            vol_ptr = C.c_void_p(0)
+        else:
+            self.leaves = BoundingVolumes(types, n, torch.empty(n * abi.leaf_dtype(types).itemsize, dtype=torch.uint8, device="cuda"))
+            bounding_volumes = bounding_volumes.contiguous()
+            vol_ptr = _ptr(bounding_volumes)
+        self.extrema = torch.empty(6, dtype=_torch_float(flt), device="cuda")
+        d = abi.BuildDesc()
+        d.types = types
+        d.n = n
+        d.built_level = built_ilevel
+        d.already_wrapped = 1 if wrapped else 0
+        alg = options.morton
+        d.compute_extrema = 1 if alg.compute_extrema else 0
+        if not alg.compute_extrema:
+            d.mins[:] = [float(v) for v in alg.mins]
+            d.maxs[:] = [float(v) for v in alg.maxs]
+        lib.call("ibvh_build", C.byref(d), vol_ptr, _ptr(self.leaves.buf), _ptr(self.nodes), _ptr(self.skips),
+                 _ptr(self.extrema), _ptr(self._scratch), self._scratch.numel(), _stream())
+
+    def struct(self):
+        b = abi.Bvh()
+        b.types = self.types
+        b.tree = self.tree._t
+        b.built_level = self.built_level
+        b.leaves = self.leaves.buf.data_ptr()
+        b.nodes = self.nodes.data_ptr() if self.nodes.numel() else 0
+        b.skips = self.skips.data_ptr()
+        return b
+
+    def __repr__(self):
+        return (f"BVH\n  built_level: {self.built_level}\n  tree:        {self.tree}\n  skips:       {tuple(self.skips.shape)}\n"
+                f"  nodes:       {tuple(self.nodes.shape)}\n  leaves:      ({len(self.leaves)},)\n")
+
+
+def default_start_level(bvh, alg=None):
+    """lvt/leaf_vs_tree.jl:4-6 and bfs/breadth_first.jl:4-6."""
+    if alg is None or isinstance(alg, LVTTraversal):
+        return max(1, bvh.built_level)
+    if isinstance(alg, BFSTraversal):
+        return max(bvh.tree.levels // 2, bvh.built_level)
+    raise ValueError(f"default_start_level not implemented for: {alg}")
+
+
+# ---------------------------------------------------------------------------------------------
+# traversal results
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class BVHTraversal:
+    """traverse.jl:54-107.  cache1 holds the contacts ((m, 2) index tensor); cache2 is the other buffer
+    (LVT: per-work-item inclusive counts; BFS: the second pair queue).  `.contacts` = cache1[:num_contacts]."""
+    start_level1: int
+    start_level2: int
+    num_checks: int
+    num_contacts: int
+    cache1: object
+    cache2: object
+    _scratch: object = None
+
+    @property
+    def contacts(self):
+        return self.cache1[: self.num_contacts]
+
+
+def _narrow_code(narrow):
+    if narrow is None:
+        return abi.NARROW_NONE
+    if narrow in (abi.NARROW_MORTON_LT, abi.NARROW_INDEX_LT, abi.NARROW_NONE):
+        return int(narrow)
+    raise NotImplementedError(
+        "arbitrary `narrow` closures cannot cross the C ABI; use NARROW_MORTON_LT / NARROW_INDEX_LT, or filter "
+        "traversal.contacts afterwards (narrow is only ever evaluated as iscontact(...) && narrow(...))")
+
+
+def _cache_tensor(cache_t, need_rows, cols, dtype, what):
+    """Reuse a cache buffer if it is large enough (resize! semantics), checking its eltype (@argcheck)."""
+    torch = _torch()
+    shape = (need_rows, cols) if cols else (need_rows,)
+    if cache_t is None:
+        return torch.empty(shape, dtype=dtype, device="cuda")
+    if cache_t.dtype != dtype or (cols and (cache_t.dim() != 2 or cache_t.shape[1] != cols)) or (not cols and cache_t.dim() != 1):
+        raise ValueError(f"eltype(cache.{what}) does not match the traversal's index type")
+    if cache_t.shape[0] < need_rows:
+        return torch.empty(shape, dtype=dtype, device="cuda")
+    return cache_t
+
+
+def _lvt_scratch(cache, n_items):
+    torch = _torch()
+    need = C.c_size_t()
+    lib.call("ibvh_lvt_scratch_bytes", int(n_items), C.byref(need))
+    s = cache._scratch if cache is not None else None
+    if s is None or s.numel() < need.value:
+        s = torch.empty(need.value, dtype=torch.uint8, device="cuda")
+    return s
+
+
+def _traverse_lvt_single(bvh, start_level, narrow, cache):
+    torch = _require_gpu()
+    idt = _torch_index(bvh.types.index_type)
+    if not (bvh.built_level <= start_level <= bvh.tree.levels <= 32):
+        raise ValueError("bvh.built_level <= start_level <= bvh.tree.levels <= 32 must hold")
+    if bvh.tree.real_nodes <= 1:  # traverse_single.jl:17-21
+        return BVHTraversal(start_level, 0, 0, 0, torch.empty((0, 2), dtype=idt, device="cuda"),
+                            torch.empty(0, dtype=idt, device="cuda"))
+    n = len(bvh.leaves)
+    counts = _cache_tensor(cache.cache2 if cache else None, n, 0, idt, "cache2")
+    scratch = _lvt_scratch(cache, n)
+    s = bvh.struct()
+    total = C.c_int64()
+    lib.call("ibvh_traverse_lvt_count", C.byref(s), start_level, narrow, _ptr(counts), C.byref(total), _ptr(scratch),
+             scratch.numel(), _stream())
+    contacts = _cache_tensor(cache.cache1 if cache else None, total.value, 2, idt, "cache1")
+    if total.value:
+        lib.call("ibvh_traverse_lvt_write", C.byref(s), start_level, narrow, _ptr(counts), _ptr(contacts), _stream())
+    return BVHTraversal(start_level, 0, 0, total.value, contacts, counts, scratch)
+
+
+def _traverse_lvt_pair(bvh1, bvh2, sl1, sl2, narrow, cache):
+    torch = _require_gpu()
+    if bvh1.types.index_type != bvh2.types.index_type:
+        raise ValueError("get_index_type(bvh2) === I must hold")  # traverse_pair.jl:50-52
+    idt = _torch_index(bvh1.types.index_type)
+    for b, sl in ((bvh1, sl1), (bvh2, sl2)):
+        if not (b.built_level <= sl <= b.tree.levels <= 32):
+            raise ValueError("bvh.built_level <= start_level <= bvh.tree.levels <= 32 must hold")
+    n = max(len(bvh1.leaves), len(bvh2.leaves))
+    counts = _cache_tensor(cache.cache2 if cache else None, n, 0, idt, "cache2")
+    scratch = _lvt_scratch(cache, n)
+    s1, s2 = bvh1.struct(), bvh2.struct()
+    total = C.c_int64()
+    lib.call("ibvh_traverse_pair_lvt_count", C.byref(s1), C.byref(s2), sl1, sl2, narrow, _ptr(counts), C.byref(total),
+             _ptr(scratch), scratch.numel(), _stream())
+    contacts = _cache_tensor(cache.cache1 if cache else None, total.value, 2, idt, "cache1")
+    if total.value:
+        lib.call("ibvh_traverse_pair_lvt_write", C.byref(s1), C.byref(s2), sl1, sl2, narrow, _ptr(counts), _ptr(contacts),
+                 _stream())
+    return BVHTraversal(sl1, sl2, 0, total.value, contacts, counts, scratch)
+
+
+def _bfs_run(entry, types, initial_capacity, cache, levels_hint, *args):
+    """Shared BFS driver: grow both queues to the reported capacity and retry (the reference's resize!)."""
+    torch = _require_gpu()
+    idt = _torch_index(types.index_type)
+    cap = max(int(initial_capacity), 1)
+    q1 = cache.cache1 if cache else None
+    q2 = cache.cache2 if cache else None
+    need = C.c_size_t()
+    lib.call("ibvh_bfs_counters_bytes", int(levels_hint), C.byref(need))
+    counters = torch.zeros(need.value, dtype=torch.uint8, device="cuda")
+    while True:
+        q1 = _cache_tensor(q1, cap, 2, idt, "cache1")
+        q2 = _cache_tensor(q2, cap, 2, idt, "cache2")
+        cap = min(q1.shape[0], q2.shape[0])
+        res = abi.BfsResult()
+        st = getattr(lib.load(), entry)(*args, _ptr(q1), _ptr(q2), cap, _ptr(counters), C.byref(res), _stream())
+        if st == abi.ERR_CAPACITY:
+            cap = int(res.required_capacity)
+            q1 = q2 = None
+            continue
+        abi.check(st, entry)
+        if res.contacts_in == 2:
+            q1, q2 = q2, q1
+        return res, q1, q2
+
+
+def _traverse_bfs_single(bvh, start_level, narrow, cache):
+    torch = _require_gpu()
+    idt = _torch_index(bvh.types.index_type)
+    if not (bvh.tree.levels >= start_level >= bvh.built_level):
+        raise ValueError("bvh.tree.levels >= start_level >= bvh.built_level must hold")
+    if bvh.tree.real_nodes <= 1:
+        e = torch.empty((0, 2), dtype=idt, device="cuda")
+        return BVHTraversal(start_level, 0, 0, 0, e, e.clone())
+    s = bvh.struct()
+    cap = C.c_int64()
+    lib.call("ibvh_bfs_initial_capacity", C.byref(s), start_level, C.byref(cap))
+    res, q1, q2 = _bfs_run("ibvh_traverse_bfs", bvh.types, cap.value, cache, bvh.tree.levels, C.byref(s), start_level, narrow)
+    return BVHTraversal(start_level, 0, res.num_checks, res.num_contacts, q1, q2)
+
+
+def _traverse_bfs_pair(bvh1, bvh2, sl1, sl2, narrow, cache):
+    _require_gpu()
+    for b, sl in ((bvh1, sl1), (bvh2, sl2)):
+        if not (b.tree.levels >= sl >= b.built_level):
+            raise ValueError("bvh.tree.levels >= start_level >= bvh.built_level must hold")
+    s1, s2 = bvh1.struct(), bvh2.struct()
+    cap = C.c_int64()
+    lib.call("ibvh_bfs_pair_initial_capacity", C.byref(s1), C.byref(s2), sl1, sl2, C.byref(cap))
+    res, q1, q2 = _bfs_run("ibvh_traverse_pair_bfs", bvh1.types, cap.value, cache, bvh1.tree.levels + bvh2.tree.levels,
+                           C.byref(s1), C.byref(s2), sl1, sl2, narrow)
+    return BVHTraversal(sl1, sl2, res.num_checks, res.num_contacts, q1, q2)
+
+
+def traverse(bvh, *args, start_level=None, start_level1=None, start_level2=None, narrow=None, cache=None, options=None):
+    """traverse(bvh, alg=LVTTraversal(); start_level, narrow, cache, options)
+       traverse(bvh1, bvh2, alg=LVTTraversal(); start_level1, start_level2, narrow, cache, options)
+    (traverse/traverse.jl:210-233).  Returns a BVHTraversal; `.contacts` is an (m, 2) tensor of 1-based index
+    pairs: (min, max) of the user indices for one BVH, (index in bvh1, index in bvh2) for two."""
+    bvh2, alg = None, None
+    for a in args:
+        if isinstance(a, BVH):
+            bvh2 = a
+        elif isinstance(a, (LVTTraversal, BFSTraversal)):
+            alg = a
+        else:
+            raise ValueError(f"Traversal algorithm not implemented: {a}")  # traverse.jl:217
+    alg = alg or LVTTraversal()
+    code = _narrow_code(narrow)
+    if bvh2 is None:
+        sl = default_start_level(bvh, alg) if start_level is None else int(start_level)
+        if isinstance(alg, LVTTraversal):
+            return _traverse_lvt_single(bvh, sl, code, cache)
+        return _traverse_bfs_single(bvh, sl, code, cache)
+    sl1 = default_start_level(bvh, alg) if start_level1 is None else int(start_level1)
+    sl2 = default_start_level(bvh2, alg) if start_level2 is None else int(start_level2)
+    if isinstance(alg, LVTTraversal):
+        return _traverse_lvt_pair(bvh, bvh2, sl1, sl2, code, cache)
+    return _traverse_bfs_pair(bvh, bvh2, sl1, sl2, code, cache)
+
+
+def traverse_rays(bvh, points, directions, alg=None, start_level=1, narrow=None, cache=None, options=None):
+    """traverse_rays(bvh, points, directions, alg=LVTTraversal(); start_level=1, narrow, cache, options)
+    (raytrace/raytrace.jl:71-80).  points, directions: (3, N) tensors as in the reference (column i = ray i);
+    contacts are (leaf.index, iray).  Rays are converted to the leaf float type (raytrace/lvt:116-125)."""
+    torch = _require_gpu()
+    alg = alg or LVTTraversal()
+    if narrow is not None:
+        raise NotImplementedError("ray `narrow` closures cannot cross the C ABI; filter traversal.contacts instead")
+    if not (points.dim() == 2 and directions.dim() == 2 and points.shape[0] == 3 and directions.shape[0] == 3):
+        raise ValueError("size(points, 1) == size(directions, 1) == 3 must hold")
+    if points.shape[1] != directions.shape[1]:
+        raise ValueError("size(points, 2) == size(directions, 2) must hold")
+    lvt = isinstance(alg, LVTTraversal)
+    if lvt and not (bvh.built_level <= start_level <= bvh.tree.levels <= 32):
+        raise ValueError("bvh.built_level <= start_level <= bvh.tree.levels <= 32 must hold")
+    if not lvt and not (bvh.tree.levels >= start_level >= bvh.built_level):
+        raise ValueError("bvh.tree.levels >= start_level >= bvh.built_level must hold")
+    idt = _torch_index(bvh.types.index_type)
+    nr = points.shape[1]
+    if nr == 0:
+        e = torch.empty((0, 2), dtype=idt, device="cuda")
+        return BVHTraversal(start_level, 0, 0, 0, e, e.clone())
+    ft = _torch_float(bvh.types.leaf_float)
+    p = points.to(device="cuda", dtype=ft).t().contiguous()  # (N, 3) row-major == (3, N) column-major
+    d = directions.to(device="cuda", dtype=ft).t().contiguous()
+    s = bvh.struct()
+    if lvt:
+        counts = _cache_tensor(cache.cache2 if cache else None, nr, 0, idt, "cache2")
+        scratch = _lvt_scratch(cache, nr)
+        total = C.c_int64()
+        lib.call("ibvh_traverse_rays_lvt_count", C.byref(s), _ptr(p), _ptr(d), nr, start_level, _ptr(counts),
+                 C.byref(total), _ptr(scratch), scratch.numel(), _stream())
+        contacts = _cache_tensor(cache.cache1 if cache else None, total.value, 2, idt, "cache1")
+        if total.value:
+            lib.call("ibvh_traverse_rays_lvt_write", C.byref(s), _ptr(p), _ptr(d), nr, start_level, _ptr(counts),
+                     _ptr(contacts), _stream())
+        return BVHTraversal(start_level, 0, 0, total.value, contacts, counts, scratch)
+    cap = C.c_int64()
+    lib.call("ibvh_bfs_rays_initial_capacity", C.byref(s), nr, start_level, C.byref(cap))
+    res, q1, q2 = _bfs_run("ibvh_traverse_rays_bfs", bvh.types, cap.value, cache, bvh.tree.levels, C.byref(s), _ptr(p),
+                           _ptr(d), nr, start_level)
+    return BVHTraversal(start_level, 0, res.num_checks, res.num_contacts, q1, q2)
+
+
+# ---------------------------------------------------------------------------------------------
+# input preparation
+# ---------------------------------------------------------------------------------------------
+def bounding_volumes_from_triangles(triangles, volume_type=None):
+    """BSphere{T}(p1,p2,p3) / BBox{T}(p1,p2,p3) for an (n, 3, 3) or (n, 9) CUDA tensor of triangles
+    (bsphere.jl:43-112, bbox.jl:59-70)."""
+    torch = _require_gpu()
+    t = triangles.reshape(triangles.shape[0], 9).contiguous()
+    vt = volume_type or BSphere(t.dtype)
+    t = t.to(_torch_float(vt.flt))
+    out = torch.empty((t.shape[0], abi.volume_width(vt.kind)), dtype=t.dtype, device="cuda")
+    lib.call("ibvh_volumes_from_triangles", vt.kind, vt.flt, _ptr(t), t.shape[0], _ptr(out), _stream())
+    return out
+
+
+def generate_spheres(n, seed, first_index=0, origin=(0.0, 0.0, 0.0), extent=(1.0, 1.0, 1.0), r0=0.01):
+    """Deterministic synthetic BSphere{Float32} cloud (counter-based SplitMix64), on device."""
+    torch = _require_gpu()
+    out = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    o = (C.c_float * 3)(*origin)
+    e = (C.c_float * 3)(*extent)
+    lib.call("ibvh_generate_spheres_f32", int(n), C.c_uint64(seed), int(first_index), o, e, C.c_float(r0), _ptr(out), _stream())
+    return out

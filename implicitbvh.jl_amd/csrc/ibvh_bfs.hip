@@ -1,0 +1,581 @@
+// ibvh_bfs.hip — breadth-first traversal (BFSTraversal) on gfx950: level-synchronous expansion of a
+// bounding-volume-test-tree held in two ping-pong pair queues; the "dynamic contact-pair work queue".
+//
+// Replaces src/traverse/breadth_first/traverse_single{,_gpu}.jl, traverse_pair{,_gpu}.jl and
+// src/raytrace/breadth_first/{breadth_first,raytrace_gpu}.jl.
+//
+// The reference's KernelAbstractions kernels do one LDS atomic per thread to reserve slots in a
+// workgroup staging buffer and one global atomic per workgroup (bfs/traverse_single_gpu.jl:65-99).
+// Here slot reservation inside a wave is atomic-free: every lane produces 0..4 pairs, the count is
+// split into bit planes and wave64 ballots + popcounts give each lane its exclusive offset; waves
+// combine through LDS, the workgroup takes ONE global atomic on the level's queue tail, stages its
+// pairs in LDS and writes them out as one contiguous, coalesced run.  Output order across workgroups
+// is arbitrary — as in the reference's GPU path, whose tests compare after sorting
+// (test/gputests.jl:71-78).  One kernel template serves all ten reference kernels through a policy.
+#include <type_traits>
+
+#include "ibvh_common.hpp"
+
+namespace ibvh {
+namespace bfs {
+
+constexpr int TPB = 256;
+
+template <class L, class N> struct TreeRef {
+    const char *leaves;
+    LeafLayout lay;
+    const N *nodes;
+    int64_t levels, virtual_leaves;
+    int64_t level;      // level of this tree's entries in the source queue
+    int64_t skips;      // level_skips(level)
+    int64_t leaf_first; // 2^(levels-1)
+    int64_t child_real; // real nodes on level+1
+    IBVH_D N node(int64_t implicit) const { return load_vol<N>(nodes + (implicit - skips - 1)); }
+    IBVH_D const char *leaf_rec(int64_t implicit) const { return leaves + (implicit - leaf_first) * lay.stride; }
+    // unsafe_isvirtual(tree, 2*implicit + 1): is the right child virtual?
+    IBVH_D bool right_child_virtual(int64_t implicit) const {
+        int64_t c = 2 * implicit + 1;
+        return c - (int64_t(1) << level) >= child_real;
+    }
+};
+
+template <class L, class N> TreeRef<L, N> make_ref(const ibvh_bvh &b, const LeafLayout &lay, int64_t level) {
+    TreeRef<L, N> r;
+    r.leaves = (const char *)b.leaves;
+    r.lay = lay;
+    r.nodes = (const N *)b.nodes;
+    r.levels = b.tree.levels;
+    r.virtual_leaves = b.tree.virtual_leaves;
+    r.level = level;
+    r.skips = level_skips(r.levels, r.virtual_leaves, level);
+    r.leaf_first = int64_t(1) << (r.levels - 1);
+    r.child_real = level < r.levels ? level_num_real(r.levels, r.virtual_leaves, level + 1) : 0;
+    return r;
+}
+
+IBVH_D bool narrow_eval(int narrow, uint64_t ma, int64_t ia, uint64_t mb, int64_t ib) {
+    if (narrow == IBVH_NARROW_MORTON_LT) return ma < mb;
+    if (narrow == IBVH_NARROW_INDEX_LT) return ia < ib;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// policies: expand(src pair) -> up to MAXOUT dst pairs
+// ------------------------------------------------------------------------------------------
+// _traverse_nodes_gpu! — bfs/traverse_single_gpu.jl:30-120 (same rules as traverse_single_cpu.jl:64-133)
+template <class L, class N, class I> struct SelfNodes {
+    static constexpr int MAXOUT = 4;
+    TreeRef<L, N> t;
+    int self_checks;
+    IBVH_D int expand(IndexPair<I> s, IndexPair<I> *out) const {
+        const I a = s.a, b = s.b;
+        if (a == b) {
+            if (t.right_child_virtual(a)) {
+                if (!self_checks) return 0;
+                out[0] = {I(2 * a), I(2 * a)};
+                return 1;
+            }
+            if (self_checks) {
+                out[0] = {I(2 * a), I(2 * a)};
+                out[1] = {I(2 * a), I(2 * a + 1)};
+                out[2] = {I(2 * a + 1), I(2 * a + 1)};
+                return 3;
+            }
+            out[0] = {I(2 * a), I(2 * a + 1)};
+            return 1;
+        }
+        if (!iscontact(t.node(a), t.node(b))) return 0;
+        // node a is left of node b, so its children are real (traverse_single_cpu.jl:103-105)
+        out[0] = {I(2 * a), I(2 * b)};
+        if (t.right_child_virtual(b)) {
+            out[1] = {I(2 * a + 1), I(2 * b)};
+            return 2;
+        }
+        out[1] = {I(2 * a), I(2 * b + 1)};
+        out[2] = {I(2 * a + 1), I(2 * b)};
+        out[3] = {I(2 * a + 1), I(2 * b + 1)};
+        return 4;
+    }
+};
+
+// _traverse_leaves_gpu! — bfs/traverse_single_gpu.jl:153-211
+template <class L, class N, class I> struct SelfLeaves {
+    static constexpr int MAXOUT = 1;
+    TreeRef<L, N> t;
+    int narrow;
+    IBVH_D int expand(IndexPair<I> s, IndexPair<I> *out) const {
+        const char *r1 = t.leaf_rec(s.a), *r2 = t.leaf_rec(s.b);
+        if (!iscontact(load_vol<L>(r1), load_vol<L>(r2))) return 0;
+        I i1 = load_index<I>(r1, t.lay), i2 = load_index<I>(r2, t.lay);
+        if (narrow != IBVH_NARROW_NONE) {
+            uint64_t m1 = narrow == IBVH_NARROW_MORTON_LT ? load_morton(r1, t.lay) : 0;
+            uint64_t m2 = narrow == IBVH_NARROW_MORTON_LT ? load_morton(r2, t.lay) : 0;
+            if (!narrow_eval(narrow, m1, i1, m2, i2)) return 0;
+        }
+        out[0] = i1 > i2 ? IndexPair<I>{i2, i1} : IndexPair<I>{i1, i2};
+        return 1;
+    }
+};
+
+// The six pair kernels of bfs/traverse_pair_gpu.jl:34-609 in one policy: which side is at leaf level
+// (LEAF1/LEAF2) and which side descends (D1/D2).
+template <class L, class N, class I, bool LEAF1, bool LEAF2, bool D1, bool D2> struct PairStep {
+    static constexpr int MAXOUT = (D1 && D2) ? 4 : ((D1 || D2) ? 2 : 1);
+    TreeRef<L, N> t1, t2;
+    int narrow;
+    IBVH_D int expand(IndexPair<I> s, IndexPair<I> *out) const {
+        const I a = s.a, b = s.b;
+        bool hit;
+        if constexpr (LEAF1 && LEAF2) {
+            // _traverse_leaves_pair_gpu! (:556-609): (leaf1.index, leaf2.index), not re-ordered
+            const char *r1 = t1.leaf_rec(a), *r2 = t2.leaf_rec(b);
+            if (!iscontact(load_vol<L>(r1), load_vol<L>(r2))) return 0;
+            I i1 = load_index<I>(r1, t1.lay), i2 = load_index<I>(r2, t2.lay);
+            if (narrow != IBVH_NARROW_NONE) {
+                uint64_t m1 = narrow == IBVH_NARROW_MORTON_LT ? load_morton(r1, t1.lay) : 0;
+                uint64_t m2 = narrow == IBVH_NARROW_MORTON_LT ? load_morton(r2, t2.lay) : 0;
+                if (!narrow_eval(narrow, m1, i1, m2, i2)) return 0;
+            }
+            out[0] = {i1, i2};
+            return 1;
+        } else if constexpr (LEAF1) {
+            hit = iscontact(load_vol<L>(t1.leaf_rec(a)), t2.node(b)); // iscontact(leaf1.volume, node2), :461-527
+        } else if constexpr (LEAF2) {
+            hit = iscontact(t1.node(a), load_vol<L>(t2.leaf_rec(b))); // :360-426
+        } else {
+            hit = iscontact(t1.node(a), t2.node(b));
+        }
+        if constexpr (!(LEAF1 && LEAF2)) {
+            if (!hit) return 0;
+            if constexpr (D1 && D2) { // _traverse_nodes_pair_gpu! (:34-119)
+                const bool v1 = t1.right_child_virtual(a), v2 = t2.right_child_virtual(b);
+                out[0] = {I(2 * a), I(2 * b)};
+                if (v1) {
+                    if (v2) return 1;
+                    out[1] = {I(2 * a), I(2 * b + 1)};
+                    return 2;
+                }
+                if (v2) {
+                    out[1] = {I(2 * a + 1), I(2 * b)};
+                    return 2;
+                }
+                out[1] = {I(2 * a), I(2 * b + 1)};
+                out[2] = {I(2 * a + 1), I(2 * b)};
+                out[3] = {I(2 * a + 1), I(2 * b + 1)};
+                return 4;
+            } else if constexpr (D1) { // _left_ kernels (:155-222, :360-426)
+                out[0] = {I(2 * a), b};
+                if (t1.right_child_virtual(a)) return 1;
+                out[1] = {I(2 * a + 1), b};
+                return 2;
+            } else { // _right_ kernels (:258-325, :461-527)
+                out[0] = {a, I(2 * b)};
+                if (t2.right_child_virtual(b)) return 1;
+                out[1] = {a, I(2 * b + 1)};
+                return 2;
+            }
+        }
+        return 0;
+    }
+};
+
+// _traverse_rays_nodes_gpu! / _traverse_rays_leaves_gpu! — raytrace/breadth_first/raytrace_gpu.jl:26-179
+template <class L, class N, class I, bool LEAF> struct RayStep {
+    static constexpr int MAXOUT = LEAF ? 1 : 2;
+    using T = typename L::elt;
+    TreeRef<L, N> t;
+    const T *points, *dirs;
+    IBVH_D int expand(IndexPair<I> s, IndexPair<I> *out) const {
+        const I a = s.a, iray = s.b;
+        const T p[3] = {points[3 * ((int64_t)iray - 1)], points[3 * ((int64_t)iray - 1) + 1], points[3 * ((int64_t)iray - 1) + 2]};
+        const T d[3] = {dirs[3 * ((int64_t)iray - 1)], dirs[3 * ((int64_t)iray - 1) + 1], dirs[3 * ((int64_t)iray - 1) + 2]};
+        if constexpr (LEAF) {
+            const char *r = t.leaf_rec(a);
+            if (!isintersection(load_vol<L>(r), p, d)) return 0;
+            out[0] = {load_index<I>(r, t.lay), iray};
+            return 1;
+        } else {
+            if (!isintersection(t.node(a), p, d)) return 0;
+            out[0] = {I(2 * a), iray};
+            if (t.right_child_virtual(a)) return 1;
+            out[1] = {I(2 * a + 1), iray};
+            return 2;
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// the level kernel: expand + wave64 ballot compaction + one global atomic per workgroup
+// ------------------------------------------------------------------------------------------
+// counters[0] = overflow flag, counters[slot] = tail of this step's destination queue
+template <class I, class Policy>
+__global__ __launch_bounds__(TPB) void level_kernel(const IndexPair<I> *__restrict__ src, int64_t num_src,
+                                                    IndexPair<I> *__restrict__ dst, int64_t capacity,
+                                                    unsigned long long *__restrict__ counters, int slot, Policy pol) {
+    constexpr int MAXOUT = Policy::MAXOUT;
+    __shared__ IndexPair<I> staged[MAXOUT * TPB];
+    __shared__ int wave_tot[TPB / 64];
+    __shared__ unsigned long long s_base;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+
+    IndexPair<I> out[MAXOUT];
+    int k = 0;
+    if (i < num_src) k = pol.expand(src[i], out);
+
+    // exclusive offset inside the wave from ballots over the bit planes of k (k <= 4)
+    const uint64_t lt = ((uint64_t)1 << lane) - 1;
+    uint64_t b0 = __ballot(k & 1), b1 = __ballot(k & 2), b2 = __ballot(k & 4);
+    int wave_prefix = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
+    int wave_sum = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+    if (lane == 0) wave_tot[w] = wave_sum;
+    __syncthreads();
+    int block_prefix = 0, total = 0;
+#pragma unroll
+    for (int j = 0; j < TPB / 64; ++j) {
+        int t = wave_tot[j];
+        if (j < w) block_prefix += t;
+        total += t;
+    }
+    const int at = block_prefix + wave_prefix;
+#pragma unroll
+    for (int j = 0; j < MAXOUT; ++j)
+        if (j < k) staged[at + j] = out[j];
+    if (threadIdx.x == 0) s_base = total ? atomicAdd(&counters[slot], (unsigned long long)total) : 0ull;
+    __syncthreads();
+    if (total == 0) return;
+    const unsigned long long base = s_base;
+    if (base + (unsigned long long)total > (unsigned long long)capacity) {
+        if (threadIdx.x == 0) counters[0] = 1ull; // overflow: the tail keeps counting so the need is known
+        return;
+    }
+    for (int p = threadIdx.x; p < total; p += TPB) dst[base + p] = staged[p];
+}
+
+// ------------------------------------------------------------------------------------------
+// initial queues — fill_initial_bvtt_* (bfs/traverse_single.jl:102-167, traverse_pair.jl:195-219,
+// raytrace/breadth_first/breadth_first.jl:116-137), in the CPU branch's order
+// ------------------------------------------------------------------------------------------
+// rows i = 0..n-1; row i holds (n - i) entries when the self pair is included, (n - 1 - i) otherwise
+IBVH_D int64_t tri_before(int64_t i, int64_t n, bool with_self) {
+    return with_self ? i * n - i * (i - 1) / 2 : i * (2 * n - i - 1) / 2;
+}
+template <class I>
+__global__ __launch_bounds__(TPB) void fill_self_kernel(IndexPair<I> *q, int64_t n, int64_t first, int with_self, int64_t total) {
+    const int64_t k = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (k >= total) return;
+    // exact unranking: double-precision guess of the row, then integer correction
+    const double t = with_self ? 2.0 * (double)n + 1.0 : 2.0 * (double)n - 1.0;
+    double disc = t * t - 8.0 * (double)k;
+    int64_t i = (int64_t)((t - sqrt(disc < 0.0 ? 0.0 : disc)) * 0.5);
+    const int64_t imax = with_self ? n - 1 : n - 2;
+    i = i < 0 ? 0 : (i > imax ? imax : i);
+    while (i > 0 && tri_before(i, n, with_self) > k) --i;
+    while (i < imax && tri_before(i + 1, n, with_self) <= k) ++i;
+    const int64_t off = k - tri_before(i, n, with_self);
+    const int64_t j = with_self ? i + off : i + 1 + off;
+    q[k] = {I(first + i), I(first + j)};
+}
+template <class I>
+__global__ __launch_bounds__(TPB) void fill_product_kernel(IndexPair<I> *q, int64_t rows, int64_t cols, int64_t first_row,
+                                                          int64_t first_col) {
+    const int64_t k = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (k >= rows * cols) return;
+    q[k] = {I(first_row + k / cols), I(first_col + k % cols)};
+}
+
+// ------------------------------------------------------------------------------------------
+// host drivers
+// ------------------------------------------------------------------------------------------
+struct Run {
+    hipStream_t st;
+    unsigned long long *counters;
+    int64_t capacity;
+    int slot = 1;
+    int64_t num = 0; // entries in the current source queue
+    int64_t checks = 0;
+    int64_t need = 0;
+    bool swapped = false;
+    void *q[2];
+    void *src() const { return q[swapped ? 1 : 0]; }
+    void *dst() const { return q[swapped ? 0 : 1]; }
+};
+
+template <class I, class Policy> int step(Run &r, const Policy &pol) {
+    unsigned long long tail = 0, ovf = 0;
+    if (r.num > 0) {
+        unsigned blocks = (unsigned)ceil_div(r.num, TPB);
+        IBVH_LAUNCH((level_kernel<I, Policy>), dim3(blocks), dim3(TPB), 0, r.st, (const IndexPair<I> *)r.src(), r.num,
+                           (IndexPair<I> *)r.dst(), r.capacity, r.counters, r.slot, pol);
+        IBVH_LAUNCH_CHECK();
+        // one blocking read per level, as the reference (bfs/traverse_single_gpu.jl:24)
+        IBVH_HIP_CHECK(hipMemcpyAsync(&tail, r.counters + r.slot, 8, hipMemcpyDeviceToHost, r.st));
+        IBVH_HIP_CHECK(hipMemcpyAsync(&ovf, r.counters, 8, hipMemcpyDeviceToHost, r.st));
+        IBVH_HIP_CHECK(hipStreamSynchronize(r.st));
+    }
+    r.slot += 1;
+    if (ovf || (int64_t)tail > r.capacity) {
+        r.need = (int64_t)tail;
+        return IBVH_ERR_CAPACITY;
+    }
+    r.num = (int64_t)tail;
+    r.swapped = !r.swapped;
+    return IBVH_OK;
+}
+
+inline size_t counters_bytes(int64_t total_levels) { return (size_t)(total_levels + 8) * 8; }
+
+inline int begin(Run &r, void *bvtt1, void *bvtt2, int64_t capacity, void *counters, int64_t total_levels, hipStream_t st) {
+    r.st = st;
+    r.counters = (unsigned long long *)counters;
+    r.capacity = capacity;
+    r.q[0] = bvtt1;
+    r.q[1] = bvtt2;
+    IBVH_HIP_CHECK(hipMemsetAsync(counters, 0, counters_bytes(total_levels), st));
+    return IBVH_OK;
+}
+
+inline void finish(const Run &r, ibvh_bfs_result *res) {
+    res->num_contacts = r.num;
+    res->num_checks = r.checks;
+    res->contacts_in = r.swapped ? 2 : 1;
+    res->required_capacity = 0;
+}
+inline int capacity_error(const Run &r, ibvh_bfs_result *res, int64_t need) {
+    res->num_contacts = 0;
+    res->num_checks = 0;
+    res->contacts_in = 1;
+    res->required_capacity = need + need / 4 + 1024; // exact need of the level that overflowed + headroom
+    return IBVH_ERR_CAPACITY;
+}
+
+inline int64_t self_initial(const ibvh_bvh &b, int64_t start_level) {
+    int64_t n = level_num_real(b.tree.levels, b.tree.virtual_leaves, start_level);
+    return start_level != b.tree.levels ? n * (n - 1) / 2 + n : n * (n - 1) / 2;
+}
+
+inline bool same_types(const ibvh_types &x, const ibvh_types &y) {
+    return x.leaf_kind == y.leaf_kind && x.leaf_float == y.leaf_float && x.node_kind == y.node_kind &&
+           x.node_float == y.node_float && x.index_type == y.index_type && x.morton_type == y.morton_type;
+}
+
+template <class L, class N, class I>
+int run_self(const ibvh_bvh &b, int64_t start_level, int narrow, void *bvtt1, void *bvtt2, int64_t capacity, void *counters,
+             ibvh_bfs_result *res, hipStream_t st) {
+    ibvh_layout lay;
+    LeafLayout dl;
+    layout_of(b.types, lay, &dl);
+    Run r;
+    if (int e = begin(r, bvtt1, bvtt2, capacity, counters, b.tree.levels, st)) return e;
+    const int64_t levels = b.tree.levels;
+    const int64_t n0 = level_num_real(levels, b.tree.virtual_leaves, start_level);
+    const int64_t total0 = self_initial(b, start_level);
+    if (total0 > capacity) return capacity_error(r, res, total0);
+    if (total0 > 0)
+        IBVH_LAUNCH((fill_self_kernel<I>), dim3((unsigned)ceil_div(total0, TPB)), dim3(TPB), 0, st, (IndexPair<I> *)bvtt1,
+                           n0, int64_t(1) << (start_level - 1), start_level != levels ? 1 : 0, total0);
+    r.num = total0;
+    r.checks = total0;
+    for (int64_t level = start_level; level < levels; ++level) {
+        SelfNodes<L, N, I> pol{make_ref<L, N>(b, dl, level), level < levels - 1 ? 1 : 0}; // self_checks (:44)
+        if (int e = step<I>(r, pol)) return e == IBVH_ERR_CAPACITY ? capacity_error(r, res, r.need) : e;
+        r.checks += r.num;
+    }
+    SelfLeaves<L, N, I> leaves{make_ref<L, N>(b, dl, levels), narrow};
+    if (int e = step<I>(r, leaves)) return e == IBVH_ERR_CAPACITY ? capacity_error(r, res, r.need) : e;
+    finish(r, res);
+    return IBVH_OK;
+}
+
+template <class L, class N, class I>
+int run_pair(const ibvh_bvh &b1, const ibvh_bvh &b2, int64_t sl1, int64_t sl2, int narrow, void *bvtt1, void *bvtt2,
+             int64_t capacity, void *counters, ibvh_bfs_result *res, hipStream_t st) {
+    ibvh_layout lay;
+    LeafLayout dl;
+    layout_of(b1.types, lay, &dl);
+    Run r;
+    const int64_t L1 = b1.tree.levels, L2 = b2.tree.levels;
+    if (int e = begin(r, bvtt1, bvtt2, capacity, counters, L1 + L2, st)) return e;
+    const int64_t nr1 = level_num_real(L1, b1.tree.virtual_leaves, sl1), nr2 = level_num_real(L2, b2.tree.virtual_leaves, sl2);
+    const int64_t total0 = nr1 * nr2;
+    if (total0 > capacity) return capacity_error(r, res, total0);
+    IBVH_LAUNCH((fill_product_kernel<I>), dim3((unsigned)ceil_div(total0, TPB)), dim3(TPB), 0, st, (IndexPair<I> *)bvtt1,
+                       nr1, nr2, int64_t(1) << (sl1 - 1), int64_t(1) << (sl2 - 1));
+    r.num = total0;
+    r.checks = total0;
+    int64_t l1 = sl1, l2 = sl2;
+    int rc = IBVH_OK;
+    auto do_step = [&](auto pol) {
+        pol.t1 = make_ref<L, N>(b1, dl, l1);
+        pol.t2 = make_ref<L, N>(b2, dl, l2);
+        pol.narrow = narrow;
+        rc = step<I>(r, pol);
+        if (rc == IBVH_OK) r.checks += r.num;
+        return rc == IBVH_OK;
+    };
+    // the six-phase descent of bfs/traverse_pair.jl:50-143
+    while (l1 < L1 - 1 && l2 < L2 - 1) {
+        if (!do_step(PairStep<L, N, I, false, false, true, true>{})) goto fail;
+        ++l1, ++l2;
+    }
+    while (l1 < L1 - 1 && l2 == L2 - 1) {
+        if (!do_step(PairStep<L, N, I, false, false, true, false>{})) goto fail;
+        ++l1;
+    }
+    while (l2 < L2 - 1 && l1 == L1 - 1) {
+        if (!do_step(PairStep<L, N, I, false, false, false, true>{})) goto fail;
+        ++l2;
+    }
+    while (l2 == L2 && l1 < L1) {
+        if (!do_step(PairStep<L, N, I, false, true, true, false>{})) goto fail;
+        ++l1;
+    }
+    while (l1 == L1 && l2 < L2) {
+        if (!do_step(PairStep<L, N, I, true, false, false, true>{})) goto fail;
+        ++l2;
+    }
+    if (l1 == L1 - 1 && l2 == L2 - 1) {
+        if (!do_step(PairStep<L, N, I, false, false, true, true>{})) goto fail;
+        ++l1, ++l2;
+    }
+    {
+        // leaf-leaf: num_checks is not incremented after the final step (bfs/traverse_pair.jl:146-150)
+        int64_t checks = r.checks;
+        if (!do_step(PairStep<L, N, I, true, true, false, false>{})) goto fail;
+        r.checks = checks;
+    }
+    finish(r, res);
+    return IBVH_OK;
+fail:
+    return rc == IBVH_ERR_CAPACITY ? capacity_error(r, res, r.need) : rc;
+}
+
+template <class L, class N, class I>
+int run_rays(const ibvh_bvh &b, const void *points, const void *dirs, int64_t num_rays, int64_t start_level, void *bvtt1,
+             void *bvtt2, int64_t capacity, void *counters, ibvh_bfs_result *res, hipStream_t st) {
+    using T = typename L::elt;
+    ibvh_layout lay;
+    LeafLayout dl;
+    layout_of(b.types, lay, &dl);
+    Run r;
+    const int64_t levels = b.tree.levels;
+    if (int e = begin(r, bvtt1, bvtt2, capacity, counters, levels, st)) return e;
+    const int64_t nr = level_num_real(levels, b.tree.virtual_leaves, start_level);
+    const int64_t total0 = nr * num_rays;
+    if (total0 > capacity) return capacity_error(r, res, total0);
+    IBVH_LAUNCH((fill_product_kernel<I>), dim3((unsigned)ceil_div(total0, TPB)), dim3(TPB), 0, st, (IndexPair<I> *)bvtt1, nr,
+                       num_rays, int64_t(1) << (start_level - 1), int64_t(1));
+    r.num = total0;
+    r.checks = total0;
+    for (int64_t level = start_level; level < levels; ++level) {
+        RayStep<L, N, I, false> pol{make_ref<L, N>(b, dl, level), (const T *)points, (const T *)dirs};
+        if (int e = step<I>(r, pol)) return e == IBVH_ERR_CAPACITY ? capacity_error(r, res, r.need) : e;
+        r.checks += r.num;
+    }
+    RayStep<L, N, I, true> leaves{make_ref<L, N>(b, dl, levels), (const T *)points, (const T *)dirs};
+    if (int e = step<I>(r, leaves)) return e == IBVH_ERR_CAPACITY ? capacity_error(r, res, r.need) : e;
+    finish(r, res);
+    return IBVH_OK;
+}
+
+inline int check_levels(const ibvh_bvh &b, int64_t sl) {
+    // @argcheck bvh.tree.levels >= start_level >= bvh.built_level (bfs/traverse_single.jl:9-11)
+    if (!(b.tree.levels >= sl && sl >= b.built_level && sl >= 1)) return IBVH_ERR_INVALID_ARG;
+    if (b.tree.levels > 62) return IBVH_ERR_INVALID_ARG;
+    return IBVH_OK;
+}
+
+template <class F> int dispatch(const ibvh_types &t, F &&f) {
+    return dispatch_leaf_node(t, [&](auto lt, auto nt) -> int {
+        return dispatch_index(t.index_type, [&](auto it) -> int { return f(lt, nt, it); });
+    });
+}
+
+} // namespace bfs
+} // namespace ibvh
+
+using namespace ibvh;
+using namespace ibvh::bfs;
+
+extern "C" {
+
+ibvh_status ibvh_bfs_counters_bytes(int64_t total_levels, size_t *bytes_out) {
+    if (!bytes_out || total_levels < 0) return IBVH_ERR_INVALID_ARG;
+    *bytes_out = counters_bytes(total_levels);
+    return IBVH_OK;
+}
+
+ibvh_status ibvh_bfs_initial_capacity(const ibvh_bvh *bvh, int64_t start_level, int64_t *pairs_out) {
+    if (!bvh || !pairs_out) return IBVH_ERR_INVALID_ARG;
+    if (int e = check_levels(*bvh, start_level)) return (ibvh_status)e;
+    *pairs_out = self_initial(*bvh, start_level);
+    return IBVH_OK;
+}
+ibvh_status ibvh_bfs_pair_initial_capacity(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, int64_t sl1, int64_t sl2,
+                                           int64_t *pairs_out) {
+    if (!bvh1 || !bvh2 || !pairs_out) return IBVH_ERR_INVALID_ARG;
+    if (int e = check_levels(*bvh1, sl1)) return (ibvh_status)e;
+    if (int e = check_levels(*bvh2, sl2)) return (ibvh_status)e;
+    *pairs_out = level_num_real(bvh1->tree.levels, bvh1->tree.virtual_leaves, sl1) *
+                 level_num_real(bvh2->tree.levels, bvh2->tree.virtual_leaves, sl2);
+    return IBVH_OK;
+}
+ibvh_status ibvh_bfs_rays_initial_capacity(const ibvh_bvh *bvh, int64_t num_rays, int64_t start_level, int64_t *pairs_out) {
+    if (!bvh || !pairs_out || num_rays < 0) return IBVH_ERR_INVALID_ARG;
+    if (int e = check_levels(*bvh, start_level)) return (ibvh_status)e;
+    *pairs_out = level_num_real(bvh->tree.levels, bvh->tree.virtual_leaves, start_level) * num_rays;
+    return IBVH_OK;
+}
+
+ibvh_status ibvh_traverse_bfs(const ibvh_bvh *bvh, int64_t start_level, int32_t narrow, void *bvtt1, void *bvtt2,
+                              int64_t capacity, void *counters, ibvh_bfs_result *result, void *stream) {
+    if (!bvh || !result) return IBVH_ERR_INVALID_ARG;
+    *result = {0, 0, 1, 0};
+    if (int e = check_levels(*bvh, start_level)) return (ibvh_status)e;
+    if (bvh->tree.real_nodes <= 1) return IBVH_OK; // bfs/traverse_single.jl:17-21
+    if (!bvtt1 || !bvtt2 || !counters || capacity < 1) return IBVH_ERR_INVALID_ARG;
+    if (bvh->types.index_type == IBVH_I32 && bvh->tree.levels > 31) return IBVH_ERR_OVERFLOW;
+    return (ibvh_status)dispatch(bvh->types, [&](auto lt, auto nt, auto it) -> int {
+        return run_self<typename decltype(lt)::type, typename decltype(nt)::type, typename decltype(it)::type>(
+            *bvh, start_level, narrow, bvtt1, bvtt2, capacity, counters, result, (hipStream_t)stream);
+    });
+}
+
+ibvh_status ibvh_traverse_pair_bfs(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, int64_t sl1, int64_t sl2, int32_t narrow,
+                                   void *bvtt1, void *bvtt2, int64_t capacity, void *counters, ibvh_bfs_result *result,
+                                   void *stream) {
+    if (!bvh1 || !bvh2 || !result) return IBVH_ERR_INVALID_ARG;
+    *result = {0, 0, 1, 0};
+    if (int e = check_levels(*bvh1, sl1)) return (ibvh_status)e;
+    if (int e = check_levels(*bvh2, sl2)) return (ibvh_status)e;
+    if (!same_types(bvh1->types, bvh2->types)) return IBVH_ERR_UNSUPPORTED;
+    if (!bvtt1 || !bvtt2 || !counters || capacity < 1) return IBVH_ERR_INVALID_ARG;
+    if (bvh1->types.index_type == IBVH_I32 && (bvh1->tree.levels > 31 || bvh2->tree.levels > 31)) return IBVH_ERR_OVERFLOW;
+    return (ibvh_status)dispatch(bvh1->types, [&](auto lt, auto nt, auto it) -> int {
+        return run_pair<typename decltype(lt)::type, typename decltype(nt)::type, typename decltype(it)::type>(
+            *bvh1, *bvh2, sl1, sl2, narrow, bvtt1, bvtt2, capacity, counters, result, (hipStream_t)stream);
+    });
+}
+
+ibvh_status ibvh_traverse_rays_bfs(const ibvh_bvh *bvh, const void *points, const void *dirs, int64_t num_rays,
+                                   int64_t start_level, void *bvtt1, void *bvtt2, int64_t capacity, void *counters,
+                                   ibvh_bfs_result *result, void *stream) {
+    if (!bvh || !result || num_rays < 0) return IBVH_ERR_INVALID_ARG;
+    *result = {0, 0, 1, 0};
+    if (int e = check_levels(*bvh, start_level)) return (ibvh_status)e;
+    if (bvh->types.leaf_float != bvh->types.node_float) return IBVH_ERR_UNSUPPORTED;
+    if (num_rays == 0) return IBVH_OK;
+    if (!points || !dirs || !bvtt1 || !bvtt2 || !counters || capacity < 1) return IBVH_ERR_INVALID_ARG;
+    if (bvh->types.index_type == IBVH_I32 && (bvh->tree.levels > 31 || num_rays > INT32_MAX)) return IBVH_ERR_OVERFLOW;
+    return (ibvh_status)dispatch(bvh->types, [&](auto lt, auto nt, auto it) -> int {
+        using L = typename decltype(lt)::type;
+        using N = typename decltype(nt)::type;
+        using I = typename decltype(it)::type;
+        if constexpr (!std::is_same<typename L::elt, typename N::elt>::value) return (int)IBVH_ERR_UNSUPPORTED;
+        else
+            return run_rays<L, N, I>(*bvh, points, dirs, num_rays, start_level, bvtt1, bvtt2, capacity, counters, result,
+                                     (hipStream_t)stream);
+    });
+}
+
+} // extern "C"

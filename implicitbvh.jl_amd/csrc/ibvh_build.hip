@@ -1,0 +1,466 @@
+// ibvh_build.hip — BVH construction on gfx950: extrema -> Morton keys -> radix sort -> gather ->
+// bottom-up merge.  Replaces src/build.jl:198-271 and src/morton/*.jl of the reference.
+//
+// Data flow (BSphere{F32} leaves, n of them; bytes per leaf in brackets):
+//   extrema_partial   read volumes [16]                         -> per-workgroup min/max
+//   extrema_final     (1 workgroup) + epsilon expansion         -> 6 scalars in HBM (no host readback)
+//   encode            read volumes [16], write key [4]          (values are implicit positions)
+//   radix sort        ibvh_sort.hip
+//   gather            read perm [4] + key [4] + volume [16 random], write record [24]
+//   aggregate         read records [24 stride, 16 used], write nodes [24 * ~1]
+#include "ibvh_common.hpp"
+
+namespace ibvh {
+namespace rsort {
+int sort_pairs(int key_bytes, int key_bits, int64_t n, void *keys, void *vals, void *keys_alt, void *vals_alt,
+               bool vals_implicit, int32_t *result_in_alt, void *scratch, size_t scratch_sz, hipStream_t st);
+size_t scratch_bytes(int64_t n);
+} // namespace rsort
+
+namespace build {
+
+constexpr int EXT_TPB = 256;
+constexpr int EXT_MAX_BLOCKS = 2048;
+
+// ------------------------------------------------------------------------------------------
+// M1: extrema of the centres — morton/utils.jl:1-72
+// ------------------------------------------------------------------------------------------
+template <class T> IBVH_D T wave_min(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        T t = __shfl_xor(v, o, 64);
+        v = v < t ? v : t;
+    }
+    return v;
+}
+template <class T> IBVH_D T wave_max(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        T t = __shfl_xor(v, o, 64);
+        v = v > t ? v : t;
+    }
+    return v;
+}
+
+// min/max are exact and order-free (no NaNs), so any reduction tree reproduces the reference's
+// mapreduce bit for bit.  Inits: min <- floatmax(T); max <- floatmin(T) (sic, utils.jl:39-40).
+template <class V>
+__global__ __launch_bounds__(EXT_TPB) void extrema_partial_kernel(const char *__restrict__ recs, int64_t stride, int64_t n,
+                                                                  typename V::elt *__restrict__ partials) {
+    using T = typename V::elt;
+    T mn[3] = {float_max<T>(), float_max<T>(), float_max<T>()};
+    T mx[3] = {float_min_normal<T>(), float_min_normal<T>(), float_min_normal<T>()};
+    for (int64_t i = (int64_t)blockIdx.x * EXT_TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EXT_TPB) {
+        V v = load_vol<V>(recs + i * stride);
+        T c[3];
+        center(v, c);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = mn[k] < c[k] ? mn[k] : c[k];
+            mx[k] = mx[k] > c[k] ? mx[k] : c[k];
+        }
+    }
+    __shared__ T s[EXT_TPB / 64][6];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        T a = wave_min(mn[k]), b = wave_max(mx[k]);
+        if (lane == 0) {
+            s[w][k] = a;
+            s[w][3 + k] = b;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        T v = s[0][threadIdx.x];
+        for (int i = 1; i < EXT_TPB / 64; ++i) {
+            T t = s[i][threadIdx.x];
+            v = threadIdx.x < 3 ? (v < t ? v : t) : (v > t ? v : t);
+        }
+        partials[(int64_t)blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+// One workgroup folds the partials and applies the epsilon expansion of
+// bounding_volumes_extrema (utils.jl:63-69): x -/+ rp*abs(x) -/+ floatmin, two roundings a side.
+template <class T>
+__global__ __launch_bounds__(EXT_TPB) void extrema_final_kernel(const T *__restrict__ partials, int nparts, int expand,
+                                                                T *__restrict__ out) {
+    T mn[3] = {float_max<T>(), float_max<T>(), float_max<T>()};
+    T mx[3] = {float_min_normal<T>(), float_min_normal<T>(), float_min_normal<T>()};
+    for (int i = threadIdx.x; i < nparts; i += EXT_TPB) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            T a = partials[i * 6 + k], b = partials[i * 6 + 3 + k];
+            mn[k] = mn[k] < a ? mn[k] : a;
+            mx[k] = mx[k] > b ? mx[k] : b;
+        }
+    }
+    __shared__ T s[EXT_TPB / 64][6];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        T a = wave_min(mn[k]), b = wave_max(mx[k]);
+        if (lane == 0) {
+            s[w][k] = a;
+            s[w][3 + k] = b;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        T v = s[0][threadIdx.x];
+        for (int i = 1; i < EXT_TPB / 64; ++i) {
+            T t = s[i][threadIdx.x];
+            v = threadIdx.x < 3 ? (v < t ? v : t) : (v > t ? v : t);
+        }
+        if (expand) {
+            const T rp = relative_precision<T>(), fm = float_min_normal<T>();
+            T a = rp * ibvh_abs(v);
+            v = threadIdx.x < 3 ? (v - a) - fm : (v + a) + fm;
+        }
+        out[threadIdx.x] = v;
+    }
+}
+
+template <class T> __global__ void extrema_set_kernel(T *out, double a0, double a1, double a2, double b0, double b1, double b2) {
+    if (threadIdx.x == 0) {
+        out[0] = T(a0);
+        out[1] = T(a1);
+        out[2] = T(a2);
+        out[3] = T(b0);
+        out[4] = T(b1);
+        out[5] = T(b2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// M2: Morton keys — morton/default.jl:63-108
+// ------------------------------------------------------------------------------------------
+template <class V, class K>
+__global__ __launch_bounds__(256) void encode_kernel(const char *__restrict__ recs, int64_t stride, int64_t n,
+                                                     const typename V::elt *__restrict__ ext, int morton_type,
+                                                     K *__restrict__ keys) {
+    using T = typename V::elt;
+    const T mins[3] = {ext[0], ext[1], ext[2]}, maxs[3] = {ext[3], ext[4], ext[5]};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        V v = load_vol<V>(recs + i * stride);
+        T c[3];
+        center(v, c);
+        keys[i] = (K)morton_encode_single(c, mins, maxs, morton_type);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// gather: sorted (key, position) -> BoundingVolume records in Morton order
+//   index = position + 1 for freshly wrapped volumes (wrap_bounding_volumes, build.jl:345-349)
+//           or the source record's own .index (build.jl:220-222)
+// ------------------------------------------------------------------------------------------
+template <class V, class I, class K>
+__global__ __launch_bounds__(256) void gather_kernel(const char *__restrict__ src, int64_t src_stride, int src_wrapped,
+                                                     LeafLayout lay, const K *__restrict__ keys,
+                                                     const uint32_t *__restrict__ perm, int64_t n, char *__restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint32_t p = perm[i];
+        const char *s = src + (int64_t)p * src_stride;
+        V v = load_vol<V>(s);
+        I idx = src_wrapped ? load_index<I>(s, lay) : (I)((int64_t)p + 1);
+        char *d = dst + i * lay.stride;
+        store_vol(d, v);
+        *(I *)(d + lay.index_off) = idx;
+        store_morton(d, lay, (uint64_t)keys[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// A1 + A2: bottom-up merge — build.jl:366-523.  One launch builds up to CH_LEVELS tree levels:
+// a workgroup owns 2*TPB consecutive inputs (leaves, or nodes of the level the previous launch
+// ended on), merges them pairwise, and keeps folding through LDS, writing every level it makes.
+// The reference launches once per level (build.jl:371-375: ~levels launches); this needs
+// ceil((levels-1)/CH_LEVELS).
+// ------------------------------------------------------------------------------------------
+constexpr int AGG_TPB = 256;
+constexpr int CH_LEVELS = 9; // 2*256 inputs -> 256,128,...,1 nodes
+
+template <class L, class N, bool FROM_LEAVES>
+__global__ __launch_bounds__(AGG_TPB) void aggregate_kernel(const char *__restrict__ in, int64_t in_stride, int64_t in_level,
+                                                            TreeDev tree, int64_t built_level, N *__restrict__ nodes) {
+    __shared__ N s_nodes[AGG_TPB];
+    const int t = threadIdx.x;
+    // level being produced first: in_level - 1
+    int64_t level = in_level - 1;
+    const int64_t in_real = FROM_LEAVES ? tree.real_leaves : level_num_real(tree.levels, tree.virtual_leaves, in_level);
+    int64_t i = (int64_t)blockIdx.x * AGG_TPB + t; // 0-based node index within `level`
+    int64_t nreal = level_num_real(tree.levels, tree.virtual_leaves, level);
+    N mine;
+    bool real = i < nreal;
+    if (real) {
+        int64_t l = 2 * i, r = 2 * i + 1; // 0-based children within in_level
+        if constexpr (FROM_LEAVES) {
+            L a = load_vol<L>(in + l * in_stride);
+            if (r < in_real) {
+                L b = load_vol<L>(in + r * in_stride);
+                mine = merge_to(a, b, (N *)nullptr);
+            } else {
+                mine = convert_to(a, (N *)nullptr);
+            }
+        } else {
+            N a = load_vol<N>(in + l * in_stride);
+            if (r < in_real) {
+                N b = load_vol<N>(in + r * in_stride);
+                mine = merge_to(a, b, (N *)nullptr);
+            } else {
+                mine = a;
+            }
+        }
+        nodes[level_start(tree.levels, tree.virtual_leaves, level) - 1 + i] = mine;
+    }
+    // fold upwards inside the workgroup
+    int count = AGG_TPB;
+#pragma unroll 1
+    for (int s = 1; s < CH_LEVELS; ++s) {
+        if (level - 1 < built_level) break; // uniform
+        __syncthreads();
+        if (t < count) s_nodes[t] = mine;
+        __syncthreads();
+        count >>= 1;
+        level -= 1;
+        const int64_t child_real = nreal;
+        nreal = level_num_real(tree.levels, tree.virtual_leaves, level);
+        i = (int64_t)blockIdx.x * count + t;
+        real = (t < count) && (i < nreal);
+        if (real) {
+            N a = s_nodes[2 * t];
+            if (2 * i + 1 < child_real) mine = merge_to(a, s_nodes[2 * t + 1], (N *)nullptr);
+            else mine = a;
+            nodes[level_start(tree.levels, tree.virtual_leaves, level) - 1 + i] = mine;
+        }
+    }
+}
+
+template <class L, class N>
+int aggregate(const char *leaves, int64_t leaf_stride, const ibvh_tree &tree, int64_t built_level, N *nodes, hipStream_t st) {
+    if (tree.real_nodes < 2) return IBVH_OK; // build.jl:266
+    TreeDev td{tree.levels, tree.real_leaves, tree.virtual_leaves};
+    // launch 1: leaves (level `levels`) -> levels-1 .. levels-CH_LEVELS.  The last-level merge always
+    // runs (aggregate_last_level!, build.jl:369), even when built_level == levels.
+    int64_t in_level = tree.levels;
+    {
+        int64_t nreal = level_num_real(tree.levels, tree.virtual_leaves, in_level - 1);
+        int64_t eff_built = built_level > tree.levels - 1 ? tree.levels - 1 : built_level;
+        IBVH_LAUNCH((aggregate_kernel<L, N, true>), dim3((unsigned)ceil_div(nreal, AGG_TPB)), dim3(AGG_TPB), 0, st,
+                           leaves, leaf_stride, in_level, td, eff_built, nodes);
+        IBVH_LAUNCH_CHECK();
+        in_level = in_level - CH_LEVELS;
+    }
+    while (in_level - 1 >= built_level && in_level - 1 >= 1) {
+        int64_t nreal = level_num_real(tree.levels, tree.virtual_leaves, in_level - 1);
+        const char *in = (const char *)(nodes + (level_start(tree.levels, tree.virtual_leaves, in_level) - 1));
+        IBVH_LAUNCH((aggregate_kernel<L, N, false>), dim3((unsigned)ceil_div(nreal, AGG_TPB)), dim3(AGG_TPB), 0, st,
+                           in, (int64_t)sizeof(N), in_level, td, built_level, nodes);
+        IBVH_LAUNCH_CHECK();
+        in_level -= CH_LEVELS;
+    }
+    return IBVH_OK;
+}
+
+// compute_skips! on device memory in the index type I (build.jl:232-239)
+template <class I> __global__ void skips_kernel(TreeDev tree, I *skips) {
+    int64_t level = threadIdx.x + 1;
+    if (level <= tree.levels) skips[level - 1] = (I)level_skips(tree.levels, tree.virtual_leaves, level);
+}
+
+inline int grid_for(int64_t n, int tpb, int max_blocks) {
+    int64_t b = ceil_div(n, tpb);
+    return (int)(b < 1 ? 1 : (b > max_blocks ? max_blocks : b));
+}
+
+// scratch carve-up -----------------------------------------------------------------------------
+struct Scratch {
+    char *partials;  // EXT_MAX_BLOCKS * 6 * 8
+    char *extrema;   // 6 * 8
+    char *keys, *keys_alt; // n * key_bytes
+    char *vals, *vals_alt; // n * 4
+    char *records;   // n * leaf_bytes (only for the in-place, already-wrapped build)
+    char *sort;      // rsort::scratch_bytes(n)
+    size_t total;
+};
+inline Scratch carve(char *base, int64_t n, int key_bytes, int64_t leaf_bytes, bool wrapped) {
+    Scratch s;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char *p = base ? base + off : nullptr;
+        off += (size_t)align_up((int64_t)bytes, 256);
+        return p;
+    };
+    s.partials = take((size_t)EXT_MAX_BLOCKS * 6 * 8);
+    s.extrema = take(64);
+    s.keys = take((size_t)n * key_bytes);
+    s.keys_alt = take((size_t)n * key_bytes);
+    s.vals = take((size_t)n * 4);
+    s.vals_alt = take((size_t)n * 4);
+    s.records = take(wrapped ? (size_t)n * leaf_bytes : 0);
+    s.sort = take(rsort::scratch_bytes(n));
+    s.total = off;
+    return s;
+}
+
+template <class V>
+int extrema(const char *recs, int64_t stride, int64_t n, int expand, typename V::elt *out, char *partials, hipStream_t st) {
+    using T = typename V::elt;
+    int blocks = grid_for(n, EXT_TPB * 4, EXT_MAX_BLOCKS);
+    IBVH_LAUNCH((extrema_partial_kernel<V>), dim3(blocks), dim3(EXT_TPB), 0, st, recs, stride, n, (T *)partials);
+    IBVH_LAUNCH((extrema_final_kernel<T>), dim3(1), dim3(EXT_TPB), 0, st, (const T *)partials, blocks, expand, out);
+    IBVH_LAUNCH_CHECK();
+    return IBVH_OK;
+}
+
+template <class V>
+int encode(const char *recs, int64_t stride, int64_t n, const typename V::elt *ext, int morton_type, void *keys, hipStream_t st) {
+    int blocks = grid_for(n, 256, 256 * 16);
+    if (morton_type == IBVH_U64)
+        IBVH_LAUNCH((encode_kernel<V, uint64_t>), dim3(blocks), dim3(256), 0, st, recs, stride, n, ext, morton_type,
+                           (uint64_t *)keys);
+    else
+        IBVH_LAUNCH((encode_kernel<V, uint32_t>), dim3(blocks), dim3(256), 0, st, recs, stride, n, ext, morton_type,
+                           (uint32_t *)keys);
+    IBVH_LAUNCH_CHECK();
+    return IBVH_OK;
+}
+
+inline int morton_key_bits(int morton_type) { return morton_type == IBVH_U16 ? 15 : (morton_type == IBVH_U32 ? 30 : 63); }
+
+} // namespace build
+} // namespace ibvh
+
+using namespace ibvh;
+using namespace ibvh::build;
+
+extern "C" {
+
+ibvh_status ibvh_build_scratch_bytes(const ibvh_types *types, int64_t n, size_t *bytes_out) {
+    if (!types || !bytes_out) return IBVH_ERR_INVALID_ARG;
+    ibvh_layout lay;
+    if (!layout_of(*types, lay)) return IBVH_ERR_UNSUPPORTED;
+    if (n < 1) return IBVH_ERR_DOMAIN;
+    int kb = types->morton_type == IBVH_U64 ? 8 : 4;
+    *bytes_out = carve(nullptr, n, kb, lay.leaf_bytes, true).total;
+    return IBVH_OK;
+}
+
+ibvh_status ibvh_extrema(const ibvh_types *types, const void *records, int32_t wrapped, int64_t n, int32_t expand,
+                         void *extrema_out, void *scratch, size_t scratch_bytes, void *stream) {
+    if (!types || !records || !extrema_out || !scratch) return IBVH_ERR_INVALID_ARG;
+    if (n < 1) return IBVH_ERR_DOMAIN;
+    if (scratch_bytes < (size_t)EXT_MAX_BLOCKS * 6 * 8) return IBVH_ERR_SCRATCH;
+    ibvh_layout lay;
+    if (!layout_of(*types, lay)) return IBVH_ERR_UNSUPPORTED;
+    int64_t stride = wrapped ? lay.leaf_bytes : lay.volume_bytes;
+    return (ibvh_status)dispatch_volume(types->leaf_kind, types->leaf_float, [&](auto lt) -> int {
+        using V = typename decltype(lt)::type;
+        return extrema<V>((const char *)records, stride, n, expand, (typename V::elt *)extrema_out, (char *)scratch,
+                          (hipStream_t)stream);
+    });
+}
+
+ibvh_status ibvh_morton_keys(const ibvh_types *types, const void *records, int32_t wrapped, int64_t n, const void *ext,
+                             void *keys_out, void *stream) {
+    if (!types || !records || !ext || !keys_out) return IBVH_ERR_INVALID_ARG;
+    if (n < 1) return IBVH_ERR_DOMAIN;
+    ibvh_layout lay;
+    if (!layout_of(*types, lay)) return IBVH_ERR_UNSUPPORTED;
+    int64_t stride = wrapped ? lay.leaf_bytes : lay.volume_bytes;
+    return (ibvh_status)dispatch_volume(types->leaf_kind, types->leaf_float, [&](auto lt) -> int {
+        using V = typename decltype(lt)::type;
+        return encode<V>((const char *)records, stride, n, (const typename V::elt *)ext, types->morton_type, keys_out,
+                         (hipStream_t)stream);
+    });
+}
+
+ibvh_status ibvh_aggregate(const ibvh_types *types, const ibvh_tree *tree, int64_t built_level, const void *leaves,
+                           void *nodes, void *stream) {
+    if (!types || !tree || !leaves) return IBVH_ERR_INVALID_ARG;
+    if (built_level < 1 || built_level > tree->levels) return IBVH_ERR_INVALID_ARG;
+    ibvh_layout lay;
+    if (!layout_of(*types, lay)) return IBVH_ERR_UNSUPPORTED;
+    if (tree->real_nodes >= 2 && !nodes) return IBVH_ERR_INVALID_ARG;
+    return (ibvh_status)dispatch_leaf_node(*types, [&](auto lt, auto nt) -> int {
+        using L = typename decltype(lt)::type;
+        using N = typename decltype(nt)::type;
+        return aggregate<L, N>((const char *)leaves, lay.leaf_bytes, *tree, built_level, (N *)nodes, (hipStream_t)stream);
+    });
+}
+
+ibvh_status ibvh_build(const ibvh_build_desc *desc, const void *volumes, void *leaves, void *nodes, void *skips,
+                       void *extrema_out, void *scratch, size_t scratch_bytes, void *stream) {
+    if (!desc || !leaves || !skips || !scratch) return IBVH_ERR_INVALID_ARG;
+    const ibvh_types &ty = desc->types;
+    ibvh_layout lay;
+    LeafLayout dlay;
+    if (!layout_of(ty, lay, &dlay)) return IBVH_ERR_UNSUPPORTED;
+    ibvh_tree tree;
+    if (ibvh_status e = ibvh_tree_shape(desc->n, &tree)) return e;
+    if (desc->n >= (int64_t(1) << 32)) return IBVH_ERR_INVALID_ARG; // positions are uint32 in the sort
+    if (ty.index_type == IBVH_I32 && tree.real_nodes > INT32_MAX) return IBVH_ERR_OVERFLOW;
+    if (desc->built_level < 1 || desc->built_level > tree.levels) return IBVH_ERR_INVALID_ARG; // build.jl:314
+    if (!desc->already_wrapped && !volumes) return IBVH_ERR_INVALID_ARG;
+    if (tree.real_nodes >= 2 && !nodes) return IBVH_ERR_INVALID_ARG;
+    const int64_t n = desc->n;
+    const int key_bytes = ty.morton_type == IBVH_U64 ? 8 : 4;
+    const bool wrapped = desc->already_wrapped != 0;
+    Scratch sc = carve((char *)scratch, n, key_bytes, lay.leaf_bytes, wrapped);
+    if (scratch_bytes < sc.total) return IBVH_ERR_SCRATCH;
+    hipStream_t st = (hipStream_t)stream;
+
+    const char *src = wrapped ? (const char *)leaves : (const char *)volumes;
+    const int64_t src_stride = wrapped ? lay.leaf_bytes : lay.volume_bytes;
+
+    int rc = dispatch_leaf_node(ty, [&](auto lt, auto nt) -> int {
+        using L = typename decltype(lt)::type;
+        using N = typename decltype(nt)::type;
+        using T = typename L::elt;
+        T *ext = (T *)sc.extrema;
+        // skips
+        TreeDev td{tree.levels, tree.real_leaves, tree.virtual_leaves};
+        if (ty.index_type == IBVH_I32) IBVH_LAUNCH((skips_kernel<int32_t>), dim3(1), dim3(64), 0, st, td, (int32_t *)skips);
+        else IBVH_LAUNCH((skips_kernel<int64_t>), dim3(1), dim3(64), 0, st, td, (int64_t *)skips);
+        // extrema (or caller-fixed bounds: morton/default.jl:52-57)
+        if (desc->compute_extrema) {
+            if (int e = extrema<L>(src, src_stride, n, 1, ext, sc.partials, st)) return e;
+        } else {
+            IBVH_LAUNCH((extrema_set_kernel<T>), dim3(1), dim3(64), 0, st, ext, desc->mins[0], desc->mins[1],
+                               desc->mins[2], desc->maxs[0], desc->maxs[1], desc->maxs[2]);
+        }
+        if (extrema_out) IBVH_HIP_CHECK(hipMemcpyAsync(extrema_out, ext, 6 * sizeof(T), hipMemcpyDeviceToDevice, st));
+        // keys
+        if (int e = encode<L>(src, src_stride, n, ext, ty.morton_type, sc.keys, st)) return e;
+        // sort (key, position)
+        int32_t in_alt = 0;
+        if (int e = rsort::sort_pairs(key_bytes, morton_key_bits(ty.morton_type), n, sc.keys, sc.vals, sc.keys_alt,
+                                      sc.vals_alt, true, &in_alt, sc.sort, rsort::scratch_bytes(n), st))
+            return e;
+        const void *skeys = in_alt ? sc.keys_alt : sc.keys;
+        const uint32_t *sperm = (const uint32_t *)(in_alt ? sc.vals_alt : sc.vals);
+        // gather into Morton order.  In-place (already wrapped) builds go through scratch records.
+        char *dst = wrapped ? sc.records : (char *)leaves;
+        int gblocks = grid_for(n, 256, 256 * 16);
+        auto launch_gather = [&](auto it) -> int {
+            using I = typename decltype(it)::type;
+            if (key_bytes == 8)
+                IBVH_LAUNCH((gather_kernel<L, I, uint64_t>), dim3(gblocks), dim3(256), 0, st, src, src_stride,
+                                   wrapped ? 1 : 0, dlay, (const uint64_t *)skeys, sperm, n, dst);
+            else
+                IBVH_LAUNCH((gather_kernel<L, I, uint32_t>), dim3(gblocks), dim3(256), 0, st, src, src_stride,
+                                   wrapped ? 1 : 0, dlay, (const uint32_t *)skeys, sperm, n, dst);
+            return IBVH_OK;
+        };
+        if (int e = dispatch_index(ty.index_type, launch_gather)) return e;
+        IBVH_LAUNCH_CHECK();
+        if (wrapped)
+            IBVH_HIP_CHECK(hipMemcpyAsync(leaves, sc.records, (size_t)n * lay.leaf_bytes, hipMemcpyDeviceToDevice, st));
+        // merge
+        return aggregate<L, N>((const char *)leaves, lay.leaf_bytes, tree, desc->built_level, (N *)nodes, st);
+    });
+    return (ibvh_status)rc;
+}
+
+} // extern "C"

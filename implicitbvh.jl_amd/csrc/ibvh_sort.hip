@@ -1,0 +1,295 @@
+// ibvh_sort.hip — stable LSB radix sort of (Morton key, uint32 position) pairs for gfx950.
+//
+// Replaces AK.sort!(leaves, by = bv -> bv.morton) (reference src/build.jl:248-253).  The
+// reference sorts whole 24-byte records with a third-party merge sort; here only (key, position)
+// pairs move through the passes and the records are gathered once at the end (ibvh_build.hip).
+//
+// One pass (8-bit digit) = three launches, no inter-workgroup communication inside a launch:
+//   hist    : per-tile digit histogram, LDS-staged (ds_add_u32), written digit-major
+//   scan    : one workgroup per digit: exclusive scan of that digit's row over tiles + digit total
+//   scatter : per tile: wave64 ballot "match" ranking (stable), LDS-staged per-wave histograms,
+//             tile reorder in LDS, then coalesced runs written to global.
+// Stability: ranks are assigned in tile order = memory order, so equal keys keep their order;
+// that is the single-task Base.sort! behaviour the oracle restates (tie order is unpinned in the
+// reference).
+#include "ibvh_common.hpp"
+
+namespace ibvh {
+namespace rsort {
+
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX = 1 << RADIX_BITS;
+
+// XCD-aware tile assignment: workgroups b and b+8 share an XCD (round-robin dispatch), so giving
+// XCD x the contiguous tile range [x*q.., ..) lets neighbouring tiles' partial lines of one digit
+// stream meet in the same L2.  Bijective for any grid size; affects speed only.
+IBVH_D int xcd_remap(int b, int nwg) {
+    int q = nwg >> 3, r = nwg & 7;
+    int xcd = b & 7, k = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+template <int TPB> IBVH_D uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_tot /* TPB/64 */, uint32_t *total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wave_tot[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < TPB / 64; ++i) {
+        uint32_t t = wave_tot[i];
+        if (i < w) base += t;
+        tot += t;
+    }
+    if (total) *total = tot;
+    __syncthreads();
+    return base + inc - v;
+}
+
+// ---- hist ---------------------------------------------------------------------------------
+template <class K, int TPB, int IPT>
+__global__ __launch_bounds__(TPB) void hist_kernel(const K *__restrict__ keys, int64_t n, int shift, uint32_t mask,
+                                                   uint32_t *__restrict__ tile_hist, int num_tiles) {
+    __shared__ uint32_t h[RADIX];
+    for (int i = threadIdx.x; i < RADIX; i += TPB) h[i] = 0;
+    __syncthreads();
+    const int tile = blockIdx.x;
+    const int64_t base = (int64_t)tile * (TPB * IPT);
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        int64_t i = base + j * TPB + threadIdx.x;
+        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < RADIX; d += TPB) tile_hist[(int64_t)d * num_tiles + tile] = h[d];
+}
+
+// ---- scan ---------------------------------------------------------------------------------
+// grid = RADIX workgroups; workgroup d turns row d of tile_hist into its exclusive prefix over
+// tiles and writes the row sum to digit_total[d].
+template <int TPB>
+__global__ __launch_bounds__(TPB) void scan_kernel(uint32_t *__restrict__ tile_hist, int num_tiles,
+                                                   uint32_t *__restrict__ digit_total) {
+    __shared__ uint32_t wave_tot[TPB / 64];
+    uint32_t *row = tile_hist + (int64_t)blockIdx.x * num_tiles;
+    uint32_t carry = 0;
+    for (int base = 0; base < num_tiles; base += TPB) {
+        int i = base + threadIdx.x;
+        uint32_t v = i < num_tiles ? row[i] : 0u;
+        uint32_t tot;
+        uint32_t ex = block_exclusive_scan<TPB>(v, wave_tot, &tot);
+        if (i < num_tiles) row[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) digit_total[blockIdx.x] = carry;
+}
+
+// ---- scatter ------------------------------------------------------------------------------
+template <class K, int TPB, int IPT>
+__global__ __launch_bounds__(TPB) void scatter_kernel(const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                      K *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+                                                      int64_t n, int shift, uint32_t mask,
+                                                      const uint32_t *__restrict__ tile_hist,
+                                                      const uint32_t *__restrict__ digit_total, int num_tiles) {
+    constexpr int W = TPB / 64;
+    constexpr int TILE = TPB * IPT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    K *s_keys = (K *)smem;                                   // TILE
+    uint32_t *s_vals = (uint32_t *)(s_keys + TILE);          // TILE
+    uint32_t *whist = s_vals + TILE;                         // W * RADIX
+    uint32_t *local_base = whist + W * RADIX;                // RADIX
+    uint32_t *delta = local_base + RADIX;                    // RADIX
+    uint32_t *wave_tot = delta + RADIX;                      // W
+
+    const int tile = xcd_remap(blockIdx.x, num_tiles);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t tile_base = (int64_t)tile * TILE;
+    const int64_t wave_base = tile_base + (int64_t)w * (64 * IPT);
+    const int valid = (int)((n - tile_base) < (int64_t)TILE ? (n - tile_base) : (int64_t)TILE);
+
+    for (int i = threadIdx.x; i < W * RADIX; i += TPB) whist[i] = 0;
+
+    // phase A: coalesced loads, wave-striped so that (w, j, lane) order == memory order
+    K key[IPT];
+    uint32_t val[IPT];
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        int64_t i = wave_base + j * 64 + lane;
+        bool ok = i < n;
+        key[j] = ok ? keys_in[i] : (K)~(K)0;
+        val[j] = ok ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
+    }
+    __syncthreads();
+
+    // phase B: stable rank inside the wave by ballot matching, running per-wave digit counters in LDS
+    uint16_t rank[IPT];
+    uint32_t *my_hist = whist + w * RADIX;
+    const uint64_t lt_mask = ((uint64_t)1 << lane) - 1;
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        uint32_t d = (uint32_t)(key[j] >> shift) & mask;
+        uint64_t peers = ~(uint64_t)0;
+#pragma unroll
+        for (int b = 0; b < RADIX_BITS; ++b) {
+            bool bit = (d >> b) & 1u;
+            uint64_t bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        uint32_t prev = my_hist[d];
+        rank[j] = (uint16_t)(prev + (uint32_t)__popcll(peers & lt_mask));
+        if ((peers & lt_mask) == 0) my_hist[d] = prev + (uint32_t)__popcll(peers); // lowest peer lane writes
+    }
+    __syncthreads();
+
+    // phase C: per digit, exclusive prefix over waves; tile-local digit bases; global deltas
+    uint32_t tot_d = 0, gtot = 0;
+    if (threadIdx.x < RADIX) {
+        const int d = threadIdx.x;
+        uint32_t run = 0;
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            uint32_t c = whist[i * RADIX + d];
+            whist[i * RADIX + d] = run;
+            run += c;
+        }
+        tot_d = run;
+        gtot = digit_total[d];
+    }
+    uint32_t lb = block_exclusive_scan<TPB>(tot_d, wave_tot, nullptr);
+    uint32_t gb = block_exclusive_scan<TPB>(gtot, wave_tot, nullptr);
+    if (threadIdx.x < RADIX) {
+        const int d = threadIdx.x;
+        local_base[d] = lb;
+        delta[d] = gb + tile_hist[(int64_t)d * num_tiles + tile] - lb; // mod 2^32
+    }
+    __syncthreads();
+
+    // phase D: tile reorder in LDS
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        uint32_t d = (uint32_t)(key[j] >> shift) & mask;
+        uint32_t pos = local_base[d] + my_hist[d] + rank[j];
+        s_keys[pos] = key[j];
+        s_vals[pos] = val[j];
+    }
+    __syncthreads();
+
+    // phase E: coalesced runs to global
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        int pos = k * TPB + threadIdx.x;
+        if (pos < valid) {
+            K kk = s_keys[pos];
+            uint32_t d = (uint32_t)(kk >> shift) & mask;
+            uint32_t dest = (uint32_t)pos + delta[d];
+            keys_out[dest] = kk;
+            vals_out[dest] = s_vals[pos];
+        }
+    }
+}
+
+template <class K, int TPB, int IPT> constexpr size_t scatter_smem() {
+    return (size_t)TPB * IPT * (sizeof(K) + 4) + (size_t)(TPB / 64) * RADIX * 4 + RADIX * 8 + (TPB / 64) * 4 + 64;
+}
+
+struct Geometry {
+    int tpb, ipt;
+    int tile() const { return tpb * ipt; }
+};
+// Small inputs get small tiles so the grid still covers the 256 CUs; large inputs get 8192-element
+// tiles so that one digit's run in a tile is >= 128 B on average.
+inline Geometry choose_geometry(int64_t n) { return n >= (int64_t(1) << 22) ? Geometry{512, 16} : Geometry{256, 8}; }
+
+size_t scratch_bytes(int64_t n) {
+    int64_t tiles = ceil_div(n, 256 * 8); // upper bound over both geometries
+    return (size_t)align_up((int64_t)RADIX * tiles * 4, 256) + RADIX * 4 + 256;
+}
+
+template <class K, int TPB, int IPT>
+int run_passes(K *keys, uint32_t *vals, K *keys_alt, uint32_t *vals_alt, int64_t n, int key_bits, bool vals_implicit,
+               int32_t *result_in_alt, void *scratch, hipStream_t st) {
+    const int num_tiles = (int)ceil_div(n, TPB * IPT);
+    uint32_t *tile_hist = (uint32_t *)scratch;
+    uint32_t *digit_total = (uint32_t *)((char *)scratch + align_up((int64_t)RADIX * num_tiles * 4, 256));
+    static bool attr_set = false;
+    constexpr size_t smem = scatter_smem<K, TPB, IPT>();
+    if (!attr_set) {
+        IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)scatter_kernel<K, TPB, IPT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    K *kin = keys, *kout = keys_alt;
+    uint32_t *vin = vals, *vout = vals_alt;
+    int flips = 0;
+    for (int shift = 0; shift < key_bits; shift += RADIX_BITS) {
+        int bits = key_bits - shift < RADIX_BITS ? key_bits - shift : RADIX_BITS;
+        uint32_t mask = (1u << bits) - 1u;
+        IBVH_LAUNCH((hist_kernel<K, TPB, IPT>), dim3(num_tiles), dim3(TPB), 0, st, kin, n, shift, mask, tile_hist,
+                           num_tiles);
+        IBVH_LAUNCH((scan_kernel<256>), dim3(RADIX), dim3(256), 0, st, tile_hist, num_tiles, digit_total);
+        IBVH_LAUNCH((scatter_kernel<K, TPB, IPT>), dim3(num_tiles), dim3(TPB), smem, st, kin,
+                           (shift == 0 && vals_implicit) ? (const uint32_t *)nullptr : vin, kout, vout, n, shift, mask,
+                           tile_hist, digit_total, num_tiles);
+        IBVH_LAUNCH_CHECK();
+        K *tk = kin;
+        kin = kout;
+        kout = tk;
+        uint32_t *tv = vin;
+        vin = vout;
+        vout = tv;
+        ++flips;
+    }
+    *result_in_alt = flips & 1;
+    return IBVH_OK;
+}
+
+// vals_implicit: the values of the first pass are the element positions 0..n-1 (vals is not read).
+int sort_pairs(int key_bytes, int key_bits, int64_t n, void *keys, void *vals, void *keys_alt, void *vals_alt,
+               bool vals_implicit, int32_t *result_in_alt, void *scratch, size_t scratch_sz, hipStream_t st) {
+    if (n < 0 || n >= (int64_t(1) << 32) || key_bits < 1 || key_bits > key_bytes * 8) return IBVH_ERR_INVALID_ARG;
+    if (scratch_sz < scratch_bytes(n)) return IBVH_ERR_SCRATCH;
+    *result_in_alt = 0;
+    if (n == 0) return IBVH_OK;
+    Geometry g = choose_geometry(n);
+    if (key_bytes == 4) {
+        if (g.tpb == 512)
+            return run_passes<uint32_t, 512, 16>((uint32_t *)keys, (uint32_t *)vals, (uint32_t *)keys_alt,
+                                                 (uint32_t *)vals_alt, n, key_bits, vals_implicit, result_in_alt, scratch, st);
+        return run_passes<uint32_t, 256, 8>((uint32_t *)keys, (uint32_t *)vals, (uint32_t *)keys_alt, (uint32_t *)vals_alt,
+                                            n, key_bits, vals_implicit, result_in_alt, scratch, st);
+    }
+    if (key_bytes == 8) {
+        if (g.tpb == 512)
+            return run_passes<uint64_t, 512, 16>((uint64_t *)keys, (uint32_t *)vals, (uint64_t *)keys_alt,
+                                                 (uint32_t *)vals_alt, n, key_bits, vals_implicit, result_in_alt, scratch, st);
+        return run_passes<uint64_t, 256, 8>((uint64_t *)keys, (uint32_t *)vals, (uint64_t *)keys_alt, (uint32_t *)vals_alt,
+                                            n, key_bits, vals_implicit, result_in_alt, scratch, st);
+    }
+    return IBVH_ERR_INVALID_ARG;
+}
+
+} // namespace rsort
+} // namespace ibvh
+
+extern "C" {
+
+ibvh_status ibvh_sort_scratch_bytes(int32_t key_bytes, int64_t n, size_t *bytes_out) {
+    if (!bytes_out || (key_bytes != 4 && key_bytes != 8) || n < 0) return IBVH_ERR_INVALID_ARG;
+    *bytes_out = ibvh::rsort::scratch_bytes(n);
+    return IBVH_OK;
+}
+
+ibvh_status ibvh_sort_pairs(int32_t key_bytes, int32_t key_bits, int64_t n, void *keys, void *vals, void *keys_alt,
+                            void *vals_alt, int32_t *result_in_alt, void *scratch, size_t scratch_bytes, void *stream) {
+    if (!result_in_alt) return IBVH_ERR_INVALID_ARG;
+    if (n > 0 && (!keys || !vals || !keys_alt || !vals_alt || !scratch)) return IBVH_ERR_INVALID_ARG;
+    return (ibvh_status)ibvh::rsort::sort_pairs(key_bytes, key_bits, n, keys, vals, keys_alt, vals_alt, false,
+                                                result_in_alt, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
+} // extern "C"

@@ -192,9 +192,12 @@ ibvh_status ibvh_aggregate(const ibvh_types *types, const ibvh_tree *tree, int64
  *   _write : pass 2, contact k of work item i lands at counts[i-1] + k (1-based), which makes
  *            the contact list order deterministic and identical to the reference's.
  * counts : one I per work item (cache2 of BVHTraversal on the GPU path, :31-32).
+ * scratch: ibvh_lvt_scratch_bytes(work items) bytes of device memory for the scan's tile sums.
  */
+ibvh_status ibvh_lvt_scratch_bytes(int64_t n_items, size_t *bytes_out); /* scratch of the _count calls */
 ibvh_status ibvh_traverse_lvt_count(const ibvh_bvh *bvh, int64_t start_level, int32_t narrow,
-                                    void *counts, int64_t *total_out, void *stream);
+                                    void *counts, int64_t *total_out, void *scratch,
+                                    size_t scratch_bytes, void *stream);
 ibvh_status ibvh_traverse_lvt_write(const ibvh_bvh *bvh, int64_t start_level, int32_t narrow,
                                     const void *counts, void *contacts, void *stream);
 
@@ -204,7 +207,7 @@ ibvh_status ibvh_traverse_lvt_write(const ibvh_bvh *bvh, int64_t start_level, in
 ibvh_status ibvh_traverse_pair_lvt_count(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2,
                                          int64_t start_level1, int64_t start_level2,
                                          int32_t narrow, void *counts, int64_t *total_out,
-                                         void *stream);
+                                         void *scratch, size_t scratch_bytes, void *stream);
 ibvh_status ibvh_traverse_pair_lvt_write(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2,
                                          int64_t start_level1, int64_t start_level2,
                                          int32_t narrow, const void *counts, void *contacts,
@@ -216,7 +219,7 @@ ibvh_status ibvh_traverse_pair_lvt_write(const ibvh_bvh *bvh1, const ibvh_bvh *b
 ibvh_status ibvh_traverse_rays_lvt_count(const ibvh_bvh *bvh, const void *points,
                                          const void *directions, int64_t num_rays,
                                          int64_t start_level, void *counts, int64_t *total_out,
-                                         void *stream);
+                                         void *scratch, size_t scratch_bytes, void *stream);
 ibvh_status ibvh_traverse_rays_lvt_write(const ibvh_bvh *bvh, const void *points,
                                          const void *directions, int64_t num_rays,
                                          int64_t start_level, const void *counts, void *contacts,
@@ -239,10 +242,13 @@ ibvh_status ibvh_bfs_pair_initial_capacity(const ibvh_bvh *bvh1, const ibvh_bvh 
                                            int64_t *pairs_out);
 ibvh_status ibvh_bfs_rays_initial_capacity(const ibvh_bvh *bvh, int64_t num_rays,
                                            int64_t start_level, int64_t *pairs_out);
+/* Bytes of the `counters` device scratch for a traversal that walks `total_levels` levels
+ * (levels of the BVH; levels1 + levels2 for a pair). */
+ibvh_status ibvh_bfs_counters_bytes(int64_t total_levels, size_t *bytes_out);
 
 /* traverse(bvh, BFSTraversal()) — bfs/traverse_single.jl:1-61.  bvtt1/bvtt2: two queues of
- * `capacity` IndexPair{I} each (cache1/cache2).  counters: DEVICE scratch of at least
- * 4 * (levels + 2) int64.  Synchronises the stream (one read per level, as the reference,
+ * `capacity` IndexPair{I} each (cache1/cache2).  counters: DEVICE scratch of
+ * ibvh_bfs_counters_bytes() bytes (queue tails, one per level).  Synchronises the stream (one read per level, as the reference,
  * bfs/traverse_single_gpu.jl:24).  On IBVH_ERR_CAPACITY grow both queues to
  * result->required_capacity and call again (the reference's resize!, bfs/traverse_single.jl:40). */
 ibvh_status ibvh_traverse_bfs(const ibvh_bvh *bvh, int64_t start_level, int32_t narrow, void *bvtt1,
@@ -276,6 +282,13 @@ ibvh_status ibvh_volumes_from_triangles(int32_t kind, int32_t flt, const void *t
 ibvh_status ibvh_generate_spheres_f32(int64_t n, uint64_t seed, int64_t first_index,
                                       const float origin[3], const float extent[3], float r0,
                                       void *volumes_out, void *stream);
+
+/* Per-launch timing, used by bench.py for the roofline figures: when enabled, every kernel the
+ * library launches is bracketed by HIP events on its launch stream.  _get synchronises on the
+ * record's stop event; names are the kernel instantiations' source spellings. */
+ibvh_status ibvh_profile_enable(int32_t on); /* also clears the records */
+ibvh_status ibvh_profile_count(int64_t *count_out);
+ibvh_status ibvh_profile_get(int64_t i, const char **name_out, float *ms_out);
 
 /* Library / device introspection. */
 const char *ibvh_version(void);

@@ -1,0 +1,430 @@
+"""GPU parity tests: the HIP library (through its C ABI and the Python mirror) against the CPU oracle on
+the same inputs.  Bit-exact for Morton codes, sorted order, node volumes (they are min/max/sqrt of
+correctly-rounded ops, so exact equality is the bar, stricter than the north star's 1 ulp) and LVT
+contact lists INCLUDING order; sorted-set equality for BFS (the reference's own GPU criterion,
+test/gputests.jl:71-78)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+import implicitbvh_amd as ibvh  # noqa: E402
+from implicitbvh_amd import abi, lib  # noqa: E402
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))
+
+NP_F = {abi.F32: np.float32, abi.F64: np.float64}
+TOKENS = {abi.BSPHERE: ibvh.BSphere, abi.BBOX: ibvh.BBox}
+
+
+def cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def random_volumes(rng, n, kind, flt, scale=6.0, size=1.0):
+    f = NP_F[flt]
+    c = (scale * rng.random((n, 3))).astype(f)
+    if kind == abi.BSPHERE:
+        r = (size * (0.1 + 0.9 * rng.random((n, 1)))).astype(f)
+        return np.concatenate([c, r], axis=1)
+    h = (size * (0.1 + 0.9 * rng.random((n, 3)))).astype(f)
+    return np.concatenate([c - h, c + h], axis=1)
+
+
+def make_options(types):
+    return ibvh.BVHOptions(index=abi.INDEX_DTYPES[types.index_type],
+                           morton=ibvh.DefaultMortonAlgorithm(abi.MORTON_DTYPES[types.morton_type]))
+
+
+def build_both(vols, types, built_level=1, indices=None):
+    o = orc.build(vols, types, built_level=built_level, indices=indices)
+    node_type = TOKENS[types.node_kind](torch.float32 if types.node_float == abi.F32 else torch.float64)
+    opts = make_options(types)
+    if indices is None:
+        g = ibvh.BVH(cuda(vols.astype(NP_F[types.leaf_float])), node_type, built_level=built_level, options=opts)
+    else:
+        bv = ibvh.BoundingVolumes.wrap(cuda(vols.astype(NP_F[types.leaf_float])), np.asarray(indices), opts)
+        g = ibvh.BVH(bv, node_type, built_level=built_level, options=opts)
+    return o, g
+
+
+def assert_bvh_equal(o, g, built_level=1):
+    gl = g.leaves.to_numpy()
+    assert gl["morton"].tolist() == o.leaves["morton"].tolist()
+    assert gl["index"].tolist() == o.leaves["index"].tolist()
+    assert gl["volume"].tobytes() == o.leaves["volume"].tobytes()
+    assert g.skips.cpu().numpy().tolist() == o.skips.tolist()
+    assert g.extrema.cpu().numpy().tobytes() == o.extrema.tobytes()
+    gn = g.nodes.cpu().numpy()
+    on = o.nodes.view(gn.dtype).reshape(gn.shape) if len(o.nodes) else gn
+    if len(o.nodes):
+        lo = orc.memory_index(o.tree, 2 ** (min(built_level, o.tree.levels - 1) - 1)) - 1 if o.tree.levels > 1 else 0
+        assert gn[lo:].tobytes() == on[lo:].tobytes()
+
+
+ALL_COMBOS = [
+    (abi.BSPHERE, abi.F32, abi.BBOX, abi.F32), (abi.BSPHERE, abi.F32, abi.BSPHERE, abi.F32),
+    (abi.BBOX, abi.F32, abi.BBOX, abi.F32), (abi.BSPHERE, abi.F64, abi.BBOX, abi.F32),
+    (abi.BSPHERE, abi.F64, abi.BBOX, abi.F64), (abi.BSPHERE, abi.F64, abi.BSPHERE, abi.F64),
+    (abi.BSPHERE, abi.F64, abi.BSPHERE, abi.F32), (abi.BBOX, abi.F64, abi.BBOX, abi.F64),
+    (abi.BBOX, abi.F64, abi.BBOX, abi.F32),
+]
+
+
+# ---------------------------------------------------------------------------------------------
+# build
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("combo", ALL_COMBOS, ids=str)
+@pytest.mark.parametrize("im", [(abi.I32, abi.U32), (abi.I64, abi.U64), (abi.I32, abi.U16)], ids=str)
+def test_build_bit_exact_all_type_combinations(combo, im):
+    rng = np.random.default_rng(hash((combo, im)) % 2**32)
+    types = abi.make_types(*combo, *im)
+    for n in (1, 2, 3, 5, 11, 64, 257, 1000, 4099):
+        vols = random_volumes(rng, n, combo[0], combo[1])
+        o, g = build_both(vols, types)
+        assert_bvh_equal(o, g)
+
+
+def test_morton_codes_equal_for_n_1_to_200():
+    """test/gputests.jl:34-48."""
+    rng = np.random.default_rng(0)
+    types = abi.make_types()
+    for n in range(1, 201):
+        vols = random_volumes(rng, n, abi.BSPHERE, abi.F32, scale=1000.0)
+        o, g = build_both(vols, types)
+        assert g.leaves.to_numpy()["morton"].tolist() == o.leaves["morton"].tolist()
+
+
+@pytest.mark.parametrize("n", [100003, 1 << 20, (1 << 22) + 12345])
+def test_build_bit_exact_large(n):
+    sph = orc.generate_spheres_f32(n, 42, r0=0.5 * (3 * 8 / (4 * np.pi * n)) ** (1 / 3))
+    g_in = ibvh.generate_spheres(n, 42, r0=0.5 * (3 * 8 / (4 * np.pi * n)) ** (1 / 3))
+    assert g_in.cpu().numpy().tobytes() == sph.tobytes()  # device generator == host generator
+    o, g = build_both(sph, abi.make_types())
+    assert_bvh_equal(o, g)
+
+
+def test_build_duplicate_codes_are_stable():
+    """Many equal Morton codes: ties keep input order (stable sort, the oracle's documented choice)."""
+    rng = np.random.default_rng(3)
+    base = random_volumes(rng, 37, abi.BSPHERE, abi.F32)
+    vols = np.repeat(base, 300, axis=0)  # 11100 leaves, 37 distinct centres
+    rng.shuffle(vols)
+    types = abi.make_types(abi.BSPHERE, abi.F32, abi.BBOX, abi.F32, abi.I32, abi.U16)
+    o, g = build_both(vols, types)
+    assert_bvh_equal(o, g)
+    o, g = build_both(vols, abi.make_types())
+    assert_bvh_equal(o, g)
+
+
+def test_build_prewrapped_keeps_user_indices_and_sorts_in_place():
+    k = G["morton_kat"]
+    vols = np.asarray(k["spheres"], np.float32)
+    o, g = build_both(vols, abi.make_types(), indices=k["indices"])
+    assert_bvh_equal(o, g)
+    l1 = g.leaves.to_numpy()[0]
+    assert int(l1["morton"]) == 0x06186186 and int(l1["index"]) == 3  # build.jl:136-152
+    rng = np.random.default_rng(5)
+    vols = random_volumes(rng, 5000, abi.BSPHERE, abi.F32)
+    idx = rng.permutation(5000) + 100
+    o, g = build_both(vols, abi.make_types(), indices=idx)
+    assert_bvh_equal(o, g)
+
+
+def test_build_levels_and_cache_reuse():
+    rng = np.random.default_rng(9)
+    vols = random_volumes(rng, 3000, abi.BSPHERE, abi.F32)
+    types = abi.make_types()
+    for bl in (1, 2, 5, orc.tree_shape(3000).levels - 1, orc.tree_shape(3000).levels):
+        o, g = build_both(vols, types, built_level=bl)
+        assert_bvh_equal(o, g, built_level=bl)
+    g1 = ibvh.BVH(cuda(vols), ibvh.BBox(torch.float32))
+    g2 = ibvh.BVH(cuda(vols), ibvh.BBox(torch.float32), cache=g1)
+    assert g2.nodes.data_ptr() == g1.nodes.data_ptr() and g2.skips.data_ptr() == g1.skips.data_ptr()
+    assert_bvh_equal(orc.build(vols, types), g2)
+    g3 = ibvh.BVH(cuda(vols), ibvh.BBox(torch.float32), built_level=0.5)
+    assert g3.built_level == orc.compute_build_level(orc.tree_shape(3000), 0.5)
+    with pytest.raises(ValueError):
+        ibvh.BVH(cuda(vols), ibvh.BBox(torch.float64), cache=g1)  # runtests.jl:915
+    with pytest.raises(abi.DomainError):
+        ibvh.BVH(torch.zeros((0, 4), device="cuda"))
+    with pytest.raises(ValueError):
+        ibvh.BVH(cuda(vols), built_level=99)
+
+
+def test_fixed_extrema_option():
+    rng = np.random.default_rng(10)
+    vols = random_volumes(rng, 2000, abi.BSPHERE, abi.F32, scale=1.0, size=0.01)
+    mins, maxs = (-0.5, -0.5, -0.5), (1.5, 1.5, 1.5)
+    o = orc.build(vols, abi.make_types(), compute_extrema=False, mins=mins, maxs=maxs)
+    opts = ibvh.BVHOptions(morton=ibvh.DefaultMortonAlgorithm(np.uint32, compute_extrema=False, mins=mins, maxs=maxs))
+    g = ibvh.BVH(cuda(vols), options=opts)
+    assert_bvh_equal(o, g)
+
+
+# ---------------------------------------------------------------------------------------------
+# stand-alone pieces through the raw C ABI
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("key_bytes,key_bits", [(4, 30), (4, 15), (4, 32), (8, 63), (8, 40)])
+@pytest.mark.parametrize("n", [1, 63, 2048, 2049, 100000, (1 << 22) + 77])
+def test_sort_pairs_matches_stable_sort(key_bytes, key_bits, n):
+    rng = np.random.default_rng(n + key_bits)
+    kdt = np.uint32 if key_bytes == 4 else np.uint64
+    # few distinct values in the low digit to stress stability
+    keys = (rng.integers(0, 1 << min(key_bits, 62), n, dtype=np.uint64) & np.uint64(~np.uint64(0xF0))).astype(kdt)
+    vals = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    ek, ev = orc.sort_pairs(keys, vals)
+    k, v = cuda(keys.view(np.int32 if key_bytes == 4 else np.int64)), cuda(vals.view(np.int32))
+    k2, v2 = torch.empty_like(k), torch.empty_like(v)
+    need = C.c_size_t()
+    lib.call("ibvh_sort_scratch_bytes", key_bytes, n, C.byref(need))
+    scratch = torch.empty(need.value, dtype=torch.uint8, device="cuda")
+    in_alt = C.c_int32()
+    lib.call("ibvh_sort_pairs", key_bytes, key_bits, n, k.data_ptr(), v.data_ptr(), k2.data_ptr(), v2.data_ptr(),
+             C.byref(in_alt), scratch.data_ptr(), need.value, None)
+    torch.cuda.synchronize()
+    rk, rv = (k2, v2) if in_alt.value else (k, v)
+    assert rk.cpu().numpy().view(kdt).tolist() == ek.tolist()
+    assert rv.cpu().numpy().view(np.uint32).tolist() == ev.tolist()
+
+
+def test_extrema_and_keys_entry_points():
+    rng = np.random.default_rng(12)
+    for kind, flt in ((abi.BSPHERE, abi.F32), (abi.BBOX, abi.F64)):
+        types = abi.make_types(kind, flt, abi.BBOX, abi.F32, abi.I32, abi.U64)
+        vols = random_volumes(rng, 12345, kind, flt, scale=-50.0)  # all-negative centres: floatmin max-init quirk
+        sv = orc.as_volumes(vols, kind, flt)
+        e = orc.extrema(types, sv, wrapped=False)
+        assert (e[3:] == np.finfo(NP_F[flt]).tiny * 2).all() or (e[3:] > 0).all()
+        dv = cuda(vols)
+        ext = torch.empty(6, dtype=dv.dtype, device="cuda")
+        scratch = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+        lib.call("ibvh_extrema", C.byref(types), dv.data_ptr(), 0, len(vols), 1, ext.data_ptr(), scratch.data_ptr(),
+                 scratch.numel(), None)
+        assert ext.cpu().numpy().tobytes() == e.tobytes()
+        keys = torch.empty(len(vols), dtype=torch.int64, device="cuda")
+        lib.call("ibvh_morton_keys", C.byref(types), dv.data_ptr(), 0, len(vols), ext.data_ptr(), keys.data_ptr(), None)
+        assert keys.cpu().numpy().view(np.uint64).tolist() == orc.morton_keys(types, sv, False, e).tolist()
+
+
+# ---------------------------------------------------------------------------------------------
+# LVT: contact lists identical INCLUDING order
+# ---------------------------------------------------------------------------------------------
+def contacts_np(trav):
+    return trav.contacts.cpu().numpy().astype(np.int64)
+
+
+def oracle_pairs(c):
+    return np.stack([c["a"], c["b"]], axis=1).astype(np.int64) if len(c) else np.zeros((0, 2), np.int64)
+
+
+@pytest.mark.parametrize("combo", ALL_COMBOS, ids=str)
+def test_lvt_self_identical_order_every_start_level(combo):
+    rng = np.random.default_rng(21)
+    types = abi.make_types(*combo)
+    for n in (1, 2, 5, 12, 100, 1001):
+        vols = random_volumes(rng, n, combo[0], combo[1])
+        o, g = build_both(vols, types)
+        for sl in range(1, o.tree.levels + 1):
+            exp = oracle_pairs(orc.traverse_lvt(o, sl)[0])
+            got = ibvh.traverse(g, ibvh.LVTTraversal(), start_level=sl)
+            assert got.num_contacts == len(exp)
+            assert (contacts_np(got) == exp).all(), (n, sl)
+        brute = sorted(map(tuple, orc.brute_force_self(combo[0], combo[1], vols).tolist()))
+        assert sorted(map(tuple, contacts_np(ibvh.traverse(g)).tolist())) == brute
+
+
+def test_readme_examples_on_gpu():
+    e = G["readme_example"]
+    for dt in (np.float32, np.float64):
+        g = ibvh.BVH(cuda(np.asarray(e["spheres"], dt)))
+        t = ibvh.traverse(g)
+        assert contacts_np(t).tolist() == e["contacts"]
+        t = ibvh.traverse(g, cache=t)
+        assert contacts_np(t).tolist() == e["contacts"]
+        assert sorted(contacts_np(ibvh.traverse(g, ibvh.BFSTraversal())).tolist()) == sorted(e["contacts"])
+    p = G["pair_example"]
+    b1, b2 = ibvh.BVH(cuda(np.asarray(p["spheres1"], np.float32))), ibvh.BVH(cuda(np.asarray(p["spheres2"], np.float32)))
+    t = ibvh.traverse(b1, b2, start_level1=p["start_level1"], start_level2=p["start_level2"])
+    assert contacts_np(t).tolist() == p["contacts"]
+    r = G["ray_example"]
+    g = ibvh.BVH(cuda(np.asarray(r["spheres"], np.float32)))
+    pts = torch.tensor(r["points"], dtype=torch.float64).t()
+    dirs = torch.tensor(r["directions"], dtype=torch.float64).t()
+    t = ibvh.traverse_rays(g, pts, dirs)
+    assert contacts_np(t).tolist() == r["contacts"]
+    assert sorted(contacts_np(ibvh.traverse_rays(g, pts, dirs, ibvh.BFSTraversal())).tolist()) == sorted(r["contacts"])
+
+
+def test_lvt_self_large_and_index_types():
+    n = 200000
+    r0 = 0.5 * (3 * 8 / (4 * np.pi * n)) ** (1 / 3)
+    sph = orc.generate_spheres_f32(n, 7, r0=r0)
+    for it, mt in ((abi.I32, abi.U32), (abi.I64, abi.U64)):
+        types = abi.make_types(abi.BSPHERE, abi.F32, abi.BBOX, abi.F32, it, mt)
+        o, g = build_both(sph, types)
+        exp = oracle_pairs(orc.traverse_lvt(o)[0])
+        got = ibvh.traverse(g)
+        assert (contacts_np(got) == exp).all()
+        assert got.cache2.cpu().numpy().tolist() == orc.traverse_lvt(o)[1].tolist()  # inclusive prefix counts
+        assert len(exp) > n  # ~1.8 contacts per leaf
+
+
+def test_lvt_pair_identical_order():
+    rng = np.random.default_rng(22)
+    types = abi.make_types()
+    for n1, n2 in ((1, 1), (1, 50), (50, 1), (22, 190), (190, 22), (300, 300), (1000, 777)):
+        a, b = random_volumes(rng, n1, abi.BSPHERE, abi.F32), random_volumes(rng, n2, abi.BSPHERE, abi.F32)
+        o1, g1 = build_both(a, types)
+        o2, g2 = build_both(b, types)
+        for sl1 in sorted({1, o1.tree.levels // 2 + 1, o1.tree.levels}):
+            for sl2 in sorted({1, o2.tree.levels // 2 + 1, o2.tree.levels}):
+                exp = oracle_pairs(orc.traverse_pair_lvt(o1, o2, sl1, sl2)[0])
+                got = ibvh.traverse(g1, g2, start_level1=sl1, start_level2=sl2)
+                assert (contacts_np(got) == exp).all(), (n1, n2, sl1, sl2)
+        brute = sorted(map(tuple, orc.brute_force_pair(abi.BSPHERE, abi.F32, a, b).tolist()))
+        assert sorted(map(tuple, contacts_np(ibvh.traverse(g1, g2)).tolist())) == brute
+
+
+def test_lvt_rays_identical_order_incl_zero_direction_components():
+    rng = np.random.default_rng(23)
+    for combo in ((abi.BSPHERE, abi.F32, abi.BBOX, abi.F32), (abi.BBOX, abi.F64, abi.BBOX, abi.F64),
+                  (abi.BSPHERE, abi.F64, abi.BSPHERE, abi.F64)):
+        types = abi.make_types(*combo)
+        f = NP_F[combo[1]]
+        for n in (1, 7, 500):
+            vols = random_volumes(rng, n, combo[0], combo[1])
+            o, g = build_both(vols, types)
+            p = (8 * rng.random((257, 3)) - 1).astype(f)
+            d = (rng.random((257, 3)) - 0.5).astype(f)
+            d[::7, 0] = 0
+            d[::11, 1] = 0
+            d[::13] = 0
+            for sl in sorted({1, o.tree.levels}):
+                exp = oracle_pairs(orc.traverse_rays_lvt(o, p, d, sl)[0])
+                got = ibvh.traverse_rays(g, cuda(p).t(), cuda(d).t(), start_level=sl)
+                assert (contacts_np(got) == exp).all()
+                bfs = ibvh.traverse_rays(g, cuda(p).t(), cuda(d).t(), ibvh.BFSTraversal(), start_level=sl)
+                eb, res = orc.traverse_rays_bfs(o, p, d, sl)
+                assert sorted(map(tuple, contacts_np(bfs).tolist())) == sorted(map(tuple, oracle_pairs(eb).tolist()))
+                assert bfs.num_checks == res.num_checks
+    with pytest.raises(ValueError):
+        ibvh.traverse_rays(g, torch.zeros((2, 5)), torch.zeros((2, 5)))
+    assert ibvh.traverse_rays(g, torch.zeros((3, 0)), torch.zeros((3, 0))).num_contacts == 0
+
+
+def test_narrow_menu_bfs_equals_lvt():
+    """runtests.jl:1230-1270 / gputests.jl:251-288 with narrow = (a, b) -> a.morton < b.morton."""
+    rng = np.random.default_rng(24)
+    types = abi.make_types()
+    for n in (2, 43, 190, 2000):
+        vols = random_volumes(rng, n, abi.BSPHERE, abi.F32)
+        o, g = build_both(vols, types)
+        exp = oracle_pairs(orc.traverse_lvt(o, narrow=abi.NARROW_MORTON_LT)[0])
+        lvt = ibvh.traverse(g, narrow=ibvh.NARROW_MORTON_LT)
+        bfs = ibvh.traverse(g, ibvh.BFSTraversal(), narrow=ibvh.NARROW_MORTON_LT)
+        assert (contacts_np(lvt) == exp).all()
+        assert sorted(map(tuple, contacts_np(bfs).tolist())) == sorted(map(tuple, exp.tolist()))
+    with pytest.raises(NotImplementedError):
+        ibvh.traverse(g, narrow=lambda a, b: True)
+
+
+# ---------------------------------------------------------------------------------------------
+# BFS: sorted-set equality + identical num_checks
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("combo", ALL_COMBOS[:5], ids=str)
+def test_bfs_self_every_start_level(combo):
+    rng = np.random.default_rng(31)
+    types = abi.make_types(*combo)
+    for n in (1, 2, 5, 12, 100, 1001):
+        vols = random_volumes(rng, n, combo[0], combo[1])
+        o, g = build_both(vols, types)
+        for sl in range(1, o.tree.levels + 1):
+            eb, res = orc.traverse_bfs(o, sl)
+            got = ibvh.traverse(g, ibvh.BFSTraversal(), start_level=sl)
+            assert sorted(map(tuple, contacts_np(got).tolist())) == sorted(map(tuple, oracle_pairs(eb).tolist())), (n, sl)
+            assert got.num_checks == res.num_checks and got.num_contacts == res.num_contacts
+
+
+def test_bfs_pair_six_phases():
+    rng = np.random.default_rng(32)
+    types = abi.make_types()
+    for n1, n2 in ((1, 1), (1, 50), (50, 1), (22, 190), (190, 22), (64, 64), (3, 500), (500, 3)):
+        a, b = random_volumes(rng, n1, abi.BSPHERE, abi.F32), random_volumes(rng, n2, abi.BSPHERE, abi.F32)
+        o1, g1 = build_both(a, types)
+        o2, g2 = build_both(b, types)
+        for sl1 in range(1, o1.tree.levels + 1):
+            for sl2 in range(1, o2.tree.levels + 1):
+                eb, res = orc.traverse_pair_bfs(o1, o2, sl1, sl2)
+                got = ibvh.traverse(g1, g2, ibvh.BFSTraversal(), start_level1=sl1, start_level2=sl2)
+                assert sorted(map(tuple, contacts_np(got).tolist())) == sorted(map(tuple, oracle_pairs(eb).tolist()))
+                assert got.num_checks == res.num_checks
+
+
+def test_bfs_large_with_capacity_growth_and_cache():
+    n = 100000
+    sph = orc.generate_spheres_f32(n, 8, r0=0.5 * (3 * 8 / (4 * np.pi * n)) ** (1 / 3))
+    o, g = build_both(sph, abi.make_types())
+    eb, res = orc.traverse_bfs(o)
+    got = ibvh.traverse(g, ibvh.BFSTraversal())
+    assert got.num_checks == res.num_checks
+    assert sorted(map(tuple, contacts_np(got).tolist())) == sorted(map(tuple, oracle_pairs(eb).tolist()))
+    again = ibvh.traverse(g, ibvh.BFSTraversal(), cache=got)
+    assert again.num_contacts == got.num_contacts
+    lvt = ibvh.traverse(g)
+    assert sorted(map(tuple, contacts_np(lvt).tolist())) == sorted(map(tuple, contacts_np(got).tolist()))
+
+
+# ---------------------------------------------------------------------------------------------
+# input preparation
+# ---------------------------------------------------------------------------------------------
+def test_triangle_volumes_bit_exact():
+    rng = np.random.default_rng(41)
+    for flt, tdt in ((abi.F32, torch.float32), (abi.F64, torch.float64)):
+        tris = (6 * rng.random((5000, 1, 3)) + rng.random((5000, 3, 3))).astype(NP_F[flt])
+        tris[::50, 2] = tris[::50, 1] + (tris[::50, 1] - tris[::50, 0])  # collinear -> degenerate branch
+        for kind, tok in ((abi.BSPHERE, ibvh.BSphere), (abi.BBOX, ibvh.BBox)):
+            exp = orc.volumes_from_triangles(kind, flt, tris.reshape(-1, 9))
+            got = ibvh.bounding_volumes_from_triangles(cuda(tris), tok(tdt))
+            assert got.cpu().numpy().tobytes() == exp.tobytes()
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size properties (BASELINE.json config 2: 1e6 leaves)
+# ---------------------------------------------------------------------------------------------
+def test_config2_one_million_properties():
+    n = 1_000_000
+    r0 = 0.5 * (3 * 8 / (4 * np.pi * n)) ** (1 / 3)
+    vols = ibvh.generate_spheres(n, 42, r0=r0)
+    g = ibvh.BVH(vols)
+    leaves = g.leaves.to_numpy()
+    m = leaves["morton"].astype(np.int64)
+    assert (np.diff(m) >= 0).all()  # sortedness
+    idx = leaves["index"].astype(np.int64)
+    assert np.array_equal(np.sort(idx), np.arange(1, n + 1))  # a permutation of 1..n
+    ties = m[1:] == m[:-1]
+    assert (idx[1:][ties] > idx[:-1][ties]).all()  # stability: ties in input order
+    host = vols.cpu().numpy()
+    assert leaves["volume"].tobytes() == host[idx - 1].tobytes()  # records follow their index
+    t = ibvh.traverse(g)
+    c = contacts_np(t)
+    assert (c[:, 0] < c[:, 1]).all() and len(np.unique(c, axis=0)) == len(c)
+    # every reported pair really touches (exact reference predicate in float32)
+    a, b = host[c[:, 0] - 1], host[c[:, 1] - 1]
+    dx = a[:, :3] - b[:, :3]
+    d2 = (dx[:, 0] * dx[:, 0] + dx[:, 1] * dx[:, 1]) + dx[:, 2] * dx[:, 2]
+    rr = a[:, 3] + b[:, 3]
+    assert (d2 <= rr * rr).all()
+    # and the whole list equals the oracle's, order included (the oracle needs a few seconds at 1e6)
+    o = orc.build(host, abi.make_types())
+    exp = oracle_pairs(orc.traverse_lvt(o)[0])
+    assert (c == exp).all()
+    idem = ibvh.traverse(g, cache=t)
+    assert (contacts_np(idem) == c).all()  # idempotence with cache reuse
