@@ -439,10 +439,14 @@ def _cache_tensor(cache_t, need_rows, cols, dtype, what):
     return cache_t
 
 
-def _lvt_scratch(cache, n_items):
+LVT_CACHE_SLOTS = 8  # contacts per work item kept from the counting pass (include/ibvh.h)
+
+
+def _lvt_scratch(cache, types, n_items, slots=None):
     torch = _torch()
     need = C.c_size_t()
-    lib.call("ibvh_lvt_scratch_bytes", int(n_items), C.byref(need))
+    lib.call("ibvh_lvt_scratch_bytes", C.byref(types), int(n_items), LVT_CACHE_SLOTS if slots is None else slots,
+             C.byref(need))
     s = cache._scratch if cache is not None else None
     if s is None or s.numel() < need.value:
         s = torch.empty(need.value, dtype=torch.uint8, device="cuda")
@@ -459,14 +463,15 @@ def _traverse_lvt_single(bvh, start_level, narrow, cache):
                             torch.empty(0, dtype=idt, device="cuda"))
     n = len(bvh.leaves)
     counts = _cache_tensor(cache.cache2 if cache else None, n, 0, idt, "cache2")
-    scratch = _lvt_scratch(cache, n)
+    scratch = _lvt_scratch(cache, bvh.types, n)
     s = bvh.struct()
     total = C.c_int64()
     lib.call("ibvh_traverse_lvt_count", C.byref(s), start_level, narrow, _ptr(counts), C.byref(total), _ptr(scratch),
              scratch.numel(), _stream())
     contacts = _cache_tensor(cache.cache1 if cache else None, total.value, 2, idt, "cache1")
     if total.value:
-        lib.call("ibvh_traverse_lvt_write", C.byref(s), start_level, narrow, _ptr(counts), _ptr(contacts), _stream())
+        lib.call("ibvh_traverse_lvt_write", C.byref(s), start_level, narrow, _ptr(counts), _ptr(contacts), _ptr(scratch),
+                 scratch.numel(), _stream())
     return BVHTraversal(start_level, 0, 0, total.value, contacts, counts, scratch)
 
 
@@ -480,7 +485,7 @@ def _traverse_lvt_pair(bvh1, bvh2, sl1, sl2, narrow, cache):
             raise ValueError("bvh.built_level <= start_level <= bvh.tree.levels <= 32 must hold")
     n = max(len(bvh1.leaves), len(bvh2.leaves))
     counts = _cache_tensor(cache.cache2 if cache else None, n, 0, idt, "cache2")
-    scratch = _lvt_scratch(cache, n)
+    scratch = _lvt_scratch(cache, bvh1.types, n)
     s1, s2 = bvh1.struct(), bvh2.struct()
     total = C.c_int64()
     lib.call("ibvh_traverse_pair_lvt_count", C.byref(s1), C.byref(s2), sl1, sl2, narrow, _ptr(counts), C.byref(total),
@@ -488,7 +493,7 @@ def _traverse_lvt_pair(bvh1, bvh2, sl1, sl2, narrow, cache):
     contacts = _cache_tensor(cache.cache1 if cache else None, total.value, 2, idt, "cache1")
     if total.value:
         lib.call("ibvh_traverse_pair_lvt_write", C.byref(s1), C.byref(s2), sl1, sl2, narrow, _ptr(counts), _ptr(contacts),
-                 _stream())
+                 _ptr(scratch), scratch.numel(), _stream())
     return BVHTraversal(sl1, sl2, 0, total.value, contacts, counts, scratch)
 
 
@@ -601,14 +606,14 @@ def traverse_rays(bvh, points, directions, alg=None, start_level=1, narrow=None,
     s = bvh.struct()
     if lvt:
         counts = _cache_tensor(cache.cache2 if cache else None, nr, 0, idt, "cache2")
-        scratch = _lvt_scratch(cache, nr)
+        scratch = _lvt_scratch(cache, bvh.types, nr, slots=0)
         total = C.c_int64()
         lib.call("ibvh_traverse_rays_lvt_count", C.byref(s), _ptr(p), _ptr(d), nr, start_level, _ptr(counts),
                  C.byref(total), _ptr(scratch), scratch.numel(), _stream())
         contacts = _cache_tensor(cache.cache1 if cache else None, total.value, 2, idt, "cache1")
         if total.value:
             lib.call("ibvh_traverse_rays_lvt_write", C.byref(s), _ptr(p), _ptr(d), nr, start_level, _ptr(counts),
-                     _ptr(contacts), _stream())
+                     _ptr(contacts), _ptr(scratch), scratch.numel(), _stream())
         return BVHTraversal(start_level, 0, 0, total.value, contacts, counts, scratch)
     cap = C.c_int64()
     lib.call("ibvh_bfs_rays_initial_capacity", C.byref(s), nr, start_level, C.byref(cap))

@@ -52,6 +52,50 @@ template <class V> IBVH_D V load_vol(const void *p) {
     __builtin_memcpy(&v, __builtin_assume_aligned(p, 8), sizeof(V));
     return v;
 }
+// Same, for a WAVE-UNIFORM address: reading through the constant address space makes the compiler
+// emit scalar loads (s_load_dwordx*), so the words land in SGPRs, cost no vector-memory issue slots
+// and one request serves the whole wave.  Only for buffers no thread of the kernel writes.
+typedef const __attribute__((address_space(4))) uint64_t *uniform_words;
+template <class V> IBVH_D V load_vol_uniform(const void *p) {
+    static_assert(sizeof(V) % 8 == 0, "volumes are multiples of 8 bytes");
+    V v;
+    uniform_words s = (uniform_words)(uintptr_t)p;
+    uint64_t *d = (uint64_t *)&v;
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(V) / 8); ++k) d[k] = s[k];
+    return v;
+}
+template <class I> IBVH_D I load_index_uniform(const char *rec, const LeafLayout &lay) {
+    typedef const __attribute__((address_space(4))) I *ip;
+    return *(ip)(uintptr_t)(rec + lay.index_off);
+}
+IBVH_D uint64_t load_morton_uniform(const char *rec, const LeafLayout &lay) {
+    const uintptr_t p = (uintptr_t)(rec + lay.morton_off);
+    if (lay.morton_bytes == 4) return *(const __attribute__((address_space(4))) uint32_t *)p;
+    if (lay.morton_bytes == 8) return *(const __attribute__((address_space(4))) uint64_t *)p;
+    return *(const __attribute__((address_space(4))) uint16_t *)p;
+}
+// Broadcast a whole record from lane `src` (wave-uniform) to every lane through SGPRs
+// (v_readlane_b32 per 32-bit word): no LDS, no memory.
+template <class V> IBVH_D V broadcast_from_lane(const V &v, int src) {
+    static_assert(sizeof(V) % 4 == 0, "records are multiples of 4 bytes");
+    V out;
+    const int *s = (const int *)&v;
+    int *d = (int *)&out;
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(V) / 4); ++k) d[k] = __builtin_amdgcn_readlane(s[k], src);
+    return out;
+}
+// Pull a whole record out of lane `src` (per-lane index): ds_bpermute_b32 per 32-bit word.
+template <class V> IBVH_D V shuffle_from(const V &v, int src) {
+    static_assert(sizeof(V) % 4 == 0, "records are multiples of 4 bytes");
+    V out;
+    const int *s = (const int *)&v;
+    int *d = (int *)&out;
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(V) / 4); ++k) d[k] = __shfl(s[k], src, 64);
+    return out;
+}
 template <class V> IBVH_D void store_vol(void *p, const V &v) {
     __builtin_memcpy(__builtin_assume_aligned(p, 8), &v, sizeof(V));
 }

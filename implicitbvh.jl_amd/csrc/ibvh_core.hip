@@ -26,15 +26,15 @@ static hipEvent_t take() {
         pool.pop_back();
         return e;
     }
-    hipEventCreate(&e);
+    (void)hipEventCreate(&e);
     return e;
 }
 void begin(const char *name, hipStream_t st) {
     Rec r{name, take(), take()};
-    hipEventRecord(r.a, st);
+    (void)hipEventRecord(r.a, st);
     recs.push_back(r);
 }
-void end(hipStream_t st) { hipEventRecord(recs.back().b, st); }
+void end(hipStream_t st) { (void)hipEventRecord(recs.back().b, st); }
 static void reset() {
     for (auto &r : recs) {
         pool.push_back(r.a);

@@ -149,6 +149,255 @@ __global__ __launch_bounds__(256) void lvt_kernel(Args<L, N, I> a) {
     if constexpr (!WRITE) a.counts[item] = (I)cnt;
 }
 
+// ------------------------------------------------------------------------------------------
+// Wave-cooperative walk for leaf queries (SELF / PAIR).
+//
+// The 64 work items of a wave are 64 consecutive Morton-sorted leaves, i.e. one compact cluster, so
+// their individual walks visit almost the same nodes.  Instead of 64 divergent walks (every load
+// instruction touching 64 different cache lines: the L1/TA-bound regime measured in round 1), the
+// wave walks the UNION of the 64 walks once, in the same left-to-right pre-order:
+//   * the current node, its level and the stack of pending right siblings are wave-uniform (SGPRs);
+//     the stack is a 32-bit mask (bit l = "the right sibling on level l of the current path is
+//     pending"), possible because the tree is implicit;
+//   * each step loads BOTH children of the current node from one uniform address (48 contiguous
+//     bytes, one cache line request for the whole wave) and every lane tests them against its own
+//     query; wave64 ballots decide where the wave goes; a lane remembers only whether it is active
+//     on the current path and, per level, whether it hit the pending sibling (one more 32-bit mask).
+// A lane reaches a leaf iff it hit every ancestor from its start-level root down — exactly the
+// reference's per-leaf walk (traverse_single.jl:157-203) — and pre-order visits leaves in
+// increasing position, so each lane emits its contacts in the reference's order.
+//
+// Contact cache: the counting pass also stores the first K contacts of every work item in a
+// slot-major scratch array (slot k of item i at [k * n_items + i]); the writing pass then copies
+// them to their final offsets and only waves with an item of more than K contacts walk again.
+// ------------------------------------------------------------------------------------------
+template <class T> struct IndexBox { // lets broadcast_from_lane move a scalar
+    T v;
+};
+template <class I> struct PairCache {
+    IndexPair<I> *slots; // K * n_items pairs, slot-major; nullptr when K == 0
+    int32_t K;
+};
+
+// Depth (in levels) of the subtrees that are brute-forced instead of walked, BBox nodes only.
+// BBox parents are the exact min/max of their children (merge.jl:30-40), so box tests are
+// monotone along a root-to-leaf path: a query that touches the box of a leaf's PARENT (level
+// levels-1) touches every ancestor's box.  The reference's walk therefore reports leaf j for query
+// q iff q touches parent(j)'s box and the leaf test passes (plus the position rule j > i of the
+// self walk) — the interior levels of a subtree only save work, they never change the result.
+// Below `cut_level` the wave tests the subtree's leaf-parents one after the other (independent,
+// contiguous, scalar loads: no dependent-latency chain), in position order, so the emission order
+// stays the reference's.  BSphere nodes (rounded merges, not nested) always take the full walk.
+constexpr int BRUTE_DEPTH = 7; // 2^7 = 128 leaves, 64 leaf-parents (one per lane) per brute-forced subtree
+
+template <class L, class N, class I, int MODE, bool WRITE>
+__global__ __launch_bounds__(256) void lvt_joint_kernel(Args<L, N, I> a, PairCache<I> cache, int cut_level) {
+    const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = item < a.n_items;
+
+    L q_leaf = {};
+    N q_node = {};
+    I q_index = 0;
+    uint64_t q_morton = 0;
+    if (valid) {
+        const char *rec = a.items + item * a.items_lay.stride;
+        q_leaf = load_vol<L>(rec);
+        q_node = convert_to(q_leaf, (N *)nullptr); // traverse_single.jl:154-155
+        q_index = load_index<I>(rec, a.items_lay);
+        if (a.narrow == IBVH_NARROW_MORTON_LT) q_morton = load_morton(rec, a.items_lay);
+    }
+
+    int64_t w = 0;
+    int64_t cnt = 0;
+    bool lane_on = valid; // takes part in the walk at all
+    if constexpr (WRITE) {
+        w = (valid && item > 0) ? (int64_t)a.counts[item - 1] : 0;
+        const int64_t mine = valid ? (int64_t)a.counts[item] - w : 0;
+        const bool over = mine > (int64_t)cache.K;
+        if (valid && !over) {
+            for (int64_t k = 0; k < mine; ++k) a.contacts[w + k] = cache.slots[k * a.n_items + item];
+        }
+        if (__ballot(over) == 0) return; // whole wave served from the cache
+        lane_on = over;
+    }
+
+    const int64_t levels = a.tree.levels, vl = a.tree.virtual_leaves;
+    const uint32_t leaf_first = 1u << (levels - 1);
+    const uint64_t self_next = (uint64_t)item + leaf_first + 1; // SELF: implicit index of this leaf, plus one
+
+    const int lane = threadIdx.x & 63;
+    // emit one contact of this lane with the leaf (lidx, lm); narrow already applied
+    auto emit = [&](I lidx) {
+        IndexPair<I> c2;
+        if constexpr (MODE == MODE_SELF) c2 = q_index > lidx ? IndexPair<I>{lidx, q_index} : IndexPair<I>{q_index, lidx};
+        else c2 = a.flip ? IndexPair<I>{lidx, q_index} : IndexPair<I>{q_index, lidx};
+        if constexpr (WRITE) {
+            a.contacts[w++] = c2;
+        } else {
+            if (cnt < (int64_t)cache.K) cache.slots[cnt * a.n_items + item] = c2;
+            ++cnt;
+        }
+    };
+    auto narrow_ok = [&](uint64_t lm, I lidx) {
+        return (MODE == MODE_PAIR && a.flip) ? narrow_eval(a.narrow, lm, lidx, q_morton, q_index)
+                                             : narrow_eval(a.narrow, q_morton, q_index, lm, lidx);
+    };
+
+    // test one leaf (wave-uniform position, scalar loads) for the lanes in `hit`, emit in place
+    auto leaf_step = [&](uint32_t c, bool hit) {
+        if constexpr (MODE == MODE_SELF) hit = hit && !((uint64_t)c + 1 <= self_next); // leaves at or left of self
+        const char *rec = a.leaves + (int64_t)(c - leaf_first) * a.lay.stride;            // uniform address
+        const L leaf = load_vol_uniform<L>(rec);
+        hit = hit && iscontact(q_leaf, leaf);
+        if (__ballot(hit) == 0) return;
+        const I lidx = load_index_uniform<I>(rec, a.lay);
+        if (a.narrow != IBVH_NARROW_NONE) {
+            const uint64_t lm = a.narrow == IBVH_NARROW_MORTON_LT ? load_morton_uniform(rec, a.lay) : 0;
+            hit = hit && narrow_ok(lm, lidx);
+        }
+        if (hit) emit(lidx);
+    };
+
+    // Brute-force the subtree rooted at (c, cl) for the lanes in `on` (they all touch its box).
+    // Roles are transposed for the box tests: lane k HOLDS leaf-parent k of the subtree (its box and
+    // its two leaf records, fetched by coalesced vector loads: one memory latency per subtree), and
+    // the wave loops over the few ACTIVE queries only: a query's box is broadcast from its lane
+    // (v_readlane), all <= 64 parents are tested at once and the ballot is the query's candidate mask.
+    // Each query lane then walks its own candidates in position order, pulling the two leaves of a
+    // candidate parent out of the holding lane with ds_bpermute.
+    const int lp = (int)levels - 1; // level of the leaf-parents
+    const int64_t lp_real = levels >= 2 ? level_num_real(levels, vl, lp) : 0;
+    const N *lp_nodes = levels >= 2 ? a.nodes + (level_start(levels, vl, lp) - 1) : nullptr;
+    auto brute = [&](uint32_t c, int cl, bool on) {
+        const int64_t first = (int64_t)(c - (1u << (cl - 1))) << (lp - cl);
+        int64_t last = first + (int64_t(1) << (lp - cl));
+        last = last < lp_real ? last : lp_real;
+        const int np = (int)(last - first); // <= 64
+        const int64_t leaf0 = 2 * first;    // 0-based position of the subtree's first leaf
+        const int64_t nl = a.tree.real_leaves - leaf0; // leaves from there on (may exceed 2*np)
+        N mybox = {};
+        L leafA = {}, leafB = {};
+        I idxA = 0, idxB = 0;
+        uint64_t morA = 0, morB = 0;
+        if (lane < np) {
+            mybox = load_vol<N>(lp_nodes + first + lane);
+            const char *rec = a.leaves + (leaf0 + 2 * lane) * a.lay.stride;
+            leafA = load_vol<L>(rec);
+            idxA = load_index<I>(rec, a.lay);
+            if (a.narrow == IBVH_NARROW_MORTON_LT) morA = load_morton(rec, a.lay);
+            if (2 * lane + 1 < nl) {
+                rec += a.lay.stride;
+                leafB = load_vol<L>(rec);
+                idxB = load_index<I>(rec, a.lay);
+                if (a.narrow == IBVH_NARROW_MORTON_LT) morB = load_morton(rec, a.lay);
+            }
+        }
+        // stage A: candidate parents of every active query
+        uint64_t mine = 0;
+        for (uint64_t todo = __ballot(on); todo != 0; todo &= todo - 1) {
+            const int q = __builtin_ctzll(todo);
+            const N qbox = broadcast_from_lane(q_node, q);
+            const uint64_t m = __ballot(lane < np && iscontact(qbox, mybox));
+            if (lane == q) mine = m;
+        }
+        // stage B: every query lane tests the leaves of its own candidates, left to right
+        while (__ballot(mine != 0) != 0) {
+            const bool has = mine != 0;
+            const int p = has ? __builtin_ctzll(mine) : 0;
+            mine &= mine - 1;
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const int64_t pos = leaf0 + 2 * p + side;
+                bool hit = has && (2 * p + side < nl);
+                if constexpr (MODE == MODE_SELF) hit = hit && pos > item; // only partners to the right
+                const L leaf = shuffle_from(side ? leafB : leafA, p);
+                const I lidx = __shfl(side ? idxB : idxA, p, 64);
+                hit = hit && iscontact(q_leaf, leaf);
+                if (a.narrow != IBVH_NARROW_NONE) {
+                    const uint64_t lm = (uint64_t)__shfl((long long)(side ? morB : morA), p, 64);
+                    hit = hit && narrow_ok(lm, lidx);
+                }
+                if (hit) emit(lidx);
+            }
+        }
+    };
+
+    // pseudo-parents: the nodes one level above the start level are entered unconditionally, which
+    // tests every start-level root exactly once (the reference's loop over inode_start:inode_end);
+    // start_level == 1 uses the pseudo node 0, whose only real child is the root 1.
+    const int64_t plevel = a.start_level - 1;
+    const int64_t roots = level_num_real(levels, vl, a.start_level);
+    const uint32_t pfirst = plevel >= 1 ? (1u << (plevel - 1)) : 0u;
+    const uint32_t pcount = (uint32_t)((roots + 1) / 2);
+
+    for (uint32_t pi = 0; pi < pcount; ++pi) {
+        uint32_t inode = pfirst + pi; // wave-uniform
+        int level = (int)plevel;      // wave-uniform
+        uint32_t pend = 0;            // wave-uniform: pending right siblings by level
+        uint32_t pendhit = 0;         // per lane: did this lane hit the pending sibling on level l
+        bool act = lane_on;           // per lane: active on the current path
+        while (true) {
+            const int cl = level + 1;
+            const uint32_t c0 = 2u * inode, c1 = c0 + 1u;
+            const bool real0 = c0 != 0u;
+            const bool real1 = (int64_t)(c1 - (1u << (cl - 1))) < level_num_real(levels, vl, cl);
+            if (cl == levels) {
+                // both children are leaves: test and emit, left then right
+                if (real0 && __ballot(act) != 0) leaf_step(c0, act);
+                if (real1 && __ballot(act) != 0) leaf_step(c1, act);
+            } else {
+                const int64_t sk = level_skips(levels, vl, cl);
+                const N *np = a.nodes + ((int64_t)c0 - sk - 1); // uniform address; c1 follows contiguously
+                bool h0 = false, h1 = false;
+                if (real0) {
+                    h0 = act;
+                    if constexpr (MODE == MODE_SELF) h0 = h0 && !(((uint64_t)c0 + 1) <= (self_next >> (levels - cl)));
+                    const N n0 = load_vol_uniform<N>(np);
+                    h0 = h0 && iscontact(q_node, n0);
+                }
+                if (real1) {
+                    h1 = act;
+                    if constexpr (MODE == MODE_SELF) h1 = h1 && !(((uint64_t)c1 + 1) <= (self_next >> (levels - cl)));
+                    const N n1 = load_vol_uniform<N>(np + 1);
+                    h1 = h1 && iscontact(q_node, n1);
+                }
+                const bool go0 = __ballot(h0) != 0;
+                const bool go1 = __ballot(h1) != 0;
+                if (cl == cut_level) {
+                    if (go0) brute(c0, cl, h0);
+                    if (go1) brute(c1, cl, h1);
+                } else {
+                    if (go0) {
+                        if (go1) {
+                            pend |= 1u << cl;
+                            pendhit = h1 ? (pendhit | (1u << cl)) : (pendhit & ~(1u << cl));
+                        }
+                        inode = c0;
+                        level = cl;
+                        act = h0;
+                        continue;
+                    }
+                    if (go1) {
+                        inode = c1;
+                        level = cl;
+                        act = h1;
+                        continue;
+                    }
+                }
+            }
+            // pop the deepest pending right sibling
+            if (pend == 0) break;
+            const int pl = 31 - __builtin_clz(pend);
+            pend &= ~(1u << pl);
+            inode = (inode >> (level - pl)) | 1u;
+            level = pl;
+            act = (pendhit >> pl) & 1u;
+        }
+    }
+    if constexpr (!WRITE)
+        if (valid) a.counts[item] = (I)cnt;
+}
+
 // ---- inclusive scan of the per-item counts (AK.accumulate!, traverse_single.jl:57) ---------------
 constexpr int SCAN_TPB = 256, SCAN_IPT = 16, SCAN_TILE = SCAN_TPB * SCAN_IPT;
 
@@ -237,7 +486,20 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_apply_kernel(I *c, int64_t n, c
     }
 }
 
-inline size_t scan_scratch_bytes(int64_t n) { return (size_t)(ceil_div(n > 0 ? n : 1, SCAN_TILE) + 8) * 8; }
+// scratch layout of the *_count / *_write calls:
+//   [0, 64)            int64 header: [0] total contacts, [1] contact-cache slots K in use
+//   [64, scan_bytes)   scan tile sums
+//   [scan_bytes, ...)  contact cache: K * n_items IndexPair{I}, slot-major
+inline size_t scan_scratch_bytes(int64_t n) {
+    return (size_t)align_up((ceil_div(n > 0 ? n : 1, SCAN_TILE) + 8) * 8, 256);
+}
+constexpr int MAX_CACHE_SLOTS = 16;
+inline int cache_slots_for(size_t scratch_bytes, int64_t n_items, int64_t pair_bytes) {
+    size_t sb = scan_scratch_bytes(n_items);
+    if (scratch_bytes <= sb || n_items <= 0) return 0;
+    int64_t k = (int64_t)((scratch_bytes - sb) / ((size_t)n_items * (size_t)pair_bytes));
+    return (int)(k > MAX_CACHE_SLOTS ? MAX_CACHE_SLOTS : k);
+}
 
 // inclusive scan in place + blocking read of the total (the reference's @allowscalar, :60)
 template <class I> int scan_counts(I *counts, int64_t n, int64_t *total_out, void *scratch, hipStream_t st) {
@@ -268,11 +530,23 @@ inline bool same_types(const ibvh_types &x, const ibvh_types &y) {
 }
 
 template <class L, class N, class I, int MODE>
-int launch(const Args<L, N, I> &a, bool write, hipStream_t st) {
+int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStream_t st) {
     if (a.n_items == 0) return IBVH_OK;
     unsigned blocks = (unsigned)ceil_div(a.n_items, 256);
-    if (write) IBVH_LAUNCH((lvt_kernel<L, N, I, MODE, true>), dim3(blocks), dim3(256), 0, st, a);
-    else IBVH_LAUNCH((lvt_kernel<L, N, I, MODE, false>), dim3(blocks), dim3(256), 0, st, a);
+    if constexpr (MODE == MODE_RAYS) {
+        // rays of one wave are not spatially coherent: each lane walks on its own
+        if (write) IBVH_LAUNCH((lvt_kernel<L, N, I, MODE, true>), dim3(blocks), dim3(256), 0, st, a);
+        else IBVH_LAUNCH((lvt_kernel<L, N, I, MODE, false>), dim3(blocks), dim3(256), 0, st, a);
+    } else {
+        // brute-forced subtrees: BBox nodes only (nested boxes), rooted no higher than the start level
+        int cut = 0;
+        if (N::kind == IBVH_BBOX && a.start_level < a.tree.levels) {
+            int64_t c = a.tree.levels - BRUTE_DEPTH;
+            cut = (int)(c > a.start_level ? c : a.start_level);
+        }
+        if (write) IBVH_LAUNCH((lvt_joint_kernel<L, N, I, MODE, true>), dim3(blocks), dim3(256), 0, st, a, cache, cut);
+        else IBVH_LAUNCH((lvt_joint_kernel<L, N, I, MODE, false>), dim3(blocks), dim3(256), 0, st, a, cache, cut);
+    }
     IBVH_LAUNCH_CHECK();
     return IBVH_OK;
 }
@@ -288,7 +562,8 @@ int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const voi
     if (!layout_of(walk->types, lay, &wl)) return IBVH_ERR_UNSUPPORTED;
     dl = wl;
     if (drv && !layout_of(drv->types, lay, &dl)) return IBVH_ERR_UNSUPPORTED;
-    if (!write && scratch_bytes < scan_scratch_bytes(n_items)) return IBVH_ERR_SCRATCH;
+    if (!scratch || scratch_bytes < scan_scratch_bytes(n_items)) return IBVH_ERR_SCRATCH;
+    const int K = MODE == MODE_RAYS ? 0 : cache_slots_for(scratch_bytes, n_items, lay.pair_bytes);
     return dispatch_leaf_node(walk->types, [&](auto lt, auto nt) -> int {
         using L = typename decltype(lt)::type;
         using N = typename decltype(nt)::type;
@@ -312,7 +587,8 @@ int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const voi
                 a.flip = flip;
                 a.counts = (I *)counts;
                 a.contacts = (IndexPair<I> *)contacts;
-                if (int e = launch<L, N, I, MODE>(a, write, st)) return e;
+                PairCache<I> cache{K ? (IndexPair<I> *)((char *)scratch + scan_scratch_bytes(n_items)) : nullptr, K};
+                if (int e = launch<L, N, I, MODE>(a, cache, write, st)) return e;
                 if (!write) return scan_counts<I>((I *)counts, n_items, total_out, scratch, st);
                 return (int)IBVH_OK;
             });
@@ -328,9 +604,15 @@ using namespace ibvh::lvt;
 
 extern "C" {
 
-ibvh_status ibvh_lvt_scratch_bytes(int64_t n_items, size_t *bytes_out) {
-    if (!bytes_out || n_items < 0) return IBVH_ERR_INVALID_ARG;
-    *bytes_out = scan_scratch_bytes(n_items);
+// Scratch for the *_count / *_write pair of calls on n_items work items.  cache_slots = contacts
+// per work item kept from the counting pass (0 = none: the writing pass walks again; 8 is a good
+// default at ~2 contacts per leaf).  The SAME buffer and size must be passed to both calls.
+ibvh_status ibvh_lvt_scratch_bytes(const ibvh_types *types, int64_t n_items, int32_t cache_slots, size_t *bytes_out) {
+    if (!types || !bytes_out || n_items < 0 || cache_slots < 0) return IBVH_ERR_INVALID_ARG;
+    ibvh_layout lay;
+    if (!layout_of(*types, lay)) return IBVH_ERR_UNSUPPORTED;
+    if (cache_slots > MAX_CACHE_SLOTS) cache_slots = MAX_CACHE_SLOTS;
+    *bytes_out = scan_scratch_bytes(n_items) + (size_t)cache_slots * (size_t)n_items * (size_t)lay.pair_bytes;
     return IBVH_OK;
 }
 
@@ -346,14 +628,14 @@ ibvh_status ibvh_traverse_lvt_count(const ibvh_bvh *bvh, int64_t start_level, in
                                        total_out, nullptr, scratch, scratch_bytes, (hipStream_t)stream);
 }
 ibvh_status ibvh_traverse_lvt_write(const ibvh_bvh *bvh, int64_t start_level, int32_t narrow, const void *counts,
-                                    void *contacts, void *stream) {
+                                    void *contacts, void *scratch, size_t scratch_bytes, void *stream) {
     if (!bvh) return IBVH_ERR_INVALID_ARG;
     if (int e = check_levels(*bvh, start_level)) return (ibvh_status)e;
     if (bvh->tree.real_nodes <= 1) return IBVH_OK;
     if (!counts || !contacts) return IBVH_ERR_INVALID_ARG;
     int64_t dummy;
     return (ibvh_status)run<MODE_SELF>(bvh, bvh, nullptr, nullptr, bvh->tree.real_leaves, start_level, narrow, 0,
-                                       (void *)counts, &dummy, contacts, nullptr, 0, (hipStream_t)stream);
+                                       (void *)counts, &dummy, contacts, scratch, scratch_bytes, (hipStream_t)stream);
 }
 
 // traverse(bvh1, bvh2, LVTTraversal()) — lvt/traverse_pair.jl:1-116
@@ -380,10 +662,11 @@ ibvh_status ibvh_traverse_pair_lvt_count(const ibvh_bvh *bvh1, const ibvh_bvh *b
     return pair_common(bvh1, bvh2, sl1, sl2, narrow, counts, total_out, nullptr, scratch, scratch_bytes, stream);
 }
 ibvh_status ibvh_traverse_pair_lvt_write(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, int64_t sl1, int64_t sl2,
-                                         int32_t narrow, const void *counts, void *contacts, void *stream) {
+                                         int32_t narrow, const void *counts, void *contacts, void *scratch,
+                                         size_t scratch_bytes, void *stream) {
     if (!contacts) return IBVH_ERR_INVALID_ARG;
     int64_t dummy;
-    return pair_common(bvh1, bvh2, sl1, sl2, narrow, (void *)counts, &dummy, contacts, nullptr, 0, stream);
+    return pair_common(bvh1, bvh2, sl1, sl2, narrow, (void *)counts, &dummy, contacts, scratch, scratch_bytes, stream);
 }
 
 // traverse_rays(bvh, points, directions, LVTTraversal()) — raytrace/leaf_vs_tree/leaf_vs_tree.jl:1-90
@@ -407,10 +690,11 @@ ibvh_status ibvh_traverse_rays_lvt_count(const ibvh_bvh *bvh, const void *points
     return rays_common(bvh, points, dirs, num_rays, sl, counts, total_out, nullptr, scratch, scratch_bytes, stream);
 }
 ibvh_status ibvh_traverse_rays_lvt_write(const ibvh_bvh *bvh, const void *points, const void *dirs, int64_t num_rays,
-                                         int64_t sl, const void *counts, void *contacts, void *stream) {
+                                         int64_t sl, const void *counts, void *contacts, void *scratch,
+                                         size_t scratch_bytes, void *stream) {
     if (num_rays > 0 && !contacts) return IBVH_ERR_INVALID_ARG;
     int64_t dummy;
-    return rays_common(bvh, points, dirs, num_rays, sl, (void *)counts, &dummy, contacts, nullptr, 0, stream);
+    return rays_common(bvh, points, dirs, num_rays, sl, (void *)counts, &dummy, contacts, scratch, scratch_bytes, stream);
 }
 
 } // extern "C"

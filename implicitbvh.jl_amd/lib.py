@@ -31,13 +31,13 @@ SIGNATURES = {
     "ibvh_sort_pairs": [_i32, _i32, _i64, _vp, _vp, _vp, _vp, _P(_i32), _vp, _sz, _vp],
     "ibvh_sort_scratch_bytes": [_i32, _i64, _P(_sz)],
     "ibvh_aggregate": [_P(abi.Types), _P(abi.Tree), _i64, _vp, _vp, _vp],
-    "ibvh_lvt_scratch_bytes": [_i64, _P(_sz)],
+    "ibvh_lvt_scratch_bytes": [_P(abi.Types), _i64, _i32, _P(_sz)],
     "ibvh_traverse_lvt_count": [_P(abi.Bvh), _i64, _i32, _vp, _P(_i64), _vp, _sz, _vp],
-    "ibvh_traverse_lvt_write": [_P(abi.Bvh), _i64, _i32, _vp, _vp, _vp],
+    "ibvh_traverse_lvt_write": [_P(abi.Bvh), _i64, _i32, _vp, _vp, _vp, _sz, _vp],
     "ibvh_traverse_pair_lvt_count": [_P(abi.Bvh), _P(abi.Bvh), _i64, _i64, _i32, _vp, _P(_i64), _vp, _sz, _vp],
-    "ibvh_traverse_pair_lvt_write": [_P(abi.Bvh), _P(abi.Bvh), _i64, _i64, _i32, _vp, _vp, _vp],
+    "ibvh_traverse_pair_lvt_write": [_P(abi.Bvh), _P(abi.Bvh), _i64, _i64, _i32, _vp, _vp, _vp, _sz, _vp],
     "ibvh_traverse_rays_lvt_count": [_P(abi.Bvh), _vp, _vp, _i64, _i64, _vp, _P(_i64), _vp, _sz, _vp],
-    "ibvh_traverse_rays_lvt_write": [_P(abi.Bvh), _vp, _vp, _i64, _i64, _vp, _vp, _vp],
+    "ibvh_traverse_rays_lvt_write": [_P(abi.Bvh), _vp, _vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp],
     "ibvh_bfs_initial_capacity": [_P(abi.Bvh), _i64, _P(_i64)],
     "ibvh_bfs_pair_initial_capacity": [_P(abi.Bvh), _P(abi.Bvh), _i64, _i64, _P(_i64)],
     "ibvh_bfs_rays_initial_capacity": [_P(abi.Bvh), _i64, _i64, _P(_i64)],

@@ -192,14 +192,19 @@ ibvh_status ibvh_aggregate(const ibvh_types *types, const ibvh_tree *tree, int64
  *   _write : pass 2, contact k of work item i lands at counts[i-1] + k (1-based), which makes
  *            the contact list order deterministic and identical to the reference's.
  * counts : one I per work item (cache2 of BVHTraversal on the GPU path, :31-32).
- * scratch: ibvh_lvt_scratch_bytes(work items) bytes of device memory for the scan's tile sums.
+ * scratch: ibvh_lvt_scratch_bytes() bytes of device memory: scan tile sums + the contact cache.
  */
-ibvh_status ibvh_lvt_scratch_bytes(int64_t n_items, size_t *bytes_out); /* scratch of the _count calls */
+/* cache_slots: contacts per work item the counting pass keeps for the writing pass (0 = none: the
+ * writing pass walks the tree again; 8 suits ~2 contacts per leaf).  Pass the SAME scratch buffer
+ * and size to the _count call and its _write call. */
+ibvh_status ibvh_lvt_scratch_bytes(const ibvh_types *types, int64_t n_items, int32_t cache_slots,
+                                   size_t *bytes_out);
 ibvh_status ibvh_traverse_lvt_count(const ibvh_bvh *bvh, int64_t start_level, int32_t narrow,
                                     void *counts, int64_t *total_out, void *scratch,
                                     size_t scratch_bytes, void *stream);
 ibvh_status ibvh_traverse_lvt_write(const ibvh_bvh *bvh, int64_t start_level, int32_t narrow,
-                                    const void *counts, void *contacts, void *stream);
+                                    const void *counts, void *contacts, void *scratch,
+                                    size_t scratch_bytes, void *stream);
 
 /* traverse(bvh1, bvh2, LVTTraversal()) — lvt/traverse_pair.jl:1-244.  The BVH with more leaves
  * supplies the work items (:15-36); contacts are always (index in bvh1, index in bvh2).
@@ -211,7 +216,7 @@ ibvh_status ibvh_traverse_pair_lvt_count(const ibvh_bvh *bvh1, const ibvh_bvh *b
 ibvh_status ibvh_traverse_pair_lvt_write(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2,
                                          int64_t start_level1, int64_t start_level2,
                                          int32_t narrow, const void *counts, void *contacts,
-                                         void *stream);
+                                         void *scratch, size_t scratch_bytes, void *stream);
 
 /* traverse_rays(bvh, points, directions, LVTTraversal()) — raytrace/leaf_vs_tree/
  * leaf_vs_tree.jl:1-228.  points/directions: (3, num_rays) column-major arrays of the leaf
@@ -223,7 +228,7 @@ ibvh_status ibvh_traverse_rays_lvt_count(const ibvh_bvh *bvh, const void *points
 ibvh_status ibvh_traverse_rays_lvt_write(const ibvh_bvh *bvh, const void *points,
                                          const void *directions, int64_t num_rays,
                                          int64_t start_level, const void *counts, void *contacts,
-                                         void *stream);
+                                         void *scratch, size_t scratch_bytes, void *stream);
 
 /* ----------------------------------------------------------------------------------- */
 /* breadth-first traversal (BFSTraversal): level-synchronous pair queues                 */

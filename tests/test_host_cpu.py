@@ -97,7 +97,7 @@ def test_scratch_queries():
     assert 10**6 * (4 + 4 + 4 + 4) <= need.value <= 10**6 * 64
     with pytest.raises(abi.DomainError):
         lib.call("ibvh_build_scratch_bytes", C.byref(t), 0, C.byref(need))
-    lib.call("ibvh_lvt_scratch_bytes", 10**6, C.byref(need))
+    lib.call("ibvh_lvt_scratch_bytes", C.byref(t), 10**6, 8, C.byref(need))
     assert need.value >= 8
     lib.call("ibvh_bfs_counters_bytes", 21, C.byref(need))
     assert need.value >= 8 * 22
