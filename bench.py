@@ -41,8 +41,8 @@ def algorithmic_bytes(kernel, n, contacts):
         "aggregate_kernel": 16.0 + 24.0 + 24.0,    # leaves' volumes + every node read once + written once
         "lvt_kernel_count": 24.0 + 24.0 + 4.0,     # leaves + nodes once + counts
         "lvt_kernel_write": 24.0 + 24.0 + 4.0 + 8.0 * c,  # + prefix read, contacts written
-        "lvt_joint_kernel_count": 24.0 + 24.0 + 4.0 + 8.0 * c,  # leaves + nodes once, counts, contact cache written
-        "lvt_joint_kernel_write": 8.0 + 16.0 * c,   # prefix read (2 x 4) + cached contacts read and written
+        "lvt_joint_kernel_count": 24.0 + 24.0 + 4.0 + 8.0 * c, "lvt_cluster_kernel_count": 24.0 + 24.0 + 4.0 + 8.0 * c,  # leaves + nodes once, counts, contact cache written
+        "lvt_joint_kernel_write": 8.0 + 16.0 * c, "lvt_cluster_kernel_write": 8.0 + 16.0 * c,   # prefix read (2 x 4) + cached contacts read and written
         "scan_reduce_kernel": 4.0, "scan_apply_kernel": 8.0,
     }
     return table.get(kernel, 0.0) * n
@@ -51,7 +51,7 @@ def algorithmic_bytes(kernel, n, contacts):
 def kernel_key(name):
     """'(lvt_kernel<L, N, I, MODE, true>)' -> 'lvt_kernel_write'."""
     base = name.strip("() ").split("<")[0].split("::")[-1].strip()
-    if base in ("lvt_kernel", "lvt_joint_kernel"):
+    if base in ("lvt_kernel", "lvt_joint_kernel", "lvt_cluster_kernel"):
         return base + ("_write" if "true>" in name.replace(" ", "") else "_count")
     return base
 

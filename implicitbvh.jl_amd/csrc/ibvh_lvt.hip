@@ -13,6 +13,8 @@
 // successor ends the walk: virtual nodes form a suffix of every level, so everything after it in
 // pre-order is virtual too.  Visitation order, hence contact order, is identical to the stack
 // version; no scratch memory, no private-array spills.
+#include <cstdlib>
+
 #include "ibvh_common.hpp"
 
 namespace ibvh {
@@ -150,28 +152,45 @@ __global__ __launch_bounds__(256) void lvt_kernel(Args<L, N, I> a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Wave-cooperative walk for leaf queries (SELF / PAIR).
+// Wave-cooperative walks for leaf queries (SELF / PAIR).
 //
-// The 64 work items of a wave are 64 consecutive Morton-sorted leaves, i.e. one compact cluster, so
-// their individual walks visit almost the same nodes.  Instead of 64 divergent walks (every load
-// instruction touching 64 different cache lines: the L1/TA-bound regime measured in round 1), the
-// wave walks the UNION of the 64 walks once, in the same left-to-right pre-order:
-//   * the current node, its level and the stack of pending right siblings are wave-uniform (SGPRs);
-//     the stack is a 32-bit mask (bit l = "the right sibling on level l of the current path is
-//     pending"), possible because the tree is implicit;
-//   * each step loads BOTH children of the current node from one uniform address (48 contiguous
-//     bytes, one cache line request for the whole wave) and every lane tests them against its own
-//     query; wave64 ballots decide where the wave goes; a lane remembers only whether it is active
-//     on the current path and, per level, whether it hit the pending sibling (one more 32-bit mask).
-// A lane reaches a leaf iff it hit every ancestor from its start-level root down — exactly the
-// reference's per-leaf walk (traverse_single.jl:157-203) — and pre-order visits leaves in
-// increasing position, so each lane emits its contacts in the reference's order.
+// The 64 work items of a wave are 64 consecutive Morton-sorted leaves — one compact cluster — so
+// their individual walks visit almost the same nodes.  64 divergent walks make every load
+// instruction touch 64 different cache lines (the L1/TA-bound regime measured first in round 1:
+// 0.86 ms per pass at 1e6 leaves).  Instead the wave works on the UNION of its 64 walks:
+//
+// (1) lvt_joint_kernel — exact, any node type.  One wave-uniform pre-order walk: the current node,
+//     its level and the stack of pending right siblings (a 32-bit mask, possible because the tree is
+//     implicit) live in SGPRs; each step scalar-loads BOTH children from one address and every lane
+//     tests them against its own query; ballots steer the wave; a lane keeps one bit "active on the
+//     current path" and one 32-bit mask "hit the pending sibling of level l".  A lane reaches a leaf
+//     iff it hit every ancestor from its start-level root down, exactly the reference's per-leaf walk
+//     (traverse_single.jl:157-203), and pre-order visits leaves in increasing position, so each lane
+//     emits its contacts in the reference's order.
+//
+// (2) lvt_cluster_kernel — BBox nodes.  BBox parents are the exact min/max of their children
+//     (merge.jl:30-40), so box tests are monotone along a root-to-leaf path: a query that touches the
+//     box of a leaf's PARENT (level levels-1) touches every ancestor's box.  The reference's walk
+//     therefore reports leaf j for query q iff q touches parent(j)'s box and the leaf test passes
+//     (plus, for the self walk, j to the right of q): the interior levels only prune, they never
+//     change the result, and ANY conservative enumeration of candidates followed by those two exact
+//     tests gives the reference's list, provided each lane emits in increasing leaf position.  So:
+//       a. frontier descent, lanes = NODES: level by level the wave tests up to 64 frontier nodes at
+//          once against the union box of its queries and compacts the children of the hits (ballot +
+//          popcount) into the next frontier in LDS — one step per level instead of one per node;
+//       b. at the cut level (subtrees of 128 leaves) each surviving subtree is brute-forced: lane k
+//          HOLDS leaf-parent k (box + both leaf records, coalesced loads, one memory latency per
+//          subtree); the wave loops over the ACTIVE queries only, broadcasting a query box
+//          (v_readlane) and testing all 64 parents at once: the ballot is that query's candidate mask;
+//       c. every query lane walks its own candidates left to right, pulling the two leaves of a
+//          candidate parent out of the holding lane with ds_bpermute, runs the exact leaf test, emits.
+//     BSphere nodes (rounded merges, not nested) and start_level == levels take kernel (1).
 //
 // Contact cache: the counting pass also stores the first K contacts of every work item in a
-// slot-major scratch array (slot k of item i at [k * n_items + i]); the writing pass then copies
-// them to their final offsets and only waves with an item of more than K contacts walk again.
+// slot-major scratch array (slot k of item i at [k * n_items + i]); the writing pass copies them to
+// their final offsets and only waves with an item of more than K contacts walk again.
 // ------------------------------------------------------------------------------------------
-template <class T> struct IndexBox { // lets broadcast_from_lane move a scalar
+template <class T> struct Boxed { // lets the lane-movement helpers carry a scalar
     T v;
 };
 template <class I> struct PairCache {
@@ -179,55 +198,54 @@ template <class I> struct PairCache {
     int32_t K;
 };
 
-// Depth (in levels) of the subtrees that are brute-forced instead of walked, BBox nodes only.
-// BBox parents are the exact min/max of their children (merge.jl:30-40), so box tests are
-// monotone along a root-to-leaf path: a query that touches the box of a leaf's PARENT (level
-// levels-1) touches every ancestor's box.  The reference's walk therefore reports leaf j for query
-// q iff q touches parent(j)'s box and the leaf test passes (plus the position rule j > i of the
-// self walk) — the interior levels of a subtree only save work, they never change the result.
-// Below `cut_level` the wave tests the subtree's leaf-parents one after the other (independent,
-// contiguous, scalar loads: no dependent-latency chain), in position order, so the emission order
-// stays the reference's.  BSphere nodes (rounded merges, not nested) always take the full walk.
-constexpr int BRUTE_DEPTH = 7; // 2^7 = 128 leaves, 64 leaf-parents (one per lane) per brute-forced subtree
+constexpr int BRUTE_DEPTH = 7;   // 2^7 = 128 leaves, 64 leaf-parents (one per lane) per brute-forced subtree
+constexpr int FRONTIER_CAP = 256; // frontier entries per wave and level (LDS); overflow -> exact walk
 
-template <class L, class N, class I, int MODE, bool WRITE>
-__global__ __launch_bounds__(256) void lvt_joint_kernel(Args<L, N, I> a, PairCache<I> cache, int cut_level) {
-    const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool valid = item < a.n_items;
+// Per-lane query state + the emission rules shared by both kernels.
+template <class L, class N, class I, int MODE, bool WRITE> struct Query {
+    const Args<L, N, I> &a;
+    const PairCache<I> &cache;
+    int64_t item;
+    bool valid, lane_on;
+    L q_leaf;
+    N q_node;
+    I q_index;
+    uint64_t q_morton;
+    int64_t w, cnt;
 
-    L q_leaf = {};
-    N q_node = {};
-    I q_index = 0;
-    uint64_t q_morton = 0;
-    if (valid) {
-        const char *rec = a.items + item * a.items_lay.stride;
-        q_leaf = load_vol<L>(rec);
-        q_node = convert_to(q_leaf, (N *)nullptr); // traverse_single.jl:154-155
-        q_index = load_index<I>(rec, a.items_lay);
-        if (a.narrow == IBVH_NARROW_MORTON_LT) q_morton = load_morton(rec, a.items_lay);
+    IBVH_D Query(const Args<L, N, I> &a_, const PairCache<I> &c_) : a(a_), cache(c_) {
+        item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        valid = item < a.n_items;
+        q_leaf = {};
+        q_node = {};
+        q_index = 0;
+        q_morton = 0;
+        w = 0;
+        cnt = 0;
+        if (valid) {
+            const char *rec = a.items + item * a.items_lay.stride;
+            q_leaf = load_vol<L>(rec);
+            q_node = convert_to(q_leaf, (N *)nullptr); // traverse_single.jl:154-155
+            q_index = load_index<I>(rec, a.items_lay);
+            if (a.narrow == IBVH_NARROW_MORTON_LT) q_morton = load_morton(rec, a.items_lay);
+        }
+        lane_on = valid;
     }
-
-    int64_t w = 0;
-    int64_t cnt = 0;
-    bool lane_on = valid; // takes part in the walk at all
-    if constexpr (WRITE) {
+    // WRITE pass: serve the item from the contact cache; returns false when the whole wave is done
+    IBVH_D bool begin_write() {
         w = (valid && item > 0) ? (int64_t)a.counts[item - 1] : 0;
         const int64_t mine = valid ? (int64_t)a.counts[item] - w : 0;
         const bool over = mine > (int64_t)cache.K;
-        if (valid && !over) {
+        if (valid && !over)
             for (int64_t k = 0; k < mine; ++k) a.contacts[w + k] = cache.slots[k * a.n_items + item];
-        }
-        if (__ballot(over) == 0) return; // whole wave served from the cache
         lane_on = over;
+        return __ballot(over) != 0;
     }
-
-    const int64_t levels = a.tree.levels, vl = a.tree.virtual_leaves;
-    const uint32_t leaf_first = 1u << (levels - 1);
-    const uint64_t self_next = (uint64_t)item + leaf_first + 1; // SELF: implicit index of this leaf, plus one
-
-    const int lane = threadIdx.x & 63;
-    // emit one contact of this lane with the leaf (lidx, lm); narrow already applied
-    auto emit = [&](I lidx) {
+    IBVH_D bool narrow_ok(uint64_t lm, I lidx) const {
+        return (MODE == MODE_PAIR && a.flip) ? narrow_eval(a.narrow, lm, lidx, q_morton, q_index)
+                                             : narrow_eval(a.narrow, q_morton, q_index, lm, lidx);
+    }
+    IBVH_D void emit(I lidx) {
         IndexPair<I> c2;
         if constexpr (MODE == MODE_SELF) c2 = q_index > lidx ? IndexPair<I>{lidx, q_index} : IndexPair<I>{q_index, lidx};
         else c2 = a.flip ? IndexPair<I>{lidx, q_index} : IndexPair<I>{q_index, lidx};
@@ -237,89 +255,33 @@ __global__ __launch_bounds__(256) void lvt_joint_kernel(Args<L, N, I> a, PairCac
             if (cnt < (int64_t)cache.K) cache.slots[cnt * a.n_items + item] = c2;
             ++cnt;
         }
-    };
-    auto narrow_ok = [&](uint64_t lm, I lidx) {
-        return (MODE == MODE_PAIR && a.flip) ? narrow_eval(a.narrow, lm, lidx, q_morton, q_index)
-                                             : narrow_eval(a.narrow, q_morton, q_index, lm, lidx);
-    };
+    }
+    IBVH_D void finish() {
+        if constexpr (!WRITE)
+            if (valid) a.counts[item] = (I)cnt;
+    }
+};
+
+// ---- (1) exact wave-uniform pre-order walk ------------------------------------------------------
+template <class L, class N, class I, int MODE, bool WRITE>
+IBVH_D void joint_walk(Query<L, N, I, MODE, WRITE> &q, const Args<L, N, I> &a) {
+    const int64_t levels = a.tree.levels, vl = a.tree.virtual_leaves;
+    const uint32_t leaf_first = 1u << (levels - 1);
+    const uint64_t self_next = (uint64_t)q.item + leaf_first + 1; // SELF: implicit index of this leaf, plus one
 
     // test one leaf (wave-uniform position, scalar loads) for the lanes in `hit`, emit in place
     auto leaf_step = [&](uint32_t c, bool hit) {
         if constexpr (MODE == MODE_SELF) hit = hit && !((uint64_t)c + 1 <= self_next); // leaves at or left of self
         const char *rec = a.leaves + (int64_t)(c - leaf_first) * a.lay.stride;            // uniform address
         const L leaf = load_vol_uniform<L>(rec);
-        hit = hit && iscontact(q_leaf, leaf);
+        hit = hit && iscontact(q.q_leaf, leaf);
         if (__ballot(hit) == 0) return;
         const I lidx = load_index_uniform<I>(rec, a.lay);
         if (a.narrow != IBVH_NARROW_NONE) {
             const uint64_t lm = a.narrow == IBVH_NARROW_MORTON_LT ? load_morton_uniform(rec, a.lay) : 0;
-            hit = hit && narrow_ok(lm, lidx);
+            hit = hit && q.narrow_ok(lm, lidx);
         }
-        if (hit) emit(lidx);
-    };
-
-    // Brute-force the subtree rooted at (c, cl) for the lanes in `on` (they all touch its box).
-    // Roles are transposed for the box tests: lane k HOLDS leaf-parent k of the subtree (its box and
-    // its two leaf records, fetched by coalesced vector loads: one memory latency per subtree), and
-    // the wave loops over the few ACTIVE queries only: a query's box is broadcast from its lane
-    // (v_readlane), all <= 64 parents are tested at once and the ballot is the query's candidate mask.
-    // Each query lane then walks its own candidates in position order, pulling the two leaves of a
-    // candidate parent out of the holding lane with ds_bpermute.
-    const int lp = (int)levels - 1; // level of the leaf-parents
-    const int64_t lp_real = levels >= 2 ? level_num_real(levels, vl, lp) : 0;
-    const N *lp_nodes = levels >= 2 ? a.nodes + (level_start(levels, vl, lp) - 1) : nullptr;
-    auto brute = [&](uint32_t c, int cl, bool on) {
-        const int64_t first = (int64_t)(c - (1u << (cl - 1))) << (lp - cl);
-        int64_t last = first + (int64_t(1) << (lp - cl));
-        last = last < lp_real ? last : lp_real;
-        const int np = (int)(last - first); // <= 64
-        const int64_t leaf0 = 2 * first;    // 0-based position of the subtree's first leaf
-        const int64_t nl = a.tree.real_leaves - leaf0; // leaves from there on (may exceed 2*np)
-        N mybox = {};
-        L leafA = {}, leafB = {};
-        I idxA = 0, idxB = 0;
-        uint64_t morA = 0, morB = 0;
-        if (lane < np) {
-            mybox = load_vol<N>(lp_nodes + first + lane);
-            const char *rec = a.leaves + (leaf0 + 2 * lane) * a.lay.stride;
-            leafA = load_vol<L>(rec);
-            idxA = load_index<I>(rec, a.lay);
-            if (a.narrow == IBVH_NARROW_MORTON_LT) morA = load_morton(rec, a.lay);
-            if (2 * lane + 1 < nl) {
-                rec += a.lay.stride;
-                leafB = load_vol<L>(rec);
-                idxB = load_index<I>(rec, a.lay);
-                if (a.narrow == IBVH_NARROW_MORTON_LT) morB = load_morton(rec, a.lay);
-            }
-        }
-        // stage A: candidate parents of every active query
-        uint64_t mine = 0;
-        for (uint64_t todo = __ballot(on); todo != 0; todo &= todo - 1) {
-            const int q = __builtin_ctzll(todo);
-            const N qbox = broadcast_from_lane(q_node, q);
-            const uint64_t m = __ballot(lane < np && iscontact(qbox, mybox));
-            if (lane == q) mine = m;
-        }
-        // stage B: every query lane tests the leaves of its own candidates, left to right
-        while (__ballot(mine != 0) != 0) {
-            const bool has = mine != 0;
-            const int p = has ? __builtin_ctzll(mine) : 0;
-            mine &= mine - 1;
-#pragma unroll
-            for (int side = 0; side < 2; ++side) {
-                const int64_t pos = leaf0 + 2 * p + side;
-                bool hit = has && (2 * p + side < nl);
-                if constexpr (MODE == MODE_SELF) hit = hit && pos > item; // only partners to the right
-                const L leaf = shuffle_from(side ? leafB : leafA, p);
-                const I lidx = __shfl(side ? idxB : idxA, p, 64);
-                hit = hit && iscontact(q_leaf, leaf);
-                if (a.narrow != IBVH_NARROW_NONE) {
-                    const uint64_t lm = (uint64_t)__shfl((long long)(side ? morB : morA), p, 64);
-                    hit = hit && narrow_ok(lm, lidx);
-                }
-                if (hit) emit(lidx);
-            }
-        }
+        if (hit) q.emit(lidx);
     };
 
     // pseudo-parents: the nodes one level above the start level are entered unconditionally, which
@@ -335,7 +297,7 @@ __global__ __launch_bounds__(256) void lvt_joint_kernel(Args<L, N, I> a, PairCac
         int level = (int)plevel;      // wave-uniform
         uint32_t pend = 0;            // wave-uniform: pending right siblings by level
         uint32_t pendhit = 0;         // per lane: did this lane hit the pending sibling on level l
-        bool act = lane_on;           // per lane: active on the current path
+        bool act = q.lane_on;         // per lane: active on the current path
         while (true) {
             const int cl = level + 1;
             const uint32_t c0 = 2u * inode, c1 = c0 + 1u;
@@ -353,36 +315,31 @@ __global__ __launch_bounds__(256) void lvt_joint_kernel(Args<L, N, I> a, PairCac
                     h0 = act;
                     if constexpr (MODE == MODE_SELF) h0 = h0 && !(((uint64_t)c0 + 1) <= (self_next >> (levels - cl)));
                     const N n0 = load_vol_uniform<N>(np);
-                    h0 = h0 && iscontact(q_node, n0);
+                    h0 = h0 && iscontact(q.q_node, n0);
                 }
                 if (real1) {
                     h1 = act;
                     if constexpr (MODE == MODE_SELF) h1 = h1 && !(((uint64_t)c1 + 1) <= (self_next >> (levels - cl)));
                     const N n1 = load_vol_uniform<N>(np + 1);
-                    h1 = h1 && iscontact(q_node, n1);
+                    h1 = h1 && iscontact(q.q_node, n1);
                 }
                 const bool go0 = __ballot(h0) != 0;
                 const bool go1 = __ballot(h1) != 0;
-                if (cl == cut_level) {
-                    if (go0) brute(c0, cl, h0);
-                    if (go1) brute(c1, cl, h1);
-                } else {
-                    if (go0) {
-                        if (go1) {
-                            pend |= 1u << cl;
-                            pendhit = h1 ? (pendhit | (1u << cl)) : (pendhit & ~(1u << cl));
-                        }
-                        inode = c0;
-                        level = cl;
-                        act = h0;
-                        continue;
-                    }
+                if (go0) {
                     if (go1) {
-                        inode = c1;
-                        level = cl;
-                        act = h1;
-                        continue;
+                        pend |= 1u << cl;
+                        pendhit = h1 ? (pendhit | (1u << cl)) : (pendhit & ~(1u << cl));
                     }
+                    inode = c0;
+                    level = cl;
+                    act = h0;
+                    continue;
+                }
+                if (go1) {
+                    inode = c1;
+                    level = cl;
+                    act = h1;
+                    continue;
                 }
             }
             // pop the deepest pending right sibling
@@ -394,8 +351,203 @@ __global__ __launch_bounds__(256) void lvt_joint_kernel(Args<L, N, I> a, PairCac
             act = (pendhit >> pl) & 1u;
         }
     }
-    if constexpr (!WRITE)
-        if (valid) a.counts[item] = (I)cnt;
+}
+
+template <class L, class N, class I, int MODE, bool WRITE>
+__global__ __launch_bounds__(256) void lvt_joint_kernel(Args<L, N, I> a, PairCache<I> cache) {
+    Query<L, N, I, MODE, WRITE> q(a, cache);
+    if constexpr (WRITE)
+        if (!q.begin_write()) return;
+    joint_walk(q, a);
+    q.finish();
+}
+
+// ---- (2) BBox nodes: frontier descent + brute-forced subtrees -----------------------------------
+template <class T> IBVH_D T wave_min_all(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        T t = __shfl_xor(v, o, 64);
+        v = v < t ? v : t;
+    }
+    return v;
+}
+template <class T> IBVH_D T wave_max_all(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        T t = __shfl_xor(v, o, 64);
+        v = v > t ? v : t;
+    }
+    return v;
+}
+
+template <class L, class N, class I, int MODE, bool WRITE>
+__global__ __launch_bounds__(256) void lvt_cluster_kernel(Args<L, N, I> a, PairCache<I> cache, int cut_level) {
+    using TN = typename N::elt;
+    __shared__ uint32_t s_frontier[4][2][FRONTIER_CAP];
+    Query<L, N, I, MODE, WRITE> q(a, cache);
+    if constexpr (WRITE)
+        if (!q.begin_write()) return;
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t levels = a.tree.levels, vl = a.tree.virtual_leaves;
+    const uint32_t leaf_first = 1u << (levels - 1);
+    const uint64_t self_next = (uint64_t)q.item + leaf_first + 1;
+    // first work item of the wave: nodes wholly at or left of it are useless to every lane (SELF)
+    const uint64_t wave_next = ((uint64_t)q.item - (uint64_t)lane) + leaf_first + 1;
+
+    // union box of the wave's active queries (inactive lanes contribute the empty box)
+    N ubox;
+    {
+        const TN big = float_max<TN>();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            ubox.lo[k] = wave_min_all(q.lane_on ? q.q_node.lo[k] : big);
+            ubox.up[k] = wave_max_all(q.lane_on ? q.q_node.up[k] : -big);
+        }
+    }
+
+    const int lp = (int)levels - 1; // level of the leaf-parents
+    const int64_t lp_real = level_num_real(levels, vl, lp);
+    const N *lp_nodes = a.nodes + (level_start(levels, vl, lp) - 1);
+
+    // b + c: brute-force the subtree rooted at node c (level cut_level) whose box is `cbox`
+    auto brute = [&](uint32_t c, const N &cbox) {
+        bool on = q.lane_on && iscontact(q.q_node, cbox);
+        if constexpr (MODE == MODE_SELF) on = on && !(((uint64_t)c + 1) <= (self_next >> (levels - cut_level)));
+        const uint64_t on_mask = __ballot(on);
+        if (on_mask == 0) return;
+        const int64_t first = (int64_t)(c - (1u << (cut_level - 1))) << (lp - cut_level);
+        int64_t last = first + (int64_t(1) << (lp - cut_level));
+        last = last < lp_real ? last : lp_real;
+        const int np = (int)(last - first); // <= 64
+        const int64_t leaf0 = 2 * first;    // 0-based position of the subtree's first leaf
+        const int64_t nl = a.tree.real_leaves - leaf0; // leaves from there on (may exceed 2*np)
+        // lanes without a parent hold the empty box: it matches nothing, no exec masking in the loop
+        N mybox;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            mybox.lo[k] = float_max<TN>();
+            mybox.up[k] = -float_max<TN>();
+        }
+        L leafA = {}, leafB = {};
+        I idxA = 0, idxB = 0;
+        uint64_t morA = 0, morB = 0;
+        if (lane < np) {
+            mybox = load_vol<N>(lp_nodes + first + lane);
+            const char *rec = a.leaves + (leaf0 + 2 * lane) * a.lay.stride;
+            leafA = load_vol<L>(rec);
+            idxA = load_index<I>(rec, a.lay);
+            if (a.narrow == IBVH_NARROW_MORTON_LT) morA = load_morton(rec, a.lay);
+            if (2 * lane + 1 < nl) {
+                rec += a.lay.stride;
+                leafB = load_vol<L>(rec);
+                idxB = load_index<I>(rec, a.lay);
+                if (a.narrow == IBVH_NARROW_MORTON_LT) morB = load_morton(rec, a.lay);
+            }
+        }
+        // stage b: candidate parents of every active query
+        uint64_t mine = 0;
+        for (uint64_t todo = on_mask; todo != 0; todo &= todo - 1) {
+            const int qi = __builtin_ctzll(todo);
+            const N qbox = broadcast_from_lane(q.q_node, qi);
+            const uint64_t m = __ballot(iscontact(qbox, mybox));
+            if (lane == qi) mine = m;
+        }
+        // stage c: every query lane tests the leaves of its own candidates, left to right
+        while (__ballot(mine != 0) != 0) {
+            const bool has = mine != 0;
+            const int p = has ? __builtin_ctzll(mine) : 0;
+            mine &= mine - 1;
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const int64_t pos = leaf0 + 2 * p + side;
+                bool hit = has && (2 * p + side < nl);
+                if constexpr (MODE == MODE_SELF) hit = hit && pos > q.item; // only partners to the right
+                const L leaf = shuffle_from(side ? leafB : leafA, p);
+                const I lidx = __shfl(side ? idxB : idxA, p, 64);
+                hit = hit && iscontact(q.q_leaf, leaf);
+                if (a.narrow != IBVH_NARROW_NONE) {
+                    const uint64_t lm = (uint64_t)__shfl((long long)(side ? morB : morA), p, 64);
+                    hit = hit && q.narrow_ok(lm, lidx);
+                }
+                if (hit) q.emit(lidx);
+            }
+        }
+    };
+
+    // a: frontier descent from the start level to the cut level.  Roots are taken in chunks so the
+    // first frontier always fits; chunks and frontier entries stay in increasing node order, which
+    // keeps every lane's emission order (increasing leaf position).
+    uint32_t *fr0 = s_frontier[wv][0], *fr1 = s_frontier[wv][1];
+    const uint32_t root_first = 1u << (a.start_level - 1);
+    const int64_t roots = level_num_real(levels, vl, a.start_level);
+    bool overflow = false;
+    for (int64_t r0 = 0; r0 < roots && !overflow; r0 += FRONTIER_CAP) {
+        int count = (int)((roots - r0) < FRONTIER_CAP ? (roots - r0) : FRONTIER_CAP);
+        for (int i = lane; i < count; i += 64) fr0[i] = root_first + (uint32_t)(r0 + i);
+        __builtin_amdgcn_wave_barrier(); // LDS is in order within a wave; keep the compiler from reordering
+        uint32_t *cur = fr0, *nxt = fr1;
+        for (int lvl = (int)a.start_level; lvl <= cut_level && count > 0; ++lvl) {
+            const N *lvl_nodes = a.nodes + (level_start(levels, vl, lvl) - 1);
+            const uint32_t lvl_first = 1u << (lvl - 1);
+            const int64_t child_real = level_num_real(levels, vl, lvl + 1);
+            int next_count = 0;
+            for (int base = 0; base < count; base += 64) {
+                const bool have = base + lane < count;
+                const uint32_t idx = have ? cur[base + lane] : 0u;
+                N box;
+                bool hit = false;
+                if (have) {
+                    box = load_vol<N>(lvl_nodes + (idx - lvl_first));
+                    hit = iscontact(ubox, box);
+                    if constexpr (MODE == MODE_SELF) hit = hit && !(((uint64_t)idx + 1) <= (wave_next >> (levels - lvl)));
+                }
+                const uint64_t hm = __ballot(hit);
+                if (lvl == cut_level) {
+                    for (uint64_t todo = hm; todo != 0; todo &= todo - 1) {
+                        const int src = __builtin_ctzll(todo);
+                        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)idx, src);
+                        const N cbox = broadcast_from_lane(box, src);
+                        brute(c, cbox);
+                    }
+                } else {
+                    // children of the hits, in order; the right child of the level's last real node
+                    // may be virtual (the left child of a real node never is)
+                    const int before = __popcll(hm & (((uint64_t)1 << lane) - 1));
+                    const int total = __popcll(hm);
+                    const bool last_virtual = hm != 0 && [&] {
+                        const int top = 63 - __builtin_clzll(hm);
+                        const uint32_t ti = (uint32_t)__builtin_amdgcn_readlane((int)idx, top);
+                        return (int64_t)(2u * ti + 1u - (1u << lvl)) >= child_real;
+                    }();
+                    const int add = 2 * total - (last_virtual ? 1 : 0);
+                    if (next_count + add > FRONTIER_CAP) {
+                        overflow = true;
+                        break;
+                    }
+                    if (hit) {
+                        nxt[next_count + 2 * before] = 2u * idx;
+                        if (2 * before + 1 < add) nxt[next_count + 2 * before + 1] = 2u * idx + 1u;
+                    }
+                    next_count += add;
+                }
+            }
+            if (overflow) break;
+            __builtin_amdgcn_wave_barrier();
+            uint32_t *t = cur;
+            cur = nxt;
+            nxt = t;
+            count = lvl == cut_level ? 0 : next_count;
+        }
+    }
+    if (overflow) {
+        // frontier too wide for LDS (heavily overlapping input): redo this wave with the exact walk.
+        // Nothing has been emitted yet unless the cut level was reached, so restart from scratch.
+        q.cnt = 0;
+        if constexpr (WRITE) q.w = (q.valid && q.item > 0) ? (int64_t)a.counts[q.item - 1] : 0;
+        joint_walk(q, a);
+    }
+    q.finish();
 }
 
 // ---- inclusive scan of the per-item counts (AK.accumulate!, traverse_single.jl:57) ---------------
@@ -538,14 +690,20 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
         if (write) IBVH_LAUNCH((lvt_kernel<L, N, I, MODE, true>), dim3(blocks), dim3(256), 0, st, a);
         else IBVH_LAUNCH((lvt_kernel<L, N, I, MODE, false>), dim3(blocks), dim3(256), 0, st, a);
     } else {
-        // brute-forced subtrees: BBox nodes only (nested boxes), rooted no higher than the start level
-        int cut = 0;
-        if (N::kind == IBVH_BBOX && a.start_level < a.tree.levels) {
-            int64_t c = a.tree.levels - BRUTE_DEPTH;
-            cut = (int)(c > a.start_level ? c : a.start_level);
+        // BBox nodes with at least one node level below the start level: frontier descent + brute force;
+        // everything else (BSphere nodes, start_level == levels): the exact joint walk
+        if constexpr (N::kind == IBVH_BBOX) {
+            if (a.start_level < a.tree.levels) {
+                const int64_t c = a.tree.levels - BRUTE_DEPTH;
+                const int cut = (int)(c > a.start_level ? c : a.start_level);
+                if (write) IBVH_LAUNCH((lvt_cluster_kernel<L, N, I, MODE, true>), dim3(blocks), dim3(256), 0, st, a, cache, cut);
+                else IBVH_LAUNCH((lvt_cluster_kernel<L, N, I, MODE, false>), dim3(blocks), dim3(256), 0, st, a, cache, cut);
+                IBVH_LAUNCH_CHECK();
+                return IBVH_OK;
+            }
         }
-        if (write) IBVH_LAUNCH((lvt_joint_kernel<L, N, I, MODE, true>), dim3(blocks), dim3(256), 0, st, a, cache, cut);
-        else IBVH_LAUNCH((lvt_joint_kernel<L, N, I, MODE, false>), dim3(blocks), dim3(256), 0, st, a, cache, cut);
+        if (write) IBVH_LAUNCH((lvt_joint_kernel<L, N, I, MODE, true>), dim3(blocks), dim3(256), 0, st, a, cache);
+        else IBVH_LAUNCH((lvt_joint_kernel<L, N, I, MODE, false>), dim3(blocks), dim3(256), 0, st, a, cache);
     }
     IBVH_LAUNCH_CHECK();
     return IBVH_OK;

@@ -277,6 +277,38 @@ def test_lvt_self_large_and_index_types():
         assert len(exp) > n  # ~1.8 contacts per leaf
 
 
+def test_lvt_dense_inputs_cache_overflow_and_frontier_overflow():
+    """Paths of the BBox fast kernel that sparse clouds never take: work items with more contacts than the
+    contact cache holds (the writing pass walks again) and frontiers wider than the LDS buffer (the wave
+    falls back to the exact joint walk).  Lists must still equal the oracle's, order included."""
+    rng = np.random.default_rng(77)
+    types = abi.make_types()
+    # ~60 contacts per leaf
+    vols = random_volumes(rng, 4000, abi.BSPHERE, abi.F32, scale=4.0, size=1.0)
+    o, g = build_both(vols, types)
+    exp = oracle_pairs(orc.traverse_lvt(o)[0])
+    assert len(exp) > 20 * 4000
+    assert (contacts_np(ibvh.traverse(g)) == exp).all()
+    for sl in (3, o.tree.levels - 1, o.tree.levels):
+        assert (contacts_np(ibvh.traverse(g, start_level=sl)) == oracle_pairs(orc.traverse_lvt(o, sl)[0])).all()
+    # everything overlaps everything: every node of every level is hit
+    vols = random_volumes(rng, 3000, abi.BSPHERE, abi.F32, scale=0.05, size=1.0)
+    o, g = build_both(vols, types)
+    exp = oracle_pairs(orc.traverse_lvt(o)[0])
+    assert len(exp) == 3000 * 2999 // 2
+    assert (contacts_np(ibvh.traverse(g)) == exp).all()
+    # pair version, both orders (flip)
+    a, b = random_volumes(rng, 1500, abi.BSPHERE, abi.F32, scale=2.0), random_volumes(rng, 900, abi.BSPHERE, abi.F32, scale=2.0)
+    (o1, g1), (o2, g2) = build_both(a, types), build_both(b, types)
+    assert (contacts_np(ibvh.traverse(g1, g2)) == oracle_pairs(orc.traverse_pair_lvt(o1, o2)[0])).all()
+    assert (contacts_np(ibvh.traverse(g2, g1)) == oracle_pairs(orc.traverse_pair_lvt(o2, o1)[0])).all()
+    # BSphere nodes (exact joint walk) on a larger cloud
+    ts = abi.make_types(abi.BSPHERE, abi.F32, abi.BSPHERE, abi.F32)
+    vols = random_volumes(rng, 30000, abi.BSPHERE, abi.F32, scale=20.0)
+    o, g = build_both(vols, ts)
+    assert (contacts_np(ibvh.traverse(g)) == oracle_pairs(orc.traverse_lvt(o)[0])).all()
+
+
 def test_lvt_pair_identical_order():
     rng = np.random.default_rng(22)
     types = abi.make_types()
