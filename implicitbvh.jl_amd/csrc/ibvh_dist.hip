@@ -1,0 +1,145 @@
+// ibvh_dist.hip — device pieces of the multi-GPU build (no counterpart in the reference, which is
+// single-device): the global centre AABB is an RCCL all-reduce of per-GPU extrema, the Morton sort a
+// distributed radix sort — splitter keys found by refining digit histograms that are all-reduced, one
+// all-to-all of packed BoundingVolume records, then the ordinary local stable sort (ibvh_build).
+// The collectives themselves are issued by the host side (implicitbvh.jl_amd/dist.py) through
+// torch.distributed (backend "nccl" = RCCL over xGMI); this file holds the kernels around them.
+#include "ibvh_common.hpp"
+
+namespace ibvh {
+namespace distk {
+
+// epsilon expansion of bounding_volumes_extrema (morton/utils.jl:63-69) applied to already reduced
+// extrema: mins - rp*|mins| - floatmin, maxs + rp*|maxs| + floatmin, two roundings per side
+template <class T> __global__ void expand_kernel(T *ext) {
+    const int k = threadIdx.x;
+    if (k < 6) {
+        const T rp = relative_precision<T>(), fm = float_min_normal<T>();
+        T v = ext[k];
+        T a = rp * ibvh_abs(v);
+        ext[k] = k < 3 ? (v - a) - fm : (v + a) + fm;
+    }
+}
+
+// Digit histograms for the splitter search: out[j][d] = #keys with (key >> prefix_shift) == prefix[j]
+// and digit d = (key >> shift) & mask; nprefix == 0: one histogram over all keys.  LDS-staged.
+constexpr int HIST_TPB = 256;
+constexpr int MAX_PREFIX = 15;
+struct Prefixes {
+    uint64_t v[MAX_PREFIX];
+};
+template <class K>
+__global__ __launch_bounds__(HIST_TPB) void key_hist_kernel(const K *__restrict__ keys, int64_t n, int shift, int bits,
+                                                            int prefix_shift, Prefixes pre, int nprefix,
+                                                            uint32_t *__restrict__ out) {
+    extern __shared__ uint32_t sh[];
+    const int nb = 1 << bits, rows = nprefix > 0 ? nprefix : 1;
+    for (int i = threadIdx.x; i < rows * nb; i += HIST_TPB) sh[i] = 0;
+    __syncthreads();
+    const uint32_t mask = (uint32_t)nb - 1u;
+    for (int64_t i = (int64_t)blockIdx.x * HIST_TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * HIST_TPB) {
+        const uint64_t k = (uint64_t)keys[i];
+        const uint32_t d = (uint32_t)(k >> shift) & mask;
+        if (nprefix == 0) {
+            atomicAdd(&sh[d], 1u);
+        } else {
+            const uint64_t p = prefix_shift >= 64 ? 0 : (k >> prefix_shift);
+            for (int j = 0; j < nprefix; ++j)
+                if (p == pre.v[j]) atomicAdd(&sh[j * nb + d], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows * nb; i += HIST_TPB) {
+        uint32_t c = sh[i];
+        if (c) atomicAdd(&out[i], c);
+    }
+}
+
+// records for the exchange: out[i] = BoundingVolume{ volumes[p], index_base + p + 1, keys[p] }, p = perm[i] or i
+template <class V, class I, class K>
+__global__ __launch_bounds__(256) void pack_kernel(const V *__restrict__ vols, const K *__restrict__ keys,
+                                                   const uint32_t *__restrict__ perm, int64_t index_base, int64_t n,
+                                                   LeafLayout lay, char *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t p = perm ? (int64_t)perm[i] : i;
+        char *d = out + i * lay.stride;
+        store_vol(d, load_vol<V>(vols + p));
+        *(I *)(d + lay.index_off) = (I)(index_base + p + 1);
+        store_morton(d, lay, (uint64_t)keys[p]);
+    }
+}
+
+} // namespace distk
+} // namespace ibvh
+
+using namespace ibvh;
+
+extern "C" {
+
+ibvh_status ibvh_expand_extrema(int32_t flt, void *extrema, void *stream) {
+    if (!extrema) return IBVH_ERR_INVALID_ARG;
+    if (flt == IBVH_F32) IBVH_LAUNCH((distk::expand_kernel<float>), dim3(1), dim3(64), 0, (hipStream_t)stream, (float *)extrema);
+    else if (flt == IBVH_F64) IBVH_LAUNCH((distk::expand_kernel<double>), dim3(1), dim3(64), 0, (hipStream_t)stream, (double *)extrema);
+    else return IBVH_ERR_INVALID_ARG;
+    return hipGetLastError() == hipSuccess ? IBVH_OK : IBVH_ERR_HIP;
+}
+
+ibvh_status ibvh_key_histogram(int32_t key_bytes, const void *keys, int64_t n, int32_t shift, int32_t bits,
+                               int32_t prefix_shift, const uint64_t *prefixes, int32_t nprefix, void *out, void *stream) {
+    if (n < 0 || bits < 1 || bits > 12 || shift < 0 || nprefix < 0 || nprefix > distk::MAX_PREFIX || !out) return IBVH_ERR_INVALID_ARG;
+    if (key_bytes != 4 && key_bytes != 8) return IBVH_ERR_INVALID_ARG;
+    if (nprefix > 0 && !prefixes) return IBVH_ERR_INVALID_ARG;
+    const int rows = nprefix > 0 ? nprefix : 1;
+    const size_t smem = (size_t)rows * ((size_t)1 << bits) * 4;
+    if (smem > 160 * 1024) return IBVH_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, smem, st) != hipSuccess) return IBVH_ERR_HIP;
+    if (n == 0) return IBVH_OK;
+    distk::Prefixes pre{};
+    for (int j = 0; j < nprefix; ++j) pre.v[j] = prefixes[j];
+    int64_t b = ceil_div(n, distk::HIST_TPB * 16);
+    unsigned blocks = (unsigned)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+    if (key_bytes == 4) {
+        if (hipFuncSetAttribute((const void *)distk::key_hist_kernel<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess)
+            return IBVH_ERR_HIP;
+        IBVH_LAUNCH((distk::key_hist_kernel<uint32_t>), dim3(blocks), dim3(distk::HIST_TPB), smem, st, (const uint32_t *)keys, n,
+                    shift, bits, prefix_shift, pre, nprefix, (uint32_t *)out);
+    } else {
+        if (hipFuncSetAttribute((const void *)distk::key_hist_kernel<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess)
+            return IBVH_ERR_HIP;
+        IBVH_LAUNCH((distk::key_hist_kernel<uint64_t>), dim3(blocks), dim3(distk::HIST_TPB), smem, st, (const uint64_t *)keys, n,
+                    shift, bits, prefix_shift, pre, nprefix, (uint32_t *)out);
+    }
+    return hipGetLastError() == hipSuccess ? IBVH_OK : IBVH_ERR_HIP;
+}
+
+ibvh_status ibvh_pack_records(const ibvh_types *types, const void *volumes, const void *keys, const void *perm,
+                              int64_t index_base, int64_t n, void *records_out, void *stream) {
+    if (!types || n < 0) return IBVH_ERR_INVALID_ARG;
+    if (n == 0) return IBVH_OK;
+    if (!volumes || !keys || !records_out) return IBVH_ERR_INVALID_ARG;
+    ibvh_layout lay;
+    LeafLayout dl;
+    if (!layout_of(*types, lay, &dl)) return IBVH_ERR_UNSUPPORTED;
+    int64_t b = ceil_div(n, 256);
+    unsigned blocks = (unsigned)(b > 4096 ? 4096 : b);
+    hipStream_t st = (hipStream_t)stream;
+    return (ibvh_status)dispatch_volume(types->leaf_kind, types->leaf_float, [&](auto vt) -> int {
+        using V = typename decltype(vt)::type;
+        return dispatch_index(types->index_type, [&](auto it) -> int {
+            using I = typename decltype(it)::type;
+            if (types->morton_type == IBVH_U64)
+                IBVH_LAUNCH((distk::pack_kernel<V, I, uint64_t>), dim3(blocks), dim3(256), 0, st, (const V *)volumes,
+                            (const uint64_t *)keys, (const uint32_t *)perm, index_base, n, dl, (char *)records_out);
+            else
+                IBVH_LAUNCH((distk::pack_kernel<V, I, uint32_t>), dim3(blocks), dim3(256), 0, st, (const V *)volumes,
+                            (const uint32_t *)keys, (const uint32_t *)perm, index_base, n, dl, (char *)records_out);
+            IBVH_LAUNCH_CHECK();
+            return (int)IBVH_OK;
+        });
+    });
+}
+
+} // extern "C"

@@ -1,0 +1,317 @@
+"""Multi-GPU BVH build: leaves sharded over the GPUs of one node, one process per GPU.
+
+The reference is single-device; this is the MI355X-native scaling path BASELINE.json's north star asks
+for.  Only the BUILD communicates; traversal stays per GPU:
+
+  1. per-GPU centre extrema (ibvh_extrema, unexpanded)  ->  RCCL all-reduce (MIN on mins, MAX on maxs):
+     min/max are exact, so the global AABB — and after the same epsilon expansion the Morton codes —
+     are bit-identical to the single-device build (morton/utils.jl:1-72);
+  2. per-GPU Morton keys (ibvh_morton_keys);
+  3. distributed radix sort: splitter keys found by refining 12-bit digit histograms from the top of the
+     key (ibvh_key_histogram, one all-reduce(SUM) of <= 15 x 4096 counters per level), so that rank r
+     receives the keys in [k_r, k_{r+1}); stable partition of the local leaves by destination
+     (one pass of the radix sort), pack into BoundingVolume records whose .index is the GLOBAL 1-based
+     leaf number (ibvh_pack_records), ONE all-to-all of the records over xGMI;
+  4. ordinary local build (ibvh_build, already_wrapped, fixed global extrema): stable LSB radix sort of
+     the received records — they arrive grouped by source rank in source order, so ties keep global
+     input order — gather, bottom-up merge.
+
+Result: rank r holds the r-th contiguous slice of the globally stable-sorted leaf sequence (concatenating
+the ranks' leaves gives exactly the single-device sorted array) and an implicit tree over its slice.
+Contacts between leaves of different slices are not found by the per-GPU self-traversal.
+
+The collective layer is a small `comm` object so the same driver runs over torch.distributed (RCCL on
+GPUs, gloo in CPU tests) or over in-process virtual ranks; the per-rank device work is an `engine`
+(HipEngine = libibvh; tests inject an oracle-backed CPU engine to exercise the host logic without a GPU).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi, lib
+from . import api
+
+
+# ---------------------------------------------------------------------------------------------
+# collectives
+# ---------------------------------------------------------------------------------------------
+class TorchComm:
+    """torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" on CPU)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+
+    def all_reduce(self, t, op):
+        ops = {"min": self.dist.ReduceOp.MIN, "max": self.dist.ReduceOp.MAX, "sum": self.dist.ReduceOp.SUM}
+        self.dist.all_reduce(t, op=ops[op], group=self.group)
+        return t
+
+    def all_to_all(self, send, send_counts, recv_counts):
+        """send: 1-D tensor partitioned by destination (send_counts elements each) -> received 1-D tensor."""
+        import torch
+        recv = torch.empty(int(sum(recv_counts)), dtype=send.dtype, device=send.device)
+        self.dist.all_to_all_single(recv, send, output_split_sizes=[int(c) for c in recv_counts],
+                                    input_split_sizes=[int(c) for c in send_counts], group=self.group)
+        return recv
+
+
+# ---------------------------------------------------------------------------------------------
+# per-rank device work
+# ---------------------------------------------------------------------------------------------
+class HipEngine:
+    """libibvh on the current GPU."""
+
+    def __init__(self):
+        self.torch = api._require_gpu()
+        self.device = "cuda"
+
+    def tensor(self, data, dtype):
+        return self.torch.tensor(data, dtype=dtype, device=self.device)
+
+    def extrema(self, types, vols):
+        torch = self.torch
+        ext = torch.empty(6, dtype=vols.dtype, device=self.device)
+        scratch = torch.empty(1 << 17, dtype=torch.uint8, device=self.device)
+        lib.call("ibvh_extrema", C.byref(types), api._ptr(vols), 0, vols.shape[0], 0, api._ptr(ext), api._ptr(scratch),
+                 scratch.numel(), api._stream())
+        return ext
+
+    def expand(self, types, ext):
+        lib.call("ibvh_expand_extrema", types.leaf_float, api._ptr(ext), api._stream())
+        return ext
+
+    def keys(self, types, vols, ext):
+        torch = self.torch
+        kd = torch.int64 if types.morton_type == abi.U64 else torch.int32
+        keys = torch.empty(vols.shape[0], dtype=kd, device=self.device)
+        lib.call("ibvh_morton_keys", C.byref(types), api._ptr(vols), 0, vols.shape[0], api._ptr(ext), api._ptr(keys),
+                 api._stream())
+        return keys
+
+    def histogram(self, keys, shift, bits, prefix_shift, prefixes):
+        torch = self.torch
+        rows = max(len(prefixes), 1)
+        out = torch.empty((rows, 1 << bits), dtype=torch.int32, device=self.device)
+        arr = (C.c_uint64 * max(len(prefixes), 1))(*[int(p) for p in prefixes]) if prefixes else None
+        lib.call("ibvh_key_histogram", keys.element_size(), api._ptr(keys), keys.numel(), shift, bits, prefix_shift, arr,
+                 len(prefixes), api._ptr(out), api._stream())
+        return out.to(torch.int64)
+
+    def partition(self, keys, splitters, nranks):
+        """Stable partition of the local leaves by destination rank: (perm, counts per rank)."""
+        torch = self.torch
+        n = keys.numel()
+        if nranks == 1:
+            return None, [n]
+        if splitters:
+            dest = torch.bucketize(keys, torch.tensor(splitters, dtype=keys.dtype, device=self.device), right=True).to(torch.int32)
+        else:
+            dest = torch.zeros(n, dtype=torch.int32, device=self.device)
+        counts = torch.bincount(dest, minlength=nranks).cpu().tolist()
+        vals = torch.arange(n, dtype=torch.int32, device=self.device)
+        d2, v2 = torch.empty_like(dest), torch.empty_like(vals)
+        need = C.c_size_t()
+        lib.call("ibvh_sort_scratch_bytes", 4, n, C.byref(need))
+        scratch = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        in_alt = C.c_int32()
+        bits = max(1, int(nranks - 1).bit_length())
+        lib.call("ibvh_sort_pairs", 4, bits, n, api._ptr(dest), api._ptr(vals), api._ptr(d2), api._ptr(v2), C.byref(in_alt),
+                 api._ptr(scratch), need.value, api._stream())
+        return (v2 if in_alt.value else vals), counts
+
+    def pack(self, types, vols, keys, perm, index_base):
+        torch = self.torch
+        lay = abi.Layout()
+        lib.call("ibvh_layout_of", C.byref(types), C.byref(lay))
+        out = torch.empty(vols.shape[0] * lay.leaf_bytes, dtype=torch.uint8, device=self.device)
+        lib.call("ibvh_pack_records", C.byref(types), api._ptr(vols), api._ptr(keys), api._ptr(perm), int(index_base),
+                 vols.shape[0], api._ptr(out), api._stream())
+        return out, lay.leaf_bytes
+
+    def build_local(self, types, records, n, ext_host, node_type, options, cache):
+        fixed = api.DefaultMortonAlgorithm(options.morton.exemplar, compute_extrema=False,
+                                           mins=tuple(float(v) for v in ext_host[:3]),
+                                           maxs=tuple(float(v) for v in ext_host[3:]))
+        opts = api.BVHOptions(index=options.index, morton=fixed, block_size=options.block_size)
+        bv = api.BoundingVolumes(types, n, records)
+        return api.BVH(bv, node_type, cache=cache, options=opts)
+
+    def to_host(self, t):
+        return t.cpu().numpy()
+
+
+# ---------------------------------------------------------------------------------------------
+# splitter search (identical arithmetic on every rank)
+# ---------------------------------------------------------------------------------------------
+DIGIT_BITS = 12
+
+
+def find_splitters(engine, comm, keys, key_bits, n_global):
+    """Keys k_1 <= ... <= k_{P-1}: rank r receives the keys in [k_r, k_{r+1}).  k_s is the key value at which
+    the global cumulative count first exceeds the balanced target s*N/P, so #(keys < k_s) <= s*N/P."""
+    P = comm.size
+    if P == 1:
+        return []
+    targets = [s * n_global // P for s in range(1, P)]
+    prefix = [0] * (P - 1)  # bits decided so far, as a value
+    below = [0] * (P - 1)   # global number of keys strictly below the decided prefix range
+    decided = 0
+    while decided < key_bits:
+        bits = min(DIGIT_BITS, key_bits - decided)
+        shift = key_bits - decided - bits
+        if decided == 0:
+            rows, row_of = [], [0] * (P - 1)
+            hist = engine.histogram(keys, shift, bits, 64, [])
+        else:
+            rows = sorted(set(prefix))
+            row_of = [rows.index(p) for p in prefix]
+            hist = engine.histogram(keys, shift, bits, shift + bits, rows)
+        comm.all_reduce(hist, "sum")
+        h = engine.to_host(hist).astype(np.int64)
+        cum = np.cumsum(h, axis=1)
+        for s in range(P - 1):
+            r = row_of[s]
+            rem = targets[s] - below[s]
+            d = int(np.searchsorted(cum[r], rem, side="right"))  # first digit with inclusive count > rem
+            d = min(d, (1 << bits) - 1)
+            below[s] += int(cum[r][d - 1]) if d > 0 else 0
+            prefix[s] = (prefix[s] << bits) | d
+        decided += bits
+    return prefix
+
+
+# ---------------------------------------------------------------------------------------------
+# the driver
+# ---------------------------------------------------------------------------------------------
+class DistributedBuilder:
+    """builder = DistributedBuilder(comm_or_group); bvh = builder.build(local_volumes, node_type, cache=..., options=...)
+
+    `local_volumes`: this rank's (n_local, 4|6) volumes; global leaf g = (sum of lower ranks' counts) + local
+    position; the returned BVH's leaves carry .index = g + 1."""
+
+    def __init__(self, comm=None, engine=None):
+        if comm is None or not hasattr(comm, "all_reduce"):
+            comm = TorchComm(comm)
+        self.comm = comm
+        self.engine = engine or HipEngine()
+        self.last = {}
+
+    def build(self, volumes, node_type=None, cache=None, options=None):
+        eng, comm = self.engine, self.comm
+        options = options or api.BVHOptions()
+        torch = api._torch()
+        node_type = node_type or api.BBox(torch.float32)
+        kind, flt = (abi.BSPHERE if volumes.shape[1] == 4 else abi.BBOX), api._float_code(volumes.dtype)
+        types = abi.make_types(kind, flt, node_type.kind, node_type.flt, options.index_code, options.morton_code)
+        if not abi.combo_supported(types):
+            raise ValueError("unsupported leaf / node type combination")
+        n_local = volumes.shape[0]
+        # global leaf numbering: exclusive prefix of the per-rank counts
+        cnt = eng.tensor([0] * comm.size, torch.int64)
+        cnt[comm.rank] = n_local
+        comm.all_reduce(cnt, "sum")
+        counts = eng.to_host(cnt).tolist()
+        base, n_global = int(sum(counts[:comm.rank])), int(sum(counts))
+        if n_global < comm.size:
+            raise abi.DomainError("fewer leaves than ranks")
+        # 1. global centre AABB
+        ext = eng.extrema(types, volumes) if n_local else None
+        fmax = float(np.finfo(abi.FLOAT_DTYPES[flt]).max)
+        fmin = float(np.finfo(abi.FLOAT_DTYPES[flt]).tiny)
+        if ext is None:  # neutral elements of the reference's reduces (morton/utils.jl:29-40)
+            ext = eng.tensor([fmax] * 3 + [fmin] * 3, volumes.dtype)
+        mins, maxs = ext[:3].clone(), ext[3:].clone()
+        comm.all_reduce(mins, "min")
+        comm.all_reduce(maxs, "max")
+        ext = torch.cat([mins, maxs])
+        eng.expand(types, ext)
+        ext_host = eng.to_host(ext)
+        # 2. keys
+        keys = eng.keys(types, volumes, ext)
+        # 3. splitters, partition, pack, exchange
+        key_bits = abi.MORTON_BITS[types.morton_type]
+        splitters = find_splitters(eng, comm, keys, key_bits, n_global)
+        perm, send_counts = eng.partition(keys, splitters, comm.size)
+        records, rec_bytes = eng.pack(types, volumes, keys, perm, base)
+        sc = eng.tensor(send_counts, torch.int64)
+        rc = comm.all_to_all(sc, [1] * comm.size, [1] * comm.size)
+        recv_counts = eng.to_host(rc).tolist()
+        recv = comm.all_to_all(records, [c * rec_bytes for c in send_counts], [c * rec_bytes for c in recv_counts])
+        n_recv = int(sum(recv_counts))
+        if n_recv < 1:
+            raise abi.DomainError("a rank received no leaves (degenerate key distribution)")
+        self.last = {"splitters": splitters, "send_counts": send_counts, "recv_counts": recv_counts, "base": base,
+                     "n_global": n_global, "extrema": ext_host}
+        # 4. local build over the received slice
+        return eng.build_local(types, recv, n_recv, ext_host, node_type, options, cache)
+
+
+# ---------------------------------------------------------------------------------------------
+# in-process virtual ranks (single-GPU emulation of P shards; used by tests and for debugging)
+# ---------------------------------------------------------------------------------------------
+class ThreadWorld:
+    def __init__(self, size):
+        import threading
+        self.size = size
+        self.barrier = threading.Barrier(size)
+        self.slots = [None] * size
+
+
+class ThreadComm:
+    """Collectives between `size` Python threads of one process (one virtual rank each)."""
+
+    def __init__(self, world, rank):
+        self.world, self.rank, self.size = world, rank, world.size
+
+    def all_reduce(self, t, op):
+        import torch
+        w = self.world
+        w.slots[self.rank] = t.clone()
+        w.barrier.wait()
+        stack = torch.stack(w.slots)
+        res = {"min": lambda s: s.min(0).values, "max": lambda s: s.max(0).values, "sum": lambda s: s.sum(0)}[op](stack)
+        w.barrier.wait()
+        t.copy_(res)
+        return t
+
+    def all_to_all(self, send, send_counts, recv_counts):
+        import torch
+        w = self.world
+        w.slots[self.rank] = (send, [int(c) for c in send_counts])
+        w.barrier.wait()
+        pieces = []
+        for src in range(self.size):
+            s, sc = w.slots[src]
+            off = sum(sc[:self.rank])
+            pieces.append(s[off:off + sc[self.rank]])
+            assert sc[self.rank] == int(recv_counts[src])
+        out = torch.cat(pieces) if pieces else send[:0]
+        w.barrier.wait()
+        return out
+
+
+def run_virtual_ranks(size, fn):
+    """Run fn(comm) on `size` virtual ranks (threads); returns the list of results in rank order."""
+    import threading
+    world = ThreadWorld(size)
+    results, errors = [None] * size, []
+
+    def work(r):
+        try:
+            results[r] = fn(ThreadComm(world, r))
+        except BaseException as e:  # noqa: BLE001 - re-raised below
+            errors.append(e)
+            world.barrier.abort()
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(size)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return results

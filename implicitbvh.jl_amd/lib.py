@@ -46,6 +46,9 @@ SIGNATURES = {
     "ibvh_traverse_pair_bfs": [_P(abi.Bvh), _P(abi.Bvh), _i64, _i64, _i32, _vp, _vp, _i64, _vp,
                                _P(abi.BfsResult), _vp],
     "ibvh_traverse_rays_bfs": [_P(abi.Bvh), _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _P(abi.BfsResult), _vp],
+    "ibvh_expand_extrema": [_i32, _vp, _vp],
+    "ibvh_key_histogram": [_i32, _vp, _i64, _i32, _i32, _i32, _P(C.c_uint64), _i32, _vp, _vp],
+    "ibvh_pack_records": [_P(abi.Types), _vp, _vp, _vp, _i64, _i64, _vp, _vp],
     "ibvh_volumes_from_triangles": [_i32, _i32, _vp, _i64, _vp, _vp],
     "ibvh_generate_spheres_f32": [_i64, C.c_uint64, _i64, _P(C.c_float), _P(C.c_float), C.c_float, _vp, _vp],
     "ibvh_profile_enable": [_i32],

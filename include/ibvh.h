@@ -274,6 +274,28 @@ ibvh_status ibvh_traverse_rays_bfs(const ibvh_bvh *bvh, const void *points, cons
                                    void *stream);
 
 /* ----------------------------------------------------------------------------------- */
+/* multi-GPU build: device pieces (collectives are issued by the host side over RCCL)    */
+/* ----------------------------------------------------------------------------------- */
+/* Epsilon expansion of bounding_volumes_extrema (morton/utils.jl:63-69) applied in place to 6
+ * already reduced values (mins then maxs) of float type `flt` in DEVICE memory: used after the
+ * all-reduce of the per-GPU extrema (ibvh_extrema with expand = 0). */
+ibvh_status ibvh_expand_extrema(int32_t flt, void *extrema, void *stream);
+
+/* Digit histograms for the splitter search of the distributed radix sort.  out (DEVICE,
+ * max(nprefix,1) x 2^bits uint32, zeroed here): out[j][d] = number of keys whose
+ * (key >> prefix_shift) == prefixes[j] and whose digit (key >> shift) & (2^bits - 1) == d;
+ * nprefix == 0 counts all keys.  bits <= 12, nprefix <= 15; `prefixes` is a HOST array. */
+ibvh_status ibvh_key_histogram(int32_t key_bytes, const void *keys, int64_t n, int32_t shift,
+                               int32_t bits, int32_t prefix_shift, const uint64_t *prefixes,
+                               int32_t nprefix, void *out, void *stream);
+
+/* Pack BoundingVolume records for the exchange: out[i] = { volumes[p], index_base + p + 1,
+ * keys[p] } with p = perm[i] (uint32) or i when perm == NULL. */
+ibvh_status ibvh_pack_records(const ibvh_types *types, const void *volumes, const void *keys,
+                              const void *perm, int64_t index_base, int64_t n, void *records_out,
+                              void *stream);
+
+/* ----------------------------------------------------------------------------------- */
 /* input preparation adjacent to the path                                               */
 /* ----------------------------------------------------------------------------------- */
 /* BSphere{T}(p1,p2,p3) (bsphere.jl:43-112) / BBox{T}(p1,p2,p3) (bbox.jl:59-70) for n triangles

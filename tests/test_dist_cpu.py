@@ -1,0 +1,169 @@
+"""Multi-rank build logic on CPU: world_size-2 gloo processes (and in-process virtual ranks) drive
+implicitbvh_amd.dist.DistributedBuilder with an oracle-backed engine standing in for the HIP kernels, so
+the splitter search, partition, exchange and global numbering are exercised without a GPU.  Property:
+concatenating the ranks' sorted leaves reproduces the single-device sorted leaf array bit for bit."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as orc
+import implicitbvh_amd as ibvh
+from implicitbvh_amd import abi
+from implicitbvh_amd import dist as ibd
+
+
+class OracleEngine:
+    """CPU stand-in for HipEngine built on the oracle (test infrastructure only)."""
+    device = "cpu"
+
+    def tensor(self, data, dtype):
+        return torch.tensor(data, dtype=dtype)
+
+    def _vols(self, types, vols):
+        return orc.as_volumes(vols.numpy(), types.leaf_kind, types.leaf_float)
+
+    def extrema(self, types, vols):
+        return torch.from_numpy(orc.extrema(types, self._vols(types, vols), wrapped=False, expand=False))
+
+    def expand(self, types, ext):
+        f = abi.FLOAT_DTYPES[types.leaf_float]
+        rp = f(1e-5) if f is np.float32 else f(1e-14)
+        fm = np.finfo(f).tiny
+        e = ext.numpy()
+        for k in range(6):
+            a = f(rp * np.abs(e[k]))
+            e[k] = f(f(e[k] - a) - fm) if k < 3 else f(f(e[k] + a) + fm)
+        return ext
+
+    def keys(self, types, vols, ext):
+        k = orc.morton_keys(types, self._vols(types, vols), False, ext.numpy())
+        return torch.from_numpy(k.astype(np.int64 if k.dtype == np.uint64 else np.int32))
+
+    def histogram(self, keys, shift, bits, prefix_shift, prefixes):
+        k = keys.numpy().astype(np.uint64)
+        d = ((k >> np.uint64(shift)) & np.uint64((1 << bits) - 1)).astype(np.int64)
+        if not prefixes:
+            return torch.from_numpy(np.bincount(d, minlength=1 << bits)[None, :].astype(np.int64))
+        p = k >> np.uint64(prefix_shift)
+        rows = [np.bincount(d[p == np.uint64(v)], minlength=1 << bits) for v in prefixes]
+        return torch.from_numpy(np.stack(rows).astype(np.int64))
+
+    def partition(self, keys, splitters, nranks):
+        k = keys.numpy()
+        dest = np.searchsorted(np.asarray(splitters, dtype=k.dtype), k, side="right") if splitters else np.zeros(len(k), int)
+        perm = np.argsort(dest, kind="stable")
+        return torch.from_numpy(perm.astype(np.int32)), np.bincount(dest, minlength=nranks).tolist()
+
+    def pack(self, types, vols, keys, perm, index_base):
+        dt = abi.leaf_dtype(types)
+        rec = np.zeros(vols.shape[0], dt)
+        p = perm.numpy().astype(np.int64)
+        rec["volume"] = self._vols(types, vols)[p]
+        rec["index"] = index_base + p + 1
+        rec["morton"] = keys.numpy()[p].astype(dt["morton"])
+        return torch.from_numpy(rec.view(np.uint8).copy()), dt.itemsize
+
+    def build_local(self, types, records, n, ext_host, node_type, options, cache):
+        rec = records.numpy().view(abi.leaf_dtype(types))
+        v = rec["volume"]
+        vols = np.concatenate([v[f].reshape(n, -1) for f in v.dtype.names], axis=1)
+        return orc.build(vols, types, indices=rec["index"], compute_extrema=False, mins=ext_host[:3], maxs=ext_host[3:])
+
+    def to_host(self, t):
+        return t.numpy()
+
+
+def cloud(n, seed, kind=abi.BSPHERE, dtype=np.float32):
+    rng = np.random.default_rng(seed)
+    c = rng.random((n, 3)) ** 2 * 10 - 3  # skewed, partly negative
+    if kind == abi.BSPHERE:
+        return np.concatenate([c, 0.01 + 0.1 * rng.random((n, 1))], axis=1).astype(dtype)
+    h = 0.01 + 0.1 * rng.random((n, 3))
+    return np.concatenate([c - h, c + h], axis=1).astype(dtype)
+
+
+def shard_bounds(n, world):
+    return [n * r // world for r in range(world + 1)]
+
+
+def check_against_single_build(vols, types, per_rank_leaves):
+    single = orc.build(vols, types)
+    cat = np.concatenate(per_rank_leaves)
+    assert len(cat) == len(vols)
+    assert cat["morton"].tolist() == single.leaves["morton"].tolist()
+    assert cat["index"].tolist() == single.leaves["index"].tolist()  # incl. stable tie order
+    assert cat["volume"].tobytes() == single.leaves["volume"].tobytes()
+
+
+def _worker(rank, world, path, n, seed, kind, flt, morton, init_file):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    try:
+        dtype = abi.FLOAT_DTYPES[flt]
+        vols = cloud(n, seed, kind, dtype)
+        b = shard_bounds(n, world)
+        local = torch.from_numpy(vols[b[rank]:b[rank + 1]].copy())
+        types = abi.make_types(kind, flt, abi.BBOX, abi.F32, abi.I32, morton)
+        opts = ibvh.BVHOptions(morton=ibvh.DefaultMortonAlgorithm(abi.MORTON_DTYPES[morton]))
+        builder = ibd.DistributedBuilder(ibd.TorchComm(), engine=OracleEngine())
+        bvh = builder.build(local, ibvh.api._VolumeType(abi.BBOX, abi.F32), options=opts)
+        np.save(os.path.join(path, f"leaves_{rank}.npy"), bvh.leaves)
+        np.save(os.path.join(path, f"ext_{rank}.npy"), builder.last["extrema"])
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,flt,morton,n", [(abi.BSPHERE, abi.F32, abi.U32, 20011), (abi.BBOX, abi.F64, abi.U64, 5003),
+                                               (abi.BSPHERE, abi.F32, abi.U16, 3001)])
+def test_gloo_world2_matches_single_device_build(kind, flt, morton, n):
+    world = 2
+    with tempfile.TemporaryDirectory() as tmp:
+        init_file = os.path.join(tmp, "rendezvous")
+        mp.spawn(_worker, args=(world, tmp, n, 1234, kind, flt, morton, init_file), nprocs=world, join=True)
+        leaves = [np.load(os.path.join(tmp, f"leaves_{r}.npy")) for r in range(world)]
+        exts = [np.load(os.path.join(tmp, f"ext_{r}.npy")) for r in range(world)]
+    types = abi.make_types(kind, flt, abi.BBOX, abi.F32, abi.I32, morton)
+    vols = cloud(n, 1234, kind, abi.FLOAT_DTYPES[flt])
+    assert exts[0].tobytes() == exts[1].tobytes() == orc.build(vols, types).extrema.tobytes()
+    check_against_single_build(vols, types, leaves)
+    assert abs(len(leaves[0]) - len(leaves[1])) <= max(2, n // 1000)  # balanced up to key multiplicity
+
+
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_virtual_ranks_cpu(world):
+    n = 30011
+    vols = cloud(n, 99)
+    types = abi.make_types()
+    b = shard_bounds(n, world)
+
+    def fn(comm):
+        builder = ibd.DistributedBuilder(comm, engine=OracleEngine())
+        bvh = builder.build(torch.from_numpy(vols[b[comm.rank]:b[comm.rank + 1]].copy()))
+        return bvh.leaves, builder.last
+    out = ibd.run_virtual_ranks(world, fn)
+    check_against_single_build(vols, types, [o[0] for o in out])
+    sizes = [len(o[0]) for o in out]
+    assert max(sizes) - min(sizes) <= 8
+    assert all(o[1]["splitters"] == out[0][1]["splitters"] for o in out)
+
+
+def test_heavy_duplicates_and_uneven_shards():
+    """Few distinct keys (ties must keep global input order) and ranks with very different shard sizes."""
+    rng = np.random.default_rng(5)
+    base = cloud(23, 7)
+    vols = np.repeat(base, 400, axis=0)
+    rng.shuffle(vols)
+    n = len(vols)
+    bounds = [0, 17, 5000, n]
+
+    def fn(comm):
+        builder = ibd.DistributedBuilder(comm, engine=OracleEngine())
+        return builder.build(torch.from_numpy(vols[bounds[comm.rank]:bounds[comm.rank + 1]].copy())).leaves
+    out = ibd.run_virtual_ranks(3, fn)
+    check_against_single_build(vols, abi.make_types(), out)

@@ -415,6 +415,41 @@ def test_bfs_large_with_capacity_growth_and_cache():
 
 
 # ---------------------------------------------------------------------------------------------
+# multi-GPU build, emulated with virtual ranks on this one GPU (HipEngine + in-process collectives)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_distributed_build_virtual_ranks_gpu(world):
+    from implicitbvh_amd import dist as ibd
+    n = 200003
+    r0 = 0.5 * (3 * 8 / (4 * np.pi * n)) ** (1 / 3)
+    host = orc.generate_spheres_f32(n, 46, r0=r0)
+    single = orc.build(host, abi.make_types())
+    bounds = [n * r // world for r in range(world + 1)]
+
+    def fn(comm):
+        vols = ibvh.generate_spheres(bounds[comm.rank + 1] - bounds[comm.rank], 46, first_index=bounds[comm.rank], r0=r0)
+        builder = ibd.DistributedBuilder(comm)
+        bvh = builder.build(vols)
+        trav = ibvh.traverse(bvh)
+        torch.cuda.synchronize()
+        return bvh.leaves.to_numpy(), bvh.nodes.cpu().numpy(), contacts_np(trav), builder.last
+    out = ibd.run_virtual_ranks(world, fn)
+    cat = np.concatenate([o[0] for o in out])
+    assert cat.tobytes() == single.leaves.tobytes()  # global stable-sorted sequence, global 1-based indices
+    for leaves, nodes, contacts, last in out:
+        assert last["extrema"].tobytes() == single.extrema.tobytes()
+        # the per-slice tree and its self-contacts equal the oracle run on the same slice
+        v = leaves["volume"]
+        sl = np.concatenate([v["x"], v["r"][:, None]], axis=1)
+        o = orc.build(sl, abi.make_types(), indices=leaves["index"], compute_extrema=False,
+                      mins=single.extrema[:3], maxs=single.extrema[3:])
+        assert nodes.tobytes() == o.nodes.tobytes()
+        assert (contacts == oracle_pairs(orc.traverse_lvt(o)[0])).all()
+    sizes = [len(o[0]) for o in out]
+    assert max(sizes) - min(sizes) <= 8
+
+
+# ---------------------------------------------------------------------------------------------
 # input preparation
 # ---------------------------------------------------------------------------------------------
 def test_triangle_volumes_bit_exact():
