@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--n", type=int, default=1_000_000, help="leaves per GPU")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="use the multi-GPU build path even with one rank")
     ap.add_argument("--cpu-n", type=int, default=0, help="leaves of the CPU baseline sample (0 = same as --n, capped)")
     args = ap.parse_args()
 
@@ -92,8 +93,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     lib.load()
 
@@ -103,7 +106,7 @@ def main():
     r0 = 0.5 * (3 * 8 / (4 * math.pi * n_global)) ** (1 / 3)
     vols = ibvh.generate_spheres(n, args.seed, first_index=rank * n, r0=r0)
 
-    if world > 1:
+    if dist is not None:
         from implicitbvh_amd import dist as ibvh_dist
         builder = ibvh_dist.DistributedBuilder(dist.group.WORLD)
 

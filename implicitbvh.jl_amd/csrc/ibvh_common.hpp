@@ -483,6 +483,16 @@ void end(hipStream_t st);
         if (::ibvh::prof::enabled) ::ibvh::prof::end(st);                        \
     } while (0)
 
+// XCD-aware workgroup -> tile assignment.  Workgroups b and b+8 share an XCD (round-robin dispatch,
+// MI355X_MICROARCH.md "Workgroup dispatch"), so handing XCD x the contiguous tile range
+// [x*q, (x+1)*q) keeps neighbouring tiles — which read each other's data (adjacent Morton ranges) —
+// behind one 4 MiB L2.  Bijective for any grid size; affects speed only, never results.
+IBVH_D int xcd_remap(int b, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = b & 7, k = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 // wave64 helpers -----------------------------------------------------------------------------
 IBVH_D int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 

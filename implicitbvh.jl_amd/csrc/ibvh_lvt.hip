@@ -214,6 +214,8 @@ template <class L, class N, class I, int MODE, bool WRITE> struct Query {
     int64_t w, cnt;
 
     IBVH_D Query(const Args<L, N, I> &a_, const PairCache<I> &c_) : a(a_), cache(c_) {
+        // (an XCD-contiguous block->tile remap was measured here in round 1: 0.44 -> 0.61 ms at 1e6 leaves,
+        // no change at 1e7, so work items keep the plain round-robin placement)
         item = (int64_t)blockIdx.x * 256 + threadIdx.x;
         valid = item < a.n_items;
         q_leaf = {};

@@ -20,15 +20,6 @@ namespace rsort {
 constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;
 
-// XCD-aware tile assignment: workgroups b and b+8 share an XCD (round-robin dispatch), so giving
-// XCD x the contiguous tile range [x*q.., ..) lets neighbouring tiles' partial lines of one digit
-// stream meet in the same L2.  Bijective for any grid size; affects speed only.
-IBVH_D int xcd_remap(int b, int nwg) {
-    int q = nwg >> 3, r = nwg & 7;
-    int xcd = b & 7, k = b >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-}
-
 template <int TPB> IBVH_D uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_tot /* TPB/64 */, uint32_t *total) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t inc = v;
