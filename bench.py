@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="use the multi-GPU build path even with one rank")
+    ap.add_argument("--extra-n", type=int, default=10_000_000,
+                    help="also report the north-star size (1e7 leaves) at N=1; 0 disables")
     ap.add_argument("--cpu-n", type=int, default=0, help="leaves of the CPU baseline sample (0 = same as --n, capped)")
     args = ap.parse_args()
 
@@ -186,6 +188,58 @@ def main():
             roofline["morton_sort_phase"] = {"ms": round(ms_phase, 4), "algorithmic_GBps": round(gbps, 1),
                                              "frac": round(gbps / HBM_PEAK_GBS, 4), "bytes_per_leaf": 152}
 
+    # measured HBM-side traffic of the dominant kernel from the committed rocprofv3 PMC passes (same command,
+    # n = 1e6): FETCH_SIZE is doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950 (calibrated here on the
+    # extrema kernel: 7829 KiB reported for 16.0e6 bytes streamed), WRITE_SIZE taken as is, KiB -> bytes
+    if roofline is not None and n == 1_000_000:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_n1e6.json")))["kernels"]
+            want = roofline["kernel"]
+            for name, v in pmc.items():
+                if kernel_key("(" + name.split("(")[0].replace("void ", "") + ")") == want and v["launches"] >= 5:
+                    roofline["traffic"] = int((2 * v["FETCH_SIZE_KiB_avg"] + v["WRITE_SIZE_KiB_avg"]) * 1024)
+                    roofline["traffic_source"] = "profiles/r01_pmc_fetch_write_n1e6.json (L2-miss bytes; Infinity-Cache hits included)"
+        except Exception:
+            pass
+
+    # ---- north-star size (1e7 leaves, single GPU): same step, fewer repetitions ---------------------
+    north_star = None
+    if world == 1 and dist is None and args.extra_n and args.extra_n != n:
+        n2 = args.extra_n
+        r02 = 0.5 * (3 * 8 / (4 * math.pi * n2)) ** (1 / 3)
+        vols2 = ibvh.generate_spheres(n2, args.seed, r0=r02)
+        st2 = (None, None)
+        for _ in range(2):
+            b2 = ibvh.BVH(vols2, cache=st2[0])
+            st2 = (b2, ibvh.traverse(b2, cache=st2[1]))
+        torch.cuda.synchronize()
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            b2 = ibvh.BVH(vols2, cache=st2[0])
+            st2 = (b2, ibvh.traverse(b2, cache=st2[1]))
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t0
+        lib.call("ibvh_profile_enable", 1)
+        for _ in range(3):
+            b2 = ibvh.BVH(vols2, cache=st2[0])
+            st2 = (b2, ibvh.traverse(b2, cache=st2[1]))
+        torch.cuda.synchronize()
+        prof2 = collect_profile(lib)
+        lib.call("ibvh_profile_enable", 0)
+        phase = ("extrema_partial_kernel", "extrema_final_kernel", "encode_kernel", "hist_kernel", "scan_kernel",
+                 "scatter_kernel", "gather_kernel")
+        ms_phase = sum(prof2[k][0] for k in phase if k in prof2) / 3
+        ms_build = sum(v[0] for k, v in prof2.items() if not k.startswith(("lvt_", "scan_reduce", "scan_partials", "scan_apply"))) / 3
+        gb = 152.0 * n2 / (ms_phase * 1e-3) / 1e9
+        north_star = {"leaves": n2, "value": round(n2 * reps / el2 / 1e6, 3), "unit": "Mleaves/s",
+                      "ms_per_step": round(el2 / reps * 1e3, 4), "contacts": st2[1].num_contacts,
+                      "build_ms": round(ms_build, 4),
+                      "morton_sort_phase": {"ms": round(ms_phase, 4), "algorithmic_GBps": round(gb, 1),
+                                            "frac": round(gb / HBM_PEAK_GBS, 4), "bytes_per_leaf": 152}}
+        del vols2, st2, b2
+        torch.cuda.empty_cache()
+
     # ---- CPU baseline: the oracle's multi-threaded restatement, rank 0 only, bounded sample --------
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -207,7 +261,16 @@ def main():
                         "sample": f"{cpu_n} BSphere{{Float32}} leaves, same generator/law as the GPU workload, "
                                   f"build {best[0]*1e3:.1f} ms + LVT traverse {best[1]*1e3:.1f} ms, {best[2]} contacts, "
                                   f"best of <=3 runs, {cores} threads",
-                        "build_ms": round(best[0] * 1e3, 3), "traverse_ms": round(best[1] * 1e3, 3)}
+                        "build_ms": round(best[0] * 1e3, 3), "traverse_ms": round(best[1] * 1e3, 3),
+                        "gpu_over_cpu": round(value / (cpu_n / (best[0] + best[1]) / 1e6), 1) if cpu_n == n else None}
+        if north_star is not None:
+            n2 = north_star["leaves"]
+            host2 = orc.generate_spheres_f32(n2, args.seed, r0=0.5 * (3 * 8 / (4 * math.pi * n2)) ** (1 / 3))
+            _, cc2, tb2, tt2 = orc.bench_build_traverse_f32(host2, cores)
+            north_star["cpu_baseline"] = {"value": round(n2 / (tb2 + tt2) / 1e6, 4), "unit": "Mleaves/s", "cores": cores,
+                                          "kind": "port", "build_ms": round(tb2 * 1e3, 2), "traverse_ms": round(tt2 * 1e3, 2),
+                                          "sample": f"{n2} leaves, one run"}
+            north_star["gpu_over_cpu"] = round(north_star["value"] / north_star["cpu_baseline"]["value"], 1)
 
     if rank == 0:
         t_trav = sum(v["ms_per_step"] for k, v in kernels.items() if k.startswith(("lvt_", "scan_"))) if kernels else None
@@ -221,7 +284,7 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"leaves sharded over {world} GPUs (RCCL build), per-GPU traversal"},
             "mcontacts_per_s": round(contacts_total * args.steps / elapsed / 1e6, 3),
             "mcontacts_per_s_traverse_only": round(contacts / (t_trav * 1e-3) / 1e6, 3) if t_trav else None,
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "north_star_1e7": north_star, "kernels": kernels,
             "profiled_ms_per_step": round(tp / prof_steps * 1e3, 4),
         }
         print(json.dumps(line))
