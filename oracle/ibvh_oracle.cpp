@@ -1007,6 +1007,37 @@ int64_t oracle_brute_force_rays(int kind, int flt, const void *volumes, int64_t 
     return cnt;
 }
 
+// ---- batch re-checks for full-size property tests -------------------------------------------
+// number of (leaf position, ray) pairs (1-based, as reported) that do NOT satisfy isintersection
+int64_t oracle_count_bad_ray_hits(int kind, int flt, const void *volumes, const void *points, const void *dirs,
+                                  const int64_t *pairs, int64_t npairs) {
+    int64_t bad = 0;
+    dispatch_volume(kind, flt, [&](auto tv) -> int {
+        using V = typename decltype(tv)::type;
+        using T = typename V::elt;
+        const V *v = (const V *)volumes;
+        const T *p = (const T *)points, *d = (const T *)dirs;
+        for (int64_t k = 0; k < npairs; ++k) {
+            int64_t i = pairs[2 * k] - 1, r = pairs[2 * k + 1] - 1;
+            if (!isintersection(v[i], p + 3 * r, d + 3 * r)) ++bad;
+        }
+        return 0;
+    });
+    return bad;
+}
+// number of (i, j) pairs (1-based) with !iscontact(a[i], b[j])
+int64_t oracle_count_bad_contacts(int kind, int flt, const void *va, const void *vb, const int64_t *pairs, int64_t npairs) {
+    int64_t bad = 0;
+    dispatch_volume(kind, flt, [&](auto tv) -> int {
+        using V = typename decltype(tv)::type;
+        const V *a = (const V *)va, *b = (const V *)vb;
+        for (int64_t k = 0; k < npairs; ++k)
+            if (!iscontact(a[pairs[2 * k] - 1], b[pairs[2 * k + 1] - 1])) ++bad;
+        return 0;
+    });
+    return bad;
+}
+
 // ---- synthetic inputs (same specification as ibvh_generate_spheres_f32) -------------------
 int oracle_generate_spheres_f32(int64_t n, uint64_t seed, int64_t first_index, const float origin[3],
                                 const float extent[3], float r0, void *out) {

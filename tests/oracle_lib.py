@@ -23,6 +23,8 @@ def _load():
     lib.oracle_brute_force_self.restype = C.c_int64
     lib.oracle_brute_force_pair.restype = C.c_int64
     lib.oracle_brute_force_rays.restype = C.c_int64
+    lib.oracle_count_bad_ray_hits.restype = C.c_int64
+    lib.oracle_count_bad_contacts.restype = C.c_int64
     lib.oracle_morton_split3_u16.restype = C.c_uint16
     lib.oracle_morton_split3_u32.restype = C.c_uint32
     lib.oracle_morton_split3_u64.restype = C.c_uint64
@@ -331,6 +333,21 @@ def brute_force_rays(kind, flt, volumes, points, directions):
         if c <= cap:
             return out[:c]
         cap = c
+
+
+def count_bad_ray_hits(kind, flt, volumes, points, directions, pairs):
+    v = as_volumes(volumes, kind, flt)
+    t = abi.FLOAT_DTYPES[flt]
+    p = np.ascontiguousarray(np.asarray(points, t).reshape(-1, 3))
+    d = np.ascontiguousarray(np.asarray(directions, t).reshape(-1, 3))
+    pr = np.ascontiguousarray(np.asarray(pairs, np.int64).reshape(-1, 2))
+    return int(lib.oracle_count_bad_ray_hits(kind, flt, _p(v), _p(p), _p(d), _p(pr), C.c_int64(len(pr))))
+
+
+def count_bad_contacts(kind, flt, va, vb, pairs):
+    a, b = as_volumes(va, kind, flt), as_volumes(vb, kind, flt)
+    pr = np.ascontiguousarray(np.asarray(pairs, np.int64).reshape(-1, 2))
+    return int(lib.oracle_count_bad_contacts(kind, flt, _p(a), _p(b), _p(pr), C.c_int64(len(pr))))
 
 
 def generate_spheres_f32(n, seed, first_index=0, origin=(0, 0, 0), extent=(1, 1, 1), r0=0.01):

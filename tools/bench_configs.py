@@ -1,0 +1,98 @@
+"""Timings of BASELINE.json configs 3 (mesh + 1e6 rays) and 4 (two 5e6 clouds, pair traverse) on one MI355X.
+Not the driver's bench line (bench.py): these are the parity-test configurations, timed for DESIGN.md."""
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import implicitbvh_amd as ibvh
+from implicitbvh_amd import lib
+from bench import collect_profile
+
+
+def timed(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3, out
+
+
+def kernels(fn):
+    lib.call("ibvh_profile_enable", 1)
+    fn()
+    torch.cuda.synchronize()
+    p = collect_profile(lib)
+    lib.call("ibvh_profile_enable", 0)
+    return {k: round(v[0], 4) for k, v in p.items() if v[0] > 0.01}
+
+
+out = {}
+# ---- config 3 -------------------------------------------------------------------------------
+from test_gpu_fullsize import torus_mesh
+tris = torch.from_numpy(torus_mesh()).cuda()
+ms_vol, vols = timed(lambda: ibvh.bounding_volumes_from_triangles(tris))
+state = {"bvh": None, "t": None}
+
+
+def build3():
+    state["bvh"] = ibvh.BVH(vols, cache=state["bvh"])
+    return state["bvh"]
+
+
+ms_build, bvh = timed(build3)
+nr = 1_000_000
+rng = np.random.default_rng(43)
+hv = vols.cpu().numpy()
+lo, hi = hv[:, :3].min(0), hv[:, :3].max(0)
+p = torch.from_numpy((lo + (hi - lo) * rng.random((nr, 3))).astype(np.float32)).cuda().t()
+d = torch.from_numpy(rng.random((nr, 3)).astype(np.float32)).cuda().t()
+
+
+def rays():
+    state["t"] = ibvh.traverse_rays(bvh, p, d, cache=state["t"])
+    return state["t"]
+
+
+ms_rays, tr = timed(rays, 3)
+out["config3"] = {"triangles": int(tris.shape[0]), "volumes_ms": round(ms_vol, 3), "build_ms": round(ms_build, 3),
+                  "rays": nr, "traverse_rays_lvt_ms": round(ms_rays, 3), "hits": tr.num_contacts,
+                  "Mrays_per_s": round(nr / ms_rays / 1e3, 2), "kernels_ms": kernels(rays)}
+state["t"] = None
+ms_self, ts = timed(lambda: ibvh.traverse(bvh), 3)
+out["config3"]["self_traverse_ms"] = round(ms_self, 3)
+out["config3"]["self_contacts"] = ts.num_contacts
+del tris, vols, bvh, tr, ts, p, d
+torch.cuda.empty_cache()
+# ---- config 4 -------------------------------------------------------------------------------
+n = 5_000_000
+r0 = 0.5 * (3 * 8 / (4 * math.pi * n)) ** (1 / 3)
+a = ibvh.generate_spheres(n, 44, r0=r0)
+b = ibvh.generate_spheres(n, 45, origin=(0.9, 0.0, 0.0), r0=r0)
+ms_b, b1 = timed(lambda: ibvh.BVH(a))
+b2 = ibvh.BVH(b)
+st = {"t": None}
+
+
+def pair():
+    st["t"] = ibvh.traverse(b1, b2, cache=st["t"])
+    return st["t"]
+
+
+ms_pair, tp = timed(pair, 3)
+out["config4"] = {"leaves_each": n, "build_ms_each": round(ms_b, 3), "pair_traverse_lvt_ms": round(ms_pair, 3),
+                  "contacts": tp.num_contacts, "Mcontacts_per_s": round(tp.num_contacts / ms_pair / 1e3, 2),
+                  "kernels_ms": kernels(pair)}
+st["t"] = None
+ms_bfs, tb = timed(lambda: ibvh.traverse(b1, b2, ibvh.BFSTraversal()), 2)
+out["config4"]["pair_traverse_bfs_ms"] = round(ms_bfs, 3)
+out["config4"]["bfs_checks"] = tb.num_checks
+print(json.dumps(out))
