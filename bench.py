@@ -51,7 +51,7 @@ def algorithmic_bytes(kernel, n, contacts):
 def kernel_key(name):
     """'(lvt_kernel<L, N, I, MODE, true>)' -> 'lvt_kernel_write'."""
     base = name.strip("() ").split("<")[0].split("::")[-1].strip()
-    if base in ("lvt_kernel", "lvt_joint_kernel", "lvt_cluster_kernel"):
+    if base in ("lvt_kernel", "lvt_rays_kernel", "lvt_joint_kernel", "lvt_cluster_kernel"):
         return base + ("_write" if "true>" in name.replace(" ", "") else "_count")
     return base
 

@@ -440,6 +440,7 @@ def _cache_tensor(cache_t, need_rows, cols, dtype, what):
 
 
 LVT_CACHE_SLOTS = 8  # contacts per work item kept from the counting pass (include/ibvh.h)
+RAY_CACHE_SLOTS = 16  # hits per ray kept from the counting pass
 
 
 def _lvt_scratch(cache, types, n_items, slots=None):
@@ -606,7 +607,7 @@ def traverse_rays(bvh, points, directions, alg=None, start_level=1, narrow=None,
     s = bvh.struct()
     if lvt:
         counts = _cache_tensor(cache.cache2 if cache else None, nr, 0, idt, "cache2")
-        scratch = _lvt_scratch(cache, bvh.types, nr, slots=0)
+        scratch = _lvt_scratch(cache, bvh.types, nr, slots=RAY_CACHE_SLOTS)
         total = C.c_int64()
         lib.call("ibvh_traverse_rays_lvt_count", C.byref(s), _ptr(p), _ptr(d), nr, start_level, _ptr(counts),
                  C.byref(total), _ptr(scratch), scratch.numel(), _stream())

@@ -5,14 +5,11 @@
 // Replaces src/traverse/leaf_vs_tree/traverse_single.jl, traverse_pair.jl and
 // src/raytrace/leaf_vs_tree/leaf_vs_tree.jl.
 //
-// The reference keeps a 32-entry per-thread stack of pending right children
-// (traverse_single.jl:188-203).  The implicit tree makes that stack redundant: the pre-order
-// successor of a finished subtree rooted at i is (i+1) >> ctz(i+1) — climb while i is a right
-// child, then step to the sibling — clamped so the climb never rises above start_level (the
-// reference iterates the start-level roots in order, which is the same sequence).  A virtual
-// successor ends the walk: virtual nodes form a suffix of every level, so everything after it in
-// pre-order is virtual too.  Visitation order, hence contact order, is identical to the stack
-// version; no scratch memory, no private-array spills.
+// Three walkers, documented where they are defined: lvt_cluster_kernel (BBox nodes: frontier descent +
+// brute-forced subtrees), lvt_joint_kernel (exact wave-uniform pre-order walk, any node type) and
+// lvt_rays_kernel (per-lane walk with a bitmask stack).  The reference's 32-entry per-thread index stack
+// (traverse_single.jl:188-203) is never needed: the tree is implicit, so "the pending right siblings of
+// the current path" is one 32-bit mask.
 #include <cstdlib>
 
 #include "ibvh_common.hpp"
@@ -46,109 +43,6 @@ IBVH_D bool narrow_eval(int narrow, uint64_t ma, int64_t ia, uint64_t mb, int64_
     if (narrow == IBVH_NARROW_MORTON_LT) return ma < mb;
     if (narrow == IBVH_NARROW_INDEX_LT) return ia < ib;
     return true;
-}
-
-template <class L, class N, class I, int MODE, bool WRITE>
-__global__ __launch_bounds__(256) void lvt_kernel(Args<L, N, I> a) {
-    using T = typename L::elt;
-    const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (item >= a.n_items) return;
-
-    // the query: a leaf (converted once to the node type for node tests, traverse_single.jl:154-155)
-    // or a ray converted to the leaf float type (raytrace/leaf_vs_tree:116-125)
-    L q_leaf;
-    N q_node;
-    I q_index = 0;
-    uint64_t q_morton = 0;
-    T p[3], d[3];
-    if constexpr (MODE == MODE_RAYS) {
-        p[0] = a.points[3 * item + 0];
-        p[1] = a.points[3 * item + 1];
-        p[2] = a.points[3 * item + 2];
-        d[0] = a.dirs[3 * item + 0];
-        d[1] = a.dirs[3 * item + 1];
-        d[2] = a.dirs[3 * item + 2];
-    } else {
-        const char *rec = a.items + item * a.items_lay.stride;
-        q_leaf = load_vol<L>(rec);
-        q_node = convert_to(q_leaf, (N *)nullptr);
-        q_index = load_index<I>(rec, a.items_lay);
-        if (a.narrow == IBVH_NARROW_MORTON_LT) q_morton = load_morton(rec, a.items_lay);
-    }
-
-    const int64_t levels = a.tree.levels, vl = a.tree.virtual_leaves;
-    const int64_t leaf_first = int64_t(1) << (levels - 1); // implicit index of leaf position 1
-    const int64_t self_implicit = item + leaf_first;       // SELF: implicit index of this leaf
-
-    int64_t cnt = 0;
-    int64_t w = 0;
-    if constexpr (WRITE) w = item == 0 ? 0 : (int64_t)a.counts[item - 1];
-
-    int64_t level = a.start_level;
-    int64_t inode = int64_t(1) << (level - 1);
-    // level_num_real(start_level) >= 1 always, so the first root is real
-    while (true) {
-        bool descend = false;
-        bool skip = false;
-        if constexpr (MODE == MODE_SELF) {
-            // ignore subtrees whose right-most reachable leaf is not to the right of this leaf
-            // (traverse_single.jl:165-167): only partners j > i are reported
-            int64_t rightmost = ((inode + 1) << (levels - level)) - 1;
-            skip = rightmost <= self_implicit;
-        }
-        if (!skip) {
-            if (level == levels) {
-                const char *rec = a.leaves + (inode - leaf_first) * a.lay.stride;
-                L leaf = load_vol<L>(rec);
-                bool hit;
-                if constexpr (MODE == MODE_RAYS) hit = isintersection(leaf, p, d);
-                else hit = iscontact(q_leaf, leaf);
-                if (hit) {
-                    I lidx = load_index<I>(rec, a.lay);
-                    if constexpr (MODE != MODE_RAYS) {
-                        if (a.narrow != IBVH_NARROW_NONE) {
-                            uint64_t lm = a.narrow == IBVH_NARROW_MORTON_LT ? load_morton(rec, a.lay) : 0;
-                            // pair with flip: narrow(leaf, bv) (traverse_pair.jl:202)
-                            hit = (MODE == MODE_PAIR && a.flip) ? narrow_eval(a.narrow, lm, lidx, q_morton, q_index)
-                                                                : narrow_eval(a.narrow, q_morton, q_index, lm, lidx);
-                        }
-                    }
-                    if (hit) {
-                        if constexpr (WRITE) {
-                            IndexPair<I> c;
-                            if constexpr (MODE == MODE_SELF) {
-                                c = q_index > lidx ? IndexPair<I>{lidx, q_index} : IndexPair<I>{q_index, lidx};
-                            } else if constexpr (MODE == MODE_PAIR) {
-                                c = a.flip ? IndexPair<I>{lidx, q_index} : IndexPair<I>{q_index, lidx};
-                            } else {
-                                c = IndexPair<I>{lidx, (I)(item + 1)};
-                            }
-                            a.contacts[w++] = c;
-                        } else {
-                            ++cnt;
-                        }
-                    }
-                }
-            } else {
-                N node = load_vol<N>(a.nodes + (inode - level_skips(levels, vl, level) - 1));
-                if constexpr (MODE == MODE_RAYS) descend = isintersection(node, p, d);
-                else descend = iscontact(q_node, node);
-            }
-        }
-        if (descend) { // the left child of a real node is always real
-            inode = 2 * inode;
-            level += 1;
-            continue;
-        }
-        // pre-order successor, never climbing above start_level
-        int64_t up = (int64_t)__builtin_ctzll((unsigned long long)(inode + 1));
-        int64_t room = level - a.start_level;
-        up = up < room ? up : room;
-        inode = (inode + 1) >> up;
-        level -= up;
-        if (inode - (int64_t(1) << (level - 1)) >= level_num_real(levels, vl, level)) break; // virtual / past the level
-    }
-    if constexpr (!WRITE) a.counts[item] = (I)cnt;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -552,6 +446,103 @@ __global__ __launch_bounds__(256) void lvt_cluster_kernel(Args<L, N, I> a, PairC
     q.finish();
 }
 
+// ---- (3) rays: per-lane walk ------------------------------------------------------------------------
+// The rays of a wave are not spatially coherent, so every lane walks on its own — but leaner than the
+// reference's loop (raytrace/leaf_vs_tree/leaf_vs_tree.jl:187-225): a step tests BOTH children of the
+// current node (adjacent in memory: one 48-byte fetch instead of two dependent ones) and the pending
+// right siblings are a 32-bit mask instead of a 32-entry stack, possible because the tree is implicit.
+// Visit order is the reference's (left subtree, then the pending sibling, deepest first), so the hits of a
+// ray come out in the same order.  Hit cache as for leaf queries (first K hits kept by the counting pass).
+template <class L, class N, class I, bool WRITE>
+__global__ __launch_bounds__(256) void lvt_rays_kernel(Args<L, N, I> a, PairCache<I> cache) {
+    using T = typename L::elt;
+    const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = item < a.n_items;
+    T p[3] = {0, 0, 0}, d[3] = {0, 0, 0};
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            p[k] = a.points[3 * item + k];
+            d[k] = a.dirs[3 * item + k];
+        }
+    }
+    int64_t w = 0, cnt = 0;
+    bool lane_on = valid;
+    if constexpr (WRITE) {
+        w = (valid && item > 0) ? (int64_t)a.counts[item - 1] : 0;
+        const int64_t mine = valid ? (int64_t)a.counts[item] - w : 0;
+        const bool over = mine > (int64_t)cache.K;
+        if (valid && !over)
+            for (int64_t k = 0; k < mine; ++k) a.contacts[w + k] = cache.slots[k * a.n_items + item];
+        if (__ballot(over) == 0) return;
+        lane_on = over;
+    }
+    auto emit = [&](I lidx) {
+        const IndexPair<I> c2{lidx, (I)(item + 1)}; // (leaf.index, iray), raytrace/lvt:200
+        if constexpr (WRITE) {
+            a.contacts[w++] = c2;
+        } else {
+            if (cnt < (int64_t)cache.K) cache.slots[cnt * a.n_items + item] = c2;
+            ++cnt;
+        }
+    };
+
+    const int levels = (int)a.tree.levels;
+    const uint32_t vl = (uint32_t)a.tree.virtual_leaves; // < 2^(levels-1) <= 2^31
+    const uint32_t leaf_first = 1u << (levels - 1);
+    const uint32_t n_leaves = (uint32_t)a.tree.real_leaves;
+    const int plevel = (int)a.start_level - 1;
+    const int64_t roots = level_num_real(a.tree.levels, a.tree.virtual_leaves, a.start_level);
+    const uint32_t pfirst = plevel >= 1 ? (1u << (plevel - 1)) : 0u;
+    const uint32_t pcount = (uint32_t)((roots + 1) / 2);
+
+    for (uint32_t pi = 0; pi < pcount; ++pi) { // uniform: pseudo-parents of the start-level roots
+        uint32_t inode = pfirst + pi;
+        int level = plevel;
+        uint32_t pend = 0;
+        bool alive = lane_on;
+        while (alive) {
+            const int cl = level + 1;
+            const uint32_t c0 = 2u * inode, c1 = c0 + 1u;
+            const uint32_t first = 1u << (cl - 1);
+            const uint32_t nreal = first - (uint32_t)((uint64_t)vl >> (levels - cl));
+            const bool real0 = c0 != 0u, real1 = (c1 - first) < nreal;
+            if (cl == levels) {
+                const char *rec = a.leaves + ((int64_t)c0 - (int64_t)leaf_first) * a.lay.stride; // c0 may be the pseudo node 0
+                if (real0 && isintersection(load_vol<L>(rec), p, d)) emit(load_index<I>(rec, a.lay));
+                if (real1 && isintersection(load_vol<L>(rec + a.lay.stride), p, d)) emit(load_index<I>(rec + a.lay.stride, a.lay));
+            } else {
+                const uint64_t v = (uint64_t)vl >> (levels - cl + 1);
+                const uint32_t sk = (uint32_t)(2 * v) - (uint32_t)__popcll(v); // level_skips(cl)
+                const N *np = a.nodes + ((int64_t)c0 - (int64_t)sk - 1);
+                const bool h0 = real0 && isintersection(load_vol<N>(real0 ? np : np + 1), p, d);
+                const bool h1 = real1 && isintersection(load_vol<N>(real1 ? np + 1 : np), p, d);
+                if (h0) {
+                    if (h1) pend |= 1u << cl;
+                    inode = c0;
+                    level = cl;
+                    continue;
+                }
+                if (h1) {
+                    inode = c1;
+                    level = cl;
+                    continue;
+                }
+            }
+            if (pend == 0) {
+                alive = false;
+            } else {
+                const int pl = 31 - __builtin_clz(pend);
+                pend &= ~(1u << pl);
+                inode = (inode >> (level - pl)) | 1u;
+                level = pl;
+            }
+        }
+    }
+    if constexpr (!WRITE)
+        if (valid) a.counts[item] = (I)cnt;
+}
+
 // ---- inclusive scan of the per-item counts (AK.accumulate!, traverse_single.jl:57) ---------------
 constexpr int SCAN_TPB = 256, SCAN_IPT = 16, SCAN_TILE = SCAN_TPB * SCAN_IPT;
 
@@ -689,8 +680,8 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
     unsigned blocks = (unsigned)ceil_div(a.n_items, 256);
     if constexpr (MODE == MODE_RAYS) {
         // rays of one wave are not spatially coherent: each lane walks on its own
-        if (write) IBVH_LAUNCH((lvt_kernel<L, N, I, MODE, true>), dim3(blocks), dim3(256), 0, st, a);
-        else IBVH_LAUNCH((lvt_kernel<L, N, I, MODE, false>), dim3(blocks), dim3(256), 0, st, a);
+        if (write) IBVH_LAUNCH((lvt_rays_kernel<L, N, I, true>), dim3(blocks), dim3(256), 0, st, a, cache);
+        else IBVH_LAUNCH((lvt_rays_kernel<L, N, I, false>), dim3(blocks), dim3(256), 0, st, a, cache);
     } else {
         // BBox nodes with at least one node level below the start level: frontier descent + brute force;
         // everything else (BSphere nodes, start_level == levels): the exact joint walk
@@ -723,7 +714,7 @@ int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const voi
     dl = wl;
     if (drv && !layout_of(drv->types, lay, &dl)) return IBVH_ERR_UNSUPPORTED;
     if (!scratch || scratch_bytes < scan_scratch_bytes(n_items)) return IBVH_ERR_SCRATCH;
-    const int K = MODE == MODE_RAYS ? 0 : cache_slots_for(scratch_bytes, n_items, lay.pair_bytes);
+    const int K = cache_slots_for(scratch_bytes, n_items, lay.pair_bytes);
     return dispatch_leaf_node(walk->types, [&](auto lt, auto nt) -> int {
         using L = typename decltype(lt)::type;
         using N = typename decltype(nt)::type;
