@@ -27,6 +27,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# kernels of the Morton+sort phase (extrema -> keys -> radix passes -> sorted records), priced at 152 B/leaf
+MORTON_SORT_KERNELS = ("extrema_partial_kernel", "extrema_final_kernel", "encode_kernel", "encode_hist_kernel", "hist_kernel",
+                       "scan_kernel", "scatter_kernel", "scatter_records_kernel", "gather_kernel")
 
 # Algorithmic bytes per LEAF and launch for the kernels of one step, for
 # BSphere{F32} leaves / BBox{F32} nodes / U32 / I32; C = contacts per leaf.
@@ -35,6 +38,8 @@ def algorithmic_bytes(kernel, n, contacts):
     table = {
         "extrema_partial_kernel": 16.0,            # read raw volumes
         "encode_kernel": 16.0 + 4.0,               # read volumes, write keys (positions are implicit)
+        "encode_hist_kernel": 16.0 + 4.0,          # same, fused with the first per-tile digit histogram
+        "scatter_records_kernel": 8.0 + 16.0 + 24.0,  # last pass: read (key, pos) + source volume, write the record
         "hist_kernel": 4.0,                        # read keys
         "scatter_kernel": 8.0 + 8.0,               # read + write (key, position)
         "gather_kernel": 4.0 + 4.0 + 16.0 + 24.0,  # perm + key + volume -> record
@@ -51,6 +56,8 @@ def algorithmic_bytes(kernel, n, contacts):
 def kernel_key(name):
     """'(lvt_kernel<L, N, I, MODE, true>)' -> 'lvt_kernel_write'."""
     base = name.strip("() ").split("<")[0].split("::")[-1].strip()
+    if base == "scatter_kernel" and "true>" in name.replace(" ", ""):
+        return "scatter_records_kernel"
     if base in ("lvt_kernel", "lvt_rays_kernel", "lvt_joint_kernel", "lvt_cluster_kernel"):
         return base + ("_write" if "true>" in name.replace(" ", "") else "_count")
     return base
@@ -181,8 +188,7 @@ def main():
                     "algorithmic_bytes_per_launch": int(ab), "avg_launch_ms": round(avg_s * 1e3, 5)}
         # Morton+sort phase (north star: >= 40 % of the HBM roofline on 152 B/leaf)
         ms_phase = sum(v["ms_per_step"] for k, v in kernels.items()
-                       if k in ("extrema_partial_kernel", "extrema_final_kernel", "encode_kernel", "hist_kernel",
-                                "scan_kernel", "scatter_kernel", "gather_kernel"))
+                       if k in MORTON_SORT_KERNELS)
         if ms_phase > 0:
             gbps = 152.0 * leaves_here / (ms_phase * 1e-3) / 1e9
             roofline["morton_sort_phase"] = {"ms": round(ms_phase, 4), "algorithmic_GBps": round(gbps, 1),
@@ -227,8 +233,7 @@ def main():
         torch.cuda.synchronize()
         prof2 = collect_profile(lib)
         lib.call("ibvh_profile_enable", 0)
-        phase = ("extrema_partial_kernel", "extrema_final_kernel", "encode_kernel", "hist_kernel", "scan_kernel",
-                 "scatter_kernel", "gather_kernel")
+        phase = MORTON_SORT_KERNELS
         ms_phase = sum(prof2[k][0] for k in phase if k in prof2) / 3
         ms_build = sum(v[0] for k, v in prof2.items() if not k.startswith(("lvt_", "scan_reduce", "scan_partials", "scan_apply"))) / 3
         gb = 152.0 * n2 / (ms_phase * 1e-3) / 1e9

@@ -12,8 +12,24 @@
 
 namespace ibvh {
 namespace rsort {
+struct RecordArgs {
+    const char *src;
+    char *dst;
+    int64_t src_stride;
+    int32_t src_wrapped;
+    int32_t vol_words;
+    int32_t index_bytes;
+    LeafLayout lay;
+};
+struct FirstPassPlan {
+    int tpb, ipt, num_tiles;
+    uint32_t *tile_hist;
+    uint32_t mask;
+};
+FirstPassPlan first_pass_plan(int64_t n, int key_bits, int key_bytes, void *scratch);
 int sort_pairs(int key_bytes, int key_bits, int64_t n, void *keys, void *vals, void *keys_alt, void *vals_alt,
-               bool vals_implicit, int32_t *result_in_alt, void *scratch, size_t scratch_sz, hipStream_t st);
+               bool vals_implicit, int32_t *result_in_alt, void *scratch, size_t scratch_sz, hipStream_t st,
+               bool first_hist_done, const RecordArgs *records);
 size_t scratch_bytes(int64_t n);
 } // namespace rsort
 
@@ -148,6 +164,35 @@ __global__ __launch_bounds__(256) void encode_kernel(const char *__restrict__ re
         center(v, c);
         keys[i] = (K)morton_encode_single(c, mins, maxs, morton_type);
     }
+}
+
+// Same, fused with the radix sort's first per-tile digit histogram: the workgroup encodes exactly the
+// keys of one sort tile and counts their lowest digit in LDS, so the sort's first hist pass (a 4 B/leaf
+// re-read of the keys plus a launch) disappears.
+template <class V, class K>
+__global__ __launch_bounds__(1024) void encode_hist_kernel(const char *__restrict__ recs, int64_t stride, int64_t n,
+                                                          const typename V::elt *__restrict__ ext, int morton_type,
+                                                          K *__restrict__ keys, int tile_elems, uint32_t mask,
+                                                          uint32_t *__restrict__ tile_hist, int num_tiles) {
+    using T = typename V::elt;
+    __shared__ uint32_t h[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const T mins[3] = {ext[0], ext[1], ext[2]}, maxs[3] = {ext[3], ext[4], ext[5]};
+    const int64_t base = (int64_t)blockIdx.x * tile_elems;
+    for (int j = threadIdx.x; j < tile_elems; j += blockDim.x) {
+        const int64_t i = base + j;
+        if (i < n) {
+            V v = load_vol<V>(recs + i * stride);
+            T c[3];
+            center(v, c);
+            const K k = (K)morton_encode_single(c, mins, maxs, morton_type);
+            keys[i] = k;
+            atomicAdd(&h[(uint32_t)k & mask], 1u);
+        }
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < 256; d += blockDim.x) tile_hist[(int64_t)d * num_tiles + blockIdx.x] = h[d];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -431,30 +476,47 @@ ibvh_status ibvh_build(const ibvh_build_desc *desc, const void *volumes, void *l
                                desc->mins[2], desc->maxs[0], desc->maxs[1], desc->maxs[2]);
         }
         if (extrema_out) IBVH_HIP_CHECK(hipMemcpyAsync(extrema_out, ext, 6 * sizeof(T), hipMemcpyDeviceToDevice, st));
-        // keys
-        if (int e = encode<L>(src, src_stride, n, ext, ty.morton_type, sc.keys, st)) return e;
-        // sort (key, position)
-        int32_t in_alt = 0;
-        if (int e = rsort::sort_pairs(key_bytes, morton_key_bits(ty.morton_type), n, sc.keys, sc.vals, sc.keys_alt,
-                                      sc.vals_alt, true, &in_alt, sc.sort, rsort::scratch_bytes(n), st))
-            return e;
-        const void *skeys = in_alt ? sc.keys_alt : sc.keys;
-        const uint32_t *sperm = (const uint32_t *)(in_alt ? sc.vals_alt : sc.vals);
-        // gather into Morton order.  In-place (already wrapped) builds go through scratch records.
-        char *dst = wrapped ? sc.records : (char *)leaves;
-        int gblocks = grid_for(n, 256, 256 * 16);
-        auto launch_gather = [&](auto it) -> int {
-            using I = typename decltype(it)::type;
-            if (key_bytes == 8)
-                IBVH_LAUNCH((gather_kernel<L, I, uint64_t>), dim3(gblocks), dim3(256), 0, st, src, src_stride,
-                                   wrapped ? 1 : 0, dlay, (const uint64_t *)skeys, sperm, n, dst);
-            else
-                IBVH_LAUNCH((gather_kernel<L, I, uint32_t>), dim3(gblocks), dim3(256), 0, st, src, src_stride,
-                                   wrapped ? 1 : 0, dlay, (const uint32_t *)skeys, sperm, n, dst);
-            return IBVH_OK;
-        };
-        if (int e = dispatch_index(ty.index_type, launch_gather)) return e;
+        // keys, fused with the first per-tile digit histogram of the sort
+        const int key_bits = morton_key_bits(ty.morton_type);
+        const rsort::FirstPassPlan plan = rsort::first_pass_plan(n, key_bits, key_bytes, sc.sort);
+        if (key_bytes == 8)
+            IBVH_LAUNCH((encode_hist_kernel<L, uint64_t>), dim3(plan.num_tiles), dim3(plan.tpb), 0, st, src, src_stride, n, ext,
+                        ty.morton_type, (uint64_t *)sc.keys, plan.tpb * plan.ipt, plan.mask, plan.tile_hist, plan.num_tiles);
+        else
+            IBVH_LAUNCH((encode_hist_kernel<L, uint32_t>), dim3(plan.num_tiles), dim3(plan.tpb), 0, st, src, src_stride, n, ext,
+                        ty.morton_type, (uint32_t *)sc.keys, plan.tpb * plan.ipt, plan.mask, plan.tile_hist, plan.num_tiles);
         IBVH_LAUNCH_CHECK();
+        // stable LSB radix sort of (key, position), then the records in Morton order
+        // (index = position + 1 for fresh volumes, build.jl:345-349, or the source record's own index, :220-222).
+        // In-place (already wrapped) builds go through scratch records.
+        // Below ~4 M leaves the LAST radix pass writes the finished records itself (one launch and one
+        // (key, position) round trip fewer: 0.157 -> 0.140 ms at 1e6); above, the dedicated gather kernel's higher
+        // occupancy serves the random volume reads better (measured at 1e7: 0.049 + 0.276 ms vs 0.350 ms fused).
+        char *dst = wrapped ? sc.records : (char *)leaves;
+        const bool fuse_records = n < (int64_t(1) << 22);
+        rsort::RecordArgs ra{src, dst, src_stride, wrapped ? 1 : 0, (int32_t)(lay.volume_bytes / 8),
+                             ty.index_type == IBVH_I32 ? 4 : 8, dlay};
+        int32_t in_alt = 0;
+        if (int e = rsort::sort_pairs(key_bytes, key_bits, n, sc.keys, sc.vals, sc.keys_alt, sc.vals_alt, true, &in_alt,
+                                      sc.sort, rsort::scratch_bytes(n), st, true, fuse_records ? &ra : nullptr))
+            return e;
+        if (!fuse_records) {
+            const void *skeys = in_alt ? sc.keys_alt : sc.keys;
+            const uint32_t *sperm = (const uint32_t *)(in_alt ? sc.vals_alt : sc.vals);
+            int gblocks = grid_for(n, 256, 256 * 16);
+            auto launch_gather = [&](auto it) -> int {
+                using I = typename decltype(it)::type;
+                if (key_bytes == 8)
+                    IBVH_LAUNCH((gather_kernel<L, I, uint64_t>), dim3(gblocks), dim3(256), 0, st, src, src_stride,
+                                wrapped ? 1 : 0, dlay, (const uint64_t *)skeys, sperm, n, dst);
+                else
+                    IBVH_LAUNCH((gather_kernel<L, I, uint32_t>), dim3(gblocks), dim3(256), 0, st, src, src_stride,
+                                wrapped ? 1 : 0, dlay, (const uint32_t *)skeys, sperm, n, dst);
+                return IBVH_OK;
+            };
+            if (int e = dispatch_index(ty.index_type, launch_gather)) return e;
+            IBVH_LAUNCH_CHECK();
+        }
         if (wrapped)
             IBVH_HIP_CHECK(hipMemcpyAsync(leaves, sc.records, (size_t)n * lay.leaf_bytes, hipMemcpyDeviceToDevice, st));
         // merge

@@ -12,6 +12,8 @@
 // Stability: ranks are assigned in tile order = memory order, so equal keys keep their order;
 // that is the single-task Base.sort! behaviour the oracle restates (tie order is unpinned in the
 // reference).
+#include <cstdlib>
+
 #include "ibvh_common.hpp"
 
 namespace ibvh {
@@ -81,12 +83,27 @@ __global__ __launch_bounds__(TPB) void scan_kernel(uint32_t *__restrict__ tile_h
 }
 
 // ---- scatter ------------------------------------------------------------------------------
-template <class K, int TPB, int IPT>
+// RECORDS = true (last pass of a BVH build): instead of writing (key, position) and gathering later, the
+// pass fetches the source volume at `position` and writes the finished BoundingVolume record straight to
+// its sorted place — the separate gather kernel and one (key, position) round trip through HBM disappear.
+// Type-generic at run time (volumes move as 8-byte words), so no extra template axis.
+struct RecordArgs {
+    const char *src;      // raw volumes or BoundingVolume records
+    char *dst;            // sorted BoundingVolume records
+    int64_t src_stride;
+    int32_t src_wrapped;  // 1: keep the source record's .index, 0: index = position + 1
+    int32_t vol_words;    // sizeof(V) / 8
+    int32_t index_bytes;  // 4 or 8
+    LeafLayout lay;
+};
+
+template <class K, int TPB, int IPT, bool RECORDS>
 __global__ __launch_bounds__(TPB) void scatter_kernel(const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                       K *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
                                                       int64_t n, int shift, uint32_t mask,
                                                       const uint32_t *__restrict__ tile_hist,
-                                                      const uint32_t *__restrict__ digit_total, int num_tiles) {
+                                                      const uint32_t *__restrict__ digit_total, int num_tiles,
+                                                      RecordArgs rec) {
     constexpr int W = TPB / 64;
     constexpr int TILE = TPB * IPT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -178,8 +195,24 @@ __global__ __launch_bounds__(TPB) void scatter_kernel(const K *__restrict__ keys
             K kk = s_keys[pos];
             uint32_t d = (uint32_t)(kk >> shift) & mask;
             uint32_t dest = (uint32_t)pos + delta[d];
-            keys_out[dest] = kk;
-            vals_out[dest] = s_vals[pos];
+            if constexpr (RECORDS) {
+                const uint32_t p = s_vals[pos];
+                const char *sp = rec.src + (int64_t)p * rec.src_stride;
+                char *dp = rec.dst + (int64_t)dest * rec.lay.stride;
+                const uint64_t *sw = (const uint64_t *)sp;
+                uint64_t *dw = (uint64_t *)dp;
+#pragma unroll
+                for (int wd = 0; wd < 6; ++wd)
+                    if (wd < rec.vol_words) dw[wd] = sw[wd];
+                if (rec.index_bytes == 4)
+                    *(int32_t *)(dp + rec.lay.index_off) = rec.src_wrapped ? *(const int32_t *)(sp + rec.lay.index_off) : (int32_t)(p + 1u);
+                else
+                    *(int64_t *)(dp + rec.lay.index_off) = rec.src_wrapped ? *(const int64_t *)(sp + rec.lay.index_off) : (int64_t)p + 1;
+                store_morton(dp, rec.lay, (uint64_t)kk);
+            } else {
+                keys_out[dest] = kk;
+                vals_out[dest] = s_vals[pos];
+            }
         }
     }
 }
@@ -192,9 +225,26 @@ struct Geometry {
     int tpb, ipt;
     int tile() const { return tpb * ipt; }
 };
+struct FirstPassPlan {
+    int tpb, ipt, num_tiles;
+    uint32_t *tile_hist;
+    uint32_t mask;
+};
 // Small inputs get small tiles so the grid still covers the 256 CUs; large inputs get 8192-element
 // tiles so that one digit's run in a tile is >= 128 B on average.
-inline Geometry choose_geometry(int64_t n) { return n >= (int64_t(1) << 22) ? Geometry{512, 16} : Geometry{256, 8}; }
+inline Geometry choose_geometry(int64_t n) {
+    static const int forced = [] {
+        const char *e = getenv("IBVH_SORT_TILE"); // tuning knob: 2048, 4096, 8192 or 16384 keys per tile
+        return e ? atoi(e) : 0;
+    }();
+    switch (forced) {
+    case 2048: return Geometry{256, 8};
+    case 4096: return Geometry{256, 16};
+    case 8192: return Geometry{512, 16};
+    case 16384: return Geometry{1024, 16};
+    }
+    return n >= (int64_t(1) << 22) ? Geometry{512, 16} : Geometry{256, 8};
+}
 
 size_t scratch_bytes(int64_t n) {
     int64_t tiles = ceil_div(n, 256 * 8); // upper bound over both geometries
@@ -203,14 +253,16 @@ size_t scratch_bytes(int64_t n) {
 
 template <class K, int TPB, int IPT>
 int run_passes(K *keys, uint32_t *vals, K *keys_alt, uint32_t *vals_alt, int64_t n, int key_bits, bool vals_implicit,
-               int32_t *result_in_alt, void *scratch, hipStream_t st) {
+               int32_t *result_in_alt, void *scratch, hipStream_t st, bool first_hist_done, const RecordArgs *records) {
     const int num_tiles = (int)ceil_div(n, TPB * IPT);
     uint32_t *tile_hist = (uint32_t *)scratch;
     uint32_t *digit_total = (uint32_t *)((char *)scratch + align_up((int64_t)RADIX * num_tiles * 4, 256));
     static bool attr_set = false;
     constexpr size_t smem = scatter_smem<K, TPB, IPT>();
     if (!attr_set) {
-        IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)scatter_kernel<K, TPB, IPT>,
+        IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)scatter_kernel<K, TPB, IPT, false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)scatter_kernel<K, TPB, IPT, true>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
@@ -220,12 +272,18 @@ int run_passes(K *keys, uint32_t *vals, K *keys_alt, uint32_t *vals_alt, int64_t
     for (int shift = 0; shift < key_bits; shift += RADIX_BITS) {
         int bits = key_bits - shift < RADIX_BITS ? key_bits - shift : RADIX_BITS;
         uint32_t mask = (1u << bits) - 1u;
-        IBVH_LAUNCH((hist_kernel<K, TPB, IPT>), dim3(num_tiles), dim3(TPB), 0, st, kin, n, shift, mask, tile_hist,
-                           num_tiles);
+        if (!(shift == 0 && first_hist_done))
+            IBVH_LAUNCH((hist_kernel<K, TPB, IPT>), dim3(num_tiles), dim3(TPB), 0, st, kin, n, shift, mask, tile_hist,
+                        num_tiles);
         IBVH_LAUNCH((scan_kernel<256>), dim3(RADIX), dim3(256), 0, st, tile_hist, num_tiles, digit_total);
-        IBVH_LAUNCH((scatter_kernel<K, TPB, IPT>), dim3(num_tiles), dim3(TPB), smem, st, kin,
-                           (shift == 0 && vals_implicit) ? (const uint32_t *)nullptr : vin, kout, vout, n, shift, mask,
-                           tile_hist, digit_total, num_tiles);
+        const uint32_t *vsrc = (shift == 0 && vals_implicit) ? (const uint32_t *)nullptr : vin;
+        const bool last = shift + RADIX_BITS >= key_bits;
+        if (last && records)
+            IBVH_LAUNCH((scatter_kernel<K, TPB, IPT, true>), dim3(num_tiles), dim3(TPB), smem, st, kin, vsrc, kout, vout, n,
+                        shift, mask, tile_hist, digit_total, num_tiles, *records);
+        else
+            IBVH_LAUNCH((scatter_kernel<K, TPB, IPT, false>), dim3(num_tiles), dim3(TPB), smem, st, kin, vsrc, kout, vout, n,
+                        shift, mask, tile_hist, digit_total, num_tiles, RecordArgs{});
         IBVH_LAUNCH_CHECK();
         K *tk = kin;
         kin = kout;
@@ -240,27 +298,47 @@ int run_passes(K *keys, uint32_t *vals, K *keys_alt, uint32_t *vals_alt, int64_t
 }
 
 // vals_implicit: the values of the first pass are the element positions 0..n-1 (vals is not read).
+// Where the first pass expects its per-tile histogram ([RADIX][num_tiles], digit-major) and the tile
+// geometry it will use, for a producer that fuses that histogram into its own pass (ibvh_build.hip).
+FirstPassPlan first_pass_plan(int64_t n, int key_bits, int key_bytes, void *scratch) {
+    Geometry g = choose_geometry(n);
+    if (key_bytes == 8 && g.tpb == 1024) g = Geometry{512, 16}; // same fallback as sort_pairs
+    FirstPassPlan p;
+    p.tpb = g.tpb;
+    p.ipt = g.ipt;
+    p.num_tiles = (int)ceil_div(n, g.tile());
+    p.tile_hist = (uint32_t *)scratch;
+    p.mask = (1u << (key_bits < RADIX_BITS ? key_bits : RADIX_BITS)) - 1u;
+    return p;
+}
+
 int sort_pairs(int key_bytes, int key_bits, int64_t n, void *keys, void *vals, void *keys_alt, void *vals_alt,
-               bool vals_implicit, int32_t *result_in_alt, void *scratch, size_t scratch_sz, hipStream_t st) {
+               bool vals_implicit, int32_t *result_in_alt, void *scratch, size_t scratch_sz, hipStream_t st,
+               bool first_hist_done, const RecordArgs *records) {
     if (n < 0 || n >= (int64_t(1) << 32) || key_bits < 1 || key_bits > key_bytes * 8) return IBVH_ERR_INVALID_ARG;
     if (scratch_sz < scratch_bytes(n)) return IBVH_ERR_SCRATCH;
     *result_in_alt = 0;
     if (n == 0) return IBVH_OK;
     Geometry g = choose_geometry(n);
+#define IBVH_SORT_CASE(K, T, P)                                                                                       \
+    if (g.tpb == T && g.ipt == P)                                                                                     \
+        return run_passes<K, T, P>((K *)keys, (uint32_t *)vals, (K *)keys_alt, (uint32_t *)vals_alt, n, key_bits,     \
+                                   vals_implicit, result_in_alt, scratch, st, first_hist_done, records);
     if (key_bytes == 4) {
-        if (g.tpb == 512)
-            return run_passes<uint32_t, 512, 16>((uint32_t *)keys, (uint32_t *)vals, (uint32_t *)keys_alt,
-                                                 (uint32_t *)vals_alt, n, key_bits, vals_implicit, result_in_alt, scratch, st);
-        return run_passes<uint32_t, 256, 8>((uint32_t *)keys, (uint32_t *)vals, (uint32_t *)keys_alt, (uint32_t *)vals_alt,
-                                            n, key_bits, vals_implicit, result_in_alt, scratch, st);
+        IBVH_SORT_CASE(uint32_t, 256, 8)
+        IBVH_SORT_CASE(uint32_t, 256, 16)
+        IBVH_SORT_CASE(uint32_t, 512, 16)
+        IBVH_SORT_CASE(uint32_t, 1024, 16)
     }
     if (key_bytes == 8) {
-        if (g.tpb == 512)
-            return run_passes<uint64_t, 512, 16>((uint64_t *)keys, (uint32_t *)vals, (uint64_t *)keys_alt,
-                                                 (uint32_t *)vals_alt, n, key_bits, vals_implicit, result_in_alt, scratch, st);
-        return run_passes<uint64_t, 256, 8>((uint64_t *)keys, (uint32_t *)vals, (uint64_t *)keys_alt, (uint32_t *)vals_alt,
-                                            n, key_bits, vals_implicit, result_in_alt, scratch, st);
+        IBVH_SORT_CASE(uint64_t, 256, 8)
+        IBVH_SORT_CASE(uint64_t, 256, 16)
+        IBVH_SORT_CASE(uint64_t, 512, 16)
+        if (g.tpb == 1024) // 16384 x 12 B does not fit the LDS: fall back to 8192
+            return run_passes<uint64_t, 512, 16>((uint64_t *)keys, (uint32_t *)vals, (uint64_t *)keys_alt, (uint32_t *)vals_alt, n,
+                                                 key_bits, vals_implicit, result_in_alt, scratch, st, first_hist_done, records);
     }
+#undef IBVH_SORT_CASE
     return IBVH_ERR_INVALID_ARG;
 }
 
@@ -280,7 +358,7 @@ ibvh_status ibvh_sort_pairs(int32_t key_bytes, int32_t key_bits, int64_t n, void
     if (!result_in_alt) return IBVH_ERR_INVALID_ARG;
     if (n > 0 && (!keys || !vals || !keys_alt || !vals_alt || !scratch)) return IBVH_ERR_INVALID_ARG;
     return (ibvh_status)ibvh::rsort::sort_pairs(key_bytes, key_bits, n, keys, vals, keys_alt, vals_alt, false,
-                                                result_in_alt, scratch, scratch_bytes, (hipStream_t)stream);
+                                                result_in_alt, scratch, scratch_bytes, (hipStream_t)stream, false, nullptr);
 }
 
 } // extern "C"
