@@ -26,7 +26,7 @@ import numpy as np
 from . import abi, lib
 
 __all__ = [
-    "BSphere", "BBox", "BoundingVolumes", "BVHOptions", "DefaultMortonAlgorithm", "ImplicitTree", "BVH",
+    "load_obj_triangles", "BSphere", "BBox", "BoundingVolumes", "BVHOptions", "DefaultMortonAlgorithm", "ImplicitTree", "BVH",
     "BVHTraversal", "LVTTraversal", "BFSTraversal", "traverse", "traverse_rays", "default_start_level",
     "memory_index", "level_indices", "isvirtual", "bounding_volumes_from_triangles", "generate_spheres",
     "NARROW_MORTON_LT", "NARROW_INDEX_LT",
@@ -372,6 +372,24 @@ class BVH:
         lib.call("ibvh_build", C.byref(d), vol_ptr, _ptr(self.leaves.buf), _ptr(self.nodes), _ptr(self.skips),
                  _ptr(self.extrema), _ptr(self._scratch), self._scratch.numel(), _stream())
 
+    @classmethod
+    def from_buffers(cls, types, n, leaves_buf, nodes, built_level=1):
+        """Wrap existing device buffers (sorted BoundingVolume records + node array, e.g. received from a peer
+        GPU) as a BVH without building anything; skips are recomputed from the tree shape."""
+        torch = _require_gpu()
+        self = cls.__new__(cls)
+        self.types = types
+        self.tree = ImplicitTree(n)
+        self.built_level = int(built_level)
+        self.leaves = BoundingVolumes(types, n, leaves_buf)
+        self.nodes = nodes
+        sk = (C.c_int64 * self.tree.levels)()
+        lib.call("ibvh_compute_skips", C.byref(self.tree._t), sk)
+        self.skips = torch.tensor(list(sk), dtype=_torch_index(types.index_type), device="cuda")
+        self.extrema = None
+        self._scratch = None
+        return self
+
     def struct(self):
         b = abi.Bvh()
         b.types = self.types
@@ -636,6 +654,30 @@ def bounding_volumes_from_triangles(triangles, volume_type=None):
     out = torch.empty((t.shape[0], abi.volume_width(vt.kind)), dtype=t.dtype, device="cuda")
     lib.call("ibvh_volumes_from_triangles", vt.kind, vt.flt, _ptr(t), t.shape[0], _ptr(out), _stream())
     return out
+
+
+def load_obj_triangles(path, dtype=None):
+    """Minimal Wavefront OBJ reader (`v x y z` / `f a b c ...`, 1-based or negative indices, `a/b/c` forms,
+    polygons fan-triangulated) -> (n, 3, 3) CUDA tensor of triangles, the input of
+    bounding_volumes_from_triangles.  Stands in for MeshIO/FileIO in the reference's benchmark scripts
+    (benchmark/bvh_contact.jl:30-36); parsing is host-side file I/O, not part of the hot path."""
+    torch = _require_gpu()
+    verts, faces = [], []
+    with open(path) as f:
+        for line in f:
+            if line.startswith("v "):
+                verts.append([float(x) for x in line.split()[1:4]])
+            elif line.startswith("f "):
+                idx = [int(tok.split("/")[0]) for tok in line.split()[1:]]
+                idx = [i - 1 if i > 0 else len(verts) + i for i in idx]
+                for k in range(1, len(idx) - 1):
+                    faces.append([idx[0], idx[k], idx[k + 1]])
+    v = np.asarray(verts, dtype=np.float64).reshape(-1, 3)
+    fa = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+    if len(fa) and (fa.min() < 0 or fa.max() >= len(v)):
+        raise ValueError("OBJ face index out of range")
+    tri = v[fa] if len(fa) else np.zeros((0, 3, 3))
+    return torch.from_numpy(tri).to(device="cuda", dtype=dtype or torch.float32)
 
 
 def generate_spheres(n, seed, first_index=0, origin=(0.0, 0.0, 0.0), extent=(1.0, 1.0, 1.0), r0=0.01):

@@ -143,6 +143,50 @@ class HipEngine:
     def to_host(self, t):
         return t.cpu().numpy()
 
+    # ---- cross-shard completion ------------------------------------------------------------------
+    def root_box(self, bvh):
+        """(lo, up) of the slice as 6 float64: the root node, or the single leaf's box."""
+        torch = self.torch
+        if bvh.nodes.shape[0] > 0:
+            v = bvh.nodes[0].to(torch.float64)
+        else:
+            v = bvh.leaves.volume[0].to(torch.float64)
+        if v.numel() == 4:  # sphere -> its box (conservative in float64)
+            v = torch.cat([v[:3] - v[3], v[:3] + v[3]])
+        return v
+
+    def export(self, bvh):
+        """leaves ‖ nodes as one byte tensor for the peer copy."""
+        torch = self.torch
+        return torch.cat([bvh.leaves.buf.view(torch.uint8), bvh.nodes.contiguous().view(torch.uint8).reshape(-1)])
+
+    def import_(self, types, n, buf):
+        torch = self.torch
+        lay = abi.Layout()
+        lib.call("ibvh_layout_of", C.byref(types), C.byref(lay))
+        lb = n * lay.leaf_bytes
+        tree = api.ImplicitTree(n)
+        nn = tree.real_nodes - tree.real_leaves
+        leaves = buf[:lb].clone()
+        ndt = api._torch_float(types.node_float)
+        nodes = buf[lb:lb + nn * lay.node_bytes].clone().view(ndt).reshape(nn, abi.volume_width(types.node_kind))
+        return api.BVH.from_buffers(types, n, leaves, nodes)
+
+    def export_bytes(self, types, n):
+        lay = abi.Layout()
+        lib.call("ibvh_layout_of", C.byref(types), C.byref(lay))
+        tree = api.ImplicitTree(n)
+        return n * lay.leaf_bytes + (tree.real_nodes - tree.real_leaves) * lay.node_bytes
+
+    def pair_contacts(self, bvh_a, bvh_b):
+        return api.traverse(bvh_a, bvh_b).contacts
+
+    def empty_contacts(self, types):
+        return self.torch.empty((0, 2), dtype=api._torch_index(types.index_type), device=self.device)
+
+    def cat(self, ts):
+        return self.torch.cat(ts)
+
 
 # ---------------------------------------------------------------------------------------------
 # splitter search (identical arithmetic on every rank)
@@ -247,7 +291,50 @@ class DistributedBuilder:
         self.last = {"splitters": splitters, "send_counts": send_counts, "recv_counts": recv_counts, "base": base,
                      "n_global": n_global, "extrema": ext_host}
         # 4. local build over the received slice
-        return eng.build_local(types, recv, n_recv, ext_host, node_type, options, cache)
+        bvh = eng.build_local(types, recv, n_recv, ext_host, node_type, options, cache)
+        self.last["types"] = types
+        self.last["n_slice"] = n_recv
+        return bvh
+
+    def cross_contacts(self, bvh):
+        """Cross-shard contact completion: contacts between leaves of DIFFERENT slices.
+
+        Root boxes of all slices are all-gathered; for every pair of slices (r < s) whose root boxes touch, rank s
+        copies its sorted leaves + nodes to rank r over xGMI and rank r runs the ordinary pair traversal
+        (ibvh_traverse_pair_lvt_*) of its tree against the received one.  Returns this rank's share as an (m, 2)
+        tensor of GLOBAL 1-based indices (index in own slice, index in the other slice).  The union over ranks of
+        the per-slice self contacts and these pairs is the contact set of the whole cloud."""
+        eng, comm = self.engine, self.comm
+        torch = api._torch()
+        types = self.last["types"]
+        P, me = comm.size, comm.rank
+        boxes = eng.tensor([[0.0] * 6] * P, torch.float64)
+        boxes[me] = eng.root_box(bvh)
+        comm.all_reduce(boxes, "sum")
+        sizes = eng.tensor([0] * P, torch.int64)
+        sizes[me] = self.last["n_slice"]
+        comm.all_reduce(sizes, "sum")
+        bx, sz = eng.to_host(boxes), eng.to_host(sizes).tolist()
+
+        def touch(a, b):
+            return bool(np.all(bx[a][3:] >= bx[b][:3]) and np.all(bx[a][:3] <= bx[b][3:]))
+        out = []
+        payload = None
+        for d in range(1, P):  # round d: rank s sends to rank s - d (if their boxes touch)
+            dst, src = me - d, me + d
+            send_counts, recv_counts = [0] * P, [0] * P
+            if dst >= 0 and touch(dst, me):
+                if payload is None:
+                    payload = eng.export(bvh)
+                send_counts[dst] = payload.numel()
+            if src < P and touch(me, src):
+                recv_counts[src] = eng.export_bytes(types, sz[src])
+            send = payload if sum(send_counts) else eng.tensor([], torch.uint8)
+            recv = comm.all_to_all(send, send_counts, recv_counts)
+            if sum(recv_counts):
+                other = eng.import_(types, sz[src], recv)
+                out.append(eng.pair_contacts(bvh, other))
+        return eng.cat(out) if out else eng.empty_contacts(types)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -77,6 +77,39 @@ class OracleEngine:
     def to_host(self, t):
         return t.numpy()
 
+    # cross-shard completion
+    def root_box(self, bvh):
+        if len(bvh.nodes):
+            v = bvh.nodes[0]
+            return torch.tensor(np.concatenate([v["lo"], v["up"]]).astype(np.float64))
+        s = bvh.leaves["volume"][0]
+        return torch.tensor(np.concatenate([s["x"] - s["r"], s["x"] + s["r"]]).astype(np.float64))
+
+    def export(self, bvh):
+        return torch.from_numpy(np.concatenate([bvh.leaves.view(np.uint8), bvh.nodes.view(np.uint8)]).copy())
+
+    def export_bytes(self, types, n):
+        t = orc.tree_shape(n)
+        return n * abi.leaf_dtype(types).itemsize + (t.real_nodes - t.real_leaves) * abi.node_dtype(types).itemsize
+
+    def import_(self, types, n, buf):
+        t = orc.tree_shape(n)
+        lb = n * abi.leaf_dtype(types).itemsize
+        leaves = buf.numpy()[:lb].copy().view(abi.leaf_dtype(types))
+        nodes = buf.numpy()[lb:].copy().view(abi.node_dtype(types))
+        skips = orc.compute_skips(t).astype(abi.INDEX_DTYPES[types.index_type])
+        return orc.HostBVH(types, t, 1, leaves, nodes, skips, None)
+
+    def pair_contacts(self, a, b):
+        c = orc.traverse_pair_lvt(a, b)[0]
+        return torch.from_numpy(np.stack([c["a"], c["b"]], axis=1).astype(np.int64).reshape(-1, 2))
+
+    def empty_contacts(self, types):
+        return torch.zeros((0, 2), dtype=torch.int64)
+
+    def cat(self, ts):
+        return torch.cat(ts)
+
 
 def cloud(n, seed, kind=abi.BSPHERE, dtype=np.float32):
     rng = np.random.default_rng(seed)
@@ -151,6 +184,33 @@ def test_virtual_ranks_cpu(world):
     sizes = [len(o[0]) for o in out]
     assert max(sizes) - min(sizes) <= 8
     assert all(o[1]["splitters"] == out[0][1]["splitters"] for o in out)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_cross_shard_completion_cpu(world):
+    """Per-slice self contacts + cross-slice pair contacts == contact set of the single-device build."""
+    n = 6007
+    rng = np.random.default_rng(21)
+    vols = np.concatenate([rng.random((n, 3)) * 4, 0.05 + 0.1 * rng.random((n, 1))], axis=1).astype(np.float32)
+    types = abi.make_types()
+    single = orc.build(vols, types)
+    c = orc.traverse_lvt(single)[0]
+    want = set(zip(c["a"].tolist(), c["b"].tolist()))
+    b = shard_bounds(n, world)
+
+    def fn(comm):
+        builder = ibd.DistributedBuilder(comm, engine=OracleEngine())
+        bvh = builder.build(torch.from_numpy(vols[b[comm.rank]:b[comm.rank + 1]].copy()))
+        own = orc.traverse_lvt(bvh)[0]
+        cross = builder.cross_contacts(bvh).numpy()
+        return set(zip(own["a"].tolist(), own["b"].tolist())), {(min(x, y), max(x, y)) for x, y in cross.tolist()}
+    out = ibd.run_virtual_ranks(world, fn)
+    got = set()
+    total = 0
+    for own, cross in out:
+        total += len(own) + len(cross)
+        got |= own | cross
+    assert total == len(got) and got == want and len(want) > n
 
 
 def test_heavy_duplicates_and_uneven_shards():

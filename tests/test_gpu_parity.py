@@ -449,6 +449,36 @@ def test_distributed_build_virtual_ranks_gpu(world):
     assert max(sizes) - min(sizes) <= 8
 
 
+@pytest.mark.parametrize("world", [2, 5])
+def test_cross_shard_completion_gives_the_global_contact_set(world):
+    """per-slice self contacts + cross-slice pair contacts == contacts of the whole cloud."""
+    from implicitbvh_amd import dist as ibd
+    n = 60011
+    r0 = 0.5 * (3 * 8 / (4 * np.pi * n)) ** (1 / 3)
+    host = orc.generate_spheres_f32(n, 47, r0=r0)
+    want = {tuple(p) for p in oracle_pairs(orc.traverse_lvt(orc.build(host, abi.make_types()))[0]).tolist()}
+    bounds = [n * r // world for r in range(world + 1)]
+
+    def fn(comm):
+        vols = ibvh.generate_spheres(bounds[comm.rank + 1] - bounds[comm.rank], 47, first_index=bounds[comm.rank], r0=r0)
+        builder = ibd.DistributedBuilder(comm)
+        bvh = builder.build(vols)
+        own = contacts_np(ibvh.traverse(bvh))
+        cross = builder.cross_contacts(bvh).cpu().numpy().astype(np.int64)
+        torch.cuda.synchronize()
+        return own, cross
+    out = ibd.run_virtual_ranks(world, fn)
+    got = set()
+    total = 0
+    for own, cross in out:
+        total += len(own) + len(cross)
+        got |= {tuple(p) for p in own.tolist()}
+        got |= {(min(a, b), max(a, b)) for a, b in cross.tolist()}
+    assert total == len(got)  # nothing reported twice
+    assert got == want
+    assert sum(len(c) for _, c in out) > 0
+
+
 # ---------------------------------------------------------------------------------------------
 # input preparation
 # ---------------------------------------------------------------------------------------------
@@ -461,6 +491,29 @@ def test_triangle_volumes_bit_exact():
             exp = orc.volumes_from_triangles(kind, flt, tris.reshape(-1, 9))
             got = ibvh.bounding_volumes_from_triangles(cuda(tris), tok(tdt))
             assert got.cpu().numpy().tobytes() == exp.tobytes()
+
+
+def test_obj_ingest_to_contacts(tmp_path):
+    """OBJ -> triangles -> bounding spheres -> BVH -> contacts, against the oracle on the same triangles."""
+    obj = tmp_path / "quad_strip.obj"
+    lines = ["# strip of quads"]
+    nx = 40
+    for i in range(nx + 1):
+        lines += [f"v {i * 0.5} 0 {0.1 * (i % 3)}", f"v {i * 0.5} 1 {0.05 * (i % 5)}"]
+    for i in range(nx):
+        a, b, c, d = 2 * i + 1, 2 * i + 2, 2 * i + 4, 2 * i + 3
+        lines.append(f"f {a}/1/1 {b}/2/2 {c}/3/3 {d}/4/4" if i % 2 else f"f {a} {b} {c} {d}")
+    lines.append("f -1 -2 -3")
+    obj.write_text("\n".join(lines))
+    tris = ibvh.load_obj_triangles(str(obj))
+    assert tris.shape == (2 * nx + 1, 3, 3)
+    vols = ibvh.bounding_volumes_from_triangles(tris)
+    host = tris.cpu().numpy().reshape(-1, 9)
+    exp = orc.volumes_from_triangles(abi.BSPHERE, abi.F32, host)
+    assert vols.cpu().numpy().tobytes() == exp.tobytes()
+    g = ibvh.BVH(vols)
+    o = orc.build(vols.cpu().numpy(), abi.make_types())
+    assert (contacts_np(ibvh.traverse(g)) == oracle_pairs(orc.traverse_lvt(o)[0])).all()
 
 
 # ---------------------------------------------------------------------------------------------
