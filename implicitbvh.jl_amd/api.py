@@ -296,7 +296,8 @@ class BVH:
     Fields: built_level, tree, skips, nodes, leaves (+ extrema: the expanded Morton bounds, device tensor).
     """
 
-    def __init__(self, bounding_volumes, node_type=None, built_level=1, cache: Optional["BVH"] = None, options=None):
+    def __init__(self, bounding_volumes, node_type=None, built_level=1, cache: Optional["BVH"] = None, options=None,
+                 _out_of_place=False):
         torch = _require_gpu()
         options = options or BVHOptions()
         node_type = node_type or BBox(torch.float32)  # default BBox{Float32} (build.jl:200)
@@ -350,7 +351,13 @@ class BVH:
         lib.call("ibvh_build_scratch_bytes", C.byref(types), n, C.byref(need))
         if self._scratch is None or self._scratch.numel() < need.value:
             self._scratch = torch.empty(need.value, dtype=torch.uint8, device="cuda")
-        if wrapped:
+        if wrapped and _out_of_place:
+            # source records stay untouched, the sorted records go to a (reused) buffer of their own
+            nbytes = n * abi.leaf_dtype(types).itemsize
+            reuse = cache is not None and cache.leaves.buf.numel() == nbytes and cache.leaves.buf.data_ptr() != bounding_volumes.buf.data_ptr()
+            self.leaves = BoundingVolumes(types, n, cache.leaves.buf if reuse else torch.empty(nbytes, dtype=torch.uint8, device="cuda"))
+            vol_ptr = _ptr(bounding_volumes.buf)
+        elif wrapped:
             self.leaves = bounding_volumes
             self.leaves.types = types  # node type is not part of the record layout
             vol_ptr = C.c_void_p(0)

@@ -456,7 +456,10 @@ ibvh_status ibvh_build(const ibvh_build_desc *desc, const void *volumes, void *l
     if (scratch_bytes < sc.total) return IBVH_ERR_SCRATCH;
     hipStream_t st = (hipStream_t)stream;
 
-    const char *src = wrapped ? (const char *)leaves : (const char *)volumes;
+    // already_wrapped with a non-NULL `volumes`: `volumes` holds the source RECORDS and `leaves` receives the sorted
+    // ones (out of place: no staging copy); with volumes == NULL the caller's `leaves` are sorted in place.
+    const bool out_of_place = wrapped && volumes != nullptr;
+    const char *src = wrapped ? (out_of_place ? (const char *)volumes : (const char *)leaves) : (const char *)volumes;
     const int64_t src_stride = wrapped ? lay.leaf_bytes : lay.volume_bytes;
 
     int rc = dispatch_leaf_node(ty, [&](auto lt, auto nt) -> int {
@@ -492,7 +495,7 @@ ibvh_status ibvh_build(const ibvh_build_desc *desc, const void *volumes, void *l
         // Below ~4 M leaves the LAST radix pass writes the finished records itself (one launch and one
         // (key, position) round trip fewer: 0.157 -> 0.140 ms at 1e6); above, the dedicated gather kernel's higher
         // occupancy serves the random volume reads better (measured at 1e7: 0.049 + 0.276 ms vs 0.350 ms fused).
-        char *dst = wrapped ? sc.records : (char *)leaves;
+        char *dst = (wrapped && !out_of_place) ? sc.records : (char *)leaves;
         const bool fuse_records = n < (int64_t(1) << 22);
         rsort::RecordArgs ra{src, dst, src_stride, wrapped ? 1 : 0, (int32_t)(lay.volume_bytes / 8),
                              ty.index_type == IBVH_I32 ? 4 : 8, dlay};
@@ -517,7 +520,7 @@ ibvh_status ibvh_build(const ibvh_build_desc *desc, const void *volumes, void *l
             if (int e = dispatch_index(ty.index_type, launch_gather)) return e;
             IBVH_LAUNCH_CHECK();
         }
-        if (wrapped)
+        if (wrapped && !out_of_place)
             IBVH_HIP_CHECK(hipMemcpyAsync(leaves, sc.records, (size_t)n * lay.leaf_bytes, hipMemcpyDeviceToDevice, st));
         // merge
         return aggregate<L, N>((const char *)leaves, lay.leaf_bytes, tree, desc->built_level, (N *)nodes, st);

@@ -3,12 +3,13 @@
 The reference is single-device; this is the MI355X-native scaling path BASELINE.json's north star asks
 for.  Only the BUILD communicates; traversal stays per GPU:
 
-  1. per-GPU centre extrema (ibvh_extrema, unexpanded)  ->  RCCL all-reduce (MIN on mins, MAX on maxs):
-     min/max are exact, so the global AABB — and after the same epsilon expansion the Morton codes —
-     are bit-identical to the single-device build (morton/utils.jl:1-72);
+  1. per-GPU centre extrema (ibvh_extrema, unexpanded)  ->  ONE RCCL all-reduce(MAX) of [-mins, maxs, one-hot
+     leaf counts] in float64: min/max are exact, so the global AABB — and after the same epsilon expansion
+     the Morton codes — are bit-identical to the single-device build (morton/utils.jl:1-72);
   2. per-GPU Morton keys (ibvh_morton_keys);
   3. distributed radix sort: splitter keys found by refining 12-bit digit histograms from the top of the
-     key (ibvh_key_histogram, one all-reduce(SUM) of <= 15 x 4096 counters per level), so that rank r
+     key (ibvh_key_histogram, one all-reduce(SUM) of <= 15 x 4096 counters per level; normally ONE level:
+     refinement stops once a splitter's bucket is lighter than 0.2 % of a shard), so that rank r
      receives the keys in [k_r, k_{r+1}); stable partition of the local leaves by destination
      (one pass of the radix sort), pack into BoundingVolume records whose .index is the GLOBAL 1-based
      leaf number (ibvh_pack_records), ONE all-to-all of the records over xGMI;
@@ -49,6 +50,13 @@ class TorchComm:
         ops = {"min": self.dist.ReduceOp.MIN, "max": self.dist.ReduceOp.MAX, "sum": self.dist.ReduceOp.SUM}
         self.dist.all_reduce(t, op=ops[op], group=self.group)
         return t
+
+    def all_gather(self, t):
+        """1-D tensor (same length on every rank) -> (size, len) tensor, row r from rank r."""
+        import torch
+        rows = [torch.empty_like(t) for _ in range(self.size)]
+        self.dist.all_gather(rows, t.contiguous(), group=self.group)  # list form: works on gloo and RCCL alike
+        return torch.stack(rows)
 
     def all_to_all(self, send, send_counts, recv_counts):
         """send: 1-D tensor partitioned by destination (send_counts elements each) -> received 1-D tensor."""
@@ -101,8 +109,9 @@ class HipEngine:
                  len(prefixes), api._ptr(out), api._stream())
         return out.to(torch.int64)
 
-    def partition(self, keys, splitters, nranks):
-        """Stable partition of the local leaves by destination rank: (perm, counts per rank)."""
+    def partition(self, keys, splitters, nranks, known_counts=None):
+        """Stable partition of the local leaves by destination rank: (perm, counts per rank).  `known_counts`:
+        the per-destination counts when the caller already derived them (saves a bincount + host sync)."""
         torch = self.torch
         n = keys.numel()
         if nranks == 1:
@@ -111,7 +120,7 @@ class HipEngine:
             dest = torch.bucketize(keys, torch.tensor(splitters, dtype=keys.dtype, device=self.device), right=True).to(torch.int32)
         else:
             dest = torch.zeros(n, dtype=torch.int32, device=self.device)
-        counts = torch.bincount(dest, minlength=nranks).cpu().tolist()
+        counts = known_counts if known_counts is not None else torch.bincount(dest, minlength=nranks).cpu().tolist()
         vals = torch.arange(n, dtype=torch.int32, device=self.device)
         d2, v2 = torch.empty_like(dest), torch.empty_like(vals)
         need = C.c_size_t()
@@ -138,7 +147,7 @@ class HipEngine:
                                            maxs=tuple(float(v) for v in ext_host[3:]))
         opts = api.BVHOptions(index=options.index, morton=fixed, block_size=options.block_size)
         bv = api.BoundingVolumes(types, n, records)
-        return api.BVH(bv, node_type, cache=cache, options=opts)
+        return api.BVH(bv, node_type, cache=cache, options=opts, _out_of_place=True)
 
     def to_host(self, t):
         return t.cpu().numpy()
@@ -194,38 +203,57 @@ class HipEngine:
 DIGIT_BITS = 12
 
 
-def find_splitters(engine, comm, keys, key_bits, n_global):
-    """Keys k_1 <= ... <= k_{P-1}: rank r receives the keys in [k_r, k_{r+1}).  k_s is the key value at which
-    the global cumulative count first exceeds the balanced target s*N/P, so #(keys < k_s) <= s*N/P."""
+def find_splitters(engine, comm, keys, key_bits, n_global, tolerance=0.002, first_hist=None):
+    """Keys k_1 <= ... <= k_{P-1}: rank r receives the keys in [k_r, k_{r+1}).
+
+    Digit histograms are refined from the top of the key, 12 bits per level (one all-reduce(SUM) of <= 15 x 4096
+    counters each).  After a level, splitter s sits on the digit whose cumulative count first exceeds the balanced
+    target s*N/P; the digits below it are decided, and the splitter may stop there (k_s = prefix << remaining bits)
+    once the bucket it landed in holds at most tolerance*N/P keys — the imbalance it can cause.  tolerance = 0
+    refines to full key resolution: #(keys < k_s) <= s*N/P < #(keys <= k_s).  `first_hist`: the already reduced
+    level-0 histogram (host array), when the caller has folded it into an earlier collective."""
     P = comm.size
     if P == 1:
-        return []
+        return [], 0
     targets = [s * n_global // P for s in range(1, P)]
-    prefix = [0] * (P - 1)  # bits decided so far, as a value
-    below = [0] * (P - 1)   # global number of keys strictly below the decided prefix range
+    allowed = tolerance * n_global / P
+    prefix = [0] * (P - 1)   # bits decided so far, as a value
+    below = [0] * (P - 1)    # global number of keys strictly below the decided prefix range
+    done = [False] * (P - 1)
+    final = [0] * (P - 1)
     decided = 0
-    while decided < key_bits:
+    while decided < key_bits and not all(done):
         bits = min(DIGIT_BITS, key_bits - decided)
         shift = key_bits - decided - bits
         if decided == 0:
             rows, row_of = [], [0] * (P - 1)
-            hist = engine.histogram(keys, shift, bits, 64, [])
+            if first_hist is not None:
+                h = np.asarray(first_hist, dtype=np.int64).reshape(1, -1)
+            else:
+                hist = engine.histogram(keys, shift, bits, 64, [])
+                comm.all_reduce(hist, "sum")
+                h = engine.to_host(hist).astype(np.int64)
         else:
-            rows = sorted(set(prefix))
-            row_of = [rows.index(p) for p in prefix]
+            rows = sorted({prefix[s] for s in range(P - 1) if not done[s]})
+            row_of = [rows.index(p) if not done[i] else 0 for i, p in enumerate(prefix)]
             hist = engine.histogram(keys, shift, bits, shift + bits, rows)
-        comm.all_reduce(hist, "sum")
-        h = engine.to_host(hist).astype(np.int64)
+            comm.all_reduce(hist, "sum")
+            h = engine.to_host(hist).astype(np.int64)
         cum = np.cumsum(h, axis=1)
         for s in range(P - 1):
+            if done[s]:
+                continue
             r = row_of[s]
             rem = targets[s] - below[s]
             d = int(np.searchsorted(cum[r], rem, side="right"))  # first digit with inclusive count > rem
             d = min(d, (1 << bits) - 1)
             below[s] += int(cum[r][d - 1]) if d > 0 else 0
             prefix[s] = (prefix[s] << bits) | d
+            if shift == 0 or int(h[r][d]) <= allowed:
+                done[s] = True
+                final[s] = prefix[s] << shift
         decided += bits
-    return prefix
+    return final, decided
 
 
 # ---------------------------------------------------------------------------------------------
@@ -237,11 +265,12 @@ class DistributedBuilder:
     `local_volumes`: this rank's (n_local, 4|6) volumes; global leaf g = (sum of lower ranks' counts) + local
     position; the returned BVH's leaves carry .index = g + 1."""
 
-    def __init__(self, comm=None, engine=None):
+    def __init__(self, comm=None, engine=None, tolerance=0.002):
         if comm is None or not hasattr(comm, "all_reduce"):
             comm = TorchComm(comm)
         self.comm = comm
         self.engine = engine or HipEngine()
+        self.tolerance = tolerance  # allowed imbalance per splitter, as a fraction of N/P (0 = exact)
         self.last = {}
 
     def build(self, volumes, node_type=None, cache=None, options=None):
@@ -254,37 +283,61 @@ class DistributedBuilder:
         if not abi.combo_supported(types):
             raise ValueError("unsupported leaf / node type combination")
         n_local = volumes.shape[0]
-        # global leaf numbering: exclusive prefix of the per-rank counts
-        cnt = eng.tensor([0] * comm.size, torch.int64)
-        cnt[comm.rank] = n_local
-        comm.all_reduce(cnt, "sum")
-        counts = eng.to_host(cnt).tolist()
+        fdt = abi.FLOAT_DTYPES[flt]
+        fmax, fmin = float(np.finfo(fdt).max), float(np.finfo(fdt).tiny)
+        # 1. ONE all-reduce(MAX) of a float64 vector [-mins, maxs, one-hot leaf counts]: the global centre AABB
+        #    (float -> double -> float is exact, and min(x) = -max(-x) exactly) and every rank's leaf count
+        #    (global numbering) in a single collective.  Neutral elements of the reference's reduces
+        #    (morton/utils.jl:29-40): floatmax for the minima, floatmin for the maxima.
+        vec = eng.tensor([-fmax] * 3 + [fmin] * 3 + [0.0] * comm.size, torch.float64)
+        if n_local:
+            e = eng.extrema(types, volumes).to(torch.float64)
+            vec[:3] = -e[:3]
+            vec[3:6] = e[3:]
+        vec[6 + comm.rank] = float(n_local)
+        if comm.size > 1:
+            comm.all_reduce(vec, "max")
+        ext = torch.cat([-vec[:3], vec[3:6]]).to(volumes.dtype)
+        eng.expand(types, ext)
+        # 2. keys + this rank's first splitter histogram; the histograms are ALL-GATHERED (P x 4096 counters), so every
+        #    rank knows the whole send matrix as soon as the splitters sit on first-level bucket boundaries (the
+        #    normal case) and no count exchange is needed.  ONE device->host copy brings back everything the host needs.
+        keys = eng.keys(types, volumes, ext)
+        key_bits = abi.MORTON_BITS[types.morton_type]
+        bits0 = min(DIGIT_BITS, key_bits)
+        shift0 = key_bits - bits0
+        hist0 = eng.histogram(keys, shift0, bits0, 64, []).reshape(-1)
+        allh = comm.all_gather(hist0) if comm.size > 1 else hist0.reshape(1, -1)
+        host = eng.to_host(torch.cat([vec, ext.to(torch.float64), allh.reshape(-1).to(torch.float64)]))
+        counts = [int(round(c)) for c in host[6:6 + comm.size]]
+        ext_host = host[6 + comm.size:12 + comm.size].astype(fdt)
+        H = np.rint(host[12 + comm.size:]).astype(np.int64).reshape(comm.size, -1)
         base, n_global = int(sum(counts[:comm.rank])), int(sum(counts))
         if n_global < comm.size:
             raise abi.DomainError("fewer leaves than ranks")
-        # 1. global centre AABB
-        ext = eng.extrema(types, volumes) if n_local else None
-        fmax = float(np.finfo(abi.FLOAT_DTYPES[flt]).max)
-        fmin = float(np.finfo(abi.FLOAT_DTYPES[flt]).tiny)
-        if ext is None:  # neutral elements of the reference's reduces (morton/utils.jl:29-40)
-            ext = eng.tensor([fmax] * 3 + [fmin] * 3, volumes.dtype)
-        mins, maxs = ext[:3].clone(), ext[3:].clone()
-        comm.all_reduce(mins, "min")
-        comm.all_reduce(maxs, "max")
-        ext = torch.cat([mins, maxs])
-        eng.expand(types, ext)
-        ext_host = eng.to_host(ext)
-        # 2. keys
-        keys = eng.keys(types, volumes, ext)
         # 3. splitters, partition, pack, exchange
-        key_bits = abi.MORTON_BITS[types.morton_type]
-        splitters = find_splitters(eng, comm, keys, key_bits, n_global)
-        perm, send_counts = eng.partition(keys, splitters, comm.size)
+        splitters, levels_used = find_splitters(eng, comm, keys, key_bits, n_global, self.tolerance, first_hist=H.sum(0))
+        send_matrix = None
+        if comm.size > 1 and levels_used <= bits0:
+            # splitters are multiples of 2^shift0: destination of a key depends on its first digit only
+            edges = [0] + [sp >> shift0 for sp in splitters] + [1 << bits0]
+            cum = np.concatenate([np.zeros((comm.size, 1), np.int64), np.cumsum(H, axis=1)], axis=1)
+            send_matrix = np.stack([cum[:, edges[r + 1]] - cum[:, edges[r]] for r in range(comm.size)], axis=1)  # [src, dst]
+        known = send_matrix[comm.rank].tolist() if send_matrix is not None else None
+        perm, send_counts = eng.partition(keys, splitters, comm.size, known)
         records, rec_bytes = eng.pack(types, volumes, keys, perm, base)
-        sc = eng.tensor(send_counts, torch.int64)
-        rc = comm.all_to_all(sc, [1] * comm.size, [1] * comm.size)
-        recv_counts = eng.to_host(rc).tolist()
-        recv = comm.all_to_all(records, [c * rec_bytes for c in send_counts], [c * rec_bytes for c in recv_counts])
+        if send_matrix is not None:
+            recv_counts = send_matrix[:, comm.rank].tolist()
+        elif comm.size > 1:
+            sc = eng.tensor(send_counts, torch.int64)
+            rc = comm.all_to_all(sc, [1] * comm.size, [1] * comm.size)
+            recv_counts = eng.to_host(rc).tolist()
+        else:
+            recv_counts = list(send_counts)
+        if comm.size > 1:
+            recv = comm.all_to_all(records, [c * rec_bytes for c in send_counts], [c * rec_bytes for c in recv_counts])
+        else:
+            recv = records
         n_recv = int(sum(recv_counts))
         if n_recv < 1:
             raise abi.DomainError("a rank received no leaves (degenerate key distribution)")
@@ -364,6 +417,15 @@ class ThreadComm:
         w.barrier.wait()
         t.copy_(res)
         return t
+
+    def all_gather(self, t):
+        import torch
+        w = self.world
+        w.slots[self.rank] = t.clone()
+        w.barrier.wait()
+        out = torch.stack(w.slots)
+        w.barrier.wait()
+        return out
 
     def all_to_all(self, send, send_counts, recv_counts):
         import torch

@@ -146,8 +146,9 @@ ibvh_status ibvh_build_scratch_bytes(const ibvh_types *types, int64_t n, size_t 
  *   wrap (build.jl:328-352) -> extrema (morton/utils.jl:1-72) -> Morton encode
  *   (morton/default.jl:63-157) -> stable ascending sort by .morton (build.jl:248-253)
  *   -> compute_skips! -> aggregate_oibvh! down to built_level (build.jl:366-523).
- * volumes : n x V raw volumes (ignored when desc->already_wrapped)
- * leaves  : n x BoundingVolume records, written (or sorted in place when already_wrapped)
+ * volumes : n x V raw volumes; with desc->already_wrapped: NULL (sort `leaves` in place) or n source
+ *           BoundingVolume records that are left untouched (`leaves` then receives the sorted copy)
+ * leaves  : n x BoundingVolume records, written (or sorted in place, see above)
  * nodes   : (real_nodes - real_leaves) x N
  * skips   : levels x I
  * extrema_out : optional 6 x double device->host copy target is NOT provided; pass NULL or a

@@ -446,7 +446,7 @@ def test_distributed_build_virtual_ranks_gpu(world):
         assert nodes.tobytes() == o.nodes.tobytes()
         assert (contacts == oracle_pairs(orc.traverse_lvt(o)[0])).all()
     sizes = [len(o[0]) for o in out]
-    assert max(sizes) - min(sizes) <= 8
+    assert max(sizes) - min(sizes) <= max(8, n // (50 * world))
 
 
 @pytest.mark.parametrize("world", [2, 5])
