@@ -106,7 +106,6 @@ def main():
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        os.environ["NCCL_DEBUG"] = os.environ.get("IBVH_NCCL_DEBUG", "WARN")  # keep RCCL's version banner off the output
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     lib.load()
 
