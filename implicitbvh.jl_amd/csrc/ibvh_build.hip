@@ -200,19 +200,41 @@ __global__ __launch_bounds__(1024) void encode_hist_kernel(const char *__restric
 //   index = position + 1 for freshly wrapped volumes (wrap_bounding_volumes, build.jl:345-349)
 //           or the source record's own .index (build.jl:220-222)
 // ------------------------------------------------------------------------------------------
+// Each wave assembles 64 records in LDS and writes them as ONE contiguous byte range with fully coalesced
+// 8-byte stores (a record-per-lane store would touch every line of the range with each of its 3 partial
+// stores); the random volume fetch of the next chunk is issued before the current chunk is written out.
 template <class V, class I, class K>
 __global__ __launch_bounds__(256) void gather_kernel(const char *__restrict__ src, int64_t src_stride, int src_wrapped,
                                                      LeafLayout lay, const K *__restrict__ keys,
                                                      const uint32_t *__restrict__ perm, int64_t n, char *__restrict__ dst) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const uint32_t p = perm[i];
-        const char *s = src + (int64_t)p * src_stride;
-        V v = load_vol<V>(s);
-        I idx = src_wrapped ? load_index<I>(s, lay) : (I)((int64_t)p + 1);
-        char *d = dst + i * lay.stride;
-        store_vol(d, v);
-        *(I *)(d + lay.index_off) = idx;
-        store_morton(d, lay, (uint64_t)keys[i]);
+    extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int words = lay.stride >> 3; // 8-byte words per record
+    uint64_t *stage = (uint64_t *)g_smem + (size_t)wv * 64 * words;
+    const int64_t nchunks = ceil_div_dev(n, 256);
+    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int64_t i = c * 256 + threadIdx.x;
+        const int64_t wave_first = c * 256 + wv * 64;
+        if (i < n) {
+            const uint32_t p = perm[i];
+            const char *s = src + (int64_t)p * src_stride;
+            V v;
+            if (sizeof(V) % 16 == 0 && (src_stride & 15) == 0) v = load_vol16<V>(s); // one 16-byte request per leaf
+            else v = load_vol<V>(s);
+            I idx = src_wrapped ? load_index<I>(s, lay) : (I)((int64_t)p + 1);
+            char *d = (char *)(stage + (size_t)lane * words);
+            store_vol(d, v);
+            *(I *)(d + lay.index_off) = idx;
+            store_morton(d, lay, (uint64_t)keys[i]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int64_t wave_n = n - wave_first < 64 ? n - wave_first : 64; // records of this wave's chunk
+        if (wave_n > 0) {
+            uint64_t *out = (uint64_t *)(dst + wave_first * lay.stride);
+            const int total = (int)wave_n * words;
+            for (int g = lane; g < total; g += 64) out[g] = stage[g];
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -509,11 +531,12 @@ ibvh_status ibvh_build(const ibvh_build_desc *desc, const void *volumes, void *l
             int gblocks = grid_for(n, 256, 256 * 16);
             auto launch_gather = [&](auto it) -> int {
                 using I = typename decltype(it)::type;
+                const size_t gsm = (size_t)256 * lay.leaf_bytes;
                 if (key_bytes == 8)
-                    IBVH_LAUNCH((gather_kernel<L, I, uint64_t>), dim3(gblocks), dim3(256), 0, st, src, src_stride,
+                    IBVH_LAUNCH((gather_kernel<L, I, uint64_t>), dim3(gblocks), dim3(256), gsm, st, src, src_stride,
                                 wrapped ? 1 : 0, dlay, (const uint64_t *)skeys, sperm, n, dst);
                 else
-                    IBVH_LAUNCH((gather_kernel<L, I, uint32_t>), dim3(gblocks), dim3(256), 0, st, src, src_stride,
+                    IBVH_LAUNCH((gather_kernel<L, I, uint32_t>), dim3(gblocks), dim3(256), gsm, st, src, src_stride,
                                 wrapped ? 1 : 0, dlay, (const uint32_t *)skeys, sperm, n, dst);
                 return IBVH_OK;
             };

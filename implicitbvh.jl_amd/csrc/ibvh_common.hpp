@@ -99,6 +99,12 @@ template <class V> IBVH_D V shuffle_from(const V &v, int src) {
 template <class V> IBVH_D void store_vol(void *p, const V &v) {
     __builtin_memcpy(__builtin_assume_aligned(p, 8), &v, sizeof(V));
 }
+// 16-byte-aligned variant (raw BSphere{F32}/{F64}, BBox{F64} arrays): global_load_dwordx4
+template <class V> IBVH_D V load_vol16(const void *p) {
+    V v;
+    __builtin_memcpy(&v, __builtin_assume_aligned(p, 16), sizeof(V));
+    return v;
+}
 template <class I> IBVH_D I load_index(const char *rec, const LeafLayout &lay) {
     return *(const I *)(rec + lay.index_off);
 }
@@ -467,6 +473,7 @@ template <class F> int dispatch_index(int index_type, F &&f) {
     } while (0)
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+IBVH_HD int64_t ceil_div_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Optional per-launch timing (ibvh_profile_* in include/ibvh.h): when enabled every kernel launch is
 // bracketed by a pair of HIP events recorded on the launch stream.  Off by default: one predictable
