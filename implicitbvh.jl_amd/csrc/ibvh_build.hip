@@ -25,8 +25,10 @@ struct FirstPassPlan {
     int tpb, ipt, num_tiles;
     uint32_t *tile_hist;
     uint32_t mask;
+    int shift, bits;
 };
 FirstPassPlan first_pass_plan(int64_t n, int key_bits, int key_bytes, void *scratch);
+bool uses_hybrid(int64_t n, int key_bits, int key_bytes);
 int sort_pairs(int key_bytes, int key_bits, int64_t n, void *keys, void *vals, void *keys_alt, void *vals_alt,
                bool vals_implicit, int32_t *result_in_alt, void *scratch, size_t scratch_sz, hipStream_t st,
                bool first_hist_done, const RecordArgs *records);
@@ -172,11 +174,11 @@ __global__ __launch_bounds__(256) void encode_kernel(const char *__restrict__ re
 template <class V, class K>
 __global__ __launch_bounds__(1024) void encode_hist_kernel(const char *__restrict__ recs, int64_t stride, int64_t n,
                                                           const typename V::elt *__restrict__ ext, int morton_type,
-                                                          K *__restrict__ keys, int tile_elems, uint32_t mask,
+                                                          K *__restrict__ keys, int tile_elems, int shift, uint32_t mask,
                                                           uint32_t *__restrict__ tile_hist, int num_tiles) {
     using T = typename V::elt;
-    __shared__ uint32_t h[256];
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) h[i] = 0;
+    extern __shared__ uint32_t h[]; // mask + 1 counters
+    for (int i = threadIdx.x; i <= (int)mask; i += blockDim.x) h[i] = 0;
     __syncthreads();
     const T mins[3] = {ext[0], ext[1], ext[2]}, maxs[3] = {ext[3], ext[4], ext[5]};
     const int64_t base = (int64_t)blockIdx.x * tile_elems;
@@ -188,11 +190,11 @@ __global__ __launch_bounds__(1024) void encode_hist_kernel(const char *__restric
             center(v, c);
             const K k = (K)morton_encode_single(c, mins, maxs, morton_type);
             keys[i] = k;
-            atomicAdd(&h[(uint32_t)k & mask], 1u);
+            atomicAdd(&h[(uint32_t)(k >> shift) & mask], 1u);
         }
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < 256; d += blockDim.x) tile_hist[(int64_t)d * num_tiles + blockIdx.x] = h[d];
+    for (int d = threadIdx.x; d <= (int)mask; d += blockDim.x) tile_hist[(int64_t)d * num_tiles + blockIdx.x] = h[d];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -505,11 +507,13 @@ ibvh_status ibvh_build(const ibvh_build_desc *desc, const void *volumes, void *l
         const int key_bits = morton_key_bits(ty.morton_type);
         const rsort::FirstPassPlan plan = rsort::first_pass_plan(n, key_bits, key_bytes, sc.sort);
         if (key_bytes == 8)
-            IBVH_LAUNCH((encode_hist_kernel<L, uint64_t>), dim3(plan.num_tiles), dim3(plan.tpb), 0, st, src, src_stride, n, ext,
-                        ty.morton_type, (uint64_t *)sc.keys, plan.tpb * plan.ipt, plan.mask, plan.tile_hist, plan.num_tiles);
+            IBVH_LAUNCH((encode_hist_kernel<L, uint64_t>), dim3(plan.num_tiles), dim3(plan.tpb), ((size_t)plan.mask + 1) * 4, st,
+                        src, src_stride, n, ext, ty.morton_type, (uint64_t *)sc.keys, plan.tpb * plan.ipt, plan.shift, plan.mask,
+                        plan.tile_hist, plan.num_tiles);
         else
-            IBVH_LAUNCH((encode_hist_kernel<L, uint32_t>), dim3(plan.num_tiles), dim3(plan.tpb), 0, st, src, src_stride, n, ext,
-                        ty.morton_type, (uint32_t *)sc.keys, plan.tpb * plan.ipt, plan.mask, plan.tile_hist, plan.num_tiles);
+            IBVH_LAUNCH((encode_hist_kernel<L, uint32_t>), dim3(plan.num_tiles), dim3(plan.tpb), ((size_t)plan.mask + 1) * 4, st,
+                        src, src_stride, n, ext, ty.morton_type, (uint32_t *)sc.keys, plan.tpb * plan.ipt, plan.shift, plan.mask,
+                        plan.tile_hist, plan.num_tiles);
         IBVH_LAUNCH_CHECK();
         // stable LSB radix sort of (key, position), then the records in Morton order
         // (index = position + 1 for fresh volumes, build.jl:345-349, or the source record's own index, :220-222).
@@ -518,7 +522,8 @@ ibvh_status ibvh_build(const ibvh_build_desc *desc, const void *volumes, void *l
         // (key, position) round trip fewer: 0.157 -> 0.140 ms at 1e6); above, the dedicated gather kernel's higher
         // occupancy serves the random volume reads better (measured at 1e7: 0.049 + 0.276 ms vs 0.350 ms fused).
         char *dst = (wrapped && !out_of_place) ? sc.records : (char *)leaves;
-        const bool fuse_records = n < (int64_t(1) << 22);
+        // (with the MSD + in-LDS hybrid, the default up to ~12.5 M leaves, the bucket kernel always writes the records)
+        const bool fuse_records = rsort::uses_hybrid(n, key_bits, key_bytes) || n < (int64_t(1) << 22);
         rsort::RecordArgs ra{src, dst, src_stride, wrapped ? 1 : 0, (int32_t)(lay.volume_bytes / 8),
                              ty.index_type == IBVH_I32 ? 4 : 8, dlay};
         int32_t in_alt = 0;

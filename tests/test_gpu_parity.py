@@ -195,6 +195,44 @@ def test_sort_pairs_matches_stable_sort(key_bytes, key_bits, n):
     assert rv.cpu().numpy().view(np.uint32).tolist() == ev.tolist()
 
 
+@pytest.mark.parametrize("key_bytes,key_bits", [(4, 30), (8, 63)])
+def test_sort_pairs_skewed_keys_take_the_oversized_bucket_path(key_bytes, key_bits):
+    """Keys concentrated on a few values of the partition digit: buckets far larger than a workgroup's LDS
+    capacity are sorted by the tiled in-bucket LSD; still a stable sort."""
+    rng = np.random.default_rng(key_bits)
+    kdt = np.uint32 if key_bytes == 4 else np.uint64
+    for n in (50_000, 700_001):
+        top = rng.choice(np.array([0, 1, 5, (1 << 11) - 1], dtype=np.uint64), n, p=[0.55, 0.3, 0.1, 0.05])
+        low = rng.integers(0, 1 << 12, n, dtype=np.uint64) << np.uint64(3)  # few distinct low values too
+        keys = ((top << np.uint64(key_bits - 11)) | low).astype(kdt)
+        vals = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+        ek, ev = orc.sort_pairs(keys, vals)
+        k, v = cuda(keys.view(np.int32 if key_bytes == 4 else np.int64)), cuda(vals.view(np.int32))
+        k2, v2 = torch.empty_like(k), torch.empty_like(v)
+        need = C.c_size_t()
+        lib.call("ibvh_sort_scratch_bytes", key_bytes, n, C.byref(need))
+        scratch = torch.empty(need.value, dtype=torch.uint8, device="cuda")
+        in_alt = C.c_int32()
+        lib.call("ibvh_sort_pairs", key_bytes, key_bits, n, k.data_ptr(), v.data_ptr(), k2.data_ptr(), v2.data_ptr(),
+                 C.byref(in_alt), scratch.data_ptr(), need.value, None)
+        torch.cuda.synchronize()
+        rk, rv = (k2, v2) if in_alt.value else (k, v)
+        assert np.array_equal(rk.cpu().numpy().view(kdt), ek)
+        assert np.array_equal(rv.cpu().numpy().view(np.uint32), ev)
+
+
+def test_build_clustered_cloud_bit_exact():
+    """Leaves piled into a few tight clusters: very uneven partition buckets in the hybrid sort."""
+    rng = np.random.default_rng(99)
+    centres = rng.random((6, 3)) * 100
+    which = rng.choice(6, 300_000, p=[0.5, 0.3, 0.1, 0.05, 0.03, 0.02])
+    c = centres[which] + rng.normal(0, 0.01, (300_000, 3))
+    vols = np.concatenate([c, 0.001 + 0.002 * rng.random((300_000, 1))], axis=1).astype(np.float32)
+    for mt in (abi.U32, abi.U64, abi.U16):
+        o, g = build_both(vols, abi.make_types(abi.BSPHERE, abi.F32, abi.BBOX, abi.F32, abi.I32, mt))
+        assert_bvh_equal(o, g)
+
+
 def test_extrema_and_keys_entry_points():
     rng = np.random.default_rng(12)
     for kind, flt in ((abi.BSPHERE, abi.F32), (abi.BBOX, abi.F64)):
