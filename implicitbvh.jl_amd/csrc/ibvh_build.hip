@@ -522,7 +522,7 @@ ibvh_status ibvh_build(const ibvh_build_desc *desc, const void *volumes, void *l
         // (key, position) round trip fewer: 0.157 -> 0.140 ms at 1e6); above, the dedicated gather kernel's higher
         // occupancy serves the random volume reads better (measured at 1e7: 0.049 + 0.276 ms vs 0.350 ms fused).
         char *dst = (wrapped && !out_of_place) ? sc.records : (char *)leaves;
-        // (with the MSD + in-LDS hybrid, the default up to ~12.5 M leaves, the bucket kernel always writes the records)
+        // (with the MSD + in-LDS hybrid, the default up to ~6 M leaves, the bucket kernel always writes the records)
         const bool fuse_records = rsort::uses_hybrid(n, key_bits, key_bytes) || n < (int64_t(1) << 22);
         rsort::RecordArgs ra{src, dst, src_stride, wrapped ? 1 : 0, (int32_t)(lay.volume_bytes / 8),
                              ty.index_type == IBVH_I32 ? 4 : 8, dlay};

@@ -97,8 +97,14 @@ struct RecordArgs {
     LeafLayout lay;
 };
 
+// Occupancy the LDS budget allows, pinned so that co-compiled instantiations cannot push the VGPR count over a
+// waves-per-SIMD step (observed: 128 -> 132 VGPRs, 4 -> 3 waves/SIMD, scatter 48 -> 66 us at 1e7 keys).
+constexpr int scatter_min_waves(int tpb, int ipt, int key_bytes) {
+    return key_bytes == 8 ? ((tpb * ipt <= 2048) ? 4 : 2) : ((tpb * ipt <= 2048) ? 6 : 4);
+}
+
 template <class K, int TPB, int IPT, bool RECORDS>
-__global__ __launch_bounds__(TPB) void scatter_kernel(const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+__global__ __launch_bounds__(TPB, scatter_min_waves(TPB, IPT, sizeof(K))) void scatter_kernel(const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                       K *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
                                                       int64_t n, int shift, uint32_t mask,
                                                       const uint32_t *__restrict__ tile_hist,
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(TPB) void scatter_kernel(const K *__restrict__ keys
 }
 
 // =============================================================================================
-// MSD + in-LDS hybrid (the default for up to ~12.5 M keys).
+// MSD + in-LDS hybrid (the default for up to ~6 M keys; larger inputs use the LSD passes above).
 //
 // LSD needs ceil(bits/8) full passes over the (key, position) pairs.  Morton codes of a point cloud
 // spread over their top bits, so ONE stable most-significant-digit partition (up to 11 bits = 2048
@@ -610,21 +616,33 @@ inline Geometry choose_geometry(int64_t n) {
 struct MsdPlan {
     int bits;     // MSD digit width (0 = do not use the hybrid)
     int capacity; // keys a bucket workgroup sorts in LDS: 2048, 4096 or 8192
+    int btpb;     // threads of the bucket workgroup (capacity / btpb keys per thread)
 };
 inline MsdPlan choose_msd(int64_t n, int key_bits, int key_bytes) {
     static const int mode = [] {
         const char *e = getenv("IBVH_SORT_MODE"); // tuning knob: "lsd" forces the plain LSD passes
         return (e && e[0] == 'l') ? 1 : 0;
     }();
-    if (mode == 1 || n < 2048 || key_bits <= 8) return {0, 0};
+    if (mode == 1 || n < 2048 || key_bits <= 8) return {0, 0, 0};
     int bits = 1;
     while (bits < MSD_MAX_BITS && bits < key_bits && (n >> bits) > 1536) ++bits;
     const int64_t avg = n >> bits;
-    const int cap_max = key_bytes == 8 ? 4096 : 8192; // LDS: capacity * (key + position) bytes
+    // Measured on MI355X (round 1): the hybrid beats plain LSD while buckets fit 4096-key workgroups
+    // (Morton+sort phase 0.366 vs 0.422 ms at 6e6 leaves, 0.109 vs 0.139 ms at 1e6) and loses with 8192-key
+    // workgroups (0.652 vs 0.589 ms at 1e7: the bucket kernel is barrier-bound), so larger inputs keep LSD.
+    const int cap_max = 4096;
     int cap = 2048;
     while (cap < cap_max && avg * 4 > cap * 3) cap *= 2; // average bucket <= 3/4 of the capacity
-    if (avg * 4 > (int64_t)cap * 3) return {0, 0};      // too many keys for one partition level: LSD
-    return {bits, cap};
+    if (avg * 4 > (int64_t)cap * 3) return {0, 0, 0};   // too many keys for one partition level: LSD
+    static const int forced_tpb = [] {
+        const char *e = getenv("IBVH_BUCKET_TPB"); // tuning knob: 256 / 512 / 1024 threads per bucket workgroup
+        return e ? atoi(e) : 0;
+    }();
+    int btpb = cap == 2048 ? 256 : (cap == 4096 ? 512 : 1024);
+    if (forced_tpb == 256 || forced_tpb == 512 || forced_tpb == 1024) btpb = forced_tpb;
+    if (cap / btpb < 8) btpb = cap / 8;
+    if (cap / btpb > 32) btpb = cap / 32;
+    return {bits, cap, btpb};
 }
 
 size_t scratch_bytes(int64_t n) {
@@ -732,7 +750,7 @@ FirstPassPlan first_pass_plan(int64_t n, int key_bits, int key_bytes, void *scra
     p.ipt = g.ipt;
     p.num_tiles = (int)ceil_div(n, g.tile());
     p.tile_hist = (uint32_t *)scratch;
-    const MsdPlan mp = uses_hybrid(n, key_bits, key_bytes) ? choose_msd(n, key_bits, key_bytes) : MsdPlan{0, 0};
+    const MsdPlan mp = uses_hybrid(n, key_bits, key_bytes) ? choose_msd(n, key_bits, key_bytes) : MsdPlan{0, 0, 0};
     if (mp.bits) { // MSD partition first: histogram of the TOP digit
         p.bits = mp.bits;
         p.shift = key_bits - mp.bits;
@@ -758,14 +776,16 @@ int sort_pairs(int key_bytes, int key_bits, int64_t n, void *keys, void *vals, v
     *result_in_alt = 0;
     if (n == 0) return IBVH_OK;
     Geometry g = choose_geometry(n);
-    const MsdPlan mp = uses_hybrid(n, key_bits, key_bytes) ? choose_msd(n, key_bits, key_bytes) : MsdPlan{0, 0};
+    const MsdPlan mp = uses_hybrid(n, key_bits, key_bytes) ? choose_msd(n, key_bits, key_bytes) : MsdPlan{0, 0, 0};
     if (mp.bits) {
         if (key_bytes == 8 && g.tpb == 1024) g = Geometry{512, 16};
 #define IBVH_MSD_CASE(K, T, P, BT, BI)                                                                                \
-    if (g.tpb == T && g.ipt == P && mp.capacity == BT * BI)                                                           \
+    if (g.tpb == T && g.ipt == P && mp.capacity == BT * BI && mp.btpb == BT)                                          \
         return run_msd<K, T, P, BT, BI>((K *)keys, (uint32_t *)vals, (K *)keys_alt, (uint32_t *)vals_alt, n, key_bits, \
                                         vals_implicit, result_in_alt, scratch, st, first_hist_done, records, mp.bits);
-#define IBVH_MSD_GEOM(K, T, P) IBVH_MSD_CASE(K, T, P, 256, 8) IBVH_MSD_CASE(K, T, P, 512, 8) IBVH_MSD_CASE(K, T, P, 1024, 8)
+#define IBVH_MSD_GEOM(K, T, P)                                                                                         \
+    IBVH_MSD_CASE(K, T, P, 256, 8) IBVH_MSD_CASE(K, T, P, 512, 8) IBVH_MSD_CASE(K, T, P, 1024, 8) IBVH_MSD_CASE(K, T, P, 256, 16) \
+    IBVH_MSD_CASE(K, T, P, 256, 32) IBVH_MSD_CASE(K, T, P, 512, 16)
         if (key_bytes == 4) {
             IBVH_MSD_GEOM(uint32_t, 256, 8)
             IBVH_MSD_GEOM(uint32_t, 256, 16)
@@ -773,10 +793,13 @@ int sort_pairs(int key_bytes, int key_bits, int64_t n, void *keys, void *vals, v
         } else {
             IBVH_MSD_CASE(uint64_t, 256, 8, 256, 8)
             IBVH_MSD_CASE(uint64_t, 256, 8, 512, 8)
+            IBVH_MSD_CASE(uint64_t, 256, 8, 256, 16)
             IBVH_MSD_CASE(uint64_t, 256, 16, 256, 8)
             IBVH_MSD_CASE(uint64_t, 256, 16, 512, 8)
+            IBVH_MSD_CASE(uint64_t, 256, 16, 256, 16)
             IBVH_MSD_CASE(uint64_t, 512, 16, 256, 8)
             IBVH_MSD_CASE(uint64_t, 512, 16, 512, 8)
+            IBVH_MSD_CASE(uint64_t, 512, 16, 256, 16)
         }
 #undef IBVH_MSD_GEOM
 #undef IBVH_MSD_CASE
