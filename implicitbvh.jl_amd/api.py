@@ -465,7 +465,7 @@ def _cache_tensor(cache_t, need_rows, cols, dtype, what):
 
 
 LVT_CACHE_SLOTS = 8  # contacts per work item kept from the counting pass (include/ibvh.h)
-RAY_CACHE_SLOTS = 16  # hits per ray kept from the counting pass
+RAY_CACHE_SLOTS = 32  # hits per ray kept from the counting pass
 
 
 def _lvt_scratch(cache, types, n_items, slots=None):

@@ -110,7 +110,7 @@ template <class L, class N, class I, int MODE, bool WRITE> struct Query {
     IBVH_D Query(const Args<L, N, I> &a_, const PairCache<I> &c_) : a(a_), cache(c_) {
         // (an XCD-contiguous block->tile remap was measured here in round 1: 0.44 -> 0.61 ms at 1e6 leaves,
         // no change at 1e7, so work items keep the plain round-robin placement)
-        item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // 64-thread (one wave) or 256-thread workgroups
         valid = item < a.n_items;
         q_leaf = {};
         q_node = {};
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_apply_kernel(I *c, int64_t n, c
 inline size_t scan_scratch_bytes(int64_t n) {
     return (size_t)align_up((ceil_div(n > 0 ? n : 1, SCAN_TILE) + 8) * 8, 256);
 }
-constexpr int MAX_CACHE_SLOTS = 16;
+constexpr int MAX_CACHE_SLOTS = 64;
 inline int cache_slots_for(size_t scratch_bytes, int64_t n_items, int64_t pair_bytes) {
     size_t sb = scan_scratch_bytes(n_items);
     if (scratch_bytes <= sb || n_items <= 0) return 0;
@@ -689,8 +689,15 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
             if (a.start_level < a.tree.levels) {
                 const int64_t c = a.tree.levels - BRUTE_DEPTH;
                 const int cut = (int)(c > a.start_level ? c : a.start_level);
-                if (write) IBVH_LAUNCH((lvt_cluster_kernel<L, N, I, MODE, true>), dim3(blocks), dim3(256), 0, st, a, cache, cut);
-                else IBVH_LAUNCH((lvt_cluster_kernel<L, N, I, MODE, false>), dim3(blocks), dim3(256), 0, st, a, cache, cut);
+                // workgroup size is free (the waves never cooperate).  Measured in round 1: one wave per workgroup
+                // (slots handed back per wave) 0.456 / 3.57 ms at 1e6 / 1e7 leaves vs 0.446 / 3.46 ms with four.
+                static const int tpb = [] {
+                    const char *e = getenv("IBVH_LVT_TPB"); // tuning knob: 64 or 256
+                    return (e && atoi(e) == 64) ? 64 : 256;
+                }();
+                const unsigned cb = (unsigned)ceil_div(a.n_items, tpb);
+                if (write) IBVH_LAUNCH((lvt_cluster_kernel<L, N, I, MODE, true>), dim3(cb), dim3(tpb), 0, st, a, cache, cut);
+                else IBVH_LAUNCH((lvt_cluster_kernel<L, N, I, MODE, false>), dim3(cb), dim3(tpb), 0, st, a, cache, cut);
                 IBVH_LAUNCH_CHECK();
                 return IBVH_OK;
             }
