@@ -57,12 +57,13 @@ def algorithmic_bytes(kernel, n, contacts):
 
 
 def kernel_key(name):
-    """'(lvt_kernel<L, N, I, MODE, true>)' -> 'lvt_kernel_write'."""
+    """'(lvt_cluster_kernel<L, N, I, MODE, true, false>)' -> 'lvt_cluster_kernel_write' (5th argument = WRITE)."""
     base = name.strip("() ").split("<")[0].split("::")[-1].strip()
     if base == "scatter_kernel" and "true>" in name.replace(" ", ""):
         return "scatter_records_kernel"
     if base in ("lvt_kernel", "lvt_rays_kernel", "lvt_joint_kernel", "lvt_cluster_kernel"):
-        return base + ("_write" if "true>" in name.replace(" ", "") else "_count")
+        flat = name.replace(" ", "")
+        return base + ("_write" if ("MODE,true" in flat or "I,true>" in flat) else "_count")
     return base
 
 

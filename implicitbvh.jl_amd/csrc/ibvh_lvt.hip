@@ -11,6 +11,7 @@
 // (traverse_single.jl:188-203) is never needed: the tree is implicit, so "the pending right siblings of
 // the current path" is one 32-bit mask.
 #include <cstdlib>
+#include <type_traits>
 
 #include "ibvh_common.hpp"
 
@@ -96,7 +97,8 @@ constexpr int BRUTE_DEPTH = 7;   // 2^7 = 128 leaves, 64 leaf-parents (one per l
 constexpr int FRONTIER_CAP = 256; // frontier entries per wave and level (LDS); overflow -> exact walk
 
 // Per-lane query state + the emission rules shared by both kernels.
-template <class L, class N, class I, int MODE, bool WRITE> struct Query {
+template <class L, class N, class I, int MODE, bool WRITE, bool NARROW> struct Query {
+    using Cnt = typename std::conditional<sizeof(I) == 8, int64_t, int32_t>::type; // contact counters / offsets
     const Args<L, N, I> &a;
     const PairCache<I> &cache;
     int64_t item;
@@ -105,7 +107,7 @@ template <class L, class N, class I, int MODE, bool WRITE> struct Query {
     N q_node;
     I q_index;
     uint64_t q_morton;
-    int64_t w, cnt;
+    Cnt w, cnt;
 
     IBVH_D Query(const Args<L, N, I> &a_, const PairCache<I> &c_) : a(a_), cache(c_) {
         // (an XCD-contiguous block->tile remap was measured here in round 1: 0.44 -> 0.61 ms at 1e6 leaves,
@@ -123,17 +125,18 @@ template <class L, class N, class I, int MODE, bool WRITE> struct Query {
             q_leaf = load_vol<L>(rec);
             q_node = convert_to(q_leaf, (N *)nullptr); // traverse_single.jl:154-155
             q_index = load_index<I>(rec, a.items_lay);
-            if (a.narrow == IBVH_NARROW_MORTON_LT) q_morton = load_morton(rec, a.items_lay);
+            if constexpr (NARROW)
+                if (a.narrow == IBVH_NARROW_MORTON_LT) q_morton = load_morton(rec, a.items_lay);
         }
         lane_on = valid;
     }
     // WRITE pass: serve the item from the contact cache; returns false when the whole wave is done
     IBVH_D bool begin_write() {
-        w = (valid && item > 0) ? (int64_t)a.counts[item - 1] : 0;
-        const int64_t mine = valid ? (int64_t)a.counts[item] - w : 0;
-        const bool over = mine > (int64_t)cache.K;
+        w = (valid && item > 0) ? (Cnt)a.counts[item - 1] : 0;
+        const Cnt mine = valid ? (Cnt)a.counts[item] - w : 0;
+        const bool over = mine > (Cnt)cache.K;
         if (valid && !over)
-            for (int64_t k = 0; k < mine; ++k) a.contacts[w + k] = cache.slots[k * a.n_items + item];
+            for (Cnt k = 0; k < mine; ++k) a.contacts[(int64_t)w + k] = cache.slots[(int64_t)k * a.n_items + item];
         lane_on = over;
         return __ballot(over) != 0;
     }
@@ -146,9 +149,10 @@ template <class L, class N, class I, int MODE, bool WRITE> struct Query {
         if constexpr (MODE == MODE_SELF) c2 = q_index > lidx ? IndexPair<I>{lidx, q_index} : IndexPair<I>{q_index, lidx};
         else c2 = a.flip ? IndexPair<I>{lidx, q_index} : IndexPair<I>{q_index, lidx};
         if constexpr (WRITE) {
-            a.contacts[w++] = c2;
+            a.contacts[(int64_t)w] = c2;
+            ++w;
         } else {
-            if (cnt < (int64_t)cache.K) cache.slots[cnt * a.n_items + item] = c2;
+            if (cnt < (Cnt)cache.K) cache.slots[(int64_t)cnt * a.n_items + item] = c2;
             ++cnt;
         }
     }
@@ -159,8 +163,8 @@ template <class L, class N, class I, int MODE, bool WRITE> struct Query {
 };
 
 // ---- (1) exact wave-uniform pre-order walk ------------------------------------------------------
-template <class L, class N, class I, int MODE, bool WRITE>
-IBVH_D void joint_walk(Query<L, N, I, MODE, WRITE> &q, const Args<L, N, I> &a) {
+template <class L, class N, class I, int MODE, bool WRITE, bool NARROW>
+IBVH_D void joint_walk(Query<L, N, I, MODE, WRITE, NARROW> &q, const Args<L, N, I> &a) {
     const int64_t levels = a.tree.levels, vl = a.tree.virtual_leaves;
     const uint32_t leaf_first = 1u << (levels - 1);
     const uint64_t self_next = (uint64_t)q.item + leaf_first + 1; // SELF: implicit index of this leaf, plus one
@@ -173,7 +177,7 @@ IBVH_D void joint_walk(Query<L, N, I, MODE, WRITE> &q, const Args<L, N, I> &a) {
         hit = hit && iscontact(q.q_leaf, leaf);
         if (__ballot(hit) == 0) return;
         const I lidx = load_index_uniform<I>(rec, a.lay);
-        if (a.narrow != IBVH_NARROW_NONE) {
+        if constexpr (NARROW) {
             const uint64_t lm = a.narrow == IBVH_NARROW_MORTON_LT ? load_morton_uniform(rec, a.lay) : 0;
             hit = hit && q.narrow_ok(lm, lidx);
         }
@@ -249,9 +253,9 @@ IBVH_D void joint_walk(Query<L, N, I, MODE, WRITE> &q, const Args<L, N, I> &a) {
     }
 }
 
-template <class L, class N, class I, int MODE, bool WRITE>
+template <class L, class N, class I, int MODE, bool WRITE, bool NARROW>
 __global__ __launch_bounds__(256) void lvt_joint_kernel(Args<L, N, I> a, PairCache<I> cache) {
-    Query<L, N, I, MODE, WRITE> q(a, cache);
+    Query<L, N, I, MODE, WRITE, NARROW> q(a, cache);
     if constexpr (WRITE)
         if (!q.begin_write()) return;
     joint_walk(q, a);
@@ -276,11 +280,11 @@ template <class T> IBVH_D T wave_max_all(T v) {
     return v;
 }
 
-template <class L, class N, class I, int MODE, bool WRITE>
-__global__ __launch_bounds__(256) void lvt_cluster_kernel(Args<L, N, I> a, PairCache<I> cache, int cut_level) {
+template <class L, class N, class I, int MODE, bool WRITE, bool NARROW>
+__global__ __launch_bounds__(256, 6) void lvt_cluster_kernel(Args<L, N, I> a, PairCache<I> cache, int cut_level) {
     using TN = typename N::elt;
     __shared__ uint32_t s_frontier[4][2][FRONTIER_CAP];
-    Query<L, N, I, MODE, WRITE> q(a, cache);
+    Query<L, N, I, MODE, WRITE, NARROW> q(a, cache);
     if constexpr (WRITE)
         if (!q.begin_write()) return;
 
@@ -327,18 +331,20 @@ __global__ __launch_bounds__(256) void lvt_cluster_kernel(Args<L, N, I> a, PairC
         }
         L leafA = {}, leafB = {};
         I idxA = 0, idxB = 0;
-        uint64_t morA = 0, morB = 0;
+        uint64_t morA = 0, morB = 0; // only live when NARROW
         if (lane < np) {
             mybox = load_vol<N>(lp_nodes + first + lane);
             const char *rec = a.leaves + (leaf0 + 2 * lane) * a.lay.stride;
             leafA = load_vol<L>(rec);
             idxA = load_index<I>(rec, a.lay);
-            if (a.narrow == IBVH_NARROW_MORTON_LT) morA = load_morton(rec, a.lay);
+            if constexpr (NARROW)
+                if (a.narrow == IBVH_NARROW_MORTON_LT) morA = load_morton(rec, a.lay);
             if (2 * lane + 1 < nl) {
                 rec += a.lay.stride;
                 leafB = load_vol<L>(rec);
                 idxB = load_index<I>(rec, a.lay);
-                if (a.narrow == IBVH_NARROW_MORTON_LT) morB = load_morton(rec, a.lay);
+                if constexpr (NARROW)
+                    if (a.narrow == IBVH_NARROW_MORTON_LT) morB = load_morton(rec, a.lay);
             }
         }
         // stage b: candidate parents of every active query
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(256) void lvt_cluster_kernel(Args<L, N, I> a, PairC
                 const L leaf = shuffle_from(side ? leafB : leafA, p);
                 const I lidx = __shfl(side ? idxB : idxA, p, 64);
                 hit = hit && iscontact(q.q_leaf, leaf);
-                if (a.narrow != IBVH_NARROW_NONE) {
+                if constexpr (NARROW) {
                     const uint64_t lm = (uint64_t)__shfl((long long)(side ? morB : morA), p, 64);
                     hit = hit && q.narrow_ok(lm, lidx);
                 }
@@ -440,7 +446,7 @@ __global__ __launch_bounds__(256) void lvt_cluster_kernel(Args<L, N, I> a, PairC
         // frontier too wide for LDS (heavily overlapping input): redo this wave with the exact walk.
         // Nothing has been emitted yet unless the cut level was reached, so restart from scratch.
         q.cnt = 0;
-        if constexpr (WRITE) q.w = (q.valid && q.item > 0) ? (int64_t)a.counts[q.item - 1] : 0;
+        if constexpr (WRITE) q.w = (q.valid && q.item > 0) ? (typename decltype(q)::Cnt)a.counts[q.item - 1] : 0;
         joint_walk(q, a);
     }
     q.finish();
@@ -696,14 +702,20 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
                     return (e && atoi(e) == 64) ? 64 : 256;
                 }();
                 const unsigned cb = (unsigned)ceil_div(a.n_items, tpb);
-                if (write) IBVH_LAUNCH((lvt_cluster_kernel<L, N, I, MODE, true>), dim3(cb), dim3(tpb), 0, st, a, cache, cut);
-                else IBVH_LAUNCH((lvt_cluster_kernel<L, N, I, MODE, false>), dim3(cb), dim3(tpb), 0, st, a, cache, cut);
+                if (a.narrow != IBVH_NARROW_NONE) {
+                    if (write) IBVH_LAUNCH((lvt_cluster_kernel<L, N, I, MODE, true, true>), dim3(cb), dim3(tpb), 0, st, a, cache, cut);
+                    else IBVH_LAUNCH((lvt_cluster_kernel<L, N, I, MODE, false, true>), dim3(cb), dim3(tpb), 0, st, a, cache, cut);
+                } else {
+                    if (write) IBVH_LAUNCH((lvt_cluster_kernel<L, N, I, MODE, true, false>), dim3(cb), dim3(tpb), 0, st, a, cache, cut);
+                    else IBVH_LAUNCH((lvt_cluster_kernel<L, N, I, MODE, false, false>), dim3(cb), dim3(tpb), 0, st, a, cache, cut);
+                }
                 IBVH_LAUNCH_CHECK();
                 return IBVH_OK;
             }
         }
-        if (write) IBVH_LAUNCH((lvt_joint_kernel<L, N, I, MODE, true>), dim3(blocks), dim3(256), 0, st, a, cache);
-        else IBVH_LAUNCH((lvt_joint_kernel<L, N, I, MODE, false>), dim3(blocks), dim3(256), 0, st, a, cache);
+        // (the exact walk keeps the run-time narrow switch: NARROW = true covers both)
+        if (write) IBVH_LAUNCH((lvt_joint_kernel<L, N, I, MODE, true, true>), dim3(blocks), dim3(256), 0, st, a, cache);
+        else IBVH_LAUNCH((lvt_joint_kernel<L, N, I, MODE, false, true>), dim3(blocks), dim3(256), 0, st, a, cache);
     }
     IBVH_LAUNCH_CHECK();
     return IBVH_OK;
