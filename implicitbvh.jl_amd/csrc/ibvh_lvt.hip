@@ -347,13 +347,28 @@ __global__ __launch_bounds__(256, 6) void lvt_cluster_kernel(Args<L, N, I> a, Pa
                     if (a.narrow == IBVH_NARROW_MORTON_LT) morB = load_morton(rec, a.lay);
             }
         }
-        // stage b: candidate parents of every active query
+        // stage b: candidate parents of every active query.  Either loop — over the active queries
+        // (lanes = parents) or over the parents that touch the union box (lanes = queries) — yields
+        // the same per-lane candidate masks; take the shorter one.
         uint64_t mine = 0;
-        for (uint64_t todo = on_mask; todo != 0; todo &= todo - 1) {
-            const int qi = __builtin_ctzll(todo);
-            const N qbox = broadcast_from_lane(q.q_node, qi);
-            const uint64_t m = __ballot(iscontact(qbox, mybox));
-            if (lane == qi) mine = m;
+        const uint64_t box_mask = __ballot(iscontact(ubox, mybox));
+        if (__popcll(box_mask) < __popcll(on_mask)) {
+            uint32_t lo = 0, hi = 0;
+            for (uint64_t todo = box_mask; todo != 0; todo &= todo - 1) {
+                const int p = __builtin_ctzll(todo);
+                const N pbox = broadcast_from_lane(mybox, p);
+                const bool h = iscontact(q.q_node, pbox);
+                if (p < 32) lo |= h ? (1u << p) : 0u;
+                else hi |= h ? (1u << (p - 32)) : 0u;
+            }
+            mine = on ? (((uint64_t)hi << 32) | lo) : 0;
+        } else {
+            for (uint64_t todo = on_mask; todo != 0; todo &= todo - 1) {
+                const int qi = __builtin_ctzll(todo);
+                const N qbox = broadcast_from_lane(q.q_node, qi);
+                const uint64_t m = __ballot(iscontact(qbox, mybox));
+                if (lane == qi) mine = m;
+            }
         }
         // stage c: every query lane tests the leaves of its own candidates, left to right
         while (__ballot(mine != 0) != 0) {
