@@ -467,6 +467,314 @@ __global__ __launch_bounds__(256, 6) void lvt_cluster_kernel(Args<L, N, I> a, Pa
     q.finish();
 }
 
+// ---- (2b) BBox nodes: frontier descent + candidate-pair queue ---------------------------------------
+// Same enumeration as lvt_cluster_kernel down to the cut level, but the leaf tests are deferred: stage b
+// appends every (query lane, leaf-parent) candidate to a per-wave LDS queue, and the queue is drained 64
+// pairs at a time with ALL lanes busy — each lane gathers the two leaves of its pair (48 contiguous bytes
+// for BSphere{Float32} records), runs the exact leaf tests and ranks its hits among the lanes that hold
+// the same query (6-ballot match-any on the query lane id), so the contacts of a query still come out in
+// increasing leaf position: queue order is (subtree, then parent) ascending for any fixed query.  The
+// per-query counters / output offsets live in LDS.  Against stage c of lvt_cluster_kernel (one round per
+// candidate of the busiest lane, ~22 % of the lanes busy at 1e6 random spheres) this runs ~4x fewer leaf-test
+// rounds and no longer loads the leaves of parents nobody touches.
+constexpr int QUEUE_CAP = 512; // candidate pairs per wave (LDS); drained whenever fewer than 64 slots are free
+
+template <class L, class N, class I, int MODE, bool WRITE, bool NARROW>
+__global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, PairCache<I> cache, int cut_level) {
+    using TN = typename N::elt;
+    using Q = Query<L, N, I, MODE, WRITE, NARROW>;
+    using Cnt = typename Q::Cnt;
+    __shared__ uint32_t s_frontier[4][2][FRONTIER_CAP];
+    __shared__ uint32_t s_queue[4][QUEUE_CAP];
+    __shared__ Cnt s_cnt[4][64];
+    Q q(a, cache);
+    if constexpr (WRITE)
+        if (!q.begin_write()) return;
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t levels = a.tree.levels, vl = a.tree.virtual_leaves;
+    const uint32_t leaf_first = 1u << (levels - 1);
+    const int64_t wave_item0 = q.item - lane;
+    const uint64_t self_next = (uint64_t)q.item + leaf_first + 1;
+    const uint64_t wave_next = (uint64_t)wave_item0 + leaf_first + 1;
+    uint32_t *queue = s_queue[wv];
+    Cnt *cnts = s_cnt[wv];
+    cnts[lane] = WRITE ? q.w : (Cnt)0; // next output offset (WRITE) / contacts so far (count pass) of query `lane`
+    int qn = 0;                        // wave-uniform: queued pairs
+
+    // Two boxes instead of one union box: 64 consecutive Morton-sorted leaves regularly straddle a big jump of
+    // the Z-curve, and the single union box of such a wave spans a large part of the scene (measured at 1e6
+    // random spheres: 23 cut-level subtrees per wave on average, 489 for the worst wave — and the kernel waits
+    // for the worst wave).  The wave splits its queries at the lane k that minimises the half-area sum of
+    // box[0..k] and box[k+1..63] (prefix / suffix min-max scans over the lanes); with the split the worst wave
+    // sees 41 subtrees, the average one 18.  Any split is valid: the two boxes only have to cover the queries.
+    N ubox_a, ubox_b;
+    {
+        const TN big = float_max<TN>();
+        bool use = q.lane_on; // NaN boxes touch nothing and must not poison the min / max
+#pragma unroll
+        for (int k = 0; k < 3; ++k) use = use && q.q_node.lo[k] == q.q_node.lo[k] && q.q_node.up[k] == q.q_node.up[k];
+        N pre, suf;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            pre.lo[k] = suf.lo[k] = use ? q.q_node.lo[k] : big;
+            pre.up[k] = suf.up[k] = use ? q.q_node.up[k] : -big;
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { // lanes without a source keep their own value: min / max are idempotent
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                TN t = __shfl_up(pre.lo[k], o, 64);
+                pre.lo[k] = pre.lo[k] < t ? pre.lo[k] : t;
+                t = __shfl_up(pre.up[k], o, 64);
+                pre.up[k] = pre.up[k] > t ? pre.up[k] : t;
+                t = __shfl_down(suf.lo[k], o, 64);
+                suf.lo[k] = suf.lo[k] < t ? suf.lo[k] : t;
+                t = __shfl_down(suf.up[k], o, 64);
+                suf.up[k] = suf.up[k] > t ? suf.up[k] : t;
+            }
+        }
+        N nxt_suf; // box of lanes lane+1 .. 63
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            nxt_suf.lo[k] = __shfl_down(suf.lo[k], 1, 64);
+            nxt_suf.up[k] = __shfl_down(suf.up[k], 1, 64);
+            if (lane == 63) {
+                nxt_suf.lo[k] = big;
+                nxt_suf.up[k] = -big;
+            }
+        }
+        auto half_area = [](const N &b) {
+            float d[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                d[k] = (float)b.up[k] - (float)b.lo[k];
+                d[k] = d[k] > 0.0f ? d[k] : 0.0f; // empty (or NaN) -> 0
+            }
+            return d[0] * d[1] + d[1] * d[2] + d[0] * d[2];
+        };
+        float cost = half_area(pre) + half_area(nxt_suf);
+        cost = cost == cost ? cost : __builtin_inff();
+        // argmin over the lanes: non-negative floats order like their bit patterns
+        uint64_t key = ((uint64_t)__float_as_uint(cost) << 32) | (uint32_t)lane;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint64_t t = (uint64_t)__shfl_xor((long long)key, o, 64);
+            key = t < key ? t : key;
+        }
+        const int ksplit = (int)(key & 63u);
+        ubox_a = broadcast_from_lane(pre, ksplit);
+        ubox_b = broadcast_from_lane(nxt_suf, ksplit);
+    }
+    auto touches_wave = [&](const N &b) { return iscontact(ubox_a, b) || iscontact(ubox_b, b); };
+    const int lp = (int)levels - 1;
+    const int64_t lp_real = level_num_real(levels, vl, lp);
+    const N *lp_nodes = a.nodes + (level_start(levels, vl, lp) - 1);
+    const int64_t n_leaves = a.tree.real_leaves;
+    const uint64_t lt_mask = ((uint64_t)1 << lane) - 1;
+
+    // c: leaf tests of queue[off, off + avail), one pair per lane
+    auto pair_step = [&](int off, int avail) {
+        const bool v = lane < avail;
+        const uint32_t e = v ? queue[off + lane] : 0u;
+        const int qi = (int)(e & 63u);
+        const int64_t pos = 2 * (int64_t)(e >> 6); // 0-based position of the pair's left leaf
+        const bool has_b = v && pos + 1 < n_leaves;
+        L leaf_a = {}, leaf_b = {};
+        I idx_a = 0, idx_b = 0;
+        uint64_t mor_a = 0, mor_b = 0;
+        const char *rec = a.leaves + pos * a.lay.stride;
+        if (v) {
+            leaf_a = load_vol<L>(rec);
+            idx_a = load_index<I>(rec, a.lay);
+            if constexpr (NARROW)
+                if (a.narrow == IBVH_NARROW_MORTON_LT) mor_a = load_morton(rec, a.lay);
+        }
+        if (has_b) {
+            leaf_b = load_vol<L>(rec + a.lay.stride);
+            idx_b = load_index<I>(rec + a.lay.stride, a.lay);
+            if constexpr (NARROW)
+                if (a.narrow == IBVH_NARROW_MORTON_LT) mor_b = load_morton(rec + a.lay.stride, a.lay);
+        }
+        const L ql = shuffle_from(q.q_leaf, qi);
+        const I qidx = __shfl(q.q_index, qi, 64);
+        const int64_t item_q = wave_item0 + qi;
+        bool hit_a = v && iscontact(ql, leaf_a), hit_b = has_b && iscontact(ql, leaf_b);
+        if constexpr (MODE == MODE_SELF) { // only partners to the right of the query
+            hit_a = hit_a && pos > item_q;
+            hit_b = hit_b && pos + 1 > item_q;
+        }
+        if constexpr (NARROW) {
+            const uint64_t qm = (uint64_t)__shfl((long long)q.q_morton, qi, 64);
+            const bool fl = MODE == MODE_PAIR && a.flip;
+            hit_a = hit_a && (fl ? narrow_eval(a.narrow, mor_a, idx_a, qm, qidx) : narrow_eval(a.narrow, qm, qidx, mor_a, idx_a));
+            hit_b = hit_b && (fl ? narrow_eval(a.narrow, mor_b, idx_b, qm, qidx) : narrow_eval(a.narrow, qm, qidx, mor_b, idx_b));
+        }
+        // lanes holding the same query (match-any on the 6-bit lane id)
+        uint64_t same = __ballot(v);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const bool bit = (qi >> b) & 1;
+            const uint64_t m = __ballot(bit);
+            same &= bit ? m : ~m;
+        }
+        const uint64_t m_a = __ballot(hit_a), m_b = __ballot(hit_b);
+        const int rank = __popcll(same & lt_mask & m_a) + __popcll(same & lt_mask & m_b);
+        const int tot = __popcll(same & m_a) + __popcll(same & m_b);
+        const Cnt base = cnts[qi];
+        __builtin_amdgcn_wave_barrier();
+        if (v && (same & lt_mask) == 0 && tot > 0) cnts[qi] = base + (Cnt)tot;
+        __builtin_amdgcn_wave_barrier();
+        auto put = [&](Cnt at, I lidx) {
+            IndexPair<I> c2;
+            if constexpr (MODE == MODE_SELF) c2 = qidx > lidx ? IndexPair<I>{lidx, qidx} : IndexPair<I>{qidx, lidx};
+            else c2 = a.flip ? IndexPair<I>{lidx, qidx} : IndexPair<I>{qidx, lidx};
+            if constexpr (WRITE) {
+                a.contacts[(int64_t)at] = c2;
+            } else {
+                if (at < (Cnt)cache.K) cache.slots[(int64_t)at * a.n_items + item_q] = c2;
+            }
+        };
+        const Cnt at = base + (Cnt)rank;
+        if (hit_a) put(at, idx_a);
+        if (hit_b) put(at + (hit_a ? 1 : 0), idx_b);
+    };
+    // drain the full 64-pair steps (all == false) or everything (all == true); a remainder moves to the front
+    auto drain = [&](bool all) {
+        int done = 0;
+        while (qn - done >= 64 || (all && qn - done > 0)) {
+            const int avail = qn - done < 64 ? qn - done : 64;
+            pair_step(done, avail);
+            done += avail;
+        }
+        const int rem = qn - done;
+        if (rem > 0 && done > 0) {
+            const uint32_t e = lane < rem ? queue[done + lane] : 0u;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rem) queue[lane] = e;
+            __builtin_amdgcn_wave_barrier();
+        }
+        qn = rem;
+    };
+
+    // b: candidates of the subtree rooted at node c (level cut_level) whose box is `cbox`
+    auto brute = [&](uint32_t c, const N &cbox) {
+        bool on = q.lane_on && iscontact(q.q_node, cbox);
+        if constexpr (MODE == MODE_SELF) on = on && !(((uint64_t)c + 1) <= (self_next >> (levels - cut_level)));
+        const uint64_t on_mask = __ballot(on);
+        if (on_mask == 0) return;
+        const int64_t first = (int64_t)(c - (1u << (cut_level - 1))) << (lp - cut_level);
+        int64_t last = first + (int64_t(1) << (lp - cut_level));
+        last = last < lp_real ? last : lp_real;
+        const int np = (int)(last - first); // <= 64
+        N mybox; // lanes without a parent hold the empty box: it matches nothing
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            mybox.lo[k] = float_max<TN>();
+            mybox.up[k] = -float_max<TN>();
+        }
+        if (lane < np) mybox = load_vol<N>(lp_nodes + first + lane);
+        const uint64_t box_mask = __ballot(touches_wave(mybox));
+        // shorter of the two loops: lanes = queries over the parents that touch the union box, or
+        // lanes = parents over the active queries
+        const bool by_box = __popcll(box_mask) < __popcll(on_mask);
+        for (uint64_t todo = by_box ? box_mask : on_mask; todo != 0; todo &= todo - 1) {
+            if (qn > QUEUE_CAP - 64) drain(false);
+            const int u = __builtin_ctzll(todo);
+            bool h;
+            uint32_t e;
+            if (by_box) {
+                const N pbox = broadcast_from_lane(mybox, u);
+                h = on && iscontact(q.q_node, pbox);
+                if constexpr (MODE == MODE_SELF) h = h && 2 * (first + u) + 1 > q.item;
+                e = (uint32_t)lane | ((uint32_t)(first + u) << 6);
+            } else {
+                const N qbox = broadcast_from_lane(q.q_node, u);
+                h = iscontact(qbox, mybox);
+                if constexpr (MODE == MODE_SELF) h = h && 2 * (first + lane) + 1 > wave_item0 + u;
+                e = (uint32_t)u | ((uint32_t)(first + lane) << 6);
+            }
+            const uint64_t hm = __ballot(h);
+            if (h) queue[qn + __popcll(hm & lt_mask)] = e;
+            qn += __popcll(hm);
+        }
+    };
+
+    // a: frontier descent (see lvt_cluster_kernel)
+    uint32_t *fr0 = s_frontier[wv][0], *fr1 = s_frontier[wv][1];
+    const uint32_t root_first = 1u << (a.start_level - 1);
+    const int64_t roots = level_num_real(levels, vl, a.start_level);
+    bool overflow = false;
+    for (int64_t r0 = 0; r0 < roots && !overflow; r0 += FRONTIER_CAP) {
+        int count = (int)((roots - r0) < FRONTIER_CAP ? (roots - r0) : FRONTIER_CAP);
+        for (int i = lane; i < count; i += 64) fr0[i] = root_first + (uint32_t)(r0 + i);
+        __builtin_amdgcn_wave_barrier();
+        uint32_t *cur = fr0, *nxt = fr1;
+        for (int lvl = (int)a.start_level; lvl <= cut_level && count > 0; ++lvl) {
+            const N *lvl_nodes = a.nodes + (level_start(levels, vl, lvl) - 1);
+            const uint32_t lvl_first = 1u << (lvl - 1);
+            const int64_t child_real = level_num_real(levels, vl, lvl + 1);
+            int next_count = 0;
+            for (int base = 0; base < count; base += 64) {
+                const bool have = base + lane < count;
+                const uint32_t idx = have ? cur[base + lane] : 0u;
+                N box;
+                bool hit = false;
+                if (have) {
+                    box = load_vol<N>(lvl_nodes + (idx - lvl_first));
+                    hit = touches_wave(box);
+                    if constexpr (MODE == MODE_SELF) hit = hit && !(((uint64_t)idx + 1) <= (wave_next >> (levels - lvl)));
+                }
+                const uint64_t hm = __ballot(hit);
+                if (lvl == cut_level) {
+                    for (uint64_t todo = hm; todo != 0; todo &= todo - 1) {
+                        const int src = __builtin_ctzll(todo);
+                        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)idx, src);
+                        const N cbox = broadcast_from_lane(box, src);
+                        brute(c, cbox);
+                    }
+                } else {
+                    const int before = __popcll(hm & lt_mask);
+                    const int total = __popcll(hm);
+                    const bool last_virtual = hm != 0 && [&] {
+                        const int top = 63 - __builtin_clzll(hm);
+                        const uint32_t ti = (uint32_t)__builtin_amdgcn_readlane((int)idx, top);
+                        return (int64_t)(2u * ti + 1u - (1u << lvl)) >= child_real;
+                    }();
+                    const int add = 2 * total - (last_virtual ? 1 : 0);
+                    if (next_count + add > FRONTIER_CAP) {
+                        overflow = true;
+                        break;
+                    }
+                    if (hit) {
+                        nxt[next_count + 2 * before] = 2u * idx;
+                        if (2 * before + 1 < add) nxt[next_count + 2 * before + 1] = 2u * idx + 1u;
+                    }
+                    next_count += add;
+                }
+            }
+            if (overflow) break;
+            __builtin_amdgcn_wave_barrier();
+            uint32_t *t = cur;
+            cur = nxt;
+            nxt = t;
+            count = lvl == cut_level ? 0 : next_count;
+        }
+    }
+    if (overflow) {
+        // frontier too wide for LDS (heavily overlapping input): redo this wave with the exact walk from
+        // scratch; whatever was already emitted is written again, identically
+        q.cnt = 0;
+        if constexpr (WRITE) q.w = (q.valid && q.item > 0) ? (Cnt)a.counts[q.item - 1] : 0;
+        joint_walk(q, a);
+        q.finish();
+        return;
+    }
+    drain(true);
+    if constexpr (!WRITE)
+        if (q.valid) a.counts[q.item] = (I)cnts[lane];
+}
+
 // ---- (3) rays: per-lane walk ------------------------------------------------------------------------
 // The rays of a wave are not spatially coherent, so every lane walks on its own — but leaner than the
 // reference's loop (raytrace/leaf_vs_tree/leaf_vs_tree.jl:187-225): a step tests BOTH children of the
@@ -717,6 +1025,21 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
                     return (e && atoi(e) == 64) ? 64 : 256;
                 }();
                 const unsigned cb = (unsigned)ceil_div(a.n_items, tpb);
+                static const bool use_queue = [] {
+                    const char *e = getenv("IBVH_LVT_QUEUE");
+                    return !(e && atoi(e) == 0);
+                }();
+                if (use_queue && a.tree.levels <= 28 && tpb == 256) { // queue entries pack (parent index << 6 | lane) in 32 bits
+                    if (a.narrow != IBVH_NARROW_NONE) {
+                        if (write) IBVH_LAUNCH((lvt_queue_kernel<L, N, I, MODE, true, true>), dim3(cb), dim3(tpb), 0, st, a, cache, cut);
+                        else IBVH_LAUNCH((lvt_queue_kernel<L, N, I, MODE, false, true>), dim3(cb), dim3(tpb), 0, st, a, cache, cut);
+                    } else {
+                        if (write) IBVH_LAUNCH((lvt_queue_kernel<L, N, I, MODE, true, false>), dim3(cb), dim3(tpb), 0, st, a, cache, cut);
+                        else IBVH_LAUNCH((lvt_queue_kernel<L, N, I, MODE, false, false>), dim3(cb), dim3(tpb), 0, st, a, cache, cut);
+                    }
+                    IBVH_LAUNCH_CHECK();
+                    return IBVH_OK;
+                }
                 if (a.narrow != IBVH_NARROW_NONE) {
                     if (write) IBVH_LAUNCH((lvt_cluster_kernel<L, N, I, MODE, true, true>), dim3(cb), dim3(tpb), 0, st, a, cache, cut);
                     else IBVH_LAUNCH((lvt_cluster_kernel<L, N, I, MODE, false, true>), dim3(cb), dim3(tpb), 0, st, a, cache, cut);
