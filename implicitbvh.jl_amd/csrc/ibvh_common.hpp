@@ -210,8 +210,9 @@ template <class TA, class TB> IBVH_HD bool iscontact(const BSphere<TA> &a, const
     return dist3sq(a.x, b.x) <= (a.r + b.r) * (a.r + b.r);
 }
 template <class TA, class TB> IBVH_HD bool iscontact(const BBox<TA> &a, const BBox<TB> &b) {
-    return (a.up[0] >= b.lo[0] && a.lo[0] <= b.up[0]) && (a.up[1] >= b.lo[1] && a.lo[1] <= b.up[1]) &&
-           (a.up[2] >= b.lo[2] && a.lo[2] <= b.up[2]);
+    // (bitwise &: six independent compares, no short-circuit branches on the GPU)
+    return (a.up[0] >= b.lo[0]) & (a.lo[0] <= b.up[0]) & (a.up[1] >= b.lo[1]) & (a.lo[1] <= b.up[1]) &
+           (a.up[2] >= b.lo[2]) & (a.lo[2] <= b.up[2]);
 }
 template <class TA, class TB> IBVH_HD bool iscontact(const BSphere<TA> &a, const BBox<TB> &b) {
     BBox<TA> ab = {{a.x[0] - a.r, a.x[1] - a.r, a.x[2] - a.r}, {a.x[0] + a.r, a.x[1] + a.r, a.x[2] + a.r}};

@@ -35,6 +35,7 @@ template <class L, class N, class I> struct Args {
     int64_t start_level;
     int32_t narrow;
     int32_t flip;
+    int32_t xcd_tiles; // work items handed out so that each XCD walks one contiguous range (speed only)
     // outputs
     I *counts;                 // count pass: per-item counts; write pass: inclusive prefix
     IndexPair<I> *contacts;
@@ -112,7 +113,8 @@ template <class L, class N, class I, int MODE, bool WRITE, bool NARROW> struct Q
     IBVH_D Query(const Args<L, N, I> &a_, const PairCache<I> &c_) : a(a_), cache(c_) {
         // (an XCD-contiguous block->tile remap was measured here in round 1: 0.44 -> 0.61 ms at 1e6 leaves,
         // no change at 1e7, so work items keep the plain round-robin placement)
-        item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // 64-thread (one wave) or 256-thread workgroups
+        const int blk = a.xcd_tiles ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+        item = (int64_t)blk * blockDim.x + threadIdx.x; // 64-thread (one wave) or 256-thread workgroups
         valid = item < a.n_items;
         q_leaf = {};
         q_node = {};
@@ -611,14 +613,14 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
             hit_b = hit_b && (fl ? narrow_eval(a.narrow, mor_b, idx_b, qm, qidx) : narrow_eval(a.narrow, qm, qidx, mor_b, idx_b));
         }
         // lanes holding the same query (match-any on the 6-bit lane id)
-        uint64_t same = __ballot(v);
+        uint64_t same = __builtin_amdgcn_ballot_w64(v);
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
             const bool bit = (qi >> b) & 1;
-            const uint64_t m = __ballot(bit);
+            const uint64_t m = __builtin_amdgcn_ballot_w64(bit);
             same &= bit ? m : ~m;
         }
-        const uint64_t m_a = __ballot(hit_a), m_b = __ballot(hit_b);
+        const uint64_t m_a = __builtin_amdgcn_ballot_w64(hit_a), m_b = __builtin_amdgcn_ballot_w64(hit_b);
         const int rank = __popcll(same & lt_mask & m_a) + __popcll(same & lt_mask & m_b);
         const int tot = __popcll(same & m_a) + __popcll(same & m_b);
         const Cnt base = cnts[qi];
@@ -654,14 +656,14 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
             if (lane < rem) queue[lane] = e;
             __builtin_amdgcn_wave_barrier();
         }
-        qn = rem;
+        qn = __builtin_amdgcn_readfirstlane(rem);
     };
 
     // b: candidates of the subtree rooted at node c (level cut_level) whose box is `cbox`
     auto brute = [&](uint32_t c, const N &cbox) {
         bool on = q.lane_on && iscontact(q.q_node, cbox);
         if constexpr (MODE == MODE_SELF) on = on && !(((uint64_t)c + 1) <= (self_next >> (levels - cut_level)));
-        const uint64_t on_mask = __ballot(on);
+        const uint64_t on_mask = __builtin_amdgcn_ballot_w64(on);
         if (on_mask == 0) return;
         const int64_t first = (int64_t)(c - (1u << (cut_level - 1))) << (lp - cut_level);
         int64_t last = first + (int64_t(1) << (lp - cut_level));
@@ -674,10 +676,18 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
             mybox.up[k] = -float_max<TN>();
         }
         if (lane < np) mybox = load_vol<N>(lp_nodes + first + lane);
-        const uint64_t box_mask = __ballot(touches_wave(mybox));
-        // shorter of the two loops: lanes = queries over the parents that touch the union box, or
-        // lanes = parents over the active queries
+        const uint32_t first32 = (uint32_t)first; // positions fit 32 bits here (levels <= 28)
+        const uint32_t right_leaf = 2u * (first32 + (uint32_t)lane) + 1u; // of this lane's parent
+        bool box_on = touches_wave(mybox);
+        if constexpr (MODE == MODE_SELF) box_on = box_on & (right_leaf > (uint32_t)wave_item0);
+        const uint64_t box_mask = __builtin_amdgcn_ballot_w64(box_on);
+        // shorter of the two loops: lanes = queries over the parents that touch the wave's boxes, or
+        // lanes = parents over the active queries.  (Measured alternative: lanes = (query, parent) pairs
+        // pulled together with ds_bpermute — as many steps as this loop has iterations, and slower.)
         const bool by_box = __popcll(box_mask) < __popcll(on_mask);
+        const uint32_t e_box = (uint32_t)lane | (first32 << 6);     // + (u << 6)
+        const uint32_t e_qry = (first32 + (uint32_t)lane) << 6;      // | u
+        const uint32_t my_item = (uint32_t)q.item;
         for (uint64_t todo = by_box ? box_mask : on_mask; todo != 0; todo &= todo - 1) {
             if (qn > QUEUE_CAP - 64) drain(false);
             const int u = __builtin_ctzll(todo);
@@ -685,18 +695,19 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
             uint32_t e;
             if (by_box) {
                 const N pbox = broadcast_from_lane(mybox, u);
-                h = on && iscontact(q.q_node, pbox);
-                if constexpr (MODE == MODE_SELF) h = h && 2 * (first + u) + 1 > q.item;
-                e = (uint32_t)lane | ((uint32_t)(first + u) << 6);
+                h = on & iscontact(q.q_node, pbox);
+                if constexpr (MODE == MODE_SELF) h = h & (2u * (first32 + (uint32_t)u) + 1u > my_item);
+                e = e_box + ((uint32_t)u << 6);
             } else {
                 const N qbox = broadcast_from_lane(q.q_node, u);
-                h = iscontact(qbox, mybox);
-                if constexpr (MODE == MODE_SELF) h = h && 2 * (first + lane) + 1 > wave_item0 + u;
-                e = (uint32_t)u | ((uint32_t)(first + lane) << 6);
+                h = box_on & iscontact(qbox, mybox);
+                if constexpr (MODE == MODE_SELF) h = h & (right_leaf > (uint32_t)wave_item0 + (uint32_t)u);
+                e = e_qry | (uint32_t)u;
             }
-            const uint64_t hm = __ballot(h);
-            if (h) queue[qn + __popcll(hm & lt_mask)] = e;
-            qn += __popcll(hm);
+            const uint64_t hm = __builtin_amdgcn_ballot_w64(h);
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+            if (h) queue[qn + rank] = e;
+            qn = __builtin_amdgcn_readfirstlane(qn + __popcll(hm));
         }
     };
 
@@ -725,7 +736,7 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
                     hit = touches_wave(box);
                     if constexpr (MODE == MODE_SELF) hit = hit && !(((uint64_t)idx + 1) <= (wave_next >> (levels - lvl)));
                 }
-                const uint64_t hm = __ballot(hit);
+                const uint64_t hm = __builtin_amdgcn_ballot_w64(hit);
                 if (lvl == cut_level) {
                     for (uint64_t todo = hm; todo != 0; todo &= todo - 1) {
                         const int src = __builtin_ctzll(todo);
@@ -1093,6 +1104,11 @@ int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const voi
                 a.start_level = start_level;
                 a.narrow = narrow;
                 a.flip = flip;
+                static const int xcd_env = [] {
+                    const char *e = getenv("IBVH_LVT_XCD"); // tuning knob
+                    return e ? atoi(e) : 0;
+                }();
+                a.xcd_tiles = MODE != MODE_RAYS && xcd_env;
                 a.counts = (I *)counts;
                 a.contacts = (IndexPair<I> *)contacts;
                 PairCache<I> cache{K ? (IndexPair<I> *)((char *)scratch + scan_scratch_bytes(n_items)) : nullptr, K};
