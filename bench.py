@@ -49,21 +49,21 @@ def algorithmic_bytes(kernel, n, contacts):
         "aggregate_kernel": 16.0 + 24.0 + 24.0,    # leaves' volumes + every node read once + written once
         "lvt_kernel_count": 24.0 + 24.0 + 4.0,     # leaves + nodes once + counts
         "lvt_kernel_write": 24.0 + 24.0 + 4.0 + 8.0 * c,  # + prefix read, contacts written
-        "lvt_joint_kernel_count": 24.0 + 24.0 + 4.0 + 8.0 * c, "lvt_cluster_kernel_count": 24.0 + 24.0 + 4.0 + 8.0 * c,
-        "lvt_queue_kernel_count": 24.0 + 24.0 + 4.0 + 8.0 * c,  # leaves + nodes once, counts, contact cache written
-        "lvt_joint_kernel_write": 8.0 + 16.0 * c, "lvt_cluster_kernel_write": 8.0 + 16.0 * c,
-        "lvt_queue_kernel_write": 8.0 + 16.0 * c,   # prefix read (2 x 4) + cached contacts read and written
+        "lvt_joint_kernel_count": 24.0 + 24.0 + 4.0 + 8.0 * c,  # leaves + nodes once, counts, contact cache written
+        "lvt_queue_kernel_count": 24.0 + 24.0 + 4.0 + 8.0 * c,
+        "lvt_joint_kernel_write": 8.0 + 16.0 * c,               # prefix read (2 x 4) + cached contacts read and written
+        "lvt_queue_kernel_write": 8.0 + 16.0 * c,
         "scan_reduce_kernel": 4.0, "scan_apply_kernel": 8.0,
     }
     return table.get(kernel, 0.0) * n
 
 
 def kernel_key(name):
-    """'(lvt_cluster_kernel<L, N, I, MODE, true, false>)' -> 'lvt_cluster_kernel_write' (5th argument = WRITE)."""
+    """'(lvt_queue_kernel<L, N, I, MODE, true, false>)' -> 'lvt_queue_kernel_write' (5th argument = WRITE)."""
     base = name.strip("() ").split("<")[0].split("::")[-1].strip()
     if base == "scatter_kernel" and "true>" in name.replace(" ", ""):
         return "scatter_records_kernel"
-    if base in ("lvt_kernel", "lvt_rays_kernel", "lvt_joint_kernel", "lvt_cluster_kernel", "lvt_queue_kernel"):
+    if base in ("lvt_kernel", "lvt_rays_kernel", "lvt_joint_kernel", "lvt_queue_kernel"):
         flat = name.replace(" ", "")
         return base + ("_write" if ("MODE,true" in flat or "I,true>" in flat) else "_count")
     return base

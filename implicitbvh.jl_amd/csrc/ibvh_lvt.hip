@@ -5,8 +5,8 @@
 // Replaces src/traverse/leaf_vs_tree/traverse_single.jl, traverse_pair.jl and
 // src/raytrace/leaf_vs_tree/leaf_vs_tree.jl.
 //
-// Three walkers, documented where they are defined: lvt_cluster_kernel (BBox nodes: frontier descent +
-// brute-forced subtrees), lvt_joint_kernel (exact wave-uniform pre-order walk, any node type) and
+// Three walkers, documented where they are defined: lvt_queue_kernel (BBox nodes: frontier descent +
+// candidate-pair queue), lvt_joint_kernel (exact wave-uniform pre-order walk, any node type) and
 // lvt_rays_kernel (per-lane walk with a bitmask stack).  The reference's 32-entry per-thread index stack
 // (traverse_single.jl:188-203) is never needed: the tree is implicit, so "the pending right siblings of
 // the current path" is one 32-bit mask.
@@ -33,6 +33,7 @@ template <class L, class N, class I> struct Args {
     const N *nodes;
     TreeDev tree;
     int64_t start_level;
+    int64_t built_level;       // nodes above it do not exist
     int32_t narrow;
     int32_t flip;
     int32_t xcd_tiles; // work items handed out so that each XCD walks one contiguous range (speed only)
@@ -64,23 +65,27 @@ IBVH_D bool narrow_eval(int narrow, uint64_t ma, int64_t ia, uint64_t mb, int64_
 //     (traverse_single.jl:157-203), and pre-order visits leaves in increasing position, so each lane
 //     emits its contacts in the reference's order.
 //
-// (2) lvt_cluster_kernel — BBox nodes.  BBox parents are the exact min/max of their children
+// (2) lvt_queue_kernel — BBox nodes.  BBox parents are the exact min/max of their children
 //     (merge.jl:30-40), so box tests are monotone along a root-to-leaf path: a query that touches the
 //     box of a leaf's PARENT (level levels-1) touches every ancestor's box.  The reference's walk
 //     therefore reports leaf j for query q iff q touches parent(j)'s box and the leaf test passes
 //     (plus, for the self walk, j to the right of q): the interior levels only prune, they never
 //     change the result, and ANY conservative enumeration of candidates followed by those two exact
-//     tests gives the reference's list, provided each lane emits in increasing leaf position.  So:
+//     tests gives the reference's list, provided each query's contacts come out in increasing leaf
+//     position.  So:
 //       a. frontier descent, lanes = NODES: level by level the wave tests up to 64 frontier nodes at
-//          once against the union box of its queries and compacts the children of the hits (ballot +
-//          popcount) into the next frontier in LDS — one step per level instead of one per node;
-//       b. at the cut level (subtrees of 128 leaves) each surviving subtree is brute-forced: lane k
-//          HOLDS leaf-parent k (box + both leaf records, coalesced loads, one memory latency per
-//          subtree); the wave loops over the ACTIVE queries only, broadcasting a query box
-//          (v_readlane) and testing all 64 parents at once: the ballot is that query's candidate mask;
-//       c. every query lane walks its own candidates left to right, pulling the two leaves of a
-//          candidate parent out of the holding lane with ds_bpermute, runs the exact leaf test, emits.
-//     BSphere nodes (rounded merges, not nested) and start_level == levels take kernel (1).
+//          once against two boxes that cover its queries and compacts the children of the hits (ballot
+//          + popcount) into the next frontier in LDS — one step per level instead of one per node;
+//       b. at the cut level (subtrees of 128 leaves) lane k loads leaf-parent k of each surviving subtree
+//          (coalesced) and the wave finds the (query, parent) candidates with the shorter of two loops:
+//          over the active queries (broadcast a query box with v_readlane, test all 64 parents at once)
+//          or over the parents that touch the wave's boxes (broadcast a parent, test all 64 queries);
+//          candidates are appended to a per-wave LDS queue;
+//       c. the queue is drained 64 candidates at a time with every lane busy: a lane gathers the two
+//          leaves of its candidate parent, runs the exact leaf tests and ranks its hits among the lanes
+//          that hold the same query.
+//     BSphere nodes (rounded merges, not nested), start_level == levels and trees deeper than 28 levels
+//     take kernel (1).
 //
 // Contact cache: the counting pass also stores the first K contacts of every work item in a
 // slot-major scratch array (slot k of item i at [k * n_items + i]); the writing pass copies them to
@@ -114,7 +119,7 @@ template <class L, class N, class I, int MODE, bool WRITE, bool NARROW> struct Q
         // (an XCD-contiguous block->tile remap was measured here in round 1: 0.44 -> 0.61 ms at 1e6 leaves,
         // no change at 1e7, so work items keep the plain round-robin placement)
         const int blk = a.xcd_tiles ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-        item = (int64_t)blk * blockDim.x + threadIdx.x; // 64-thread (one wave) or 256-thread workgroups
+        item = (int64_t)blk * blockDim.x + threadIdx.x;
         valid = item < a.n_items;
         q_leaf = {};
         q_node = {};
@@ -282,203 +287,16 @@ template <class T> IBVH_D T wave_max_all(T v) {
     return v;
 }
 
-template <class L, class N, class I, int MODE, bool WRITE, bool NARROW>
-__global__ __launch_bounds__(256, 6) void lvt_cluster_kernel(Args<L, N, I> a, PairCache<I> cache, int cut_level) {
-    using TN = typename N::elt;
-    __shared__ uint32_t s_frontier[4][2][FRONTIER_CAP];
-    Query<L, N, I, MODE, WRITE, NARROW> q(a, cache);
-    if constexpr (WRITE)
-        if (!q.begin_write()) return;
-
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t levels = a.tree.levels, vl = a.tree.virtual_leaves;
-    const uint32_t leaf_first = 1u << (levels - 1);
-    const uint64_t self_next = (uint64_t)q.item + leaf_first + 1;
-    // first work item of the wave: nodes wholly at or left of it are useless to every lane (SELF)
-    const uint64_t wave_next = ((uint64_t)q.item - (uint64_t)lane) + leaf_first + 1;
-
-    // union box of the wave's active queries (inactive lanes contribute the empty box)
-    N ubox;
-    {
-        const TN big = float_max<TN>();
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            ubox.lo[k] = wave_min_all(q.lane_on ? q.q_node.lo[k] : big);
-            ubox.up[k] = wave_max_all(q.lane_on ? q.q_node.up[k] : -big);
-        }
-    }
-
-    const int lp = (int)levels - 1; // level of the leaf-parents
-    const int64_t lp_real = level_num_real(levels, vl, lp);
-    const N *lp_nodes = a.nodes + (level_start(levels, vl, lp) - 1);
-
-    // b + c: brute-force the subtree rooted at node c (level cut_level) whose box is `cbox`
-    auto brute = [&](uint32_t c, const N &cbox) {
-        bool on = q.lane_on && iscontact(q.q_node, cbox);
-        if constexpr (MODE == MODE_SELF) on = on && !(((uint64_t)c + 1) <= (self_next >> (levels - cut_level)));
-        const uint64_t on_mask = __ballot(on);
-        if (on_mask == 0) return;
-        const int64_t first = (int64_t)(c - (1u << (cut_level - 1))) << (lp - cut_level);
-        int64_t last = first + (int64_t(1) << (lp - cut_level));
-        last = last < lp_real ? last : lp_real;
-        const int np = (int)(last - first); // <= 64
-        const int64_t leaf0 = 2 * first;    // 0-based position of the subtree's first leaf
-        const int64_t nl = a.tree.real_leaves - leaf0; // leaves from there on (may exceed 2*np)
-        // lanes without a parent hold the empty box: it matches nothing, no exec masking in the loop
-        N mybox;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            mybox.lo[k] = float_max<TN>();
-            mybox.up[k] = -float_max<TN>();
-        }
-        L leafA = {}, leafB = {};
-        I idxA = 0, idxB = 0;
-        uint64_t morA = 0, morB = 0; // only live when NARROW
-        if (lane < np) {
-            mybox = load_vol<N>(lp_nodes + first + lane);
-            const char *rec = a.leaves + (leaf0 + 2 * lane) * a.lay.stride;
-            leafA = load_vol<L>(rec);
-            idxA = load_index<I>(rec, a.lay);
-            if constexpr (NARROW)
-                if (a.narrow == IBVH_NARROW_MORTON_LT) morA = load_morton(rec, a.lay);
-            if (2 * lane + 1 < nl) {
-                rec += a.lay.stride;
-                leafB = load_vol<L>(rec);
-                idxB = load_index<I>(rec, a.lay);
-                if constexpr (NARROW)
-                    if (a.narrow == IBVH_NARROW_MORTON_LT) morB = load_morton(rec, a.lay);
-            }
-        }
-        // stage b: candidate parents of every active query.  Either loop — over the active queries
-        // (lanes = parents) or over the parents that touch the union box (lanes = queries) — yields
-        // the same per-lane candidate masks; take the shorter one.
-        uint64_t mine = 0;
-        const uint64_t box_mask = __ballot(iscontact(ubox, mybox));
-        if (__popcll(box_mask) < __popcll(on_mask)) {
-            uint32_t lo = 0, hi = 0;
-            for (uint64_t todo = box_mask; todo != 0; todo &= todo - 1) {
-                const int p = __builtin_ctzll(todo);
-                const N pbox = broadcast_from_lane(mybox, p);
-                const bool h = iscontact(q.q_node, pbox);
-                if (p < 32) lo |= h ? (1u << p) : 0u;
-                else hi |= h ? (1u << (p - 32)) : 0u;
-            }
-            mine = on ? (((uint64_t)hi << 32) | lo) : 0;
-        } else {
-            for (uint64_t todo = on_mask; todo != 0; todo &= todo - 1) {
-                const int qi = __builtin_ctzll(todo);
-                const N qbox = broadcast_from_lane(q.q_node, qi);
-                const uint64_t m = __ballot(iscontact(qbox, mybox));
-                if (lane == qi) mine = m;
-            }
-        }
-        // stage c: every query lane tests the leaves of its own candidates, left to right
-        while (__ballot(mine != 0) != 0) {
-            const bool has = mine != 0;
-            const int p = has ? __builtin_ctzll(mine) : 0;
-            mine &= mine - 1;
-#pragma unroll
-            for (int side = 0; side < 2; ++side) {
-                const int64_t pos = leaf0 + 2 * p + side;
-                bool hit = has && (2 * p + side < nl);
-                if constexpr (MODE == MODE_SELF) hit = hit && pos > q.item; // only partners to the right
-                const L leaf = shuffle_from(side ? leafB : leafA, p);
-                const I lidx = __shfl(side ? idxB : idxA, p, 64);
-                hit = hit && iscontact(q.q_leaf, leaf);
-                if constexpr (NARROW) {
-                    const uint64_t lm = (uint64_t)__shfl((long long)(side ? morB : morA), p, 64);
-                    hit = hit && q.narrow_ok(lm, lidx);
-                }
-                if (hit) q.emit(lidx);
-            }
-        }
-    };
-
-    // a: frontier descent from the start level to the cut level.  Roots are taken in chunks so the
-    // first frontier always fits; chunks and frontier entries stay in increasing node order, which
-    // keeps every lane's emission order (increasing leaf position).
-    uint32_t *fr0 = s_frontier[wv][0], *fr1 = s_frontier[wv][1];
-    const uint32_t root_first = 1u << (a.start_level - 1);
-    const int64_t roots = level_num_real(levels, vl, a.start_level);
-    bool overflow = false;
-    for (int64_t r0 = 0; r0 < roots && !overflow; r0 += FRONTIER_CAP) {
-        int count = (int)((roots - r0) < FRONTIER_CAP ? (roots - r0) : FRONTIER_CAP);
-        for (int i = lane; i < count; i += 64) fr0[i] = root_first + (uint32_t)(r0 + i);
-        __builtin_amdgcn_wave_barrier(); // LDS is in order within a wave; keep the compiler from reordering
-        uint32_t *cur = fr0, *nxt = fr1;
-        for (int lvl = (int)a.start_level; lvl <= cut_level && count > 0; ++lvl) {
-            const N *lvl_nodes = a.nodes + (level_start(levels, vl, lvl) - 1);
-            const uint32_t lvl_first = 1u << (lvl - 1);
-            const int64_t child_real = level_num_real(levels, vl, lvl + 1);
-            int next_count = 0;
-            for (int base = 0; base < count; base += 64) {
-                const bool have = base + lane < count;
-                const uint32_t idx = have ? cur[base + lane] : 0u;
-                N box;
-                bool hit = false;
-                if (have) {
-                    box = load_vol<N>(lvl_nodes + (idx - lvl_first));
-                    hit = iscontact(ubox, box);
-                    if constexpr (MODE == MODE_SELF) hit = hit && !(((uint64_t)idx + 1) <= (wave_next >> (levels - lvl)));
-                }
-                const uint64_t hm = __ballot(hit);
-                if (lvl == cut_level) {
-                    for (uint64_t todo = hm; todo != 0; todo &= todo - 1) {
-                        const int src = __builtin_ctzll(todo);
-                        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)idx, src);
-                        const N cbox = broadcast_from_lane(box, src);
-                        brute(c, cbox);
-                    }
-                } else {
-                    // children of the hits, in order; the right child of the level's last real node
-                    // may be virtual (the left child of a real node never is)
-                    const int before = __popcll(hm & (((uint64_t)1 << lane) - 1));
-                    const int total = __popcll(hm);
-                    const bool last_virtual = hm != 0 && [&] {
-                        const int top = 63 - __builtin_clzll(hm);
-                        const uint32_t ti = (uint32_t)__builtin_amdgcn_readlane((int)idx, top);
-                        return (int64_t)(2u * ti + 1u - (1u << lvl)) >= child_real;
-                    }();
-                    const int add = 2 * total - (last_virtual ? 1 : 0);
-                    if (next_count + add > FRONTIER_CAP) {
-                        overflow = true;
-                        break;
-                    }
-                    if (hit) {
-                        nxt[next_count + 2 * before] = 2u * idx;
-                        if (2 * before + 1 < add) nxt[next_count + 2 * before + 1] = 2u * idx + 1u;
-                    }
-                    next_count += add;
-                }
-            }
-            if (overflow) break;
-            __builtin_amdgcn_wave_barrier();
-            uint32_t *t = cur;
-            cur = nxt;
-            nxt = t;
-            count = lvl == cut_level ? 0 : next_count;
-        }
-    }
-    if (overflow) {
-        // frontier too wide for LDS (heavily overlapping input): redo this wave with the exact walk.
-        // Nothing has been emitted yet unless the cut level was reached, so restart from scratch.
-        q.cnt = 0;
-        if constexpr (WRITE) q.w = (q.valid && q.item > 0) ? (typename decltype(q)::Cnt)a.counts[q.item - 1] : 0;
-        joint_walk(q, a);
-    }
-    q.finish();
-}
-
-// ---- (2b) BBox nodes: frontier descent + candidate-pair queue ---------------------------------------
-// Same enumeration as lvt_cluster_kernel down to the cut level, but the leaf tests are deferred: stage b
-// appends every (query lane, leaf-parent) candidate to a per-wave LDS queue, and the queue is drained 64
-// pairs at a time with ALL lanes busy — each lane gathers the two leaves of its pair (48 contiguous bytes
-// for BSphere{Float32} records), runs the exact leaf tests and ranks its hits among the lanes that hold
-// the same query (6-ballot match-any on the query lane id), so the contacts of a query still come out in
-// increasing leaf position: queue order is (subtree, then parent) ascending for any fixed query.  The
-// per-query counters / output offsets live in LDS.  Against stage c of lvt_cluster_kernel (one round per
-// candidate of the busiest lane, ~22 % of the lanes busy at 1e6 random spheres) this runs ~4x fewer leaf-test
-// rounds and no longer loads the leaves of parents nobody touches.
+// ---- (2) BBox nodes: frontier descent + candidate-pair queue ----------------------------------------
+// Stage c in detail: each lane gathers the two leaves of its pair (48 contiguous bytes for BSphere{Float32}
+// records), runs the exact leaf tests and ranks its hits among the lanes that hold the same query (6-ballot
+// match-any on the query lane id), so the contacts of a query still come out in increasing leaf position:
+// queue order is (subtree, then parent) ascending for any fixed query.  The per-query counters / output
+// offsets live in LDS.  History (round 1, 1e6 random spheres, count pass): per-lane walks 0.86 ms; exact joint
+// walk 0.72; subtrees brute-forced with per-lane candidate masks and one leaf-test round per candidate of the
+// busiest lane (~22 % of the lanes busy) 0.40; this kernel with ONE union box per wave 0.40 (the kernel waited
+// for the few waves whose 64 leaves straddle a big Z-curve jump: 489 subtrees against 23 on average); with the
+// two-box split 0.25.
 constexpr int QUEUE_CAP = 512; // candidate pairs per wave (LDS); drained whenever fewer than 64 slots are free
 
 template <class L, class N, class I, int MODE, bool WRITE, bool NARROW>
@@ -711,7 +529,8 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
         }
     };
 
-    // a: frontier descent (see lvt_cluster_kernel)
+    // a: frontier descent from the start level to the cut level.  Roots are taken in chunks so the first
+    // frontier always fits; chunks and frontier entries stay in increasing node order.
     uint32_t *fr0 = s_frontier[wv][0], *fr1 = s_frontier[wv][1];
     const uint32_t root_first = 1u << (a.start_level - 1);
     const int64_t roots = level_num_real(levels, vl, a.start_level);
@@ -1027,39 +846,25 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
         // everything else (BSphere nodes, start_level == levels): the exact joint walk
         if constexpr (N::kind == IBVH_BBOX) {
             if (a.start_level < a.tree.levels) {
-                const int64_t c = a.tree.levels - BRUTE_DEPTH;
-                const int cut = (int)(c > a.start_level ? c : a.start_level);
-                // workgroup size is free (the waves never cooperate).  Measured in round 1: one wave per workgroup
-                // (slots handed back per wave) 0.456 / 3.57 ms at 1e6 / 1e7 leaves vs 0.446 / 3.46 ms with four.
-                static const int tpb = [] {
-                    const char *e = getenv("IBVH_LVT_TPB"); // tuning knob: 64 or 256
-                    return (e && atoi(e) == 64) ? 64 : 256;
-                }();
-                const unsigned cb = (unsigned)ceil_div(a.n_items, tpb);
-                static const bool use_queue = [] {
-                    const char *e = getenv("IBVH_LVT_QUEUE");
-                    return !(e && atoi(e) == 0);
-                }();
-                if (use_queue && a.tree.levels <= 28 && tpb == 256) { // queue entries pack (parent index << 6 | lane) in 32 bits
-                    if (a.narrow != IBVH_NARROW_NONE) {
-                        if (write) IBVH_LAUNCH((lvt_queue_kernel<L, N, I, MODE, true, true>), dim3(cb), dim3(tpb), 0, st, a, cache, cut);
-                        else IBVH_LAUNCH((lvt_queue_kernel<L, N, I, MODE, false, true>), dim3(cb), dim3(tpb), 0, st, a, cache, cut);
+                if (a.tree.levels <= 28) { // queue entries pack (parent index << 6 | lane) in 32 bits; deeper trees take the exact walk
+                    // With BBox nodes the contact list does not depend on the start level (monotone box tests, see the
+                    // header comment), so the descent starts where one 64-lane step covers all roots instead of
+                    // scanning the 2^(start_level-1) roots the caller named (512 at 1e6 leaves), if those nodes exist.
+                    Args<L, N, I> aq = a;
+                    const int64_t top = a.built_level > 7 ? a.built_level : 7;
+                    if (aq.start_level > top) aq.start_level = top;
+                    const int64_t c = aq.tree.levels - BRUTE_DEPTH;
+                    const int cut = (int)(c > aq.start_level ? c : aq.start_level);
+                    if (aq.narrow != IBVH_NARROW_NONE) {
+                        if (write) IBVH_LAUNCH((lvt_queue_kernel<L, N, I, MODE, true, true>), dim3(blocks), dim3(256), 0, st, aq, cache, cut);
+                        else IBVH_LAUNCH((lvt_queue_kernel<L, N, I, MODE, false, true>), dim3(blocks), dim3(256), 0, st, aq, cache, cut);
                     } else {
-                        if (write) IBVH_LAUNCH((lvt_queue_kernel<L, N, I, MODE, true, false>), dim3(cb), dim3(tpb), 0, st, a, cache, cut);
-                        else IBVH_LAUNCH((lvt_queue_kernel<L, N, I, MODE, false, false>), dim3(cb), dim3(tpb), 0, st, a, cache, cut);
+                        if (write) IBVH_LAUNCH((lvt_queue_kernel<L, N, I, MODE, true, false>), dim3(blocks), dim3(256), 0, st, aq, cache, cut);
+                        else IBVH_LAUNCH((lvt_queue_kernel<L, N, I, MODE, false, false>), dim3(blocks), dim3(256), 0, st, aq, cache, cut);
                     }
                     IBVH_LAUNCH_CHECK();
                     return IBVH_OK;
                 }
-                if (a.narrow != IBVH_NARROW_NONE) {
-                    if (write) IBVH_LAUNCH((lvt_cluster_kernel<L, N, I, MODE, true, true>), dim3(cb), dim3(tpb), 0, st, a, cache, cut);
-                    else IBVH_LAUNCH((lvt_cluster_kernel<L, N, I, MODE, false, true>), dim3(cb), dim3(tpb), 0, st, a, cache, cut);
-                } else {
-                    if (write) IBVH_LAUNCH((lvt_cluster_kernel<L, N, I, MODE, true, false>), dim3(cb), dim3(tpb), 0, st, a, cache, cut);
-                    else IBVH_LAUNCH((lvt_cluster_kernel<L, N, I, MODE, false, false>), dim3(cb), dim3(tpb), 0, st, a, cache, cut);
-                }
-                IBVH_LAUNCH_CHECK();
-                return IBVH_OK;
             }
         }
         // (the exact walk keeps the run-time narrow switch: NARROW = true covers both)
@@ -1102,6 +907,7 @@ int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const voi
                 a.nodes = (const N *)walk->nodes;
                 a.tree = TreeDev{walk->tree.levels, walk->tree.real_leaves, walk->tree.virtual_leaves};
                 a.start_level = start_level;
+                a.built_level = walk->built_level;
                 a.narrow = narrow;
                 a.flip = flip;
                 static const int xcd_env = [] {
