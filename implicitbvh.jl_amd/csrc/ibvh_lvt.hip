@@ -312,11 +312,21 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
         if (!q.begin_write()) return;
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t levels = a.tree.levels, vl = a.tree.virtual_leaves;
+    // Everything wave-uniform below is 32-bit on purpose (levels <= 28, so node indices and leaf positions are
+    // < 2^28): the scalar unit has no ordered 64-bit compare, a 64-bit uniform compare is done by the VALU, its
+    // result counts as divergent and turns every loop that depends on it into an exec-masked one.
+    const int levels = (int)a.tree.levels;
+    const uint32_t vl = (uint32_t)a.tree.virtual_leaves;
+    auto num_real = [&](int level) -> uint32_t { return (1u << (level - 1)) - (vl >> (levels - level)); };
+    auto first_mem = [&](int level) -> uint32_t { // 0-based memory index of the level's first node
+        const uint32_t v = vl >> (levels - (level - 1));
+        return (1u << (level - 1)) - (2u * v - (uint32_t)__builtin_popcount(v)) - 1u;
+    };
     const uint32_t leaf_first = 1u << (levels - 1);
-    const int64_t wave_item0 = q.item - lane;
-    const uint64_t self_next = (uint64_t)q.item + leaf_first + 1;
-    const uint64_t wave_next = (uint64_t)wave_item0 + leaf_first + 1;
+    const uint32_t my_item = (uint32_t)q.item;
+    const uint32_t wave_item0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_item);
+    const uint32_t self_next = my_item + leaf_first + 1u;
+    const uint32_t wave_next = wave_item0 + leaf_first + 1u;
     uint32_t *queue = s_queue[wv];
     Cnt *cnts = s_cnt[wv];
     cnts[lane] = WRITE ? q.w : (Cnt)0; // next output offset (WRITE) / contacts so far (count pass) of query `lane`
@@ -387,10 +397,10 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
         ubox_b = broadcast_from_lane(nxt_suf, ksplit);
     }
     auto touches_wave = [&](const N &b) { return iscontact(ubox_a, b) || iscontact(ubox_b, b); };
-    const int lp = (int)levels - 1;
-    const int64_t lp_real = level_num_real(levels, vl, lp);
-    const N *lp_nodes = a.nodes + (level_start(levels, vl, lp) - 1);
-    const int64_t n_leaves = a.tree.real_leaves;
+    const int lp = levels - 1;
+    const uint32_t lp_real = num_real(lp);
+    const N *lp_nodes = a.nodes + first_mem(lp);
+    const uint32_t n_leaves = (uint32_t)a.tree.real_leaves;
     const uint64_t lt_mask = ((uint64_t)1 << lane) - 1;
 
     // c: leaf tests of queue[off, off + avail), one pair per lane
@@ -398,12 +408,12 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
         const bool v = lane < avail;
         const uint32_t e = v ? queue[off + lane] : 0u;
         const int qi = (int)(e & 63u);
-        const int64_t pos = 2 * (int64_t)(e >> 6); // 0-based position of the pair's left leaf
-        const bool has_b = v && pos + 1 < n_leaves;
+        const uint32_t pos = 2u * (e >> 6); // 0-based position of the pair's left leaf
+        const bool has_b = v & (pos + 1u < n_leaves);
         L leaf_a = {}, leaf_b = {};
         I idx_a = 0, idx_b = 0;
         uint64_t mor_a = 0, mor_b = 0;
-        const char *rec = a.leaves + pos * a.lay.stride;
+        const char *rec = a.leaves + (int64_t)pos * a.lay.stride;
         if (v) {
             leaf_a = load_vol<L>(rec);
             idx_a = load_index<I>(rec, a.lay);
@@ -418,11 +428,11 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
         }
         const L ql = shuffle_from(q.q_leaf, qi);
         const I qidx = __shfl(q.q_index, qi, 64);
-        const int64_t item_q = wave_item0 + qi;
-        bool hit_a = v && iscontact(ql, leaf_a), hit_b = has_b && iscontact(ql, leaf_b);
+        const uint32_t item_q = wave_item0 + (uint32_t)qi;
+        bool hit_a = v & iscontact(ql, leaf_a), hit_b = has_b & iscontact(ql, leaf_b);
         if constexpr (MODE == MODE_SELF) { // only partners to the right of the query
-            hit_a = hit_a && pos > item_q;
-            hit_b = hit_b && pos + 1 > item_q;
+            hit_a = hit_a & (pos > item_q);
+            hit_b = hit_b & (pos + 1u > item_q);
         }
         if constexpr (NARROW) {
             const uint64_t qm = (uint64_t)__shfl((long long)q.q_morton, qi, 64);
@@ -452,7 +462,7 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
             if constexpr (WRITE) {
                 a.contacts[(int64_t)at] = c2;
             } else {
-                if (at < (Cnt)cache.K) cache.slots[(int64_t)at * a.n_items + item_q] = c2;
+                if (at < (Cnt)cache.K) cache.slots[(int64_t)at * a.n_items + (int64_t)item_q] = c2;
             }
         };
         const Cnt at = base + (Cnt)rank;
@@ -480,24 +490,23 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
     // b: candidates of the subtree rooted at node c (level cut_level) whose box is `cbox`
     auto brute = [&](uint32_t c, const N &cbox) {
         bool on = q.lane_on && iscontact(q.q_node, cbox);
-        if constexpr (MODE == MODE_SELF) on = on && !(((uint64_t)c + 1) <= (self_next >> (levels - cut_level)));
+        if constexpr (MODE == MODE_SELF) on = on & !((c + 1u) <= (self_next >> (levels - cut_level)));
         const uint64_t on_mask = __builtin_amdgcn_ballot_w64(on);
         if (on_mask == 0) return;
-        const int64_t first = (int64_t)(c - (1u << (cut_level - 1))) << (lp - cut_level);
-        int64_t last = first + (int64_t(1) << (lp - cut_level));
+        const uint32_t first32 = (c - (1u << (cut_level - 1))) << (lp - cut_level); // 0-based, within level lp
+        uint32_t last = first32 + (1u << (lp - cut_level));
         last = last < lp_real ? last : lp_real;
-        const int np = (int)(last - first); // <= 64
+        const int np = (int)(last - first32); // <= 64
         N mybox; // lanes without a parent hold the empty box: it matches nothing
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             mybox.lo[k] = float_max<TN>();
             mybox.up[k] = -float_max<TN>();
         }
-        if (lane < np) mybox = load_vol<N>(lp_nodes + first + lane);
-        const uint32_t first32 = (uint32_t)first; // positions fit 32 bits here (levels <= 28)
+        if (lane < np) mybox = load_vol<N>(lp_nodes + (first32 + (uint32_t)lane));
         const uint32_t right_leaf = 2u * (first32 + (uint32_t)lane) + 1u; // of this lane's parent
         bool box_on = touches_wave(mybox);
-        if constexpr (MODE == MODE_SELF) box_on = box_on & (right_leaf > (uint32_t)wave_item0);
+        if constexpr (MODE == MODE_SELF) box_on = box_on & (right_leaf > wave_item0);
         const uint64_t box_mask = __builtin_amdgcn_ballot_w64(box_on);
         // shorter of the two loops: lanes = queries over the parents that touch the wave's boxes, or
         // lanes = parents over the active queries.  (Measured alternative: lanes = (query, parent) pairs
@@ -505,7 +514,6 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
         const bool by_box = __popcll(box_mask) < __popcll(on_mask);
         const uint32_t e_box = (uint32_t)lane | (first32 << 6);     // + (u << 6)
         const uint32_t e_qry = (first32 + (uint32_t)lane) << 6;      // | u
-        const uint32_t my_item = (uint32_t)q.item;
         for (uint64_t todo = by_box ? box_mask : on_mask; todo != 0; todo &= todo - 1) {
             if (qn > QUEUE_CAP - 64) drain(false);
             const int u = __builtin_ctzll(todo);
@@ -519,7 +527,7 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
             } else {
                 const N qbox = broadcast_from_lane(q.q_node, u);
                 h = box_on & iscontact(qbox, mybox);
-                if constexpr (MODE == MODE_SELF) h = h & (right_leaf > (uint32_t)wave_item0 + (uint32_t)u);
+                if constexpr (MODE == MODE_SELF) h = h & (right_leaf > wave_item0 + (uint32_t)u);
                 e = e_qry | (uint32_t)u;
             }
             const uint64_t hm = __builtin_amdgcn_ballot_w64(h);
@@ -532,18 +540,19 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
     // a: frontier descent from the start level to the cut level.  Roots are taken in chunks so the first
     // frontier always fits; chunks and frontier entries stay in increasing node order.
     uint32_t *fr0 = s_frontier[wv][0], *fr1 = s_frontier[wv][1];
-    const uint32_t root_first = 1u << (a.start_level - 1);
-    const int64_t roots = level_num_real(levels, vl, a.start_level);
+    const int start_level = (int)a.start_level;
+    const uint32_t root_first = 1u << (start_level - 1);
+    const int roots = (int)num_real(start_level);
     bool overflow = false;
-    for (int64_t r0 = 0; r0 < roots && !overflow; r0 += FRONTIER_CAP) {
-        int count = (int)((roots - r0) < FRONTIER_CAP ? (roots - r0) : FRONTIER_CAP);
+    for (int r0 = 0; r0 < roots && !overflow; r0 += FRONTIER_CAP) {
+        int count = (roots - r0) < FRONTIER_CAP ? (roots - r0) : FRONTIER_CAP;
         for (int i = lane; i < count; i += 64) fr0[i] = root_first + (uint32_t)(r0 + i);
         __builtin_amdgcn_wave_barrier();
         uint32_t *cur = fr0, *nxt = fr1;
-        for (int lvl = (int)a.start_level; lvl <= cut_level && count > 0; ++lvl) {
-            const N *lvl_nodes = a.nodes + (level_start(levels, vl, lvl) - 1);
+        for (int lvl = start_level; lvl <= cut_level && count > 0; ++lvl) {
+            const N *lvl_nodes = a.nodes + first_mem(lvl);
             const uint32_t lvl_first = 1u << (lvl - 1);
-            const int64_t child_real = level_num_real(levels, vl, lvl + 1);
+            const uint32_t child_real = num_real(lvl + 1);
             int next_count = 0;
             for (int base = 0; base < count; base += 64) {
                 const bool have = base + lane < count;
@@ -553,7 +562,7 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
                 if (have) {
                     box = load_vol<N>(lvl_nodes + (idx - lvl_first));
                     hit = touches_wave(box);
-                    if constexpr (MODE == MODE_SELF) hit = hit && !(((uint64_t)idx + 1) <= (wave_next >> (levels - lvl)));
+                    if constexpr (MODE == MODE_SELF) hit = hit & !((idx + 1u) <= (wave_next >> (levels - lvl)));
                 }
                 const uint64_t hm = __builtin_amdgcn_ballot_w64(hit);
                 if (lvl == cut_level) {
@@ -569,7 +578,7 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
                     const bool last_virtual = hm != 0 && [&] {
                         const int top = 63 - __builtin_clzll(hm);
                         const uint32_t ti = (uint32_t)__builtin_amdgcn_readlane((int)idx, top);
-                        return (int64_t)(2u * ti + 1u - (1u << lvl)) >= child_real;
+                        return (2u * ti + 1u - (1u << lvl)) >= child_real;
                     }();
                     const int add = 2 * total - (last_virtual ? 1 : 0);
                     if (next_count + add > FRONTIER_CAP) {
