@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
     const int roots = (int)num_real(start_level);
     bool overflow = false;
     for (int r0 = 0; r0 < roots && !overflow; r0 += FRONTIER_CAP) {
-        int count = (roots - r0) < FRONTIER_CAP ? (roots - r0) : FRONTIER_CAP;
+        int count = __builtin_amdgcn_readfirstlane((roots - r0) < FRONTIER_CAP ? (roots - r0) : FRONTIER_CAP);
         for (int i = lane; i < count; i += 64) fr0[i] = root_first + (uint32_t)(r0 + i);
         __builtin_amdgcn_wave_barrier();
         uint32_t *cur = fr0, *nxt = fr1;
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
                         const uint32_t ti = (uint32_t)__builtin_amdgcn_readlane((int)idx, top);
                         return (2u * ti + 1u - (1u << lvl)) >= child_real;
                     }();
-                    const int add = 2 * total - (last_virtual ? 1 : 0);
+                    const int add = __builtin_amdgcn_readfirstlane(2 * total - (last_virtual ? 1 : 0)); // (readfirstlane: tell the compiler it is uniform)
                     if (next_count + add > FRONTIER_CAP) {
                         overflow = true;
                         break;
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
                         nxt[next_count + 2 * before] = 2u * idx;
                         if (2 * before + 1 < add) nxt[next_count + 2 * before + 1] = 2u * idx + 1u;
                     }
-                    next_count += add;
+                    next_count = __builtin_amdgcn_readfirstlane(next_count + add);
                 }
             }
             if (overflow) break;
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
             uint32_t *t = cur;
             cur = nxt;
             nxt = t;
-            count = lvl == cut_level ? 0 : next_count;
+            count = __builtin_amdgcn_readfirstlane(lvl == cut_level ? 0 : next_count);
         }
     }
     if (overflow) {
