@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
         ubox_a = broadcast_from_lane(pre, ksplit);
         ubox_b = broadcast_from_lane(nxt_suf, ksplit);
     }
-    auto touches_wave = [&](const N &b) { return iscontact(ubox_a, b) || iscontact(ubox_b, b); };
+    auto touches_wave = [&](const N &b) { return iscontact(ubox_a, b) | iscontact(ubox_b, b); };
     const int lp = levels - 1;
     const uint32_t lp_real = num_real(lp);
     const N *lp_nodes = a.nodes + first_mem(lp);
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
 
     // b: candidates of the subtree rooted at node c (level cut_level) whose box is `cbox`
     auto brute = [&](uint32_t c, const N &cbox) {
-        bool on = q.lane_on && iscontact(q.q_node, cbox);
+        bool on = q.lane_on & iscontact(q.q_node, cbox);
         if constexpr (MODE == MODE_SELF) on = on & !((c + 1u) <= (self_next >> (levels - cut_level)));
         const uint64_t on_mask = __builtin_amdgcn_ballot_w64(on);
         if (on_mask == 0) return;
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
         // shorter of the two loops: lanes = queries over the parents that touch the wave's boxes, or
         // lanes = parents over the active queries.  (Measured alternative: lanes = (query, parent) pairs
         // pulled together with ds_bpermute — as many steps as this loop has iterations, and slower.)
-        const bool by_box = __popcll(box_mask) < __popcll(on_mask);
+        const bool by_box = (int)__popcll(box_mask) < (int)__popcll(on_mask); // (int: keeps the compare on the scalar unit)
         const uint32_t e_box = (uint32_t)lane | (first32 << 6);     // + (u << 6)
         const uint32_t e_qry = (first32 + (uint32_t)lane) << 6;      // | u
         for (uint64_t todo = by_box ? box_mask : on_mask; todo != 0; todo &= todo - 1) {
