@@ -242,10 +242,11 @@ constexpr int MSD_MAX_BITS = 11;
 // the same digit that precede key j in (j, lane) order within this wave, counted through my_hist
 template <class K, int IPT>
 IBVH_D void wave_rank(const K (&key)[IPT], int shift, uint32_t mask, int bits, uint16_t *my_hist, int lane,
-                      uint16_t (&rank)[IPT]) {
+                      uint16_t (&rank)[IPT], int jmax = IPT) {
     const uint64_t lt_mask = ((uint64_t)1 << lane) - 1;
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
+        if (j >= jmax) break; // (wave-uniform) rows beyond the wave's share hold nothing
         const uint32_t d = (uint32_t)(key[j] >> shift) & mask;
         uint64_t peers = ~(uint64_t)0;
         for (int b = 0; b < bits; ++b) {
@@ -430,12 +431,12 @@ __global__ __launch_bounds__(TPB) void bucket_sort_kernel(K *__restrict__ kalt, 
     const int passes = (low_bits + 7) / 8;
 
     // one stable 8-bit pass over the CAP keys held in registers (wave-striped); result in s_keys / s_vals
-    auto lds_pass = [&](K(&key)[IPT], uint32_t(&val)[IPT], int shift, int bits, uint32_t &tot_d) {
+    auto lds_pass = [&](K(&key)[IPT], uint32_t(&val)[IPT], int shift, int bits, uint32_t &tot_d, int jmax) {
         const uint32_t mask = (1u << bits) - 1u;
         for (int i = threadIdx.x; i < W * R; i += TPB) whist[i] = 0;
         __syncthreads();
         uint16_t rank[IPT];
-        wave_rank<K, IPT>(key, shift, mask, bits, my_hist, lane, rank);
+        wave_rank<K, IPT>(key, shift, mask, bits, my_hist, lane, rank, jmax);
         __syncthreads();
         tot_d = 0;
         if (threadIdx.x < R) {
@@ -454,6 +455,7 @@ __global__ __launch_bounds__(TPB) void bucket_sort_kernel(K *__restrict__ kalt, 
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
+            if (j >= jmax) break;
             const uint32_t d = (uint32_t)(key[j] >> shift) & mask;
             const uint32_t pos = local_base[d] + my_hist[d] + rank[j];
             s_keys[pos] = key[j];
@@ -464,21 +466,28 @@ __global__ __launch_bounds__(TPB) void bucket_sort_kernel(K *__restrict__ kalt, 
 
     if (m <= CAP) {
         // ---- fast path: the whole bucket lives in LDS --------------------------------------------
+        // The m keys are dealt to the waves in equal contiguous shares of `chunk` (a multiple of 64), so that a
+        // bucket of CAP/4 keys keeps all waves busy with a quarter of the ranking work each instead of leaving
+        // it to wave 0 while the others rank padding.  (w, j, lane) order is still memory order.
+        const int chunk = (int)((m + W * 64 - 1) / (W * 64)) * 64;
+        const int jmax = chunk / 64; // <= IPT
         K key[IPT];
         uint32_t val[IPT];
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
-            const int idx = w * 64 * IPT + j * 64 + lane;
-            const bool ok = idx < m;
+            const int idx = w * chunk + j * 64 + lane;
+            const bool ok = j < jmax && idx < m;
             key[j] = ok ? kalt[start + idx] : (K) ~(K)0; // sentinels: maximal digit every pass, last in order
             val[j] = ok ? valt[start + idx] : 0u;
         }
         if (passes == 0) {
 #pragma unroll
             for (int j = 0; j < IPT; ++j) {
-                const int idx = w * 64 * IPT + j * 64 + lane;
-                s_keys[idx] = key[j];
-                s_vals[idx] = val[j];
+                const int idx = w * chunk + j * 64 + lane;
+                if (j < jmax) {
+                    s_keys[idx] = key[j];
+                    s_vals[idx] = val[j];
+                }
             }
             __syncthreads();
         }
@@ -486,13 +495,15 @@ __global__ __launch_bounds__(TPB) void bucket_sort_kernel(K *__restrict__ kalt, 
             const int shift = 8 * p;
             const int bits = low_bits - shift < 8 ? low_bits - shift : 8;
             uint32_t tot_d;
-            lds_pass(key, val, shift, bits, tot_d);
+            lds_pass(key, val, shift, bits, tot_d, jmax);
             if (p + 1 < passes) {
 #pragma unroll
                 for (int j = 0; j < IPT; ++j) {
-                    const int idx = w * 64 * IPT + j * 64 + lane;
-                    key[j] = s_keys[idx];
-                    val[j] = s_vals[idx];
+                    const int idx = w * chunk + j * 64 + lane;
+                    if (j < jmax) {
+                        key[j] = s_keys[idx];
+                        val[j] = s_vals[idx];
+                    }
                 }
                 __syncthreads();
             }
@@ -535,7 +546,7 @@ __global__ __launch_bounds__(TPB) void bucket_sort_kernel(K *__restrict__ kalt, 
                 val[j] = ok ? src_v[start + t0 + idx] : 0u;
             }
             uint32_t tot_d;
-            lds_pass(key, val, shift, bits, tot_d);
+            lds_pass(key, val, shift, bits, tot_d, IPT);
             for (int pos = threadIdx.x; pos < cnt; pos += TPB) {
                 const K kk = s_keys[pos];
                 const uint32_t d = (uint32_t)(kk >> shift) & mask;
@@ -624,8 +635,12 @@ inline MsdPlan choose_msd(int64_t n, int key_bits, int key_bytes) {
         return (e && e[0] == 'l') ? 1 : 0;
     }();
     if (mode == 1 || n < 2048 || key_bits <= 8) return {0, 0, 0};
+    static const int msd_avg_max = [] {
+        const char *e = getenv("IBVH_MSD_AVG"); // tuning knob: largest average bucket before another partition bit is taken
+        return e ? atoi(e) : 1536;
+    }();
     int bits = 1;
-    while (bits < MSD_MAX_BITS && bits < key_bits && (n >> bits) > 1536) ++bits;
+    while (bits < MSD_MAX_BITS && bits < key_bits && (n >> bits) > msd_avg_max) ++bits;
     const int64_t avg = n >> bits;
     // Measured on MI355X (round 1): the hybrid beats plain LSD while buckets fit 4096-key workgroups
     // (Morton+sort phase 0.366 vs 0.422 ms at 6e6 leaves, 0.109 vs 0.139 ms at 1e6) and loses with 8192-key
