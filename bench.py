@@ -69,6 +69,21 @@ def kernel_key(name):
     return base
 
 
+def pmc_key(demangled):
+    """rocprofv3's demangled kernel name -> the same key kernel_key() gives the library's launch label."""
+    import re
+    m = re.match(r"(?:void )?(?:\w+::)*(\w+)(<.*>)?\(", demangled)
+    if not m:
+        return demangled
+    base, targs = m.group(1), m.group(2) or ""
+    flags = re.findall(r"\b(true|false)\b", targs)
+    if base == "scatter_kernel" and flags[:1] == ["true"]:
+        return "scatter_records_kernel"
+    if base in ("lvt_rays_kernel", "lvt_joint_kernel", "lvt_queue_kernel"):
+        return base + ("_write" if flags[:1] == ["true"] else "_count")
+    return base
+
+
 def collect_profile(lib):
     cnt = C.c_int64()
     lib.call("ibvh_profile_count", C.byref(cnt))
@@ -200,17 +215,18 @@ def main():
             roofline["morton_sort_phase"] = {"ms": round(ms_phase, 4), "algorithmic_GBps": round(gbps, 1),
                                              "frac": round(gbps / HBM_PEAK_GBS, 4), "bytes_per_leaf": 152}
 
-    # measured HBM-side traffic of the dominant kernel from the committed rocprofv3 PMC passes (same command,
-    # n = 1e6): FETCH_SIZE is doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950 (calibrated here on the
-    # extrema kernel: 7829 KiB reported for 16.0e6 bytes streamed), WRITE_SIZE taken as is, KiB -> bytes
-    if roofline is not None and n == 1_000_000:
+    # measured HBM-side traffic of the dominant kernel from the committed rocprofv3 PMC passes (same command, made
+    # by tools/profile_round.sh + tools/pmc_traffic.py): FETCH_SIZE is doubled as MI355X_MICROARCH.md §HBM
+    # prescribes for gfx950 (calibrated here on the extrema kernel: 7.7 MiB reported for 16.0e6 bytes streamed),
+    # WRITE_SIZE taken as is, KiB -> bytes
+    if roofline is not None and n in (1_000_000, 10_000_000):
+        fname = "r01_pmc_fetch_write_n1e6.json" if n == 1_000_000 else "r01_pmc_fetch_write_n1e7.json"
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_n1e6.json")))["kernels"]
-            want = roofline["kernel"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", fname)))["kernels"]
             for name, v in pmc.items():
-                if kernel_key("(" + name.split("(")[0].replace("void ", "") + ")") == want and v["launches"] >= 5:
+                if pmc_key(name) == roofline["kernel"] and v["launches"] >= 5:
                     roofline["traffic"] = int((2 * v["FETCH_SIZE_KiB_avg"] + v["WRITE_SIZE_KiB_avg"]) * 1024)
-                    roofline["traffic_source"] = "profiles/r01_pmc_fetch_write_n1e6.json (L2-miss bytes; Infinity-Cache hits included)"
+                    roofline["traffic_source"] = f"profiles/{fname} (2*FETCH_SIZE + WRITE_SIZE: L2-miss bytes; Infinity-Cache hits included)"
         except Exception:
             pass
 
