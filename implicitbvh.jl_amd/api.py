@@ -424,21 +424,64 @@ def default_start_level(bvh, alg=None):
 # ---------------------------------------------------------------------------------------------
 # traversal results
 # ---------------------------------------------------------------------------------------------
-@dataclass
 class BVHTraversal:
     """traverse.jl:54-107.  cache1 holds the contacts ((m, 2) index tensor); cache2 is the other buffer
-    (LVT: per-work-item inclusive counts; BFS: the second pair queue).  `.contacts` = cache1[:num_contacts]."""
-    start_level1: int
-    start_level2: int
-    num_checks: int
-    num_contacts: int
-    cache1: object
-    cache2: object
-    _scratch: object = None
+    (LVT: per-work-item inclusive counts; BFS: the second pair queue).  `.contacts` = cache1[:num_contacts].
+
+    LVT traversals that were given a large-enough `cache` are enqueued without any host synchronisation
+    (ibvh_traverse_*_lvt_enqueue): `num_contacts` is then read from the device the first time it is asked for
+    (that read is the reference's `@allowscalar`, moved to where the value is needed).  If the contact buffer
+    taken from the cache turns out too small, the writing pass runs then, into a new buffer — which needs the
+    traversal's counts and scratch to be intact, i.e. not handed to a later call as `cache=` in between."""
+
+    def __init__(self, start_level1, start_level2, num_checks, num_contacts, cache1, cache2, _scratch=None, _pending=None):
+        self.start_level1 = start_level1
+        self.start_level2 = start_level2
+        self.num_checks = num_checks
+        self._num_contacts = num_contacts
+        self._cache1 = cache1
+        self.cache2 = cache2
+        self._scratch = _scratch
+        self._pending = _pending  # (total: 1-element device tensor, capacity, finish(total) -> contacts tensor)
+        self._donated = False
+
+    def _resolve(self):
+        if self._pending is None:
+            return
+        total_t, capacity, finish = self._pending
+        self._pending = None
+        total = int(total_t.item())  # the blocking read
+        if self._cache1.dtype == _torch().int32 and total > 2**31 - 1:
+            raise OverflowError("more than typemax(Int32) contacts")
+        if total > capacity:
+            if self._donated:
+                raise RuntimeError("this traversal's buffers were reused as `cache=` before its contact count was read, and "
+                                   "the cached contact buffer was too small for it: read .num_contacts before reusing the cache")
+            self._cache1 = finish(total)
+        self._num_contacts = total
+
+    @property
+    def num_contacts(self):
+        self._resolve()
+        return self._num_contacts
+
+    @property
+    def cache1(self):
+        self._resolve()
+        return self._cache1
 
     @property
     def contacts(self):
         return self.cache1[: self.num_contacts]
+
+    def _capacity(self):
+        """rows of the contact buffer, without forcing the count to be read"""
+        return self._cache1.shape[0] if self._cache1 is not None else 0
+
+    def _donate(self):
+        """the buffers are about to be reused by another traversal"""
+        self._donated = True
+        return self._cache1
 
 
 def _narrow_code(narrow):
@@ -468,6 +511,23 @@ LVT_CACHE_SLOTS = 8  # contacts per work item kept from the counting pass (inclu
 RAY_CACHE_SLOTS = 32  # hits per ray kept from the counting pass
 
 
+def _speculative_buffer(cache, idt):
+    """The cached contact buffer, if the traversal may be enqueued against it without knowing the count."""
+    if cache is None or not isinstance(cache, BVHTraversal):
+        return None
+    buf = cache._donate()
+    if buf is None or buf.dim() != 2 or buf.shape[1] != 2 or buf.shape[0] == 0:
+        return None
+    if buf.dtype != idt:
+        raise ValueError("eltype(cache.cache1) does not match the traversal's index type")
+    return buf
+
+
+def _keep_total(scratch):
+    """Private copy of the scratch header's total (the scratch itself may be reused by the next call)."""
+    return scratch[:8].view(_torch().int64).clone()
+
+
 def _lvt_scratch(cache, types, n_items, slots=None):
     torch = _torch()
     need = C.c_size_t()
@@ -491,6 +551,17 @@ def _traverse_lvt_single(bvh, start_level, narrow, cache):
     counts = _cache_tensor(cache.cache2 if cache else None, n, 0, idt, "cache2")
     scratch = _lvt_scratch(cache, bvh.types, n)
     s = bvh.struct()
+    spec = _speculative_buffer(cache, idt)
+    if spec is not None:
+        lib.call("ibvh_traverse_lvt_enqueue", C.byref(s), start_level, narrow, _ptr(counts), _ptr(spec), spec.shape[0],
+                 _ptr(scratch), scratch.numel(), _stream())
+
+        def finish(total):
+            contacts = torch.empty((total, 2), dtype=idt, device="cuda")
+            lib.call("ibvh_traverse_lvt_write", C.byref(s), start_level, narrow, _ptr(counts), _ptr(contacts), _ptr(scratch),
+                     scratch.numel(), _stream())
+            return contacts
+        return BVHTraversal(start_level, 0, 0, None, spec, counts, scratch, _pending=(_keep_total(scratch), spec.shape[0], finish))
     total = C.c_int64()
     lib.call("ibvh_traverse_lvt_count", C.byref(s), start_level, narrow, _ptr(counts), C.byref(total), _ptr(scratch),
              scratch.numel(), _stream())

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(EXT_TPB) void extrema_partial_kernel(const char *__
 // bounding_volumes_extrema (utils.jl:63-69): x -/+ rp*abs(x) -/+ floatmin, two roundings a side.
 template <class T>
 __global__ __launch_bounds__(EXT_TPB) void extrema_final_kernel(const T *__restrict__ partials, int nparts, int expand,
-                                                                T *__restrict__ out) {
+                                                                T *__restrict__ out, T *__restrict__ out2) {
     T mn[3] = {float_max<T>(), float_max<T>(), float_max<T>()};
     T mx[3] = {float_min_normal<T>(), float_min_normal<T>(), float_min_normal<T>()};
     for (int i = threadIdx.x; i < nparts; i += EXT_TPB) {
@@ -137,10 +137,11 @@ __global__ __launch_bounds__(EXT_TPB) void extrema_final_kernel(const T *__restr
             v = threadIdx.x < 3 ? (v - a) - fm : (v + a) + fm;
         }
         out[threadIdx.x] = v;
+        if (out2) out2[threadIdx.x] = v; // the caller's copy (ibvh_build's extrema_out): no separate 24-byte memcpy
     }
 }
 
-template <class T> __global__ void extrema_set_kernel(T *out, double a0, double a1, double a2, double b0, double b1, double b2) {
+template <class T> __global__ void extrema_set_kernel(T *out, T *out2, double a0, double a1, double a2, double b0, double b1, double b2) {
     if (threadIdx.x == 0) {
         out[0] = T(a0);
         out[1] = T(a1);
@@ -148,6 +149,8 @@ template <class T> __global__ void extrema_set_kernel(T *out, double a0, double 
         out[3] = T(b0);
         out[4] = T(b1);
         out[5] = T(b2);
+        if (out2)
+            for (int k = 0; k < 6; ++k) out2[k] = out[k];
     }
 }
 
@@ -374,11 +377,12 @@ inline Scratch carve(char *base, int64_t n, int key_bytes, int64_t leaf_bytes, b
 }
 
 template <class V>
-int extrema(const char *recs, int64_t stride, int64_t n, int expand, typename V::elt *out, char *partials, hipStream_t st) {
+int extrema(const char *recs, int64_t stride, int64_t n, int expand, typename V::elt *out, char *partials, hipStream_t st,
+            typename V::elt *out2 = nullptr) {
     using T = typename V::elt;
     int blocks = grid_for(n, EXT_TPB * 4, EXT_MAX_BLOCKS);
     IBVH_LAUNCH((extrema_partial_kernel<V>), dim3(blocks), dim3(EXT_TPB), 0, st, recs, stride, n, (T *)partials);
-    IBVH_LAUNCH((extrema_final_kernel<T>), dim3(1), dim3(EXT_TPB), 0, st, (const T *)partials, blocks, expand, out);
+    IBVH_LAUNCH((extrema_final_kernel<T>), dim3(1), dim3(EXT_TPB), 0, st, (const T *)partials, blocks, expand, out, out2);
     IBVH_LAUNCH_CHECK();
     return IBVH_OK;
 }
@@ -497,12 +501,11 @@ ibvh_status ibvh_build(const ibvh_build_desc *desc, const void *volumes, void *l
         else IBVH_LAUNCH((skips_kernel<int64_t>), dim3(1), dim3(64), 0, st, td, (int64_t *)skips);
         // extrema (or caller-fixed bounds: morton/default.jl:52-57)
         if (desc->compute_extrema) {
-            if (int e = extrema<L>(src, src_stride, n, 1, ext, sc.partials, st)) return e;
+            if (int e = extrema<L>(src, src_stride, n, 1, ext, sc.partials, st, (T *)extrema_out)) return e;
         } else {
-            IBVH_LAUNCH((extrema_set_kernel<T>), dim3(1), dim3(64), 0, st, ext, desc->mins[0], desc->mins[1],
+            IBVH_LAUNCH((extrema_set_kernel<T>), dim3(1), dim3(64), 0, st, ext, (T *)extrema_out, desc->mins[0], desc->mins[1],
                                desc->mins[2], desc->maxs[0], desc->maxs[1], desc->maxs[2]);
         }
-        if (extrema_out) IBVH_HIP_CHECK(hipMemcpyAsync(extrema_out, ext, 6 * sizeof(T), hipMemcpyDeviceToDevice, st));
         // keys, fused with the first per-tile digit histogram of the sort
         const int key_bits = morton_key_bits(ty.morton_type);
         const rsort::FirstPassPlan plan = rsort::first_pass_plan(n, key_bits, key_bytes, sc.sort);

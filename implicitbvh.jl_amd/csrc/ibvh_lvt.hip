@@ -40,7 +40,15 @@ template <class L, class N, class I> struct Args {
     // outputs
     I *counts;                 // count pass: per-item counts; write pass: inclusive prefix
     IndexPair<I> *contacts;
+    // *_enqueue: the writing pass was launched before the host knew the total; it does nothing unless
+    // *guard_total <= guard_capacity (guard_total == nullptr: unguarded)
+    const int64_t *guard_total;
+    int64_t guard_capacity;
 };
+
+IBVH_D int64_t load_total_uniform(const int64_t *p) {
+    return *(const __attribute__((address_space(4))) int64_t *)(uintptr_t)p; // one s_load, same value for every lane
+}
 
 IBVH_D bool narrow_eval(int narrow, uint64_t ma, int64_t ia, uint64_t mb, int64_t ib) {
     if (narrow == IBVH_NARROW_MORTON_LT) return ma < mb;
@@ -139,6 +147,7 @@ template <class L, class N, class I, int MODE, bool WRITE, bool NARROW> struct Q
     }
     // WRITE pass: serve the item from the contact cache; returns false when the whole wave is done
     IBVH_D bool begin_write() {
+        if (a.guard_total != nullptr && load_total_uniform(a.guard_total) > a.guard_capacity) return false;
         w = (valid && item > 0) ? (Cnt)a.counts[item - 1] : 0;
         const Cnt mine = valid ? (Cnt)a.counts[item] - w : 0;
         const bool over = mine > (Cnt)cache.K;
@@ -637,6 +646,7 @@ __global__ __launch_bounds__(256) void lvt_rays_kernel(Args<L, N, I> a, PairCach
     int64_t w = 0, cnt = 0;
     bool lane_on = valid;
     if constexpr (WRITE) {
+        if (a.guard_total != nullptr && load_total_uniform(a.guard_total) > a.guard_capacity) return;
         w = (valid && item > 0) ? (int64_t)a.counts[item - 1] : 0;
         const int64_t mine = valid ? (int64_t)a.counts[item] - w : 0;
         const bool over = mine > (int64_t)cache.K;
@@ -814,7 +824,7 @@ inline int cache_slots_for(size_t scratch_bytes, int64_t n_items, int64_t pair_b
     return (int)(k > MAX_CACHE_SLOTS ? MAX_CACHE_SLOTS : k);
 }
 
-// inclusive scan in place + blocking read of the total (the reference's @allowscalar, :60)
+// inclusive scan in place + (total_out != nullptr) blocking read of the total (the reference's @allowscalar, :60)
 template <class I> int scan_counts(I *counts, int64_t n, int64_t *total_out, void *scratch, hipStream_t st) {
     int64_t nparts = ceil_div(n, SCAN_TILE);
     int64_t *totals = (int64_t *)scratch;
@@ -823,6 +833,7 @@ template <class I> int scan_counts(I *counts, int64_t n, int64_t *total_out, voi
     IBVH_LAUNCH(scan_partials_kernel, dim3(1), dim3(SCAN_TPB), 0, st, partials, nparts, totals);
     IBVH_LAUNCH((scan_apply_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, partials);
     IBVH_LAUNCH_CHECK();
+    if (!total_out) return IBVH_OK; // *_enqueue: the total stays in the scratch header, nobody waits
     int64_t total = 0;
     IBVH_HIP_CHECK(hipMemcpyAsync(&total, totals, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     IBVH_HIP_CHECK(hipStreamSynchronize(st));
@@ -857,11 +868,12 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
             if (a.start_level < a.tree.levels) {
                 if (a.tree.levels <= 28) { // queue entries pack (parent index << 6 | lane) in 32 bits; deeper trees take the exact walk
                     // With BBox nodes the contact list does not depend on the start level (monotone box tests, see the
-                    // header comment), so the descent starts where one 64-lane step covers all roots instead of
-                    // scanning the 2^(start_level-1) roots the caller named (512 at 1e6 leaves), if those nodes exist.
+                    // header comment), so the descent always starts where one 64-lane step covers all roots (level 7,
+                    // or the highest built level below it) whatever level the caller named.
                     Args<L, N, I> aq = a;
-                    const int64_t top = a.built_level > 7 ? a.built_level : 7;
-                    if (aq.start_level > top) aq.start_level = top;
+                    int64_t top = a.built_level > 7 ? a.built_level : 7; // level 7: 64 nodes, one 64-lane step
+                    if (top > a.tree.levels - 1) top = a.tree.levels - 1;
+                    aq.start_level = top; // also when the caller named a HIGHER level: levels 1..6 hold < 64 nodes each
                     const int64_t c = aq.tree.levels - BRUTE_DEPTH;
                     const int cut = (int)(c > aq.start_level ? c : aq.start_level);
                     if (aq.narrow != IBVH_NARROW_NONE) {
@@ -888,8 +900,9 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
 template <int MODE>
 int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const void *dirs, int64_t n_items,
         int64_t start_level, int32_t narrow, int32_t flip, void *counts, int64_t *total_out, void *contacts, void *scratch,
-        size_t scratch_bytes, hipStream_t st) {
-    const bool write = contacts != nullptr;
+        size_t scratch_bytes, hipStream_t st, bool enqueue = false, int64_t capacity = 0) {
+    // three shapes: count (contacts == nullptr), write (contacts, !enqueue), enqueue = count + scan + guarded write
+    const bool write = contacts != nullptr && !enqueue;
     ibvh_layout lay;
     LeafLayout wl, dl;
     if (!layout_of(walk->types, lay, &wl)) return IBVH_ERR_UNSUPPORTED;
@@ -926,9 +939,17 @@ int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const voi
                 a.xcd_tiles = MODE != MODE_RAYS && xcd_env;
                 a.counts = (I *)counts;
                 a.contacts = (IndexPair<I> *)contacts;
+                a.guard_total = nullptr;
+                a.guard_capacity = 0;
                 PairCache<I> cache{K ? (IndexPair<I> *)((char *)scratch + scan_scratch_bytes(n_items)) : nullptr, K};
                 if (int e = launch<L, N, I, MODE>(a, cache, write, st)) return e;
-                if (!write) return scan_counts<I>((I *)counts, n_items, total_out, scratch, st);
+                if (write) return (int)IBVH_OK;
+                if (int e = scan_counts<I>((I *)counts, n_items, enqueue ? nullptr : total_out, scratch, st)) return e;
+                if (enqueue && capacity > 0) {
+                    a.guard_total = (const int64_t *)scratch; // header [0]: total contacts
+                    a.guard_capacity = sizeof(I) == 4 && capacity > (int64_t)INT32_MAX ? (int64_t)INT32_MAX : capacity;
+                    return launch<L, N, I, MODE>(a, cache, true, st);
+                }
                 return (int)IBVH_OK;
             });
         }
@@ -977,10 +998,35 @@ ibvh_status ibvh_traverse_lvt_write(const ibvh_bvh *bvh, int64_t start_level, in
                                        (void *)counts, &dummy, contacts, scratch, scratch_bytes, (hipStream_t)stream);
 }
 
+// count + scan + writing pass in one go, WITHOUT the host read of the total in between (the reference blocks there,
+// traverse_single.jl:53-60): the writing pass is launched right behind the scan and does nothing unless the total
+// fits `capacity` pairs.  The total stays in the scratch header: read it with ibvh_lvt_total whenever convenient;
+// if it exceeds `capacity`, call ibvh_traverse_lvt_write with a larger buffer (counts and scratch are ready for it).
+ibvh_status ibvh_traverse_lvt_enqueue(const ibvh_bvh *bvh, int64_t start_level, int32_t narrow, void *counts, void *contacts,
+                                      int64_t capacity, void *scratch, size_t scratch_bytes, void *stream) {
+    if (!bvh || capacity < 0) return IBVH_ERR_INVALID_ARG;
+    if (int e = check_levels(*bvh, start_level)) return (ibvh_status)e;
+    if (!scratch || scratch_bytes < scan_scratch_bytes(bvh->tree.real_leaves)) return IBVH_ERR_SCRATCH;
+    if (bvh->tree.real_nodes <= 1) { // traverse_single.jl:17-21: no contacts
+        if (hipMemsetAsync(scratch, 0, 8, (hipStream_t)stream) != hipSuccess) return IBVH_ERR_HIP;
+        return IBVH_OK;
+    }
+    if (!counts || (capacity > 0 && !contacts)) return IBVH_ERR_INVALID_ARG;
+    return (ibvh_status)run<MODE_SELF>(bvh, bvh, nullptr, nullptr, bvh->tree.real_leaves, start_level, narrow, 0, counts,
+                                       nullptr, contacts, scratch, scratch_bytes, (hipStream_t)stream, true, capacity);
+}
+// blocking read of the total contact count a *_count / *_enqueue call left in the scratch header
+ibvh_status ibvh_lvt_total(const void *scratch, int64_t *total_out, void *stream) {
+    if (!scratch || !total_out) return IBVH_ERR_INVALID_ARG;
+    if (hipMemcpyAsync(total_out, scratch, sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return IBVH_ERR_HIP;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return IBVH_ERR_HIP;
+    return IBVH_OK;
+}
+
 // traverse(bvh1, bvh2, LVTTraversal()) — lvt/traverse_pair.jl:1-116
 static ibvh_status pair_common(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, int64_t sl1, int64_t sl2, int32_t narrow,
                                void *counts, int64_t *total_out, void *contacts, void *scratch, size_t scratch_bytes,
-                               void *stream) {
+                               void *stream, bool enqueue = false, int64_t capacity = 0) {
     if (!bvh1 || !bvh2) return IBVH_ERR_INVALID_ARG;
     if (int e = check_levels(*bvh1, sl1)) return (ibvh_status)e;
     if (int e = check_levels(*bvh2, sl2)) return (ibvh_status)e;
@@ -991,7 +1037,7 @@ static ibvh_status pair_common(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, int64
     const ibvh_bvh *drv = flip ? bvh2 : bvh1, *oth = flip ? bvh1 : bvh2;
     return (ibvh_status)run<MODE_PAIR>(drv, oth, nullptr, nullptr, drv->tree.real_leaves, flip ? sl1 : sl2, narrow,
                                        flip ? 1 : 0, counts, total_out, contacts, scratch, scratch_bytes,
-                                       (hipStream_t)stream);
+                                       (hipStream_t)stream, enqueue, capacity);
 }
 ibvh_status ibvh_traverse_pair_lvt_count(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, int64_t sl1, int64_t sl2,
                                          int32_t narrow, void *counts, int64_t *total_out, void *scratch,
@@ -1008,17 +1054,27 @@ ibvh_status ibvh_traverse_pair_lvt_write(const ibvh_bvh *bvh1, const ibvh_bvh *b
     return pair_common(bvh1, bvh2, sl1, sl2, narrow, (void *)counts, &dummy, contacts, scratch, scratch_bytes, stream);
 }
 
+ibvh_status ibvh_traverse_pair_lvt_enqueue(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, int64_t sl1, int64_t sl2,
+                                           int32_t narrow, void *counts, void *contacts, int64_t capacity, void *scratch,
+                                           size_t scratch_bytes, void *stream) {
+    if (!scratch || capacity < 0 || (capacity > 0 && !contacts)) return IBVH_ERR_INVALID_ARG;
+    return pair_common(bvh1, bvh2, sl1, sl2, narrow, counts, nullptr, contacts, scratch, scratch_bytes, stream, true, capacity);
+}
+
 // traverse_rays(bvh, points, directions, LVTTraversal()) — raytrace/leaf_vs_tree/leaf_vs_tree.jl:1-90
 static ibvh_status rays_common(const ibvh_bvh *bvh, const void *points, const void *dirs, int64_t num_rays, int64_t sl,
                                void *counts, int64_t *total_out, void *contacts, void *scratch, size_t scratch_bytes,
-                               void *stream) {
+                               void *stream, bool enqueue = false, int64_t capacity = 0) {
     if (!bvh || num_rays < 0) return IBVH_ERR_INVALID_ARG;
     if (int e = check_levels(*bvh, sl)) return (ibvh_status)e;
     if (bvh->types.leaf_float != bvh->types.node_float) return IBVH_ERR_UNSUPPORTED;
-    if (num_rays == 0) return IBVH_OK; // :22-26
+    if (num_rays == 0) { // :22-26
+        if (enqueue && scratch && hipMemsetAsync(scratch, 0, 8, (hipStream_t)stream) != hipSuccess) return IBVH_ERR_HIP;
+        return IBVH_OK;
+    }
     if (!points || !dirs || !counts) return IBVH_ERR_INVALID_ARG;
     return (ibvh_status)run<MODE_RAYS>(nullptr, bvh, points, dirs, num_rays, sl, 0, 0, counts, total_out, contacts,
-                                       scratch, scratch_bytes, (hipStream_t)stream);
+                                       scratch, scratch_bytes, (hipStream_t)stream, enqueue, capacity);
 }
 ibvh_status ibvh_traverse_rays_lvt_count(const ibvh_bvh *bvh, const void *points, const void *dirs, int64_t num_rays,
                                          int64_t sl, void *counts, int64_t *total_out, void *scratch,
@@ -1034,6 +1090,12 @@ ibvh_status ibvh_traverse_rays_lvt_write(const ibvh_bvh *bvh, const void *points
     if (num_rays > 0 && !contacts) return IBVH_ERR_INVALID_ARG;
     int64_t dummy;
     return rays_common(bvh, points, dirs, num_rays, sl, (void *)counts, &dummy, contacts, scratch, scratch_bytes, stream);
+}
+ibvh_status ibvh_traverse_rays_lvt_enqueue(const ibvh_bvh *bvh, const void *points, const void *dirs, int64_t num_rays,
+                                           int64_t sl, void *counts, void *contacts, int64_t capacity, void *scratch,
+                                           size_t scratch_bytes, void *stream) {
+    if (!scratch || capacity < 0 || (capacity > 0 && !contacts)) return IBVH_ERR_INVALID_ARG;
+    return rays_common(bvh, points, dirs, num_rays, sl, counts, nullptr, contacts, scratch, scratch_bytes, stream, true, capacity);
 }
 
 } // extern "C"

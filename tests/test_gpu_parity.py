@@ -347,6 +347,81 @@ def test_lvt_dense_inputs_cache_overflow_and_frontier_overflow():
     assert (contacts_np(ibvh.traverse(g)) == oracle_pairs(orc.traverse_lvt(o)[0])).all()
 
 
+def test_lvt_enqueue_without_host_sync_matches_the_two_call_protocol():
+    """ibvh_traverse_lvt_enqueue (count + scan + guarded writing pass, no host read in between) through the C ABI:
+    same counts, same contacts as _count/_write when the buffer is large enough; nothing written and the right
+    total when it is not, after which _write completes the job."""
+    rng = np.random.default_rng(5)
+    types = abi.make_types()
+    vols = random_volumes(rng, 20000, abi.BSPHERE, abi.F32, scale=14.0)
+    o, g = build_both(vols, types)
+    exp, exp_counts = orc.traverse_lvt(o)
+    exp = oracle_pairs(exp)
+    n = len(vols)
+    s = g.struct()
+    need = C.c_size_t()
+    lib.call("ibvh_lvt_scratch_bytes", C.byref(types), n, 8, C.byref(need))
+    scratch = torch.zeros(need.value, dtype=torch.uint8, device="cuda")
+    counts = torch.zeros(n, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    # large enough
+    cap = len(exp) + 100
+    contacts = torch.full((cap, 2), -7, dtype=torch.int32, device="cuda")
+    lib.call("ibvh_traverse_lvt_enqueue", C.byref(s), 1, 0, counts.data_ptr(), contacts.data_ptr(), cap, scratch.data_ptr(),
+             scratch.numel(), stream)
+    total = C.c_int64()
+    lib.call("ibvh_lvt_total", scratch.data_ptr(), C.byref(total), stream)
+    assert total.value == len(exp)
+    assert counts.cpu().numpy().tolist() == exp_counts.tolist()
+    got = contacts.cpu().numpy()
+    assert (got[: len(exp)] == exp).all() and (got[len(exp):] == -7).all()
+    # exactly enough, then one too few: the guarded pass must not touch the buffer
+    for cap, written in ((len(exp), True), (len(exp) - 1, False)):
+        contacts = torch.full((len(exp), 2), -7, dtype=torch.int32, device="cuda")
+        lib.call("ibvh_traverse_lvt_enqueue", C.byref(s), 1, 0, counts.data_ptr(), contacts.data_ptr(), cap,
+                 scratch.data_ptr(), scratch.numel(), stream)
+        lib.call("ibvh_lvt_total", scratch.data_ptr(), C.byref(total), stream)
+        assert total.value == len(exp)
+        got = contacts.cpu().numpy()
+        assert (got == exp).all() if written else (got == -7).all()
+    lib.call("ibvh_traverse_lvt_write", C.byref(s), 1, 0, counts.data_ptr(), contacts.data_ptr(), scratch.data_ptr(),
+             scratch.numel(), stream)
+    assert (contacts.cpu().numpy() == exp).all()
+    # capacity 0: counting only
+    lib.call("ibvh_traverse_lvt_enqueue", C.byref(s), 1, 0, counts.data_ptr(), None, 0, scratch.data_ptr(), scratch.numel(), stream)
+    lib.call("ibvh_lvt_total", scratch.data_ptr(), C.byref(total), stream)
+    assert total.value == len(exp)
+
+
+def test_lvt_cache_reuse_is_lazy_and_grows_when_the_cached_buffer_is_too_small():
+    """Python mirror: traverse(bvh; cache=previous) enqueues against the cached contact buffer and reads the
+    count only when asked; a buffer that turns out too small is replaced at that point."""
+    rng = np.random.default_rng(6)
+    types = abi.make_types()
+    small = random_volumes(rng, 3000, abi.BSPHERE, abi.F32, scale=30.0)   # few contacts
+    big = random_volumes(rng, 30000, abi.BSPHERE, abi.F32, scale=14.0)    # many
+    (os_, gs), (ob, gb) = build_both(small, types), build_both(big, types)
+    exp_s, exp_b = oracle_pairs(orc.traverse_lvt(os_)[0]), oracle_pairs(orc.traverse_lvt(ob)[0])
+    assert 0 < len(exp_s) < len(exp_b)
+    t1 = ibvh.traverse(gs)
+    assert (contacts_np(t1) == exp_s).all()
+    t2 = ibvh.traverse(gb, cache=t1)            # cached buffer too small: resolved on first access
+    assert t2._pending is not None
+    assert t2.num_contacts == len(exp_b) and (contacts_np(t2) == exp_b).all()
+    t3 = ibvh.traverse(gb, cache=t2)            # large enough now: written speculatively
+    assert t3._pending is not None
+    assert (contacts_np(t3) == exp_b).all() and t3.cache1.data_ptr() == t2.cache1.data_ptr()
+    t4 = ibvh.traverse(gs, cache=t3)            # shrinking: same buffer, fewer contacts
+    assert (contacts_np(t4) == exp_s).all()
+    # an unread traversal whose buffers were handed on and whose cached buffer was too small cannot be completed
+    t5 = ibvh.traverse(gs)
+    t6 = ibvh.traverse(gb, cache=t5)
+    t7 = ibvh.traverse(gb, cache=t6)
+    with pytest.raises(RuntimeError):
+        t6.num_contacts
+    assert (contacts_np(t7) == exp_b).all()
+
+
 def test_lvt_pair_identical_order():
     rng = np.random.default_rng(22)
     types = abi.make_types()
