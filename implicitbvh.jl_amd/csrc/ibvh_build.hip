@@ -309,6 +309,26 @@ __global__ __launch_bounds__(AGG_TPB) void aggregate_kernel(const char *__restri
     }
 }
 
+// The top of the tree: one workgroup folds all levels above `in_level` (<= AGG_TOP_MAX inputs) through global
+// memory, a barrier per level; same merge_to as below, so the nodes are bit-identical.
+constexpr int AGG_TOP_TPB = 1024, AGG_TOP_MAX = 4096;
+template <class N>
+__global__ __launch_bounds__(AGG_TOP_TPB) void aggregate_top_kernel(TreeDev tree, int64_t in_level, int64_t built_level, N *nodes) {
+    for (int64_t level = in_level - 1; level >= built_level && level >= 1; --level) {
+        const int64_t nreal = level_num_real(tree.levels, tree.virtual_leaves, level);
+        const int64_t child_real = level_num_real(tree.levels, tree.virtual_leaves, level + 1);
+        const N *in = nodes + (level_start(tree.levels, tree.virtual_leaves, level + 1) - 1);
+        N *out = nodes + (level_start(tree.levels, tree.virtual_leaves, level) - 1);
+        for (int64_t i = threadIdx.x; i < nreal; i += AGG_TOP_TPB) {
+            const N a = load_vol<N>(in + 2 * i);
+            if (2 * i + 1 < child_real) store_vol(out + i, merge_to(a, load_vol<N>(in + 2 * i + 1), (N *)nullptr));
+            else store_vol(out + i, a);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 template <class L, class N>
 int aggregate(const char *leaves, int64_t leaf_stride, const ibvh_tree &tree, int64_t built_level, N *nodes, hipStream_t st) {
     if (tree.real_nodes < 2) return IBVH_OK; // build.jl:266
@@ -325,6 +345,12 @@ int aggregate(const char *leaves, int64_t leaf_stride, const ibvh_tree &tree, in
         in_level = in_level - CH_LEVELS;
     }
     while (in_level - 1 >= built_level && in_level - 1 >= 1) {
+        if (level_num_real(tree.levels, tree.virtual_leaves, in_level) <= AGG_TOP_MAX) {
+            // few nodes left: ONE workgroup folds every remaining level (a launch costs more than these levels)
+            IBVH_LAUNCH((aggregate_top_kernel<N>), dim3(1), dim3(AGG_TOP_TPB), 0, st, td, in_level, built_level, nodes);
+            IBVH_LAUNCH_CHECK();
+            break;
+        }
         int64_t nreal = level_num_real(tree.levels, tree.virtual_leaves, in_level - 1);
         const char *in = (const char *)(nodes + (level_start(tree.levels, tree.virtual_leaves, in_level) - 1));
         IBVH_LAUNCH((aggregate_kernel<L, N, false>), dim3((unsigned)ceil_div(nreal, AGG_TPB)), dim3(AGG_TPB), 0, st,
