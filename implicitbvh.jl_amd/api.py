@@ -584,6 +584,17 @@ def _traverse_lvt_pair(bvh1, bvh2, sl1, sl2, narrow, cache):
     counts = _cache_tensor(cache.cache2 if cache else None, n, 0, idt, "cache2")
     scratch = _lvt_scratch(cache, bvh1.types, n)
     s1, s2 = bvh1.struct(), bvh2.struct()
+    spec = _speculative_buffer(cache, idt)
+    if spec is not None:
+        lib.call("ibvh_traverse_pair_lvt_enqueue", C.byref(s1), C.byref(s2), sl1, sl2, narrow, _ptr(counts), _ptr(spec),
+                 spec.shape[0], _ptr(scratch), scratch.numel(), _stream())
+
+        def finish(total):
+            contacts = torch.empty((total, 2), dtype=idt, device="cuda")
+            lib.call("ibvh_traverse_pair_lvt_write", C.byref(s1), C.byref(s2), sl1, sl2, narrow, _ptr(counts), _ptr(contacts),
+                     _ptr(scratch), scratch.numel(), _stream())
+            return contacts
+        return BVHTraversal(sl1, sl2, 0, None, spec, counts, scratch, _pending=(_keep_total(scratch), spec.shape[0], finish))
     total = C.c_int64()
     lib.call("ibvh_traverse_pair_lvt_count", C.byref(s1), C.byref(s2), sl1, sl2, narrow, _ptr(counts), C.byref(total),
              _ptr(scratch), scratch.numel(), _stream())
@@ -704,6 +715,18 @@ def traverse_rays(bvh, points, directions, alg=None, start_level=1, narrow=None,
     if lvt:
         counts = _cache_tensor(cache.cache2 if cache else None, nr, 0, idt, "cache2")
         scratch = _lvt_scratch(cache, bvh.types, nr, slots=RAY_CACHE_SLOTS)
+        spec = _speculative_buffer(cache, idt)
+        if spec is not None:
+            lib.call("ibvh_traverse_rays_lvt_enqueue", C.byref(s), _ptr(p), _ptr(d), nr, start_level, _ptr(counts), _ptr(spec),
+                     spec.shape[0], _ptr(scratch), scratch.numel(), _stream())
+
+            def finish(total):
+                contacts = torch.empty((total, 2), dtype=idt, device="cuda")
+                lib.call("ibvh_traverse_rays_lvt_write", C.byref(s), _ptr(p), _ptr(d), nr, start_level, _ptr(counts),
+                         _ptr(contacts), _ptr(scratch), scratch.numel(), _stream())
+                return contacts
+            return BVHTraversal(start_level, 0, 0, None, spec, counts, scratch,
+                                _pending=(_keep_total(scratch), spec.shape[0], finish))
         total = C.c_int64()
         lib.call("ibvh_traverse_rays_lvt_count", C.byref(s), _ptr(p), _ptr(d), nr, start_level, _ptr(counts),
                  C.byref(total), _ptr(scratch), scratch.numel(), _stream())

@@ -422,6 +422,31 @@ def test_lvt_cache_reuse_is_lazy_and_grows_when_the_cached_buffer_is_too_small()
     assert (contacts_np(t7) == exp_b).all()
 
 
+def test_lvt_pair_and_rays_cache_reuse_enqueue_paths():
+    """pair and ray traversals with `cache=`: enqueued against the cached buffer (ibvh_traverse_pair_lvt_enqueue /
+    ibvh_traverse_rays_lvt_enqueue), same lists as the oracle, both when the buffer fits and when it must grow."""
+    rng = np.random.default_rng(8)
+    types = abi.make_types()
+    a, b = random_volumes(rng, 5000, abi.BSPHERE, abi.F32, scale=5.0), random_volumes(rng, 3000, abi.BSPHERE, abi.F32, scale=5.0)
+    (o1, g1), (o2, g2) = build_both(a, types), build_both(b, types)
+    exp12, exp21 = oracle_pairs(orc.traverse_pair_lvt(o1, o2)[0]), oracle_pairs(orc.traverse_pair_lvt(o2, o1)[0])
+    t = ibvh.traverse(g1, g2)
+    assert (contacts_np(t) == exp12).all()
+    t = ibvh.traverse(g2, g1, cache=t)
+    assert t._pending is not None and (contacts_np(t) == exp21).all()
+    tiny = ibvh.traverse(g1, g2, cache=ibvh.traverse(ibvh.BVH(cuda(a[:40]), ibvh.BBox(torch.float32))))  # buffer too small
+    assert (contacts_np(tiny) == exp12).all()
+    pts = (5.0 * rng.random((3, 700))).astype(np.float32)
+    dirs = rng.standard_normal((3, 700)).astype(np.float32)
+    exp_r = oracle_pairs(orc.traverse_rays_lvt(o1, np.ascontiguousarray(pts.T), np.ascontiguousarray(dirs.T))[0])  # oracle: (N, 3)
+    r = ibvh.traverse_rays(g1, cuda(pts), cuda(dirs))
+    assert (contacts_np(r) == exp_r).all()
+    r2 = ibvh.traverse_rays(g1, cuda(pts[:, :300]), cuda(dirs[:, :300]), cache=r)
+    assert r2._pending is not None
+    assert (contacts_np(r2) == oracle_pairs(orc.traverse_rays_lvt(o1, np.ascontiguousarray(pts[:, :300].T),
+                                                                 np.ascontiguousarray(dirs[:, :300].T))[0])).all()
+
+
 def test_lvt_pair_identical_order():
     rng = np.random.default_rng(22)
     types = abi.make_types()
