@@ -510,8 +510,9 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
         };
         const Cnt at = base + (Cnt)rank;
         const int n_a = __popcll(m_a);
-        if (hit_a) put(at, idx_a, wfill + __popcll(m_a & lt_mask));
-        if (hit_b) put(at + (hit_a ? 1 : 0), idx_b, wfill + n_a + __popcll(m_b & lt_mask));
+        auto below = [](uint64_t m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+        if (hit_a) put(at, idx_a, wfill + below(m_a));
+        if (hit_b) put(at + (hit_a ? 1 : 0), idx_b, wfill + n_a + below(m_b));
         if constexpr (!WRITE) wfill = __builtin_amdgcn_readfirstlane(wfill + n_a + __popcll(m_b));
     };
     // drain the full 64-pair steps (all == false) or everything (all == true); a remainder moves to the front
