@@ -306,6 +306,68 @@ template <class T> IBVH_D T wave_max_all(T v) {
 // busiest lane (~22 % of the lanes busy) 0.40; this kernel with ONE union box per wave 0.40 (the kernel waited
 // for the few waves whose 64 leaves straddle a big Z-curve jump: 489 subtrees against 23 on average); with the
 // two-box split 0.25.
+// Stage c's inner step for Float32 boxes, hand-scheduled: test the wave-uniform box S (SGPRs) against every lane's
+// box V (iscontact: S.lo <= V.up and S.up >= V.lo per axis — the same ordered compares as the C++ operators), plus
+// one unsigned compare (the self walk's "a leaf to the right of the query" prune), starting from the lanes in
+// `init`; the surviving lanes append their entry `e` to the LDS queue at lds_base + 4 * (number of surviving lanes
+// below).  v_cmpx narrows EXEC directly, so the chain needs no s_and per compare and the append runs under the
+// result mask without a saveexec — 17 VALU + 4 SALU where the compiler's version took 21 + 14.  Returns the mask.
+template <bool THR_GT>
+IBVH_D uint64_t test_and_append_f32(uint64_t init, float slo0, float slo1, float slo2, float sup0, float sup1, float sup2,
+                                     float vlo0, float vlo1, float vlo2, float vup0, float vup1, float vup2, uint32_t sthr,
+                                     uint32_t vcmp, uint32_t e, uint32_t lds_base) {
+    uint64_t hm, saved;
+    uint32_t tmp;
+    if constexpr (THR_GT) {
+        asm volatile("s_nop 1\n\t"
+                     "s_mov_b64 %[sv], exec\n\t"
+                     "s_mov_b64 exec, %[init]\n\t"
+                     "v_cmpx_le_f32 %[slo0], %[vup0]\n\t"
+                     "v_cmpx_ge_f32 %[sup0], %[vlo0]\n\t"
+                     "v_cmpx_le_f32 %[slo1], %[vup1]\n\t"
+                     "v_cmpx_ge_f32 %[sup1], %[vlo1]\n\t"
+                     "v_cmpx_le_f32 %[slo2], %[vup2]\n\t"
+                     "v_cmpx_ge_f32 %[sup2], %[vlo2]\n\t"
+                     "v_cmpx_gt_u32 %[sthr], %[vcmp]\n\t"
+                     "s_mov_b64 %[hm], exec\n\t"
+                     "s_nop 1\n\t"
+                     "v_mbcnt_lo_u32_b32 %[tmp], exec_lo, 0\n\t"
+                     "v_mbcnt_hi_u32_b32 %[tmp], exec_hi, %[tmp]\n\t"
+                     "v_lshl_add_u32 %[tmp], %[tmp], 2, %[base]\n\t"
+                     "ds_write_b32 %[tmp], %[e]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [hm] "=&s"(hm), [sv] "=&s"(saved), [tmp] "=&v"(tmp)
+                     : [init] "s"(init), [slo0] "s"(slo0), [slo1] "s"(slo1), [slo2] "s"(slo2), [sup0] "s"(sup0), [sup1] "s"(sup1),
+                       [sup2] "s"(sup2), [vlo0] "v"(vlo0), [vlo1] "v"(vlo1), [vlo2] "v"(vlo2), [vup0] "v"(vup0), [vup1] "v"(vup1),
+                       [vup2] "v"(vup2), [sthr] "s"(sthr), [vcmp] "v"(vcmp), [e] "v"(e), [base] "s"(lds_base)
+                     : "vcc", "memory");
+    } else {
+        asm volatile("s_nop 1\n\t"
+                     "s_mov_b64 %[sv], exec\n\t"
+                     "s_mov_b64 exec, %[init]\n\t"
+                     "v_cmpx_le_f32 %[slo0], %[vup0]\n\t"
+                     "v_cmpx_ge_f32 %[sup0], %[vlo0]\n\t"
+                     "v_cmpx_le_f32 %[slo1], %[vup1]\n\t"
+                     "v_cmpx_ge_f32 %[sup1], %[vlo1]\n\t"
+                     "v_cmpx_le_f32 %[slo2], %[vup2]\n\t"
+                     "v_cmpx_ge_f32 %[sup2], %[vlo2]\n\t"
+                     "v_cmpx_lt_u32 %[sthr], %[vcmp]\n\t"
+                     "s_mov_b64 %[hm], exec\n\t"
+                     "s_nop 1\n\t"
+                     "v_mbcnt_lo_u32_b32 %[tmp], exec_lo, 0\n\t"
+                     "v_mbcnt_hi_u32_b32 %[tmp], exec_hi, %[tmp]\n\t"
+                     "v_lshl_add_u32 %[tmp], %[tmp], 2, %[base]\n\t"
+                     "ds_write_b32 %[tmp], %[e]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [hm] "=&s"(hm), [sv] "=&s"(saved), [tmp] "=&v"(tmp)
+                     : [init] "s"(init), [slo0] "s"(slo0), [slo1] "s"(slo1), [slo2] "s"(slo2), [sup0] "s"(sup0), [sup1] "s"(sup1),
+                       [sup2] "s"(sup2), [vlo0] "v"(vlo0), [vlo1] "v"(vlo1), [vlo2] "v"(vlo2), [vup0] "v"(vup0), [vup1] "v"(vup1),
+                       [vup2] "v"(vup2), [sthr] "s"(sthr), [vcmp] "v"(vcmp), [e] "v"(e), [base] "s"(lds_base)
+                     : "vcc", "memory");
+    }
+    return hm;
+}
+
 constexpr int QUEUE_CAP = 512; // candidate pairs per wave (LDS); drained whenever fewer than 64 slots are free
 
 template <class L, class N, class I, int MODE, bool WRITE, bool NARROW>
@@ -317,7 +379,7 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
     __shared__ uint32_t s_queue[4][QUEUE_CAP];
     __shared__ Cnt s_cnt[4][64];
     Q q(a, cache);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // (uniform: LDS bases stay scalar)
     // Wave-dense contact cache.  The wave owns the scratch bytes its 64 items own in the slot-major layout of the
     // other walkers ([item0 * K, (item0 + 64) * K) pairs) but fills them densely, in discovery order, with
     // (pair, query lane | position within that query's list << 6) entries behind a 16-byte header {fill}: the
@@ -560,26 +622,56 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
         const bool by_box = (int)__popcll(box_mask) < (int)__popcll(on_mask); // (int: keeps the compare on the scalar unit)
         const uint32_t e_box = (uint32_t)lane | (first32 << 6);     // + (u << 6)
         const uint32_t e_qry = (first32 + (uint32_t)lane) << 6;      // | u
-        for (uint64_t todo = by_box ? box_mask : on_mask; todo != 0; todo &= todo - 1) {
-            if (qn > QUEUE_CAP - 64) drain(false);
-            const int u = __builtin_ctzll(todo);
-            bool h;
-            uint32_t e;
+        if constexpr (std::is_same<TN, float>::value) {
+            // hand-scheduled step (test_and_append_f32); the pair walk has no prune: thresholds that always pass
+            const uint32_t queue_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)queue;
             if (by_box) {
-                const N pbox = broadcast_from_lane(mybox, u);
-                h = on & iscontact(q.q_node, pbox);
-                if constexpr (MODE == MODE_SELF) h = h & (2u * (first32 + (uint32_t)u) + 1u > my_item);
-                e = e_box + ((uint32_t)u << 6);
+                for (uint64_t todo = box_mask; todo != 0; todo &= todo - 1) {
+                    if (qn > QUEUE_CAP - 64) drain(false);
+                    const int u = __builtin_ctzll(todo);
+                    const N p = broadcast_from_lane(mybox, u);
+                    const uint32_t thr = MODE == MODE_SELF ? 2u * (first32 + (uint32_t)u) + 1u : 0xffffffffu; // > my_item
+                    const uint64_t hm = test_and_append_f32<true>(on_mask, p.lo[0], p.lo[1], p.lo[2], p.up[0], p.up[1], p.up[2],
+                                                                  q.q_node.lo[0], q.q_node.lo[1], q.q_node.lo[2], q.q_node.up[0],
+                                                                  q.q_node.up[1], q.q_node.up[2], thr, MODE == MODE_SELF ? my_item : 0u,
+                                                                  e_box + ((uint32_t)u << 6), queue_lds + 4u * (uint32_t)qn);
+                    qn += (int)__popcll(hm);
+                }
             } else {
-                const N qbox = broadcast_from_lane(q.q_node, u);
-                h = box_on & iscontact(qbox, mybox);
-                if constexpr (MODE == MODE_SELF) h = h & (right_leaf > wave_item0 + (uint32_t)u);
-                e = e_qry | (uint32_t)u;
+                for (uint64_t todo = on_mask; todo != 0; todo &= todo - 1) {
+                    if (qn > QUEUE_CAP - 64) drain(false);
+                    const int u = __builtin_ctzll(todo);
+                    const N qb = broadcast_from_lane(q.q_node, u);
+                    const uint32_t thr = MODE == MODE_SELF ? wave_item0 + (uint32_t)u : 0u; // < right_leaf
+                    const uint64_t hm = test_and_append_f32<false>(box_mask, qb.lo[0], qb.lo[1], qb.lo[2], qb.up[0], qb.up[1], qb.up[2],
+                                                                   mybox.lo[0], mybox.lo[1], mybox.lo[2], mybox.up[0], mybox.up[1],
+                                                                   mybox.up[2], thr, MODE == MODE_SELF ? right_leaf : 1u,
+                                                                   e_qry | (uint32_t)u, queue_lds + 4u * (uint32_t)qn);
+                    qn += (int)__popcll(hm);
+                }
             }
-            const uint64_t hm = __builtin_amdgcn_ballot_w64(h);
-            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
-            if (h) queue[qn + rank] = e;
-            qn = __builtin_amdgcn_readfirstlane(qn + __popcll(hm));
+        } else {
+            for (uint64_t todo = by_box ? box_mask : on_mask; todo != 0; todo &= todo - 1) {
+                if (qn > QUEUE_CAP - 64) drain(false);
+                const int u = __builtin_ctzll(todo);
+                bool h;
+                uint32_t e;
+                if (by_box) {
+                    const N pbox = broadcast_from_lane(mybox, u);
+                    h = on & iscontact(q.q_node, pbox);
+                    if constexpr (MODE == MODE_SELF) h = h & (2u * (first32 + (uint32_t)u) + 1u > my_item);
+                    e = e_box + ((uint32_t)u << 6);
+                } else {
+                    const N qbox = broadcast_from_lane(q.q_node, u);
+                    h = box_on & iscontact(qbox, mybox);
+                    if constexpr (MODE == MODE_SELF) h = h & (right_leaf > wave_item0 + (uint32_t)u);
+                    e = e_qry | (uint32_t)u;
+                }
+                const uint64_t hm = __builtin_amdgcn_ballot_w64(h);
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+                if (h) queue[qn + rank] = e;
+                qn = __builtin_amdgcn_readfirstlane(qn + __popcll(hm));
+            }
         }
     };
 
