@@ -203,7 +203,7 @@ class HipEngine:
 DIGIT_BITS = 12
 
 
-def find_splitters(engine, comm, keys, key_bits, n_global, tolerance=0.002, first_hist=None):
+def find_splitters(engine, comm, keys, key_bits, n_global, tolerance=0.005, first_hist=None):
     """Keys k_1 <= ... <= k_{P-1}: rank r receives the keys in [k_r, k_{r+1}).
 
     Digit histograms are refined from the top of the key, 12 bits per level (one all-reduce(SUM) of <= 15 x 4096
@@ -265,7 +265,7 @@ class DistributedBuilder:
     `local_volumes`: this rank's (n_local, 4|6) volumes; global leaf g = (sum of lower ranks' counts) + local
     position; the returned BVH's leaves carry .index = g + 1."""
 
-    def __init__(self, comm=None, engine=None, tolerance=0.002):
+    def __init__(self, comm=None, engine=None, tolerance=0.005):
         if comm is None or not hasattr(comm, "all_reduce"):
             comm = TorchComm(comm)
         self.comm = comm
