@@ -1,4 +1,5 @@
-"""Timings of BASELINE.json configs 3 (mesh + 1e6 rays) and 4 (two 5e6 clouds, pair traverse) on one MI355X.
+"""Timings of BASELINE.json configs 2 (1e6 spheres: LVT and BFS, cold and cached build), 3 (mesh + 1e6 rays) and 4
+(two 5e6 clouds, pair traverse) on one MI355X.
 Not the driver's bench line (bench.py): these are the parity-test configurations, timed for DESIGN.md."""
 import json
 import math
@@ -36,6 +37,38 @@ def kernels(fn):
 
 
 out = {}
+# ---- config 2: LVT and BFS, build cold and with cache= reuse ---------------------------------
+n2 = 1_000_000
+v2 = ibvh.generate_spheres(n2, 42, r0=0.5 * (3 * 8 / (4 * math.pi * n2)) ** (1 / 3))
+ms_cold, _ = timed(lambda: ibvh.BVH(v2))
+s2 = {"bvh": None, "lvt": None, "bfs": None}
+
+
+def build2():
+    s2["bvh"] = ibvh.BVH(v2, cache=s2["bvh"])
+    return s2["bvh"]
+
+
+def lvt2():
+    s2["lvt"] = ibvh.traverse(s2["bvh"], cache=s2["lvt"])
+    return s2["lvt"]
+
+
+def bfs2():
+    s2["bfs"] = ibvh.traverse(s2["bvh"], ibvh.BFSTraversal(), cache=s2["bfs"])
+    return s2["bfs"]
+
+
+ms_warm, _ = timed(build2, 10)
+ms_lvt, t_lvt = timed(lvt2, 10)
+ms_bfs2, t_bfs = timed(bfs2, 5)
+out["config2"] = {"leaves": n2, "build_cold_ms": round(ms_cold, 3), "build_cache_ms": round(ms_warm, 3),
+                  "traverse_lvt_ms": round(ms_lvt, 3), "traverse_bfs_ms": round(ms_bfs2, 3), "contacts": t_lvt.num_contacts,
+                  "bfs_contacts": t_bfs.num_contacts, "bfs_checks": t_bfs.num_checks,
+                  "Mcontacts_per_s_lvt": round(t_lvt.num_contacts / ms_lvt / 1e3, 1),
+                  "Mcontacts_per_s_bfs": round(t_bfs.num_contacts / ms_bfs2 / 1e3, 1)}
+del v2, s2, t_lvt, t_bfs
+torch.cuda.empty_cache()
 # ---- config 3 -------------------------------------------------------------------------------
 from test_gpu_fullsize import torus_mesh
 tris = torch.from_numpy(torus_mesh()).cuda()
