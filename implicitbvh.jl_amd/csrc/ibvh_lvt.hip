@@ -124,8 +124,11 @@ template <class L, class N, class I, int MODE, bool WRITE, bool NARROW> struct Q
     Cnt w, cnt;
 
     IBVH_D Query(const Args<L, N, I> &a_, const PairCache<I> &c_) : a(a_), cache(c_) {
-        // (an XCD-contiguous block->tile remap was measured here in round 1: 0.44 -> 0.61 ms at 1e6 leaves,
-        // no change at 1e7, so work items keep the plain round-robin placement)
+        // XCD-contiguous placement: workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2;
+        // handing XCD x one contiguous range of the (Morton-sorted) items keeps neighbouring waves, which read the same
+        // nodes and leaves, behind one L2.  Time-neutral for this issue-bound kernel but L2-miss traffic drops 4x
+        // (rocprofv3 FETCH_SIZE per count launch: 88 -> 22 MB at 1e6 leaves, 898 -> 263 MB at 1e7), i.e. to the
+        // algorithmic bytes.  (An earlier measurement, when the kernel was still tail-bound, had shown a slowdown.)
         const int blk = a.xcd_tiles ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
         item = (int64_t)blk * blockDim.x + threadIdx.x;
         valid = item < a.n_items;
@@ -1100,8 +1103,8 @@ int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const voi
                 a.narrow = narrow;
                 a.flip = flip;
                 static const int xcd_env = [] {
-                    const char *e = getenv("IBVH_LVT_XCD"); // tuning knob
-                    return e ? atoi(e) : 0;
+                    const char *e = getenv("IBVH_LVT_XCD"); // tuning knob: 0 = plain round-robin placement
+                    return e ? atoi(e) : 1;
                 }();
                 a.xcd_tiles = MODE != MODE_RAYS && xcd_env;
                 a.counts = (I *)counts;
