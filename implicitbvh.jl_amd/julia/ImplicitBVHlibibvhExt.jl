@@ -142,6 +142,26 @@ function ImplicitBVH.traverse(
                 d.types, n, LVT_CACHE_SLOTS, need), "ibvh_lvt_scratch_bytes")
     scratch = ROCVector{UInt8}(undef, need[])
     total = Ref{Int64}(0)
+    if !isnothing(cache) && length(cache.cache1) > 0
+        # cache reuse: enqueue pass 1 + scan + a guarded pass 2 against the cached buffer without a host read in between
+        # (the GPU never idles); read the total afterwards and fall through to the ordinary _write only if it did not fit.
+        eltype(cache.cache1) === IndexPair{I} || throw(ArgumentError("eltype(cache.cache1) === IndexPair{I} must hold"))
+        check(ccall((:ibvh_traverse_lvt_enqueue, libibvh), Cint,
+                    (Ref{IbvhBvh}, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+                    d, start_level, narrow_code(narrow), devptr(counts), devptr(cache.cache1), length(cache.cache1),
+                    devptr(scratch), need[], stream_ptr()), "ibvh_traverse_lvt_enqueue")
+        check(ccall((:ibvh_lvt_total, libibvh), Cint, (Ptr{Cvoid}, Ref{Int64}, Ptr{Cvoid}), devptr(scratch), total, stream_ptr()),
+              "ibvh_lvt_total")                             # the reference's @allowscalar (:60), after the work is queued
+        if total[] <= length(cache.cache1)
+            return BVHTraversal(Int(start_level), 0, Int(total[]), cache.cache1, counts)
+        end
+        resize!(cache.cache1, total[])
+        check(ccall((:ibvh_traverse_lvt_write, libibvh), Cint,
+                    (Ref{IbvhBvh}, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+                    d, start_level, narrow_code(narrow), devptr(counts), devptr(cache.cache1), devptr(scratch), need[],
+                    stream_ptr()), "ibvh_traverse_lvt_write")
+        return BVHTraversal(Int(start_level), 0, Int(total[]), cache.cache1, counts)
+    end
     check(ccall((:ibvh_traverse_lvt_count, libibvh), Cint,
                 (Ref{IbvhBvh}, Int64, Int32, Ptr{Cvoid}, Ref{Int64}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
                 d, start_level, narrow_code(narrow), devptr(counts), total, devptr(scratch), need[], stream_ptr()),
