@@ -763,6 +763,65 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
     }
 }
 
+// ---- (3a) rays: the walk of one lane -----
+// The per-lane depth-first walk of one ray (see lvt_rays_kernel); `emit(leaf index)` is called for every hit leaf, in
+// the reference's order.
+template <class L, class N, class I, class T, class Emit>
+IBVH_D void ray_dfs(const Args<L, N, I> &a, const T (&p)[3], const T (&d)[3], bool lane_on, Emit &&emit) {
+    const int levels = (int)a.tree.levels;
+    const uint32_t vl = (uint32_t)a.tree.virtual_leaves; // < 2^(levels-1) <= 2^31
+    const uint32_t leaf_first = 1u << (levels - 1);
+    const uint32_t n_leaves = (uint32_t)a.tree.real_leaves;
+    const int plevel = (int)a.start_level - 1;
+    const int64_t roots = level_num_real(a.tree.levels, a.tree.virtual_leaves, a.start_level);
+    const uint32_t pfirst = plevel >= 1 ? (1u << (plevel - 1)) : 0u;
+    const uint32_t pcount = (uint32_t)((roots + 1) / 2);
+
+    for (uint32_t pi = 0; pi < pcount; ++pi) { // uniform: pseudo-parents of the start-level roots
+        uint32_t inode = pfirst + pi;
+        int level = plevel;
+        uint32_t pend = 0;
+        bool alive = lane_on;
+        while (alive) {
+            const int cl = level + 1;
+            const uint32_t c0 = 2u * inode, c1 = c0 + 1u;
+            const uint32_t first = 1u << (cl - 1);
+            const uint32_t nreal = first - (uint32_t)((uint64_t)vl >> (levels - cl));
+            const bool real0 = c0 != 0u, real1 = (c1 - first) < nreal;
+            if (cl == levels) {
+                const char *rec = a.leaves + ((int64_t)c0 - (int64_t)leaf_first) * a.lay.stride; // c0 may be the pseudo node 0
+                if (real0 && isintersection(load_vol<L>(rec), p, d)) emit(load_index<I>(rec, a.lay));
+                if (real1 && isintersection(load_vol<L>(rec + a.lay.stride), p, d)) emit(load_index<I>(rec + a.lay.stride, a.lay));
+            } else {
+                const uint64_t v = (uint64_t)vl >> (levels - cl + 1);
+                const uint32_t sk = (uint32_t)(2 * v) - (uint32_t)__popcll(v); // level_skips(cl)
+                const N *np = a.nodes + ((int64_t)c0 - (int64_t)sk - 1);
+                const bool h0 = real0 && isintersection(load_vol<N>(real0 ? np : np + 1), p, d);
+                const bool h1 = real1 && isintersection(load_vol<N>(real1 ? np + 1 : np), p, d);
+                if (h0) {
+                    if (h1) pend |= 1u << cl;
+                    inode = c0;
+                    level = cl;
+                    continue;
+                }
+                if (h1) {
+                    inode = c1;
+                    level = cl;
+                    continue;
+                }
+            }
+            if (pend == 0) {
+                alive = false;
+            } else {
+                const int pl = 31 - __builtin_clz(pend);
+                pend &= ~(1u << pl);
+                inode = (inode >> (level - pl)) | 1u;
+                level = pl;
+            }
+        }
+    }
+}
+
 // ---- (3) rays: per-lane walk ------------------------------------------------------------------------
 // The rays of a wave are not spatially coherent, so every lane walks on its own — but leaner than the
 // reference's loop (raytrace/leaf_vs_tree/leaf_vs_tree.jl:187-225): a step tests BOTH children of the
@@ -831,58 +890,7 @@ __global__ __launch_bounds__(256) void lvt_rays_kernel(Args<L, N, I> a, PairCach
         }
     };
 
-    const int levels = (int)a.tree.levels;
-    const uint32_t vl = (uint32_t)a.tree.virtual_leaves; // < 2^(levels-1) <= 2^31
-    const uint32_t leaf_first = 1u << (levels - 1);
-    const uint32_t n_leaves = (uint32_t)a.tree.real_leaves;
-    const int plevel = (int)a.start_level - 1;
-    const int64_t roots = level_num_real(a.tree.levels, a.tree.virtual_leaves, a.start_level);
-    const uint32_t pfirst = plevel >= 1 ? (1u << (plevel - 1)) : 0u;
-    const uint32_t pcount = (uint32_t)((roots + 1) / 2);
-
-    for (uint32_t pi = 0; pi < pcount; ++pi) { // uniform: pseudo-parents of the start-level roots
-        uint32_t inode = pfirst + pi;
-        int level = plevel;
-        uint32_t pend = 0;
-        bool alive = lane_on;
-        while (alive) {
-            const int cl = level + 1;
-            const uint32_t c0 = 2u * inode, c1 = c0 + 1u;
-            const uint32_t first = 1u << (cl - 1);
-            const uint32_t nreal = first - (uint32_t)((uint64_t)vl >> (levels - cl));
-            const bool real0 = c0 != 0u, real1 = (c1 - first) < nreal;
-            if (cl == levels) {
-                const char *rec = a.leaves + ((int64_t)c0 - (int64_t)leaf_first) * a.lay.stride; // c0 may be the pseudo node 0
-                if (real0 && isintersection(load_vol<L>(rec), p, d)) emit(load_index<I>(rec, a.lay));
-                if (real1 && isintersection(load_vol<L>(rec + a.lay.stride), p, d)) emit(load_index<I>(rec + a.lay.stride, a.lay));
-            } else {
-                const uint64_t v = (uint64_t)vl >> (levels - cl + 1);
-                const uint32_t sk = (uint32_t)(2 * v) - (uint32_t)__popcll(v); // level_skips(cl)
-                const N *np = a.nodes + ((int64_t)c0 - (int64_t)sk - 1);
-                const bool h0 = real0 && isintersection(load_vol<N>(real0 ? np : np + 1), p, d);
-                const bool h1 = real1 && isintersection(load_vol<N>(real1 ? np + 1 : np), p, d);
-                if (h0) {
-                    if (h1) pend |= 1u << cl;
-                    inode = c0;
-                    level = cl;
-                    continue;
-                }
-                if (h1) {
-                    inode = c1;
-                    level = cl;
-                    continue;
-                }
-            }
-            if (pend == 0) {
-                alive = false;
-            } else {
-                const int pl = 31 - __builtin_clz(pend);
-                pend &= ~(1u << pl);
-                inode = (inode >> (level - pl)) | 1u;
-                level = pl;
-            }
-        }
-    }
+    ray_dfs(a, p, d, lane_on, emit);
     if constexpr (!WRITE) {
         if (valid) a.counts[item] = (I)cnt;
         __builtin_amdgcn_wave_barrier();
@@ -1029,6 +1037,10 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
     unsigned blocks = (unsigned)ceil_div(a.n_items, 256);
     if constexpr (MODE == MODE_RAYS) {
         // rays of one wave are not spatially coherent: each lane walks on its own
+        // (A breadth-first variant with 16 lanes per ray and per-level LDS frontiers was measured in round 1: with
+        // frontiers that fit it halves the time of SMALL batches (1e5 rays: 1.1 -> 0.67 ms, the heaviest ray no longer
+        // walks on one lane), but rays grazing the surface outgrow any LDS slice that still allows a decent occupancy
+        // and at 1e6 rays it was 2x slower than this walk, so it was dropped.)
         if (write) IBVH_LAUNCH((lvt_rays_kernel<L, N, I, true>), dim3(blocks), dim3(256), 0, st, a, cache);
         else IBVH_LAUNCH((lvt_rays_kernel<L, N, I, false>), dim3(blocks), dim3(256), 0, st, a, cache);
     } else {
