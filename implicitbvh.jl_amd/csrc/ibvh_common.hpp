@@ -501,6 +501,17 @@ IBVH_D int xcd_remap(int b, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+// Block-cyclic variant: XCD x gets RUNS of `run` consecutive tiles, the runs dealt round-robin — neighbouring tiles
+// still share an L2 while a workload whose cost is concentrated in part of the index range (two partially
+// overlapping clouds) is still spread over all XCDs.  Bijective for any grid size (the ragged tail is left as is).
+IBVH_D int xcd_run_remap(int b, int nwg, int run) {
+    const int period = 8 * run;
+    const int full = (nwg / period) * period;
+    if (b >= full) return b;
+    const int xcd = b & 7, k = b >> 3; // k-th workgroup that lands on this XCD
+    return ((k / run) * 8 + xcd) * run + (k % run);
+}
+
 // wave64 helpers -----------------------------------------------------------------------------
 IBVH_D int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 

@@ -124,12 +124,15 @@ template <class L, class N, class I, int MODE, bool WRITE, bool NARROW> struct Q
     Cnt w, cnt;
 
     IBVH_D Query(const Args<L, N, I> &a_, const PairCache<I> &c_) : a(a_), cache(c_) {
-        // XCD-contiguous placement: workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2;
-        // handing XCD x one contiguous range of the (Morton-sorted) items keeps neighbouring waves, which read the same
-        // nodes and leaves, behind one L2.  Time-neutral for this issue-bound kernel but L2-miss traffic drops 4x
-        // (rocprofv3 FETCH_SIZE per count launch: 88 -> 22 MB at 1e6 leaves, 898 -> 263 MB at 1e7), i.e. to the
-        // algorithmic bytes.  (An earlier measurement, when the kernel was still tail-bound, had shown a slowdown.)
-        const int blk = a.xcd_tiles ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+        // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2; handing an
+        // XCD RUNS of 64 consecutive workgroups (16 K Morton-sorted items) keeps neighbouring waves, which read the same
+        // nodes and leaves, behind one L2.  Time-neutral for this issue-bound kernel, but L2-miss traffic drops
+        // (rocprofv3 FETCH_SIZE per count launch at 1e6 leaves: 88 MB round robin, 38 MB with runs of 64, 22 MB with ONE
+        // contiguous range per XCD).  One range per XCD is not the default because a workload whose cost sits in part
+        // of the index range (config 4: two clouds overlapping by 10 %) then loads a few XCDs only (0.37 -> 0.47 ms);
+        // runs of 64 keep it at 0.38 ms.
+        const int blk = a.xcd_tiles == 1 ? xcd_remap((int)blockIdx.x, (int)gridDim.x)
+                        : (a.xcd_tiles > 1 ? xcd_run_remap((int)blockIdx.x, (int)gridDim.x, a.xcd_tiles) : (int)blockIdx.x);
         item = (int64_t)blk * blockDim.x + threadIdx.x;
         valid = item < a.n_items;
         q_leaf = {};
@@ -1115,10 +1118,10 @@ int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const voi
                 a.narrow = narrow;
                 a.flip = flip;
                 static const int xcd_env = [] {
-                    const char *e = getenv("IBVH_LVT_XCD"); // tuning knob: 0 = plain round-robin placement
-                    return e ? atoi(e) : 1;
+                    const char *e = getenv("IBVH_LVT_XCD"); // tuning knob: 0 = round robin, 1 = one range per XCD, n = runs of n
+                    return e ? atoi(e) : 64;
                 }();
-                a.xcd_tiles = MODE != MODE_RAYS && xcd_env;
+                a.xcd_tiles = MODE != MODE_RAYS ? xcd_env : 0; // 0: round robin, 1: one contiguous range per XCD, n > 1: runs of n
                 a.counts = (I *)counts;
                 a.contacts = (IndexPair<I> *)contacts;
                 a.guard_total = nullptr;
