@@ -21,6 +21,28 @@ template <class T> __global__ void expand_kernel(T *ext) {
     }
 }
 
+// The all-reduce(MAX) vector of the distributed build, assembled on device in one launch:
+// vec = [-mins(3), maxs(3), one-hot leaf counts(nranks)] as float64 (float -> double is exact and min x = -max(-x)),
+// with the reference's neutral elements (morton/utils.jl:29-40: floatmax for minima, floatmin for maxima) when this
+// rank has no leaves.
+template <class T> __global__ void pack_extrema_kernel(const T *ext, int has_data, int rank, int nranks, double n_local, double *vec) {
+    const int k = threadIdx.x;
+    if (k < 3) vec[k] = has_data ? -(double)ext[k] : -(double)float_max<T>();
+    else if (k < 6) vec[k] = has_data ? (double)ext[k] : (double)float_min_normal<T>();
+    else if (k < 6 + nranks) vec[k] = (k - 6 == rank) ? n_local : 0.0;
+}
+// ... and taken apart again after the collective: global extrema in the leaf float type, epsilon-expanded
+// (double -> float of values that came from floats is exact).
+template <class T> __global__ void unpack_extrema_kernel(const double *vec, T *ext) {
+    const int k = threadIdx.x;
+    if (k < 6) {
+        const T rp = relative_precision<T>(), fm = float_min_normal<T>();
+        const T v = k < 3 ? (T)(-vec[k]) : (T)vec[k];
+        const T a = rp * ibvh_abs(v);
+        ext[k] = k < 3 ? (v - a) - fm : (v + a) + fm;
+    }
+}
+
 // Digit histograms for the splitter search: out[j][d] = #keys with (key >> prefix_shift) == prefix[j]
 // and digit d = (key >> shift) & mask; nprefix == 0: one histogram over all keys.  LDS-staged.
 constexpr int HIST_TPB = 256;
@@ -80,6 +102,26 @@ ibvh_status ibvh_expand_extrema(int32_t flt, void *extrema, void *stream) {
     if (!extrema) return IBVH_ERR_INVALID_ARG;
     if (flt == IBVH_F32) IBVH_LAUNCH((distk::expand_kernel<float>), dim3(1), dim3(64), 0, (hipStream_t)stream, (float *)extrema);
     else if (flt == IBVH_F64) IBVH_LAUNCH((distk::expand_kernel<double>), dim3(1), dim3(64), 0, (hipStream_t)stream, (double *)extrema);
+    else return IBVH_ERR_INVALID_ARG;
+    return hipGetLastError() == hipSuccess ? IBVH_OK : IBVH_ERR_HIP;
+}
+
+ibvh_status ibvh_dist_pack_extrema(int32_t flt, const void *extrema, int32_t has_data, int32_t rank, int32_t nranks,
+                                   int64_t n_local, void *vec_out, void *stream) {
+    if (!vec_out || nranks < 1 || nranks > 1018 || rank < 0 || rank >= nranks || n_local < 0 || (has_data && !extrema)) return IBVH_ERR_INVALID_ARG;
+    if (flt == IBVH_F32)
+        IBVH_LAUNCH((distk::pack_extrema_kernel<float>), dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float *)extrema, has_data,
+                    rank, nranks, (double)n_local, (double *)vec_out);
+    else if (flt == IBVH_F64)
+        IBVH_LAUNCH((distk::pack_extrema_kernel<double>), dim3(1), dim3(1024), 0, (hipStream_t)stream, (const double *)extrema, has_data,
+                    rank, nranks, (double)n_local, (double *)vec_out);
+    else return IBVH_ERR_INVALID_ARG;
+    return hipGetLastError() == hipSuccess ? IBVH_OK : IBVH_ERR_HIP;
+}
+ibvh_status ibvh_dist_unpack_extrema(int32_t flt, const void *vec, void *extrema_out, void *stream) {
+    if (!vec || !extrema_out) return IBVH_ERR_INVALID_ARG;
+    if (flt == IBVH_F32) IBVH_LAUNCH((distk::unpack_extrema_kernel<float>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const double *)vec, (float *)extrema_out);
+    else if (flt == IBVH_F64) IBVH_LAUNCH((distk::unpack_extrema_kernel<double>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const double *)vec, (double *)extrema_out);
     else return IBVH_ERR_INVALID_ARG;
     return hipGetLastError() == hipSuccess ? IBVH_OK : IBVH_ERR_HIP;
 }

@@ -92,6 +92,22 @@ class HipEngine:
         lib.call("ibvh_expand_extrema", types.leaf_float, api._ptr(ext), api._stream())
         return ext
 
+    def pack_extrema(self, types, volumes, rank, nranks):
+        """[-mins, maxs, one-hot leaf counts] as float64 on device: local extrema + ONE small kernel."""
+        torch = self.torch
+        n_local = volumes.shape[0]
+        vec = torch.empty(6 + nranks, dtype=torch.float64, device=self.device)
+        e = self.extrema(types, volumes) if n_local else None
+        lib.call("ibvh_dist_pack_extrema", types.leaf_float, api._ptr(e) if n_local else None, 1 if n_local else 0, rank, nranks,
+                 n_local, api._ptr(vec), api._stream())
+        return vec
+
+    def unpack_extrema(self, types, vec, dtype):
+        """global extrema in the leaf float type, epsilon-expanded, from the reduced vector (one kernel)"""
+        ext = self.torch.empty(6, dtype=dtype, device=self.device)
+        lib.call("ibvh_dist_unpack_extrema", types.leaf_float, api._ptr(vec), api._ptr(ext), api._stream())
+        return ext
+
     def keys(self, types, vols, ext):
         torch = self.torch
         kd = torch.int64 if types.morton_type == abi.U64 else torch.int32
@@ -100,14 +116,14 @@ class HipEngine:
                  api._stream())
         return keys
 
-    def histogram(self, keys, shift, bits, prefix_shift, prefixes):
+    def histogram(self, keys, shift, bits, prefix_shift, prefixes, raw=False):
         torch = self.torch
         rows = max(len(prefixes), 1)
         out = torch.empty((rows, 1 << bits), dtype=torch.int32, device=self.device)
         arr = (C.c_uint64 * max(len(prefixes), 1))(*[int(p) for p in prefixes]) if prefixes else None
         lib.call("ibvh_key_histogram", keys.element_size(), api._ptr(keys), keys.numel(), shift, bits, prefix_shift, arr,
                  len(prefixes), api._ptr(out), api._stream())
-        return out.to(torch.int64)
+        return out if raw else out.to(torch.int64)
 
     def partition(self, keys, splitters, nranks, known_counts=None):
         """Stable partition of the local leaves by destination rank: (perm, counts per rank).  `known_counts`:
@@ -289,29 +305,43 @@ class DistributedBuilder:
         #    (float -> double -> float is exact, and min(x) = -max(-x) exactly) and every rank's leaf count
         #    (global numbering) in a single collective.  Neutral elements of the reference's reduces
         #    (morton/utils.jl:29-40): floatmax for the minima, floatmin for the maxima.
-        vec = eng.tensor([-fmax] * 3 + [fmin] * 3 + [0.0] * comm.size, torch.float64)
-        if n_local:
-            e = eng.extrema(types, volumes).to(torch.float64)
-            vec[:3] = -e[:3]
-            vec[3:6] = e[3:]
-        vec[6 + comm.rank] = float(n_local)
+        if hasattr(eng, "pack_extrema"):
+            vec = eng.pack_extrema(types, volumes, comm.rank, comm.size)
+        else:  # engines without the fused kernels (the CPU test engine)
+            vec = eng.tensor([-fmax] * 3 + [fmin] * 3 + [0.0] * comm.size, torch.float64)
+            if n_local:
+                e = eng.extrema(types, volumes).to(torch.float64)
+                vec[:3] = -e[:3]
+                vec[3:6] = e[3:]
+            vec[6 + comm.rank] = float(n_local)
         if comm.size > 1:
             comm.all_reduce(vec, "max")
-        ext = torch.cat([-vec[:3], vec[3:6]]).to(volumes.dtype)
-        eng.expand(types, ext)
+        if hasattr(eng, "unpack_extrema"):
+            ext = eng.unpack_extrema(types, vec, volumes.dtype)
+        else:
+            ext = torch.cat([-vec[:3], vec[3:6]]).to(volumes.dtype)
+            eng.expand(types, ext)
         # 2. keys + this rank's first splitter histogram; the histograms are ALL-GATHERED (P x 4096 counters), so every
         #    rank knows the whole send matrix as soon as the splitters sit on first-level bucket boundaries (the
-        #    normal case) and no count exchange is needed.  ONE device->host copy brings back everything the host needs.
+        #    normal case) and no count exchange is needed.  ONE device->host copy (raw bytes of the three pieces)
+        #    brings back everything the host needs.
         keys = eng.keys(types, volumes, ext)
         key_bits = abi.MORTON_BITS[types.morton_type]
         bits0 = min(DIGIT_BITS, key_bits)
         shift0 = key_bits - bits0
-        hist0 = eng.histogram(keys, shift0, bits0, 64, []).reshape(-1)
+        try:
+            hist0 = eng.histogram(keys, shift0, bits0, 64, [], raw=True).reshape(-1)
+        except TypeError:
+            hist0 = eng.histogram(keys, shift0, bits0, 64, []).reshape(-1)
         allh = comm.all_gather(hist0) if comm.size > 1 else hist0.reshape(1, -1)
-        host = eng.to_host(torch.cat([vec, ext.to(torch.float64), allh.reshape(-1).to(torch.float64)]))
-        counts = [int(round(c)) for c in host[6:6 + comm.size]]
-        ext_host = host[6 + comm.size:12 + comm.size].astype(fdt)
-        H = np.rint(host[12 + comm.size:]).astype(np.int64).reshape(comm.size, -1)
+        allh = allh.contiguous()
+        blob = eng.to_host(torch.cat([vec.view(torch.uint8), ext.contiguous().view(torch.uint8), allh.view(torch.uint8).reshape(-1)]))
+        nv, ne = 8 * (6 + comm.size), 6 * ext.element_size()
+        host_vec = np.frombuffer(blob[:nv].tobytes(), dtype=np.float64)
+        counts = [int(round(c)) for c in host_vec[6:6 + comm.size]]
+        ext_host = np.frombuffer(blob[nv:nv + ne].tobytes(), dtype=fdt).copy()
+        hdt = np.int32 if allh.element_size() == 4 else np.int64
+        H = np.frombuffer(blob[nv + ne:].tobytes(), dtype=hdt).astype(np.int64).reshape(comm.size, -1)
         base, n_global = int(sum(counts[:comm.rank])), int(sum(counts))
         if n_global < comm.size:
             raise abi.DomainError("fewer leaves than ranks")

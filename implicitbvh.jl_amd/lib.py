@@ -51,6 +51,8 @@ SIGNATURES = {
                                _P(abi.BfsResult), _vp],
     "ibvh_traverse_rays_bfs": [_P(abi.Bvh), _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _P(abi.BfsResult), _vp],
     "ibvh_expand_extrema": [_i32, _vp, _vp],
+    "ibvh_dist_pack_extrema": [_i32, _vp, _i32, _i32, _i32, _i64, _vp, _vp],
+    "ibvh_dist_unpack_extrema": [_i32, _vp, _vp, _vp],
     "ibvh_key_histogram": [_i32, _vp, _i64, _i32, _i32, _i32, _P(C.c_uint64), _i32, _vp, _vp],
     "ibvh_pack_records": [_P(abi.Types), _vp, _vp, _vp, _i64, _i64, _vp, _vp],
     "ibvh_volumes_from_triangles": [_i32, _i32, _vp, _i64, _vp, _vp],

@@ -304,6 +304,15 @@ ibvh_status ibvh_traverse_rays_bfs(const ibvh_bvh *bvh, const void *points, cons
  * all-reduce of the per-GPU extrema (ibvh_extrema with expand = 0). */
 ibvh_status ibvh_expand_extrema(int32_t flt, void *extrema, void *stream);
 
+/* The all-reduce(MAX) vector of the distributed build, assembled / taken apart on device (one launch each, no
+ * host round trip): vec_out (DEVICE, 6 + nranks float64) = [-mins(3), maxs(3), one-hot leaf counts]; `extrema`:
+ * this GPU's 6 UNEXPANDED centre extrema of float type `flt` (ibvh_extrema with expand = 0), ignored when
+ * has_data == 0 (neutral elements of morton/utils.jl:29-40 are written).  _unpack converts the reduced vector back
+ * to `flt` and applies the epsilon expansion (morton/utils.jl:63-69). */
+ibvh_status ibvh_dist_pack_extrema(int32_t flt, const void *extrema, int32_t has_data, int32_t rank,
+                                   int32_t nranks, int64_t n_local, void *vec_out, void *stream);
+ibvh_status ibvh_dist_unpack_extrema(int32_t flt, const void *vec, void *extrema_out, void *stream);
+
 /* Digit histograms for the splitter search of the distributed radix sort.  out (DEVICE,
  * max(nprefix,1) x 2^bits uint32, zeroed here): out[j][d] = number of keys whose
  * (key >> prefix_shift) == prefixes[j] and whose digit (key >> shift) & (2^bits - 1) == d;
