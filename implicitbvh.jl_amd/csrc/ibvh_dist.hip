@@ -7,7 +7,33 @@
 #include "ibvh_common.hpp"
 
 namespace ibvh {
+namespace rsort { // ibvh_sort.hip
+struct RecordArgs;
+int sort_pairs(int key_bytes, int key_bits, int64_t n, void *keys, void *vals, void *keys_alt, void *vals_alt, bool vals_implicit,
+               int32_t *result_in_alt, void *scratch, size_t scratch_sz, hipStream_t st, bool first_hist_done,
+               const RecordArgs *records);
+size_t scratch_bytes(int64_t n);
+} // namespace rsort
 namespace distk {
+
+// destination rank of every key: the number of splitters <= key (keys in [k_r, k_{r+1}) go to rank r)
+constexpr int MAX_SPLITTERS = 255;
+struct Splitters {
+    uint64_t v[MAX_SPLITTERS];
+};
+template <class K>
+__global__ __launch_bounds__(256) void dest_kernel(const K *__restrict__ keys, int64_t n, Splitters sp, int nsplit, uint32_t *__restrict__ dest) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint64_t k = (uint64_t)keys[i];
+        int lo = 0, hi = nsplit; // first splitter > k
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sp.v[mid] <= k) lo = mid + 1;
+            else hi = mid;
+        }
+        dest[i] = (uint32_t)lo;
+    }
+}
 
 // epsilon expansion of bounding_volumes_extrema (morton/utils.jl:63-69) applied to already reduced
 // extrema: mins - rp*|mins| - floatmin, maxs + rp*|maxs| + floatmin, two roundings per side
@@ -123,6 +149,42 @@ ibvh_status ibvh_dist_unpack_extrema(int32_t flt, const void *vec, void *extrema
     if (flt == IBVH_F32) IBVH_LAUNCH((distk::unpack_extrema_kernel<float>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const double *)vec, (float *)extrema_out);
     else if (flt == IBVH_F64) IBVH_LAUNCH((distk::unpack_extrema_kernel<double>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const double *)vec, (double *)extrema_out);
     else return IBVH_ERR_INVALID_ARG;
+    return hipGetLastError() == hipSuccess ? IBVH_OK : IBVH_ERR_HIP;
+}
+
+// Stable partition of the local leaves by destination rank: perm_out[j] = source position of the j-th leaf in
+// (destination rank, source position) order.  One destination kernel + ONE stable radix pass over (rank, position).
+ibvh_status ibvh_dist_partition_scratch_bytes(int64_t n, size_t *bytes_out) {
+    if (!bytes_out || n < 0) return IBVH_ERR_INVALID_ARG;
+    *bytes_out = (size_t)align_up(n * 4, 256) * 3 + rsort::scratch_bytes(n);
+    return IBVH_OK;
+}
+ibvh_status ibvh_dist_partition(int32_t key_bytes, const void *keys, int64_t n, const uint64_t *splitters, int32_t nranks,
+                                void *perm_out, void *scratch, size_t scratch_bytes, void *stream) {
+    if (n < 0 || nranks < 1 || (key_bytes != 4 && key_bytes != 8)) return IBVH_ERR_INVALID_ARG;
+    if (nranks - 1 > distk::MAX_SPLITTERS) return IBVH_ERR_UNSUPPORTED;
+    if (n == 0) return IBVH_OK;
+    if (!keys || !perm_out || !scratch || (nranks > 1 && !splitters)) return IBVH_ERR_INVALID_ARG;
+    size_t need;
+    ibvh_dist_partition_scratch_bytes(n, &need);
+    if (scratch_bytes < need) return IBVH_ERR_SCRATCH;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t slab = (size_t)align_up(n * 4, 256);
+    uint32_t *dest = (uint32_t *)scratch, *dest_alt = (uint32_t *)((char *)scratch + slab), *vals_pri = (uint32_t *)((char *)scratch + 2 * slab);
+    void *sort_scratch = (char *)scratch + 3 * slab;
+    distk::Splitters sp;
+    for (int i = 0; i < nranks - 1; ++i) sp.v[i] = splitters[i];
+    const int blocks = (int)(ceil_div(n, 256) < 4096 ? ceil_div(n, 256) : 4096);
+    if (key_bytes == 8) IBVH_LAUNCH((distk::dest_kernel<uint64_t>), dim3(blocks), dim3(256), 0, st, (const uint64_t *)keys, n, sp, nranks - 1, dest);
+    else IBVH_LAUNCH((distk::dest_kernel<uint32_t>), dim3(blocks), dim3(256), 0, st, (const uint32_t *)keys, n, sp, nranks - 1, dest);
+    int bits = 1;
+    while ((1 << bits) < nranks) ++bits; // <= 8: exactly one LSD pass, whose output lands in the alternate buffers
+    int32_t in_alt = 0;
+    if (int e = rsort::sort_pairs(4, bits, n, dest, vals_pri, dest_alt, perm_out, true, &in_alt, sort_scratch, rsort::scratch_bytes(n), st,
+                                  false, nullptr))
+        return (ibvh_status)e;
+    if (!in_alt) // (cannot happen for one pass; keep the contract anyway)
+        if (hipMemcpyAsync(perm_out, vals_pri, (size_t)n * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return IBVH_ERR_HIP;
     return hipGetLastError() == hipSuccess ? IBVH_OK : IBVH_ERR_HIP;
 }
 

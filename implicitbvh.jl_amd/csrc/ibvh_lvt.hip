@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
         ubox_a = broadcast_from_lane(pre, ksplit);
         ubox_b = broadcast_from_lane(nxt_suf, ksplit);
     }
-    auto touches_wave = [&](const N &b) { return iscontact(ubox_a, b) | iscontact(ubox_b, b); };
+    auto touches_wave = [&](const N &b) { return (bool)((int)iscontact(ubox_a, b) | (int)iscontact(ubox_b, b)); };
     const int lp = levels - 1;
     const uint32_t lp_real = num_real(lp);
     const N *lp_nodes = a.nodes + first_mem(lp);

@@ -132,6 +132,16 @@ class HipEngine:
         n = keys.numel()
         if nranks == 1:
             return None, [n]
+        if known_counts is not None and nranks <= 256:
+            # fused path: destination kernel + one stable radix pass inside the library (ibvh_dist_partition)
+            perm = torch.empty(n, dtype=torch.int32, device=self.device)
+            need = C.c_size_t()
+            lib.call("ibvh_dist_partition_scratch_bytes", n, C.byref(need))
+            scratch = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+            arr = (C.c_uint64 * max(len(splitters), 1))(*[int(sp) for sp in splitters])
+            lib.call("ibvh_dist_partition", keys.element_size(), api._ptr(keys), n, arr, nranks, api._ptr(perm), api._ptr(scratch),
+                     need.value, api._stream())
+            return perm, list(known_counts)
         if splitters:
             dest = torch.bucketize(keys, torch.tensor(splitters, dtype=keys.dtype, device=self.device), right=True).to(torch.int32)
         else:

@@ -53,6 +53,8 @@ SIGNATURES = {
     "ibvh_expand_extrema": [_i32, _vp, _vp],
     "ibvh_dist_pack_extrema": [_i32, _vp, _i32, _i32, _i32, _i64, _vp, _vp],
     "ibvh_dist_unpack_extrema": [_i32, _vp, _vp, _vp],
+    "ibvh_dist_partition_scratch_bytes": [_i64, _P(_sz)],
+    "ibvh_dist_partition": [_i32, _vp, _i64, _P(C.c_uint64), _i32, _vp, _vp, _sz, _vp],
     "ibvh_key_histogram": [_i32, _vp, _i64, _i32, _i32, _i32, _P(C.c_uint64), _i32, _vp, _vp],
     "ibvh_pack_records": [_P(abi.Types), _vp, _vp, _vp, _i64, _i64, _vp, _vp],
     "ibvh_volumes_from_triangles": [_i32, _i32, _vp, _i64, _vp, _vp],

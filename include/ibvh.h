@@ -313,6 +313,14 @@ ibvh_status ibvh_dist_pack_extrema(int32_t flt, const void *extrema, int32_t has
                                    int32_t nranks, int64_t n_local, void *vec_out, void *stream);
 ibvh_status ibvh_dist_unpack_extrema(int32_t flt, const void *vec, void *extrema_out, void *stream);
 
+/* Stable partition of the local leaves by destination rank (keys in [splitters[r-1], splitters[r]) go to rank r;
+ * `splitters`: nranks - 1 ascending keys in HOST memory): perm_out[j] (DEVICE, n x uint32) = source position of the
+ * j-th leaf in (destination, source position) order.  nranks <= 256. */
+ibvh_status ibvh_dist_partition_scratch_bytes(int64_t n, size_t *bytes_out);
+ibvh_status ibvh_dist_partition(int32_t key_bytes, const void *keys, int64_t n, const uint64_t *splitters,
+                                int32_t nranks, void *perm_out, void *scratch, size_t scratch_bytes,
+                                void *stream);
+
 /* Digit histograms for the splitter search of the distributed radix sort.  out (DEVICE,
  * max(nprefix,1) x 2^bits uint32, zeroed here): out[j][d] = number of keys whose
  * (key >> prefix_shift) == prefixes[j] and whose digit (key >> shift) & (2^bits - 1) == d;
