@@ -272,22 +272,27 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as orc  # the checker, here only as the timed CPU baseline
-        cores = os.cpu_count() or 1
+        ncpu = os.cpu_count() or 1
         cpu_n = args.cpu_n or min(n, 2_000_000)
         host = orc.generate_spheres_f32(cpu_n, args.seed, r0=0.5 * (3 * 8 / (4 * math.pi * cpu_n)) ** (1 / 3))
+        # the host is shared and SMT-threaded: more threads are not always faster, so a few thread counts are tried and
+        # the best run is the baseline (its thread count is what `cores` reports)
+        candidates = sorted({max(1, ncpu), max(1, ncpu // 2), max(1, ncpu // 4), min(32, ncpu)}, reverse=True)
         best = None
         t_budget = time.perf_counter()
-        for _ in range(3):
-            _, cc, tb, tt = orc.bench_build_traverse_f32(host, cores)
-            if best is None or tb + tt < best[0] + best[1]:
-                best = (tb, tt, len(cc))
+        for threads in candidates:
+            for _ in range(3):
+                _, cc, tb, tt = orc.bench_build_traverse_f32(host, threads)
+                if best is None or tb + tt < best[0] + best[1]:
+                    best = (tb, tt, len(cc), threads)
             if time.perf_counter() - t_budget > 25:
                 break
+        cores = best[3]
         cpu_baseline = {"value": round(cpu_n / (best[0] + best[1]) / 1e6, 4), "unit": "Mleaves/s", "cores": cores,
                         "kind": "port",
                         "sample": f"{cpu_n} BSphere{{Float32}} leaves, same generator/law as the GPU workload, "
                                   f"build {best[0]*1e3:.1f} ms + LVT traverse {best[1]*1e3:.1f} ms, {best[2]} contacts, "
-                                  f"best of <=3 runs, {cores} threads",
+                                  f"best run over thread counts {candidates} (<= 3 runs each), {cores} threads",
                         "build_ms": round(best[0] * 1e3, 3), "traverse_ms": round(best[1] * 1e3, 3),
                         "gpu_over_cpu": round(value / (cpu_n / (best[0] + best[1]) / 1e6), 1) if cpu_n == n else None}
         if north_star is not None:

@@ -1058,17 +1058,16 @@ int oracle_generate_spheres_f32(int64_t n, uint64_t seed, int64_t first_index, c
 // ranges the way the reference's CPU path is (AK.itask_partition, lvt/traverse_single.jl:94-111):
 // extrema, encode, chunked stable sort + stable merges, per-level merges, two-pass LVT.
 } // extern "C"
+// Fork-join over `threads` contiguous ranges on the OpenMP runtime (persistent team, spinning barriers): the phases
+// of the baseline are short (a tree level, a radix pass) and spawning 256 std::threads for each of them cost more
+// than the work itself.  Every logical range is executed exactly once whatever team size the runtime grants.
 template <class F> static void parallel_ranges(int64_t n, int threads, F &&f) {
     if (threads <= 1 || n < 2 * threads) {
         f(0, int64_t(0), n);
         return;
     }
-    std::vector<std::thread> th;
-    for (int t = 0; t < threads; ++t) {
-        int64_t lo = n * t / threads, hi = n * (t + 1) / threads;
-        th.emplace_back([=, &f] { f(t, lo, hi); });
-    }
-    for (auto &x : th) x.join();
+#pragma omp parallel for schedule(static, 1) num_threads(threads)
+    for (int t = 0; t < threads; ++t) f(t, n * t / threads, n * (t + 1) / threads);
 }
 extern "C" {
 
@@ -1115,21 +1114,48 @@ int oracle_bench_build_traverse_f32(const void *volumes, int64_t n, int threads,
     parallel_ranges(n, threads, [&](int, int64_t lo, int64_t hi) {
         for (int64_t i = lo; i < hi; ++i) leaves[i].morton = morton_encode_single<M>(leaves[i].volume.x, ext, ext + 3);
     });
-    // chunked stable sort + pairwise stable merges
-    auto cmp = [](const Rec &a, const Rec &b) { return a.morton < b.morton; };
-    if (used == 1) std::stable_sort(leaves, leaves + n, cmp);
-    else {
-        std::vector<int64_t> bounds(used + 1);
-        for (int t = 0; t <= used; ++t) bounds[t] = n * t / used;
-        parallel_ranges(n, threads, [&](int, int64_t lo, int64_t hi) { std::stable_sort(leaves + lo, leaves + hi, cmp); });
-        for (int width = 1; width < used; width *= 2) {
-            std::vector<std::thread> th;
-            for (int t = 0; t + width < used; t += 2 * width) {
-                int64_t lo = bounds[t], mid = bounds[t + width], hi = bounds[std::min(t + 2 * width, used)];
-                th.emplace_back([=] { std::inplace_merge(leaves + lo, leaves + mid, leaves + hi, cmp); });
+    // stable sort by Morton code: parallel LSB radix sort of (code, position) pairs, 8-bit digits, then one gather of
+    // the records (same result as a stable comparison sort of the records; per-thread histograms over contiguous
+    // chunks keep it stable)
+    if (used == 1) {
+        auto cmp = [](const Rec &a, const Rec &b) { return a.morton < b.morton; };
+        std::stable_sort(leaves, leaves + n, cmp);
+    } else {
+        std::vector<uint32_t> ka(n), kb(n), va(n), vb(n);
+        parallel_ranges(n, threads, [&](int, int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i) {
+                ka[i] = leaves[i].morton;
+                va[i] = (uint32_t)i;
             }
-            for (auto &x : th) x.join();
+        });
+        std::vector<int64_t> hist((size_t)used * 256), offs((size_t)used * 256);
+        uint32_t *kin = ka.data(), *kout = kb.data(), *vin = va.data(), *vout = vb.data();
+        for (int shift = 0; shift < 30; shift += 8) {
+            parallel_ranges(n, threads, [&](int t, int64_t lo, int64_t hi) {
+                int64_t *h = &hist[(size_t)t * 256];
+                for (int d = 0; d < 256; ++d) h[d] = 0;
+                for (int64_t i = lo; i < hi; ++i) ++h[(kin[i] >> shift) & 255u];
+            });
+            int64_t run = 0;
+            for (int d = 0; d < 256; ++d)
+                for (int t = 0; t < used; ++t) {
+                    offs[(size_t)t * 256 + d] = run;
+                    run += hist[(size_t)t * 256 + d];
+                }
+            parallel_ranges(n, threads, [&](int t, int64_t lo, int64_t hi) {
+                int64_t *o = &offs[(size_t)t * 256];
+                for (int64_t i = lo; i < hi; ++i) {
+                    const int64_t dst = o[(kin[i] >> shift) & 255u]++;
+                    kout[dst] = kin[i];
+                    vout[dst] = vin[i];
+                }
+            });
+            std::swap(kin, kout);
+            std::swap(vin, vout);
         }
+        parallel_ranges(n, threads, [&](int, int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i) leaves[i] = Rec{vols[vin[i]], I(vin[i] + 1), kin[i]};
+        });
     }
     // merges, level by level
     N *nodes = (N *)nodes_out;
