@@ -279,6 +279,32 @@ def test_lvt_self_identical_order_every_start_level(combo):
         assert sorted(map(tuple, contacts_np(ibvh.traverse(g)).tolist())) == brute
 
 
+@pytest.mark.parametrize("combo", [c for c in ALL_COMBOS if c[2] == abi.BBOX], ids=str)
+def test_lvt_queue_kernel_medium_clouds_all_box_combinations(combo):
+    """The BBox-node fast kernel at a size where every wave runs the full pipeline (frontier descent, both candidate
+    loops, queue drains, dense cache) for every leaf / node float combination — Float32 nodes take the hand-scheduled
+    step, Float64 nodes the compiler's — with both index types, the narrow menu, and a pair traversal with flip."""
+    rng = np.random.default_rng(31)
+    n = 40000
+    vols = random_volumes(rng, n, combo[0], combo[1], scale=22.0)
+    for it, mt in ((abi.I32, abi.U32), (abi.I64, abi.U64)):
+        types = abi.make_types(*combo, it, mt)
+        o, g = build_both(vols, types)
+        exp = oracle_pairs(orc.traverse_lvt(o)[0])
+        assert len(exp) > n // 2
+        t = ibvh.traverse(g)
+        assert (contacts_np(t) == exp).all()
+        assert (contacts_np(ibvh.traverse(g, cache=t)) == exp).all()
+        for nar in (ibvh.NARROW_MORTON_LT, ibvh.NARROW_INDEX_LT):
+            assert (contacts_np(ibvh.traverse(g, narrow=nar)) == oracle_pairs(orc.traverse_lvt(o, narrow=nar)[0])).all()
+    types = abi.make_types(*combo)
+    other = random_volumes(rng, n // 3, combo[0], combo[1], scale=22.0)
+    (o1, g1), (o2, g2) = build_both(vols, types), build_both(other, types)
+    assert (contacts_np(ibvh.traverse(g1, g2)) == oracle_pairs(orc.traverse_pair_lvt(o1, o2)[0])).all()
+    assert (contacts_np(ibvh.traverse(g2, g1, narrow=ibvh.NARROW_INDEX_LT)) ==
+            oracle_pairs(orc.traverse_pair_lvt(o2, o1, narrow=abi.NARROW_INDEX_LT)[0])).all()
+
+
 def test_readme_examples_on_gpu():
     e = G["readme_example"]
     for dt in (np.float32, np.float64):
