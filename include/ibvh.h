@@ -195,9 +195,11 @@ ibvh_status ibvh_aggregate(const ibvh_types *types, const ibvh_tree *tree, int64
  * counts : one I per work item (cache2 of BVHTraversal on the GPU path, :31-32).
  * scratch: ibvh_lvt_scratch_bytes() bytes of device memory: scan tile sums + the contact cache.
  */
-/* cache_slots: contacts per work item the counting pass keeps for the writing pass (0 = none: the
- * writing pass walks the tree again; 8 suits ~2 contacts per leaf).  Pass the SAME scratch buffer
- * and size to the _count call and its _write call. */
+/* cache_slots: contacts per work item (on average) the counting pass keeps for the writing pass (0 = none: the
+ * writing pass walks the tree again; 8 suits ~2 contacts per leaf).  The BBox-node and ray walkers pool the slots of
+ * the 64 work items of a wave (a wave walks again only if ALL its items together found more than ~42 * cache_slots
+ * contacts); the exact walk keeps the first cache_slots contacts of every item.  Pass the SAME scratch buffer and size
+ * to the _count call and its _write call. */
 ibvh_status ibvh_lvt_scratch_bytes(const ibvh_types *types, int64_t n_items, int32_t cache_slots,
                                    size_t *bytes_out);
 ibvh_status ibvh_traverse_lvt_count(const ibvh_bvh *bvh, int64_t start_level, int32_t narrow,
