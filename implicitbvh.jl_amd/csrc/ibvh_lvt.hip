@@ -95,9 +95,10 @@ IBVH_D bool narrow_eval(int narrow, uint64_t ma, int64_t ia, uint64_t mb, int64_
 //     BSphere nodes (rounded merges, not nested), start_level == levels and trees deeper than 28 levels
 //     take kernel (1).
 //
-// Contact cache: the counting pass also stores the first K contacts of every work item in a
-// slot-major scratch array (slot k of item i at [k * n_items + i]); the writing pass copies them to
-// their final offsets and only waves with an item of more than K contacts walk again.
+// Contact cache (K * n_items pairs of scratch).  Kernel (1) stores the first K contacts of every work item
+// slot-major (slot k of item i at [k * n_items + i]); its writing pass copies them to their final offsets and only
+// waves with an item of more than K contacts walk again.  Kernels (2) and (3) pool the slots of a wave's 64 items
+// and fill them densely (see the kernels): their writing pass walks again only if the whole wave overflowed.
 // ------------------------------------------------------------------------------------------
 template <class T> struct Boxed { // lets the lane-movement helpers carry a scalar
     T v;
