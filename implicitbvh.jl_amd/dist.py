@@ -9,7 +9,7 @@ for.  Only the BUILD communicates; traversal stays per GPU:
   2. per-GPU Morton keys (ibvh_morton_keys);
   3. distributed radix sort: splitter keys found by refining 12-bit digit histograms from the top of the
      key (ibvh_key_histogram, one all-reduce(SUM) of <= 15 x 4096 counters per level; normally ONE level:
-     refinement stops once a splitter's bucket is lighter than 0.2 % of a shard), so that rank r
+     refinement stops once a splitter's bucket is lighter than 0.5 % of a shard), so that rank r
      receives the keys in [k_r, k_{r+1}); stable partition of the local leaves by destination
      (one pass of the radix sort), pack into BoundingVolume records whose .index is the GLOBAL 1-based
      leaf number (ibvh_pack_records), ONE all-to-all of the records over xGMI;
