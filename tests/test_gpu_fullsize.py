@@ -14,6 +14,10 @@ import implicitbvh_amd as ibvh  # noqa: E402
 from implicitbvh_amd import abi  # noqa: E402
 
 
+def contacts_np(trav):
+    return trav.contacts.cpu().numpy().astype(np.int64)
+
+
 def torus_mesh(u=1898, v=1897):
     """Deterministic surrogate for xyzrgb_dragon.obj (absent from the reference repo, benchmark/README.md:3):
     a displaced torus tessellation with 2*u*v ~ 7.2 M triangles, i.e. a 2-manifold leaf distribution."""
@@ -103,3 +107,66 @@ def test_config4_pair_two_5e6_clouds_full_size():
     bfs = ibvh.traverse(b1, b2, ibvh.BFSTraversal())
     cb = bfs.contacts.cpu().numpy().astype(np.int64)
     assert np.array_equal(np.unique(cb[:, 0] * (n + 1) + cb[:, 1]), np.unique(c[:, 0] * (n + 1) + c[:, 1]))
+
+
+def test_north_star_ten_million_properties():
+    """The north-star size (1e7 leaves, one GPU) through size-independent properties: sortedness, permutation,
+    stability, records follow their index, every node is the exact merge of its children (spot-checked per level),
+    every reported pair touches and is reported once, per-leaf counts agree with the list, BFS finds the same SET of
+    contacts, and a second traversal into the cached buffers is identical."""
+    n = 10_000_000
+    r0 = 0.5 * (3 * 8 / (4 * np.pi * n)) ** (1 / 3)
+    vols = ibvh.generate_spheres(n, 42, r0=r0)
+    g = ibvh.BVH(vols)
+    leaves = g.leaves.to_numpy()
+    m = leaves["morton"].astype(np.int64)
+    assert (np.diff(m) >= 0).all()
+    idx = leaves["index"].astype(np.int64)
+    seen = np.zeros(n + 1, np.uint8)
+    seen[idx] = 1
+    assert seen[1:].all() and len(idx) == n                      # a permutation of 1..n
+    ties = m[1:] == m[:-1]
+    assert (idx[1:][ties] > idx[:-1][ties]).all()                # stable
+    host = vols.cpu().numpy()
+    assert leaves["volume"].tobytes() == host[idx - 1].tobytes()  # records follow their index
+    # nodes: level l node i == merge(children); checked exactly on random samples of every level
+    tree = orc.tree_shape(n)
+    nodes = g.nodes.cpu().numpy()                                # (real_nodes - real_leaves, 6) float32 boxes
+    rng = np.random.default_rng(3)
+    lv = leaves["volume"]
+    leaf_lo = lv["x"] - lv["r"][:, None]
+    leaf_up = lv["x"] + lv["r"][:, None]
+    for level in range(tree.levels - 1, 0, -1):
+        first = orc.memory_index(tree, 2 ** (level - 1)) - 1
+        nreal = 2 ** (level - 1) - (tree.virtual_leaves >> (tree.levels - level))
+        pick = np.unique(rng.integers(0, nreal, size=min(nreal, 2000)))
+        if level == tree.levels - 1:
+            l, r = 2 * pick, np.minimum(2 * pick + 1, n - 1)
+            lo = np.minimum(leaf_lo[l], leaf_lo[r])
+            up = np.maximum(leaf_up[l], leaf_up[r])
+        else:
+            cfirst = orc.memory_index(tree, 2 ** level) - 1
+            creal = 2 ** level - (tree.virtual_leaves >> (tree.levels - level - 1))
+            l, r = cfirst + 2 * pick, cfirst + np.minimum(2 * pick + 1, creal - 1)
+            lo = np.minimum(nodes[l, :3], nodes[r, :3])
+            up = np.maximum(nodes[l, 3:], nodes[r, 3:])
+        assert np.array_equal(nodes[first + pick, :3], lo) and np.array_equal(nodes[first + pick, 3:], up), level
+    t = ibvh.traverse(g)
+    c = contacts_np(t)
+    assert len(c) > n and (c[:, 0] < c[:, 1]).all()
+    key = c[:, 0] * (n + 1) + c[:, 1]
+    assert len(np.unique(key)) == len(key)                       # nothing reported twice
+    a, b = host[c[:, 0] - 1], host[c[:, 1] - 1]
+    dx = a[:, :3] - b[:, :3]
+    d2 = (dx[:, 0] * dx[:, 0] + dx[:, 1] * dx[:, 1]) + dx[:, 2] * dx[:, 2]
+    rr = a[:, 3] + b[:, 3]
+    assert (d2 <= rr * rr).all()                                 # the reference's float32 predicate, exactly
+    counts = t.cache2.cpu().numpy().astype(np.int64)[:n]         # inclusive prefix of the per-leaf counts
+    assert counts[-1] == len(c) and (np.diff(counts) >= 0).all()
+    again = ibvh.traverse(g, cache=t)
+    assert again.num_contacts == len(c) and (contacts_np(again) == c).all()
+    bfs = ibvh.traverse(g, ibvh.BFSTraversal())
+    cb = contacts_np(bfs)
+    assert len(cb) == len(c)
+    assert np.array_equal(np.sort(cb[:, 0] * (n + 1) + cb[:, 1]), np.sort(key))
+
