@@ -47,8 +47,7 @@ def algorithmic_bytes(kernel, n, contacts):
         "scatter_kernel": 8.0 + 8.0,               # read + write (key, position)
         "gather_kernel": 4.0 + 4.0 + 16.0 + 24.0,  # perm + key + volume -> record
         "aggregate_kernel": 16.0 + 24.0 + 24.0,    # leaves' volumes + every node read once + written once
-        "lvt_kernel_count": 24.0 + 24.0 + 4.0,     # leaves + nodes once + counts
-        "lvt_kernel_write": 24.0 + 24.0 + 4.0 + 8.0 * c,  # + prefix read, contacts written
+        "lvt_rays_kernel_count": 0.0, "lvt_rays_kernel_write": 0.0,  # (rays are not part of the bench step)
         "lvt_joint_kernel_count": 24.0 + 24.0 + 4.0 + 8.0 * c,  # leaves + nodes once, counts, contact cache written
         "lvt_queue_kernel_count": 24.0 + 24.0 + 4.0 + 8.0 * c,
         "lvt_joint_kernel_write": 8.0 + 16.0 * c,               # prefix read (2 x 4) + cached contacts read and written
@@ -63,7 +62,7 @@ def kernel_key(name):
     base = name.strip("() ").split("<")[0].split("::")[-1].strip()
     if base == "scatter_kernel" and "true>" in name.replace(" ", ""):
         return "scatter_records_kernel"
-    if base in ("lvt_kernel", "lvt_rays_kernel", "lvt_joint_kernel", "lvt_queue_kernel"):
+    if base in ("lvt_rays_kernel", "lvt_joint_kernel", "lvt_queue_kernel"):
         flat = name.replace(" ", "")
         return base + ("_write" if ("MODE,true" in flat or "I,true>" in flat) else "_count")
     return base

@@ -100,9 +100,6 @@ IBVH_D bool narrow_eval(int narrow, uint64_t ma, int64_t ia, uint64_t mb, int64_
 // waves with an item of more than K contacts walk again.  Kernels (2) and (3) pool the slots of a wave's 64 items
 // and fill them densely (see the kernels): their writing pass walks again only if the whole wave overflowed.
 // ------------------------------------------------------------------------------------------
-template <class T> struct Boxed { // lets the lane-movement helpers carry a scalar
-    T v;
-};
 template <class I> struct PairCache {
     IndexPair<I> *slots; // K * n_items pairs, slot-major; nullptr when K == 0
     int32_t K;
