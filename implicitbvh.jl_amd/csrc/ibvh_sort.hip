@@ -48,18 +48,32 @@ template <int TPB> IBVH_D uint32_t block_exclusive_scan(uint32_t v, uint32_t *wa
 template <class K, int TPB, int IPT>
 __global__ __launch_bounds__(TPB) void hist_kernel(const K *__restrict__ keys, int64_t n, int shift, uint32_t mask,
                                                    uint32_t *__restrict__ tile_hist, int num_tiles) {
-    __shared__ uint32_t h[RADIX];
-    for (int i = threadIdx.x; i < RADIX; i += TPB) h[i] = 0;
+    // one private copy of the histogram per wave: the LDS atomics of different waves never collide
+    constexpr int W = TPB / 64;
+    __shared__ uint32_t h[W][RADIX];
+    for (int i = threadIdx.x; i < W * RADIX; i += TPB) (&h[0][0])[i] = 0;
     __syncthreads();
     const int tile = blockIdx.x;
     const int64_t base = (int64_t)tile * (TPB * IPT);
+    uint32_t *mine = h[threadIdx.x >> 6];
+    K key[IPT];
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) { // all loads first, then the atomics
+        const int64_t i = base + j * TPB + threadIdx.x;
+        key[j] = i < n ? keys[i] : (K)0;
+    }
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
-        int64_t i = base + j * TPB + threadIdx.x;
-        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & mask], 1u);
+        const int64_t i = base + j * TPB + threadIdx.x;
+        if (i < n) atomicAdd(&mine[(uint32_t)(key[j] >> shift) & mask], 1u);
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < RADIX; d += TPB) tile_hist[(int64_t)d * num_tiles + tile] = h[d];
+    for (int d = threadIdx.x; d < RADIX; d += TPB) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) s += h[w][d];
+        tile_hist[(int64_t)d * num_tiles + tile] = s;
+    }
 }
 
 // ---- scan ---------------------------------------------------------------------------------
