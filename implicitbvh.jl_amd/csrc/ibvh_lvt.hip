@@ -835,7 +835,7 @@ IBVH_D void ray_dfs(const Args<L, N, I> &a, const T (&p)[3], const T (&d)[3], bo
 template <class L, class N, class I, bool WRITE>
 __global__ __launch_bounds__(256) void lvt_rays_kernel(Args<L, N, I> a, PairCache<I> cache) {
     using T = typename L::elt;
-    const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // (launched with one wave per workgroup, see launch())
     const bool valid = item < a.n_items;
     T p[3] = {0, 0, 0}, d[3] = {0, 0, 0};
     if (valid) {
@@ -1044,8 +1044,10 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
         // frontiers that fit it halves the time of SMALL batches (1e5 rays: 1.1 -> 0.67 ms, the heaviest ray no longer
         // walks on one lane), but rays grazing the surface outgrow any LDS slice that still allows a decent occupancy
         // and at 1e6 rays it was 2x slower than this walk, so it was dropped.)
-        if (write) IBVH_LAUNCH((lvt_rays_kernel<L, N, I, true>), dim3(blocks), dim3(256), 0, st, a, cache);
-        else IBVH_LAUNCH((lvt_rays_kernel<L, N, I, false>), dim3(blocks), dim3(256), 0, st, a, cache);
+        // one wave per workgroup: a wave's time is its heaviest ray, and a finished wave should hand its slot back at once
+        const unsigned rblocks = (unsigned)ceil_div(a.n_items, 64);
+        if (write) IBVH_LAUNCH((lvt_rays_kernel<L, N, I, true>), dim3(rblocks), dim3(64), 0, st, a, cache);
+        else IBVH_LAUNCH((lvt_rays_kernel<L, N, I, false>), dim3(rblocks), dim3(64), 0, st, a, cache);
     } else {
         // BBox nodes with at least one node level below the start level: frontier descent + brute force;
         // everything else (BSphere nodes, start_level == levels): the exact joint walk
