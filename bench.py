@@ -258,7 +258,7 @@ def main():
         lib.call("ibvh_profile_enable", 0)
         phase = MORTON_SORT_KERNELS
         ms_phase = sum(prof2[k][0] for k in phase if k in prof2) / 3
-        ms_build = sum(v[0] for k, v in prof2.items() if not k.startswith(("lvt_", "scan_reduce", "scan_partials", "scan_apply"))) / 3
+        ms_build = sum(v[0] for k, v in prof2.items() if not k.startswith(("lvt_", "scan_reduce", "scan_apply"))) / 3
         gb = 152.0 * n2 / (ms_phase * 1e-3) / 1e9
         north_star = {"leaves": n2, "value": round(n2 * reps / el2 / 1e6, 3), "unit": "Mleaves/s",
                       "ms_per_step": round(el2 / reps * 1e3, 4), "contacts": st2[1].num_contacts,

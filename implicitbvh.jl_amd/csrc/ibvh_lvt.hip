@@ -929,36 +929,14 @@ template <class I> __global__ __launch_bounds__(SCAN_TPB) void scan_reduce_kerne
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 // one workgroup: exclusive scan of the tile sums in place; total -> totals[0]
-__global__ __launch_bounds__(SCAN_TPB) void scan_partials_kernel(int64_t *partials, int64_t nparts, int64_t *totals) {
-    __shared__ int64_t s_w[SCAN_TPB / 64];
-    int64_t carry = 0;
-    for (int64_t base = 0; base < nparts; base += SCAN_TPB) {
-        int64_t i = base + threadIdx.x;
-        int64_t v = i < nparts ? partials[i] : 0, inc = v;
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            int64_t t = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += t;
-        }
-        if (lane == 63) s_w[w] = inc;
-        __syncthreads();
-        int64_t wb = 0, tot = 0;
-#pragma unroll
-        for (int k = 0; k < SCAN_TPB / 64; ++k) {
-            int64_t t = s_w[k];
-            if (k < w) wb += t;
-            tot += t;
-        }
-        __syncthreads();
-        if (i < nparts) partials[i] = carry + wb + inc - v;
-        carry += tot;
-    }
-    if (threadIdx.x == 0) totals[0] = carry;
-}
+// Every workgroup derives its own tile offset from the raw tile sums (a redundant reduction of <= a few thousand
+// values) instead of waiting for a single-workgroup scan launch in between; the last tile also publishes the total.
 template <class I>
-__global__ __launch_bounds__(SCAN_TPB) void scan_apply_kernel(I *c, int64_t n, const int64_t *partials) {
-    __shared__ int64_t s_w[SCAN_TPB / 64];
+__global__ __launch_bounds__(SCAN_TPB) void scan_apply_kernel(I *c, int64_t n, const int64_t *partials, int64_t *totals) {
+    __shared__ int64_t s_w[SCAN_TPB / 64], s_p[SCAN_TPB / 64];
+    int64_t before = 0;
+    for (int64_t j = threadIdx.x; j < (int64_t)blockIdx.x; j += SCAN_TPB) before += partials[j];
+    const int64_t tile_offset = block_sum(before, s_p);
     // thread owns SCAN_IPT consecutive items so the in-thread running sum is in memory order
     int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_IPT;
     int64_t v[SCAN_IPT], sum = 0;
@@ -981,13 +959,14 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_apply_kernel(I *c, int64_t n, c
 #pragma unroll
     for (int k = 0; k < SCAN_TPB / 64; ++k)
         if (k < w) wb += s_w[k];
-    int64_t run = partials[blockIdx.x] + wb + inc - sum;
+    int64_t run = tile_offset + wb + inc - sum;
 #pragma unroll
     for (int j = 0; j < SCAN_IPT; ++j) {
         int64_t i = base + j;
         run += v[j];
         if (i < n) c[i] = (I)run;
     }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_TPB - 1) totals[0] = run; // inclusive value of the last item
 }
 
 // scratch layout of the *_count / *_write calls:
@@ -1011,8 +990,7 @@ template <class I> int scan_counts(I *counts, int64_t n, int64_t *total_out, voi
     int64_t *totals = (int64_t *)scratch;
     int64_t *partials = totals + 8;
     IBVH_LAUNCH((scan_reduce_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, partials);
-    IBVH_LAUNCH(scan_partials_kernel, dim3(1), dim3(SCAN_TPB), 0, st, partials, nparts, totals);
-    IBVH_LAUNCH((scan_apply_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, partials);
+    IBVH_LAUNCH((scan_apply_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, partials, totals);
     IBVH_LAUNCH_CHECK();
     if (!total_out) return IBVH_OK; // *_enqueue: the total stays in the scratch header, nobody waits
     int64_t total = 0;
