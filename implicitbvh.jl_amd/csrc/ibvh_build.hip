@@ -99,11 +99,27 @@ __global__ __launch_bounds__(EXT_TPB) void extrema_partial_kernel(const char *__
     }
 }
 
+// compute_skips! on device memory (build.jl:232-239), folded into whichever single-workgroup kernel the build launches
+// first (one launch less than a kernel of its own)
+struct SkipsOut {
+    TreeDev tree;
+    void *skips; // nullptr: nothing to write
+    int index_bytes;
+};
+IBVH_D void write_skips(const SkipsOut &so) {
+    const int64_t level = (int64_t)threadIdx.x + 1;
+    if (so.skips == nullptr || level > so.tree.levels) return;
+    const int64_t v = level_skips(so.tree.levels, so.tree.virtual_leaves, level);
+    if (so.index_bytes == 4) ((int32_t *)so.skips)[level - 1] = (int32_t)v;
+    else ((int64_t *)so.skips)[level - 1] = v;
+}
+
 // One workgroup folds the partials and applies the epsilon expansion of
 // bounding_volumes_extrema (utils.jl:63-69): x -/+ rp*abs(x) -/+ floatmin, two roundings a side.
 template <class T>
 __global__ __launch_bounds__(EXT_TPB) void extrema_final_kernel(const T *__restrict__ partials, int nparts, int expand,
-                                                                T *__restrict__ out, T *__restrict__ out2) {
+                                                                T *__restrict__ out, T *__restrict__ out2, SkipsOut so) {
+    write_skips(so);
     T mn[3] = {float_max<T>(), float_max<T>(), float_max<T>()};
     T mx[3] = {float_min_normal<T>(), float_min_normal<T>(), float_min_normal<T>()};
     for (int i = threadIdx.x; i < nparts; i += EXT_TPB) {
@@ -141,7 +157,8 @@ __global__ __launch_bounds__(EXT_TPB) void extrema_final_kernel(const T *__restr
     }
 }
 
-template <class T> __global__ void extrema_set_kernel(T *out, T *out2, double a0, double a1, double a2, double b0, double b1, double b2) {
+template <class T> __global__ void extrema_set_kernel(T *out, T *out2, double a0, double a1, double a2, double b0, double b1, double b2, SkipsOut so) {
+    write_skips(so);
     if (threadIdx.x == 0) {
         out[0] = T(a0);
         out[1] = T(a1);
@@ -404,11 +421,11 @@ inline Scratch carve(char *base, int64_t n, int key_bytes, int64_t leaf_bytes, b
 
 template <class V>
 int extrema(const char *recs, int64_t stride, int64_t n, int expand, typename V::elt *out, char *partials, hipStream_t st,
-            typename V::elt *out2 = nullptr) {
+            typename V::elt *out2 = nullptr, SkipsOut so = SkipsOut{TreeDev{0, 0, 0}, nullptr, 4}) {
     using T = typename V::elt;
     int blocks = grid_for(n, EXT_TPB * 4, EXT_MAX_BLOCKS);
     IBVH_LAUNCH((extrema_partial_kernel<V>), dim3(blocks), dim3(EXT_TPB), 0, st, recs, stride, n, (T *)partials);
-    IBVH_LAUNCH((extrema_final_kernel<T>), dim3(1), dim3(EXT_TPB), 0, st, (const T *)partials, blocks, expand, out, out2);
+    IBVH_LAUNCH((extrema_final_kernel<T>), dim3(1), dim3(EXT_TPB), 0, st, (const T *)partials, blocks, expand, out, out2, so);
     IBVH_LAUNCH_CHECK();
     return IBVH_OK;
 }
@@ -523,14 +540,13 @@ ibvh_status ibvh_build(const ibvh_build_desc *desc, const void *volumes, void *l
         T *ext = (T *)sc.extrema;
         // skips
         TreeDev td{tree.levels, tree.real_leaves, tree.virtual_leaves};
-        if (ty.index_type == IBVH_I32) IBVH_LAUNCH((skips_kernel<int32_t>), dim3(1), dim3(64), 0, st, td, (int32_t *)skips);
-        else IBVH_LAUNCH((skips_kernel<int64_t>), dim3(1), dim3(64), 0, st, td, (int64_t *)skips);
+        const SkipsOut so{td, skips, ty.index_type == IBVH_I32 ? 4 : 8};
         // extrema (or caller-fixed bounds: morton/default.jl:52-57)
         if (desc->compute_extrema) {
-            if (int e = extrema<L>(src, src_stride, n, 1, ext, sc.partials, st, (T *)extrema_out)) return e;
+            if (int e = extrema<L>(src, src_stride, n, 1, ext, sc.partials, st, (T *)extrema_out, so)) return e;
         } else {
             IBVH_LAUNCH((extrema_set_kernel<T>), dim3(1), dim3(64), 0, st, ext, (T *)extrema_out, desc->mins[0], desc->mins[1],
-                               desc->mins[2], desc->maxs[0], desc->maxs[1], desc->maxs[2]);
+                               desc->mins[2], desc->maxs[0], desc->maxs[1], desc->maxs[2], so);
         }
         // keys, fused with the first per-tile digit histogram of the sort
         const int key_bits = morton_key_bits(ty.morton_type);
