@@ -312,18 +312,6 @@ __global__ __launch_bounds__(TPB) void hist_wide_kernel(const K *__restrict__ ke
     for (int d = threadIdx.x; d < radix; d += TPB) tile_hist[(int64_t)d * num_tiles + blockIdx.x] = hw[d];
 }
 
-// exclusive scan of the digit totals -> bucket_start[0 .. radix] (one workgroup)
-__global__ __launch_bounds__(256) void bucket_start_kernel(const uint32_t *__restrict__ digit_total, int radix,
-                                                           uint32_t *__restrict__ bucket_start) {
-    __shared__ uint32_t a[1 << MSD_MAX_BITS];
-    __shared__ uint32_t wt[4];
-    for (int i = threadIdx.x; i < radix; i += 256) a[i] = digit_total[i];
-    __syncthreads();
-    const uint32_t total = lds_exclusive_scan<256>(a, radix, wt);
-    for (int i = threadIdx.x; i < radix; i += 256) bucket_start[i] = a[i];
-    if (threadIdx.x == 0) bucket_start[radix] = total;
-}
-
 // stable partition of (key, position) by the digit (key >> shift) of `bits` <= 11 bits; positions are implicit
 template <class K, int TPB, int IPT>
 __global__ __launch_bounds__(TPB) void scatter_wide_kernel(const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
@@ -425,7 +413,7 @@ IBVH_D void write_record(const RecordArgs &rec, uint32_t p, uint64_t dest, uint6
 template <class K, int TPB, int IPT, bool RECORDS>
 __global__ __launch_bounds__(TPB) void bucket_sort_kernel(K *__restrict__ kalt, uint32_t *__restrict__ valt,
                                                           K *__restrict__ kpri, uint32_t *__restrict__ vpri,
-                                                          const uint32_t *__restrict__ bucket_start, int low_bits,
+                                                          const uint32_t *__restrict__ bucket_start /* digit totals */, int low_bits,
                                                           RecordArgs rec) {
     constexpr int W = TPB / 64;
     constexpr int CAP = TPB * IPT;
@@ -437,9 +425,15 @@ __global__ __launch_bounds__(TPB) void bucket_sort_kernel(K *__restrict__ kalt, 
     uint32_t *gbase = local_base + R;                     // R
     uint32_t *wave_tot = gbase + R;                       // 16
     uint16_t *whist = (uint16_t *)(wave_tot + 16);        // W * R
-    const int64_t start = bucket_start[blockIdx.x];
-    const int64_t m = (int64_t)bucket_start[blockIdx.x + 1] - start;
+    // the bucket's range: every workgroup sums the digit totals in front of its own digit (<= 2047 values) instead of
+    // waiting for a one-workgroup prefix-sum launch
+    const int64_t m = (int64_t)bucket_start[blockIdx.x]; // (digit totals, not yet scanned)
     if (m == 0) return;
+    uint32_t before = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += TPB) before += bucket_start[i];
+    uint32_t start32 = 0;
+    block_exclusive_scan<TPB>(before, wave_tot, &start32);
+    const int64_t start = (int64_t)start32;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint16_t *my_hist = whist + w * R;
     const int passes = (low_bits + 7) / 8;
@@ -734,7 +728,6 @@ int run_msd(K *keys, uint32_t *vals, K *keys_alt, uint32_t *vals_alt, int64_t n,
     const int shift = key_bits - msd_bits;
     uint32_t *tile_hist = (uint32_t *)scratch;
     uint32_t *digit_total = (uint32_t *)((char *)scratch + align_up((int64_t)radix * num_tiles * 4, 256));
-    uint32_t *bucket_start = digit_total + radix + 8;
     const size_t ssm = scatter_wide_smem<K, TPB, IPT>(msd_bits);
     constexpr size_t bsm = bucket_smem<K, BT, BI>();
     static bool attr_set = false;
@@ -751,16 +744,15 @@ int run_msd(K *keys, uint32_t *vals, K *keys_alt, uint32_t *vals_alt, int64_t n,
         IBVH_LAUNCH((hist_wide_kernel<K, TPB, IPT>), dim3(num_tiles), dim3(TPB), (size_t)radix * 4, st, keys, n, shift, msd_bits,
                     tile_hist, num_tiles);
     IBVH_LAUNCH((scan_kernel<256>), dim3(radix), dim3(256), 0, st, tile_hist, num_tiles, digit_total);
-    IBVH_LAUNCH(bucket_start_kernel, dim3(1), dim3(256), 0, st, digit_total, radix, bucket_start);
     IBVH_LAUNCH((scatter_wide_kernel<K, TPB, IPT>), dim3(num_tiles), dim3(TPB), ssm, st, keys,
                 vals_implicit ? (const uint32_t *)nullptr : vals, keys_alt, vals_alt, n, shift, msd_bits, tile_hist, digit_total,
                 num_tiles);
     if (records)
         IBVH_LAUNCH((bucket_sort_kernel<K, BT, BI, true>), dim3(radix), dim3(BT), bsm, st, keys_alt, vals_alt, keys, vals,
-                    bucket_start, shift, *records);
+                    digit_total, shift, *records);
     else
         IBVH_LAUNCH((bucket_sort_kernel<K, BT, BI, false>), dim3(radix), dim3(BT), bsm, st, keys_alt, vals_alt, keys, vals,
-                    bucket_start, shift, RecordArgs{});
+                    digit_total, shift, RecordArgs{});
     IBVH_LAUNCH_CHECK();
     *result_in_alt = 0; // sorted pairs (when no records are requested) end in the primary buffers
     return IBVH_OK;
