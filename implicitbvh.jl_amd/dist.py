@@ -112,6 +112,8 @@ class HipEngine:
         torch = self.torch
         kd = torch.int64 if types.morton_type == abi.U64 else torch.int32
         keys = torch.empty(vols.shape[0], dtype=kd, device=self.device)
+        if vols.shape[0] == 0:  # a rank without leaves still takes part in every collective
+            return keys
         lib.call("ibvh_morton_keys", C.byref(types), api._ptr(vols), 0, vols.shape[0], api._ptr(ext), api._ptr(keys),
                  api._stream())
         return keys
@@ -120,6 +122,9 @@ class HipEngine:
         torch = self.torch
         rows = max(len(prefixes), 1)
         out = torch.empty((rows, 1 << bits), dtype=torch.int32, device=self.device)
+        if keys.numel() == 0:
+            out.zero_()
+            return out if raw else out.to(torch.int64)
         arr = (C.c_uint64 * max(len(prefixes), 1))(*[int(p) for p in prefixes]) if prefixes else None
         lib.call("ibvh_key_histogram", keys.element_size(), api._ptr(keys), keys.numel(), shift, bits, prefix_shift, arr,
                  len(prefixes), api._ptr(out), api._stream())
@@ -132,6 +137,8 @@ class HipEngine:
         n = keys.numel()
         if nranks == 1:
             return None, [n]
+        if n == 0:
+            return torch.empty(0, dtype=torch.int32, device=self.device), [0] * nranks
         if known_counts is not None and nranks <= 256:
             # fused path: destination kernel + one stable radix pass inside the library (ibvh_dist_partition)
             perm = torch.empty(n, dtype=torch.int32, device=self.device)
@@ -163,6 +170,8 @@ class HipEngine:
         lay = abi.Layout()
         lib.call("ibvh_layout_of", C.byref(types), C.byref(lay))
         out = torch.empty(vols.shape[0] * lay.leaf_bytes, dtype=torch.uint8, device=self.device)
+        if vols.shape[0] == 0:
+            return out, lay.leaf_bytes
         lib.call("ibvh_pack_records", C.byref(types), api._ptr(vols), api._ptr(keys), api._ptr(perm), int(index_base),
                  vols.shape[0], api._ptr(out), api._stream())
         return out, lay.leaf_bytes

@@ -613,6 +613,43 @@ def test_distributed_build_virtual_ranks_gpu(world):
     assert max(sizes) - min(sizes) <= max(8, n // (50 * world))
 
 
+@pytest.mark.parametrize("world,tolerance", [(3, 0.0), (4, 0.005)])
+def test_distributed_build_clustered_duplicates_and_ragged_shards_gpu(world, tolerance):
+    """The distributed build on input that defeats the one-level splitter search — clustered centres, many exact
+    duplicates (equal keys straddle rank boundaries), ragged shard sizes including an EMPTY rank — with exact splitters
+    (tolerance 0: refinement to full key resolution, count exchange, the tensor-op partition path) and the default:
+    the concatenated slices must still be the single-device sorted array, bit for bit."""
+    from implicitbvh_amd import dist as ibd
+    rng = np.random.default_rng(9)
+    n = 60000
+    base = (rng.random((300, 3)) * 4).astype(np.float32)
+    c = base[rng.integers(0, 300, n)] + (0.01 * rng.standard_normal((n, 3))).astype(np.float32)
+    c[rng.random(n) < 0.3] = base[7]                     # 30 % exact duplicates of one point
+    host = np.concatenate([c, (0.02 + 0.05 * rng.random((n, 1))).astype(np.float32)], axis=1)
+    single = orc.build(host, abi.make_types())
+    cuts = sorted(rng.integers(0, n, world - 1).tolist())
+    bounds = [0] + cuts + [n]
+    bounds[1] = bounds[0]                                # rank 0 holds nothing
+    dev = cuda(host)
+
+    def fn(comm):
+        vols = dev[bounds[comm.rank]:bounds[comm.rank + 1]].contiguous()
+        builder = ibd.DistributedBuilder(comm, tolerance=tolerance)
+        bvh = builder.build(vols)
+        torch.cuda.synchronize()
+        leaves = bvh.leaves.to_numpy()
+        leaves["index"] = leaves["index"]                # (global numbering follows the concatenated shards)
+        return leaves, builder.last
+    out = ibd.run_virtual_ranks(world, fn)
+    cat = np.concatenate([o[0] for o in out])
+    for field in ("morton", "index"):
+        assert cat[field].tolist() == single.leaves[field].tolist(), field
+    assert cat["volume"].tobytes() == single.leaves["volume"].tobytes()
+    if tolerance == 0.0:
+        sizes = [len(o[0]) for o in out]
+        assert max(sizes) - min(sizes) <= 1              # exact splitters: perfectly balanced
+
+
 @pytest.mark.parametrize("world", [2, 5])
 def test_cross_shard_completion_gives_the_global_contact_set(world):
     """per-slice self contacts + cross-slice pair contacts == contacts of the whole cloud."""
