@@ -83,19 +83,22 @@ def one_case(rng, log):
     types = abi.make_types(*combo, it, mt)
     n = int(rng.choice([1, 2, 3, 7, 64, 65, 127, 129, 500, 2047, 2049, 5000, 20000, 60000]))
     vols = cloud(rng, n, combo[0], combo[1])
-    built = 1
+    levels0 = orc.tree_shape(n).levels
+    built = 1 if rng.random() < 0.6 else int(rng.integers(1, levels0 + 1))  # partial builds: nodes above `built` do not exist
     o, g = build(vols, types, built)
     levels = o.tree.levels
-    log.append(f"combo={combo} it={it} mt={mt} n={n} levels={levels}")
+    log.append(f"combo={combo} it={it} mt={mt} n={n} levels={levels} built={built}")
     gl = g.leaves.to_numpy()
     for field in ("morton", "index"):  # (field-wise: UInt16 codes leave two padding bytes in the record)
         assert gl[field].tolist() == o.leaves[field].tolist(), field
     assert gl["volume"].tobytes() == o.leaves["volume"].tobytes(), "leaf volumes"
     if len(o.nodes):
-        assert g.nodes.cpu().numpy().tobytes() == o.nodes.tobytes(), "nodes"
+        lo = orc.memory_index(o.tree, 2 ** (min(built, levels - 1) - 1)) - 1 if levels > 1 else 0  # first built node
+        gn = g.nodes.cpu().numpy()
+        assert gn[lo:].tobytes() == o.nodes.view(gn.dtype).reshape(gn.shape)[lo:].tobytes(), "nodes"
     # LVT self, a few start levels, narrow menu, cache chain
     cache = None
-    for sl in sorted({1, max(1, levels // 2), max(1, levels - 1), levels} & set(range(1, levels + 1))):
+    for sl in sorted({built, max(built, levels // 2), max(built, levels - 1), levels} & set(range(built, levels + 1))):
         nar = int(rng.choice([abi.NARROW_NONE, abi.NARROW_NONE, abi.NARROW_MORTON_LT, abi.NARROW_INDEX_LT]))
         exp = orc.traverse_lvt(o, sl, narrow=nar)
         if len(exp[0]) > 6_000_000:
@@ -107,7 +110,7 @@ def one_case(rng, log):
         cache = t
     # BFS self
     if n <= 20000:
-        sl = int(rng.integers(1, levels + 1))
+        sl = int(rng.integers(built, levels + 1))
         eb, res = orc.traverse_bfs(o, sl)
         if len(eb) < 3_000_000:
             b = ibvh.traverse(g, ibvh.BFSTraversal(), start_level=sl)
@@ -118,7 +121,8 @@ def one_case(rng, log):
     other = cloud(rng, n2, combo[0], combo[1])
     o2, g2 = build(other, types)
     for (oa, ga, ob, gb) in ((o, g, o2, g2), (o2, g2, o, g)):
-        sl1, sl2 = int(rng.integers(1, oa.tree.levels + 1)), int(rng.integers(1, ob.tree.levels + 1))
+        sl1 = int(rng.integers(oa.built_level, oa.tree.levels + 1))
+        sl2 = int(rng.integers(ob.built_level, ob.tree.levels + 1))
         nar = int(rng.choice([abi.NARROW_NONE, abi.NARROW_INDEX_LT]))
         exp = orc.traverse_pair_lvt(oa, ob, sl1, sl2, narrow=nar)[0]
         if len(exp) > 6_000_000:
@@ -136,7 +140,7 @@ def one_case(rng, log):
         p = (lo + (hi - lo) * rng.random((nr, 3))).astype(f)
         d = rng.standard_normal((nr, 3)).astype(f)
         d[rng.random(nr) < 0.1, rng.integers(0, 3)] = 0
-        sl = int(rng.integers(1, levels + 1))
+        sl = int(rng.integers(built, levels + 1))
         exp = orc.traverse_rays_lvt(o, p, d, sl)[0]
         if len(exp) < 6_000_000:
             t = ibvh.traverse_rays(g, cuda(p).t(), cuda(d).t(), start_level=sl, cache=cache if rng.random() < 0.5 else None)
