@@ -305,6 +305,31 @@ def test_lvt_queue_kernel_medium_clouds_all_box_combinations(combo):
             oracle_pairs(orc.traverse_pair_lvt(o2, o1, narrow=abi.NARROW_INDEX_LT)[0])).all()
 
 
+@pytest.mark.parametrize("flt", [abi.F32, abi.F64], ids=["f32", "f64"])
+def test_extreme_value_inputs_bit_exact(flt):
+    """Inputs at the edges of the float range: denormal-sized and 1e30-sized scenes (squares overflow to inf), zero and
+    negative radii, all leaves identical, a large offset, all-negative coordinates (the floatmin max-init quirk).  Codes,
+    order, extrema, every node and the contact list must still equal the oracle's, bit for bit."""
+    f = NP_F[flt]
+    rng = np.random.default_rng(5)
+    types = abi.make_types(abi.BSPHERE, flt, abi.BBOX, flt)
+    n = 3000
+    base = np.concatenate([rng.random((n, 3)), 0.02 + 0.03 * rng.random((n, 1))], axis=1)
+    tiny, huge = (1e-38, 1e30) if flt == abi.F32 else (1e-300, 1e250)
+    zero_r, neg_r, offset, negative = base.copy(), base.copy(), base.copy(), base.copy()
+    zero_r[:, 3] = 0
+    neg_r[::3, 3] *= -1
+    offset[:, :3] += 1e6
+    negative[:, :3] -= 5
+    for name, vols in (("denormal", base * tiny), ("huge", base * huge), ("zero radius", zero_r), ("negative radii", neg_r),
+                       ("identical", np.tile(base[:1], (500, 1))), ("offset", offset), ("negative", negative)):
+        o, g = build_both(vols.astype(f), types)
+        assert_bvh_equal(o, g)
+        exp = oracle_pairs(orc.traverse_lvt(o)[0])
+        assert (contacts_np(ibvh.traverse(g)) == exp).all(), name
+        assert sorted(map(tuple, contacts_np(ibvh.traverse(g, ibvh.BFSTraversal())).tolist())) == sorted(map(tuple, exp.tolist())), name
+
+
 def test_readme_examples_on_gpu():
     e = G["readme_example"]
     for dt in (np.float32, np.float64):
