@@ -327,7 +327,12 @@ def test_extreme_value_inputs_bit_exact(flt):
         assert_bvh_equal(o, g)
         exp = oracle_pairs(orc.traverse_lvt(o)[0])
         assert (contacts_np(ibvh.traverse(g)) == exp).all(), name
-        assert sorted(map(tuple, contacts_np(ibvh.traverse(g, ibvh.BFSTraversal())).tolist())) == sorted(map(tuple, exp.tolist())), name
+        # (BFS against the oracle's BFS, not against LVT: where squares underflow to zero the leaf test passes for any
+        # pair that is reached, and the two traversals prune differently on the way down)
+        eb, res = orc.traverse_bfs(o)
+        bfs = ibvh.traverse(g, ibvh.BFSTraversal())
+        assert sorted(map(tuple, contacts_np(bfs).tolist())) == sorted(map(tuple, oracle_pairs(eb).tolist())), name
+        assert bfs.num_checks == res.num_checks, name
 
 
 def test_readme_examples_on_gpu():
