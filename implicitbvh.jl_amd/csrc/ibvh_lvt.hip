@@ -92,8 +92,8 @@ IBVH_D bool narrow_eval(int narrow, uint64_t ma, int64_t ia, uint64_t mb, int64_
 //       c. the queue is drained 64 candidates at a time with every lane busy: a lane gathers the two
 //          leaves of its candidate parent, runs the exact leaf tests and ranks its hits among the lanes
 //          that hold the same query.
-//     BSphere nodes (rounded merges, not nested), start_level == levels and trees deeper than 28 levels
-//     take kernel (1).
+//     BSphere nodes (rounded merges, not nested), start_level == levels and trees deeper than 31 levels
+//     take kernel (1); trees of 29 .. 31 levels use 64-bit queue entries (WIDE).
 //
 // Contact cache (K * n_items pairs of scratch).  Kernel (1) stores the first K contacts of every work item
 // slot-major (slot k of item i at [k * n_items + i]); its writing pass copies them to their final offsets and only
@@ -374,13 +374,15 @@ IBVH_D uint64_t test_and_append_f32(uint64_t init, float slo0, float slo1, float
 
 constexpr int QUEUE_CAP = 512; // candidate pairs per wave (LDS); drained whenever fewer than 64 slots are free
 
-template <class L, class N, class I, int MODE, bool WRITE, bool NARROW>
+// WIDE: 64-bit queue entries for trees of 29 .. 31 levels (leaf-parent indices beyond 2^26), see launch().
+template <class L, class N, class I, int MODE, bool WRITE, bool NARROW, bool WIDE>
 __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, PairCache<I> cache, int cut_level) {
     using TN = typename N::elt;
     using Q = Query<L, N, I, MODE, WRITE, NARROW>;
     using Cnt = typename Q::Cnt;
     __shared__ uint32_t s_frontier[4][2][FRONTIER_CAP];
-    __shared__ uint32_t s_queue[4][QUEUE_CAP];
+    using QE = typename std::conditional<WIDE, uint64_t, uint32_t>::type; // queue entry: query lane | leaf-parent index << 6
+    __shared__ QE s_queue[4][QUEUE_CAP];
     __shared__ Cnt s_cnt[4][64];
     Q q(a, cache);
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // (uniform: LDS bases stay scalar)
@@ -419,8 +421,8 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
         q.lane_on = q.valid; // every item of the wave walks again
     }
 
-    // Everything wave-uniform below is 32-bit on purpose (levels <= 28, so node indices and leaf positions are
-    // < 2^28): the scalar unit has no ordered 64-bit compare, a 64-bit uniform compare is done by the VALU, its
+    // Everything wave-uniform below is 32-bit on purpose (levels <= 31, so node indices and leaf positions stay
+    // below 2^31): the scalar unit has no ordered 64-bit compare, a 64-bit uniform compare is done by the VALU, its
     // result counts as divergent and turns every loop that depends on it into an exec-masked one.
     const int levels = (int)a.tree.levels;
     const uint32_t vl = (uint32_t)a.tree.virtual_leaves;
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
     const uint32_t wave_item0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_item);
     const uint32_t self_next = my_item + leaf_first + 1u;
     const uint32_t wave_next = wave_item0 + leaf_first + 1u;
-    uint32_t *queue = s_queue[wv];
+    QE *queue = s_queue[wv];
     Cnt *cnts = s_cnt[wv];
     cnts[lane] = WRITE ? q.w : (Cnt)0; // next output offset (WRITE) / contacts so far (count pass) of query `lane`
     int qn = 0;                        // wave-uniform: queued pairs
@@ -513,9 +515,9 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
     // c: leaf tests of queue[off, off + avail), one pair per lane
     auto pair_step = [&](int off, int avail) {
         const bool v = lane < avail;
-        const uint32_t e = v ? queue[off + lane] : 0u;
+        const QE e = v ? queue[off + lane] : (QE)0;
         const int qi = (int)(e & 63u);
-        const uint32_t pos = 2u * (e >> 6); // 0-based position of the pair's left leaf
+        const uint32_t pos = 2u * (uint32_t)(e >> 6); // 0-based position of the pair's left leaf
         const bool has_b = v & (pos + 1u < n_leaves);
         L leaf_a = {}, leaf_b = {};
         I idx_a = 0, idx_b = 0;
@@ -591,7 +593,7 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
         }
         const int rem = qn - done;
         if (rem > 0 && done > 0) {
-            const uint32_t e = lane < rem ? queue[done + lane] : 0u;
+            const QE e = lane < rem ? queue[done + lane] : (QE)0;
             __builtin_amdgcn_wave_barrier();
             if (lane < rem) queue[lane] = e;
             __builtin_amdgcn_wave_barrier();
@@ -624,9 +626,9 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
         // lanes = parents over the active queries.  (Measured alternative: lanes = (query, parent) pairs
         // pulled together with ds_bpermute — as many steps as this loop has iterations, and slower.)
         const bool by_box = (int)__popcll(box_mask) < (int)__popcll(on_mask); // (int: keeps the compare on the scalar unit)
-        const uint32_t e_box = (uint32_t)lane | (first32 << 6);     // + (u << 6)
-        const uint32_t e_qry = (first32 + (uint32_t)lane) << 6;      // | u
-        if constexpr (std::is_same<TN, float>::value) {
+        const QE e_box = (QE)lane | ((QE)first32 << 6);             // + (u << 6)
+        const QE e_qry = (QE)(first32 + (uint32_t)lane) << 6;       // | u
+        if constexpr (std::is_same<TN, float>::value && !WIDE) {
             // hand-scheduled step (test_and_append_f32); the pair walk has no prune: thresholds that always pass
             const uint32_t queue_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)queue;
             if (by_box) {
@@ -661,17 +663,17 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
                 if (qn > QUEUE_CAP - 64) drain(false);
                 const int u = __builtin_ctzll(todo);
                 bool h;
-                uint32_t e;
+                QE e;
                 if (by_box) {
                     const N pbox = broadcast_from_lane(mybox, u);
                     h = on & iscontact(q.q_node, pbox);
                     if constexpr (MODE == MODE_SELF) h = h & (2u * (first32 + (uint32_t)u) + 1u > my_item);
-                    e = e_box + ((uint32_t)u << 6);
+                    e = e_box + ((QE)u << 6);
                 } else {
                     const N qbox = broadcast_from_lane(q.q_node, u);
                     h = box_on & iscontact(qbox, mybox);
                     if constexpr (MODE == MODE_SELF) h = h & (right_leaf > wave_item0 + (uint32_t)u);
-                    e = e_qry | (uint32_t)u;
+                    e = e_qry | (QE)u;
                 }
                 const uint64_t hm = __builtin_amdgcn_ballot_w64(h);
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
@@ -1031,7 +1033,15 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
         // everything else (BSphere nodes, start_level == levels): the exact joint walk
         if constexpr (N::kind == IBVH_BBOX) {
             if (a.start_level < a.tree.levels) {
-                if (a.tree.levels <= 28) { // queue entries pack (parent index << 6 | lane) in 32 bits; deeper trees take the exact walk
+                static const bool force_wide = [] {
+                    const char *e = getenv("IBVH_LVT_WIDE"); // test knob: 64-bit queue entries for every tree
+                    return e && atoi(e) != 0;
+                }();
+                // queue entries pack (leaf-parent index << 6 | lane): 32 bits up to 28 levels (134 M leaves), 64 bits up to
+                // 31 levels (wave-uniform arithmetic is 32-bit: positions + 2^(levels-1) must stay below 2^32); deeper
+                // trees take the exact walk
+                if (a.tree.levels <= 31) {
+                    const bool wide = force_wide || a.tree.levels > 28;
                     // With BBox nodes the contact list does not depend on the start level (monotone box tests, see the
                     // header comment), so the descent always starts where one 64-lane step covers all roots (level 7,
                     // or the highest built level below it) whatever level the caller named.
@@ -1041,13 +1051,20 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
                     aq.start_level = top; // also when the caller named a HIGHER level: levels 1..6 hold < 64 nodes each
                     const int64_t c = aq.tree.levels - BRUTE_DEPTH;
                     const int cut = (int)(c > aq.start_level ? c : aq.start_level);
-                    if (aq.narrow != IBVH_NARROW_NONE) {
-                        if (write) IBVH_LAUNCH((lvt_queue_kernel<L, N, I, MODE, true, true>), dim3(blocks), dim3(256), 0, st, aq, cache, cut);
-                        else IBVH_LAUNCH((lvt_queue_kernel<L, N, I, MODE, false, true>), dim3(blocks), dim3(256), 0, st, aq, cache, cut);
-                    } else {
-                        if (write) IBVH_LAUNCH((lvt_queue_kernel<L, N, I, MODE, true, false>), dim3(blocks), dim3(256), 0, st, aq, cache, cut);
-                        else IBVH_LAUNCH((lvt_queue_kernel<L, N, I, MODE, false, false>), dim3(blocks), dim3(256), 0, st, aq, cache, cut);
+                    const int variant = (write ? 1 : 0) | (aq.narrow != IBVH_NARROW_NONE ? 2 : 0) | (wide ? 4 : 0);
+#define IBVH_QUEUE_LAUNCH(W_, N_, D_)                                                                                 \
+    IBVH_LAUNCH((lvt_queue_kernel<L, N, I, MODE, W_, N_, D_>), dim3(blocks), dim3(256), 0, st, aq, cache, cut)
+                    switch (variant) {
+                    case 0: IBVH_QUEUE_LAUNCH(false, false, false); break;
+                    case 1: IBVH_QUEUE_LAUNCH(true, false, false); break;
+                    case 2: IBVH_QUEUE_LAUNCH(false, true, false); break;
+                    case 3: IBVH_QUEUE_LAUNCH(true, true, false); break;
+                    case 4: IBVH_QUEUE_LAUNCH(false, false, true); break;
+                    case 5: IBVH_QUEUE_LAUNCH(true, false, true); break;
+                    case 6: IBVH_QUEUE_LAUNCH(false, true, true); break;
+                    default: IBVH_QUEUE_LAUNCH(true, true, true); break;
                     }
+#undef IBVH_QUEUE_LAUNCH
                     IBVH_LAUNCH_CHECK();
                     return IBVH_OK;
                 }
