@@ -77,11 +77,12 @@ def build(vols, types, built_level=1):
     return o, g
 
 
-def one_case(rng, log):
+def one_case(rng, log, light=False):
     combo = COMBOS[rng.integers(0, len(COMBOS))]
     it, mt = [(abi.I32, abi.U32), (abi.I64, abi.U64), (abi.I32, abi.U16), (abi.I64, abi.U32)][rng.integers(0, 4)]
     types = abi.make_types(*combo, it, mt)
-    n = int(rng.choice([1, 2, 3, 7, 64, 65, 127, 129, 500, 2047, 2049, 5000, 20000, 60000]))
+    sizes = [1, 2, 3, 7, 64, 65, 127, 129, 500, 2047, 2049, 5000, 20000, 60000]
+    n = int(rng.choice(sizes[:-2] if light else sizes))  # (light: the in-suite slices keep the oracle's share small)
     vols = cloud(rng, n, combo[0], combo[1])
     levels0 = orc.tree_shape(n).levels
     built = 1 if rng.random() < 0.6 else int(rng.integers(1, levels0 + 1))  # partial builds: nodes above `built` do not exist
@@ -147,13 +148,13 @@ def one_case(rng, log):
             assert (got(t) == pairs(exp)).all(), f"rays sl={sl}"
 
 
-def main(seconds=60.0, seed=0, verbose=True):
+def main(seconds=60.0, seed=0, verbose=True, light=False):
     rng = np.random.default_rng(seed)
     t0, cases = time.time(), 0
     while time.time() - t0 < seconds:
         log = []
         try:
-            one_case(rng, log)
+            one_case(rng, log, light)
         except Exception:
             print("FAILED case", cases, "seed", seed, *log, file=sys.stderr)
             raise
@@ -164,4 +165,5 @@ def main(seconds=60.0, seed=0, verbose=True):
 
 
 if __name__ == "__main__":
-    main(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    main(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
+         light=len(sys.argv) > 3 and sys.argv[3] == "light")

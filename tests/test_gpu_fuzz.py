@@ -8,7 +8,7 @@ torch = pytest.importorskip("torch")
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_random_configurations_match_the_oracle(seed):
     import fuzz_gpu
-    assert fuzz_gpu.main(seconds=8.0, seed=seed, verbose=False) >= 1
+    assert fuzz_gpu.main(seconds=8.0, seed=seed, verbose=False, light=True) >= 1
 
 
 def test_64_bit_queue_entries_match_the_oracle():
@@ -20,7 +20,7 @@ def test_64_bit_queue_entries_match_the_oracle():
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, IBVH_LVT_WIDE="1")
-    out = subprocess.run([sys.executable, os.path.join(here, "fuzz_gpu.py"), "10", "7"], cwd=here, env=env,
+    out = subprocess.run([sys.executable, os.path.join(here, "fuzz_gpu.py"), "10", "7", "light"], cwd=here, env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "fuzz ok" in out.stdout
