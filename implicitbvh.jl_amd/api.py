@@ -523,9 +523,54 @@ def _speculative_buffer(cache, idt):
     return buf
 
 
+class _LvtScratch:
+    """The LVT scratch buffer of a chain of traversals that hand each other their buffers through `cache=`.
+
+    The library keeps the total contact count in the first 8 bytes of the scratch it is given.  A traversal that was
+    enqueued without a host read (`*_enqueue`) fetches that total later, possibly after the next traversal has already
+    reused the buffer, so every call gets its OWN 64-byte header: the buffer carries a 4 KiB prefix of 64 header slots and
+    call k hands the library `base + 64 * (k mod 64)` as its scratch pointer (count and write of one traversal use the
+    same pointer, which is all the layout requires).  No copy of the total is needed, and a traversal's header survives
+    the next 63 calls on the same buffer."""
+    SLOTS, SLOT_BYTES = 64, 64
+
+    def __init__(self, nbytes):
+        self.buf = _torch().empty(nbytes + self.SLOTS * self.SLOT_BYTES, dtype=_torch().uint8, device="cuda")
+        self.calls = 0
+        self.slot = 0
+
+    def capacity(self):
+        return self.buf.numel() - self.SLOTS * self.SLOT_BYTES
+
+    def next_call(self):
+        self.slot = self.calls % self.SLOTS
+        self.calls += 1
+        return self
+
+    # what _ptr() and the call sites use: the pointer / size handed to the library for the CURRENT call
+    def data_ptr(self):
+        return self.buf.data_ptr() + self.slot * self.SLOT_BYTES
+
+    def numel(self):
+        return self.capacity()
+
+    def header(self):
+        """(view of this call's header words [total, -, -], token to detect that the slot was recycled)"""
+        off = self.slot * self.SLOT_BYTES
+        return self.buf[off:off + 8].view(_torch().int64), (self, self.slot, self.calls)
+
+
 def _keep_total(scratch):
-    """Private copy of the scratch header's total (the scratch itself may be reused by the next call)."""
-    return scratch[:8].view(_torch().int64).clone()
+    """The device-side total of the call just enqueued on `scratch` (no copy: the call owns its header slot)."""
+    view, (owner, slot, calls) = scratch.header()
+
+    class _Total:
+        def item(self_inner):
+            if owner.calls - calls >= owner.SLOTS:
+                raise RuntimeError("this traversal's contact count was never read and its scratch header has been recycled "
+                                   f"by {owner.SLOTS} later traversals on the same cache")
+            return view.item()
+    return _Total()
 
 
 def _cache_slots(cache, n_items, default):
@@ -548,9 +593,9 @@ def _lvt_scratch(cache, types, n_items, slots=None):
     lib.call("ibvh_lvt_scratch_bytes", C.byref(types), int(n_items), _cache_slots(cache, n_items, LVT_CACHE_SLOTS if slots is None else slots),
              C.byref(need))
     s = cache._scratch if cache is not None else None
-    if s is None or s.numel() < need.value:
-        s = torch.empty(need.value, dtype=torch.uint8, device="cuda")
-    return s
+    if not isinstance(s, _LvtScratch) or s.capacity() < need.value:
+        s = _LvtScratch(need.value)
+    return s.next_call()
 
 
 def _traverse_lvt_single(bvh, start_level, narrow, cache):
@@ -564,25 +609,26 @@ def _traverse_lvt_single(bvh, start_level, narrow, cache):
     n = len(bvh.leaves)
     counts = _cache_tensor(cache.cache2 if cache else None, n, 0, idt, "cache2")
     scratch = _lvt_scratch(cache, bvh.types, n)
+    sp, sn = _ptr(scratch), scratch.numel()  # frozen now: the object hands out a new header slot per call
     s = bvh.struct()
     spec = _speculative_buffer(cache, idt)
     if spec is not None:
         lib.call("ibvh_traverse_lvt_enqueue", C.byref(s), start_level, narrow, _ptr(counts), _ptr(spec), spec.shape[0],
-                 _ptr(scratch), scratch.numel(), _stream())
+                 sp, sn, _stream())
 
         def finish(total):
             contacts = torch.empty((total, 2), dtype=idt, device="cuda")
-            lib.call("ibvh_traverse_lvt_write", C.byref(s), start_level, narrow, _ptr(counts), _ptr(contacts), _ptr(scratch),
-                     scratch.numel(), _stream())
+            lib.call("ibvh_traverse_lvt_write", C.byref(s), start_level, narrow, _ptr(counts), _ptr(contacts), sp,
+                     sn, _stream())
             return contacts
         return BVHTraversal(start_level, 0, 0, None, spec, counts, scratch, _pending=(_keep_total(scratch), spec.shape[0], finish))
     total = C.c_int64()
-    lib.call("ibvh_traverse_lvt_count", C.byref(s), start_level, narrow, _ptr(counts), C.byref(total), _ptr(scratch),
-             scratch.numel(), _stream())
+    lib.call("ibvh_traverse_lvt_count", C.byref(s), start_level, narrow, _ptr(counts), C.byref(total), sp,
+             sn, _stream())
     contacts = _cache_tensor(cache.cache1 if cache else None, total.value, 2, idt, "cache1")
     if total.value:
-        lib.call("ibvh_traverse_lvt_write", C.byref(s), start_level, narrow, _ptr(counts), _ptr(contacts), _ptr(scratch),
-                 scratch.numel(), _stream())
+        lib.call("ibvh_traverse_lvt_write", C.byref(s), start_level, narrow, _ptr(counts), _ptr(contacts), sp,
+                 sn, _stream())
     return BVHTraversal(start_level, 0, 0, total.value, contacts, counts, scratch)
 
 
@@ -597,25 +643,26 @@ def _traverse_lvt_pair(bvh1, bvh2, sl1, sl2, narrow, cache):
     n = max(len(bvh1.leaves), len(bvh2.leaves))
     counts = _cache_tensor(cache.cache2 if cache else None, n, 0, idt, "cache2")
     scratch = _lvt_scratch(cache, bvh1.types, n)
+    sp, sn = _ptr(scratch), scratch.numel()  # frozen now: the object hands out a new header slot per call
     s1, s2 = bvh1.struct(), bvh2.struct()
     spec = _speculative_buffer(cache, idt)
     if spec is not None:
         lib.call("ibvh_traverse_pair_lvt_enqueue", C.byref(s1), C.byref(s2), sl1, sl2, narrow, _ptr(counts), _ptr(spec),
-                 spec.shape[0], _ptr(scratch), scratch.numel(), _stream())
+                 spec.shape[0], sp, sn, _stream())
 
         def finish(total):
             contacts = torch.empty((total, 2), dtype=idt, device="cuda")
             lib.call("ibvh_traverse_pair_lvt_write", C.byref(s1), C.byref(s2), sl1, sl2, narrow, _ptr(counts), _ptr(contacts),
-                     _ptr(scratch), scratch.numel(), _stream())
+                     sp, sn, _stream())
             return contacts
         return BVHTraversal(sl1, sl2, 0, None, spec, counts, scratch, _pending=(_keep_total(scratch), spec.shape[0], finish))
     total = C.c_int64()
     lib.call("ibvh_traverse_pair_lvt_count", C.byref(s1), C.byref(s2), sl1, sl2, narrow, _ptr(counts), C.byref(total),
-             _ptr(scratch), scratch.numel(), _stream())
+             sp, sn, _stream())
     contacts = _cache_tensor(cache.cache1 if cache else None, total.value, 2, idt, "cache1")
     if total.value:
         lib.call("ibvh_traverse_pair_lvt_write", C.byref(s1), C.byref(s2), sl1, sl2, narrow, _ptr(counts), _ptr(contacts),
-                 _ptr(scratch), scratch.numel(), _stream())
+                 sp, sn, _stream())
     return BVHTraversal(sl1, sl2, 0, total.value, contacts, counts, scratch)
 
 
@@ -729,25 +776,26 @@ def traverse_rays(bvh, points, directions, alg=None, start_level=1, narrow=None,
     if lvt:
         counts = _cache_tensor(cache.cache2 if cache else None, nr, 0, idt, "cache2")
         scratch = _lvt_scratch(cache, bvh.types, nr, slots=RAY_CACHE_SLOTS)
+        sp, sn = _ptr(scratch), scratch.numel()  # frozen now: the object hands out a new header slot per call
         spec = _speculative_buffer(cache, idt)
         if spec is not None:
             lib.call("ibvh_traverse_rays_lvt_enqueue", C.byref(s), _ptr(p), _ptr(d), nr, start_level, _ptr(counts), _ptr(spec),
-                     spec.shape[0], _ptr(scratch), scratch.numel(), _stream())
+                     spec.shape[0], sp, sn, _stream())
 
             def finish(total):
                 contacts = torch.empty((total, 2), dtype=idt, device="cuda")
                 lib.call("ibvh_traverse_rays_lvt_write", C.byref(s), _ptr(p), _ptr(d), nr, start_level, _ptr(counts),
-                         _ptr(contacts), _ptr(scratch), scratch.numel(), _stream())
+                         _ptr(contacts), sp, sn, _stream())
                 return contacts
             return BVHTraversal(start_level, 0, 0, None, spec, counts, scratch,
                                 _pending=(_keep_total(scratch), spec.shape[0], finish))
         total = C.c_int64()
         lib.call("ibvh_traverse_rays_lvt_count", C.byref(s), _ptr(p), _ptr(d), nr, start_level, _ptr(counts),
-                 C.byref(total), _ptr(scratch), scratch.numel(), _stream())
+                 C.byref(total), sp, sn, _stream())
         contacts = _cache_tensor(cache.cache1 if cache else None, total.value, 2, idt, "cache1")
         if total.value:
             lib.call("ibvh_traverse_rays_lvt_write", C.byref(s), _ptr(p), _ptr(d), nr, start_level, _ptr(counts),
-                     _ptr(contacts), _ptr(scratch), scratch.numel(), _stream())
+                     _ptr(contacts), sp, sn, _stream())
         return BVHTraversal(start_level, 0, 0, total.value, contacts, counts, scratch)
     cap = C.c_int64()
     lib.call("ibvh_bfs_rays_initial_capacity", C.byref(s), nr, start_level, C.byref(cap))
