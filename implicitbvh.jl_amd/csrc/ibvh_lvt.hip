@@ -420,6 +420,21 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
         }
         q.lane_on = q.valid; // every item of the wave walks again
     }
+    // Pair walk: a wave none of whose queries touches the other tree's ROOT box finds nothing — leave before the
+    // two-box split and the descent (two partially overlapping clouds: most waves of the larger one).  The root
+    // exists only in a fully built tree.
+    if constexpr (MODE == MODE_PAIR) {
+        if (a.built_level <= 1 && a.tree.levels >= 2) {
+            const N root = load_vol_uniform<N>(a.nodes);
+            if (__builtin_amdgcn_ballot_w64(q.lane_on & iscontact(q.q_node, root)) == 0) {
+                if constexpr (!WRITE) {
+                    if (q.valid) a.counts[q.item] = (I)0;
+                    if (region && lane == 0) *(int *)region = 0;
+                }
+                return;
+            }
+        }
+    }
 
     // Everything wave-uniform below is 32-bit on purpose (levels <= 31, so node indices and leaf positions stay
     // below 2^31): the scalar unit has no ordered 64-bit compare, a 64-bit uniform compare is done by the VALU, its
