@@ -30,7 +30,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # kernels of the Morton+sort phase (extrema -> keys -> radix passes -> sorted records), priced at 152 B/leaf
 MORTON_SORT_KERNELS = ("extrema_partial_kernel", "extrema_final_kernel", "encode_kernel", "encode_hist_kernel", "hist_kernel",
                        "hist_wide_kernel", "scan_kernel", "bucket_start_kernel", "scatter_kernel", "scatter_wide_kernel",
-                       "scatter_records_kernel", "bucket_sort_kernel", "gather_kernel")
+                       "scatter_records_kernel", "bucket_sort_kernel", "gather_kernel", "scan_tiles_kernel", "partition_kernel",
+                       "finish_kernel")
 
 # Algorithmic bytes per LEAF and launch for the kernels of one step, for
 # BSphere{F32} leaves / BBox{F32} nodes / U32 / I32; C = contacts per leaf.
@@ -43,6 +44,8 @@ def algorithmic_bytes(kernel, n, contacts):
         "scatter_records_kernel": 8.0 + 16.0 + 24.0,  # last pass: read (key, pos) + source volume, write the record
         "scatter_wide_kernel": 4.0 + 8.0,             # MSD partition: read keys (positions implicit), write (key, pos)
         "bucket_sort_kernel": 8.0 + 16.0 + 24.0,      # read (key, pos) + source volume, write the sorted record
+        "partition_kernel": 4.0 + 16.0 + 24.0,        # MSD partition of whole records: read key + source volume, write the record
+        "finish_kernel": 24.0 + 24.0,                 # per-bucket in-LDS finish: read the partitioned record, write the sorted one
         "hist_kernel": 4.0,                        # read keys
         "scatter_kernel": 8.0 + 8.0,               # read + write (key, position)
         "gather_kernel": 4.0 + 4.0 + 16.0 + 24.0,  # perm + key + volume -> record

@@ -9,18 +9,10 @@
 //   gather            read perm [4] + key [4] + volume [16 random], write record [24]
 //   aggregate         read records [24 stride, 16 used], write nodes [24 * ~1]
 #include "ibvh_common.hpp"
+#include "ibvh_radix.hpp"
 
 namespace ibvh {
-namespace rsort {
-struct RecordArgs {
-    const char *src;
-    char *dst;
-    int64_t src_stride;
-    int32_t src_wrapped;
-    int32_t vol_words;
-    int32_t index_bytes;
-    LeafLayout lay;
-};
+namespace rsort { // ibvh_sort.hip: LSD passes over (key, position) pairs (+ the MSD / in-LDS hybrid on pairs)
 struct FirstPassPlan {
     int tpb, ipt, num_tiles;
     uint32_t *tile_hist;
@@ -34,6 +26,16 @@ int sort_pairs(int key_bytes, int key_bits, int64_t n, void *keys, void *vals, v
                bool first_hist_done, const RecordArgs *records);
 size_t scratch_bytes(int64_t n);
 } // namespace rsort
+namespace msd { // ibvh_msd.hip: MSD partition of whole records + in-LDS finish per bucket (the default path)
+struct Plan {
+    int bits, shift, ptpb, pipt, num_tiles, ftpb, fipt;
+    uint32_t *tile_hist, *tile_scan, *digit_total;
+};
+Plan make_plan(int64_t n, int key_bits, int key_bytes, int leaf_bytes, void *sort_scratch);
+size_t scratch_bytes(int64_t n);
+int sort_records(const Plan &p, int key_bytes, const void *keys, int64_t n, const rsort::RecordArgs &ra, char *out, void *kalt,
+                 uint32_t *valt, void *kpri, uint32_t *vpri, hipStream_t st);
+} // namespace msd
 
 namespace build {
 
@@ -195,7 +197,7 @@ template <class V, class K>
 __global__ __launch_bounds__(1024) void encode_hist_kernel(const char *__restrict__ recs, int64_t stride, int64_t n,
                                                           const typename V::elt *__restrict__ ext, int morton_type,
                                                           K *__restrict__ keys, int tile_elems, int shift, uint32_t mask,
-                                                          uint32_t *__restrict__ tile_hist, int num_tiles) {
+                                                          uint32_t *__restrict__ tile_hist, int num_tiles, int tile_major) {
     using T = typename V::elt;
     extern __shared__ uint32_t h[]; // mask + 1 counters
     for (int i = threadIdx.x; i <= (int)mask; i += blockDim.x) h[i] = 0;
@@ -214,7 +216,12 @@ __global__ __launch_bounds__(1024) void encode_hist_kernel(const char *__restric
         }
     }
     __syncthreads();
-    for (int d = threadIdx.x; d <= (int)mask; d += blockDim.x) tile_hist[(int64_t)d * num_tiles + blockIdx.x] = h[d];
+    // digit-major ([digit][tile]) for the LSD passes of ibvh_sort.hip, tile-major ([tile][digit], one coalesced row)
+    // for the MSD partition of ibvh_msd.hip
+    if (tile_major)
+        for (int d = threadIdx.x; d <= (int)mask; d += blockDim.x) tile_hist[(int64_t)blockIdx.x * (mask + 1) + d] = h[d];
+    else
+        for (int d = threadIdx.x; d <= (int)mask; d += blockDim.x) tile_hist[(int64_t)d * num_tiles + blockIdx.x] = h[d];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -395,7 +402,7 @@ struct Scratch {
     char *extrema;   // 6 * 8
     char *keys, *keys_alt; // n * key_bytes
     char *vals, *vals_alt; // n * 4
-    char *records;   // n * leaf_bytes (only for the in-place, already-wrapped build)
+    char *records;   // n * leaf_bytes: the partitioned records (and the staging of an in-place LSD build)
     char *sort;      // rsort::scratch_bytes(n)
     size_t total;
 };
@@ -413,8 +420,9 @@ inline Scratch carve(char *base, int64_t n, int key_bytes, int64_t leaf_bytes, b
     s.keys_alt = take((size_t)n * key_bytes);
     s.vals = take((size_t)n * 4);
     s.vals_alt = take((size_t)n * 4);
-    s.records = take(wrapped ? (size_t)n * leaf_bytes : 0);
-    s.sort = take(rsort::scratch_bytes(n));
+    s.records = take((size_t)n * leaf_bytes);
+    const size_t a = rsort::scratch_bytes(n), b = msd::scratch_bytes(n);
+    s.sort = take(a > b ? a : b);
     s.total = off;
     return s;
 }
@@ -550,16 +558,30 @@ ibvh_status ibvh_build(const ibvh_build_desc *desc, const void *volumes, void *l
         }
         // keys, fused with the first per-tile digit histogram of the sort
         const int key_bits = morton_key_bits(ty.morton_type);
-        const rsort::FirstPassPlan plan = rsort::first_pass_plan(n, key_bits, key_bytes, sc.sort);
+        const msd::Plan mp = msd::make_plan(n, key_bits, key_bytes, (int)lay.leaf_bytes, sc.sort);
+        rsort::FirstPassPlan plan;
+        if (mp.bits) plan = rsort::FirstPassPlan{mp.ptpb, mp.pipt, mp.num_tiles, mp.tile_hist, (1u << mp.bits) - 1u, mp.shift, mp.bits};
+        else plan = rsort::first_pass_plan(n, key_bits, key_bytes, sc.sort);
         if (key_bytes == 8)
             IBVH_LAUNCH((encode_hist_kernel<L, uint64_t>), dim3(plan.num_tiles), dim3(plan.tpb), ((size_t)plan.mask + 1) * 4, st,
                         src, src_stride, n, ext, ty.morton_type, (uint64_t *)sc.keys, plan.tpb * plan.ipt, plan.shift, plan.mask,
-                        plan.tile_hist, plan.num_tiles);
+                        plan.tile_hist, plan.num_tiles, mp.bits ? 1 : 0);
         else
             IBVH_LAUNCH((encode_hist_kernel<L, uint32_t>), dim3(plan.num_tiles), dim3(plan.tpb), ((size_t)plan.mask + 1) * 4, st,
                         src, src_stride, n, ext, ty.morton_type, (uint32_t *)sc.keys, plan.tpb * plan.ipt, plan.shift, plan.mask,
-                        plan.tile_hist, plan.num_tiles);
+                        plan.tile_hist, plan.num_tiles, mp.bits ? 1 : 0);
         IBVH_LAUNCH_CHECK();
+        if (mp.bits) {
+            // the default: ONE partition of the finished records by the top bits of their key, buckets finished in LDS
+            // (ibvh_msd.hip).  index = position + 1 for fresh volumes (build.jl:345-349) or the source record's own
+            // index (:220-222); in-place builds read `leaves`, stage in scratch and write `leaves`: no extra copy.
+            rsort::RecordArgs ra{src, sc.records, src_stride, wrapped ? 1 : 0, (int32_t)(lay.volume_bytes / 8),
+                                 ty.index_type == IBVH_I32 ? 4 : 8, dlay};
+            if (int e = msd::sort_records(mp, key_bytes, sc.keys, n, ra, (char *)leaves, sc.keys_alt, (uint32_t *)sc.vals_alt, sc.keys,
+                                          (uint32_t *)sc.vals, st))
+                return e;
+            return aggregate<L, N>((const char *)leaves, lay.leaf_bytes, tree, desc->built_level, (N *)nodes, st);
+        }
         // stable LSB radix sort of (key, position), then the records in Morton order
         // (index = position + 1 for fresh volumes, build.jl:345-349, or the source record's own index, :220-222).
         // In-place (already wrapped) builds go through scratch records.

@@ -1,0 +1,659 @@
+// ibvh_msd.hip — the build's sort: ONE most-significant-digit partition of whole BoundingVolume records, then an
+// in-LDS finish per bucket.  gfx950 only.
+//
+// Replaces AK.sort!(leaves, by = bv -> bv.morton) + wrap_bounding_volumes (reference src/build.jl:248-253, 328-352).
+//
+// Why not LSD passes over (key, position) pairs + a gather (ibvh_sort.hip, round 1): after the last LSD pass the
+// source position of sorted element i is random, so the gather pays one 64-byte HBM sector per 16-byte volume
+// (measured at 1e7 leaves: 2 x FETCH + WRITE = 1.58 GB for 0.48 GB of algorithmic bytes, 0.23 ms of the phase's
+// 0.54).  Morton codes of a cloud spread over their top bits, so here the records themselves are partitioned ONCE
+// by the top `bits` (<= 12) bits of their key — source volumes are read in order (streaming), a tile's records of
+// one bucket land next to the previous tile's (XCD-contiguous tile ranges, so the partial lines of neighbouring
+// tiles meet in one L2) — and every bucket (a few thousand records, L2-sized) is then finished by one workgroup:
+// keys -> LDS, stable LSD passes on the remaining bits entirely in LDS, records copied from the bucket's
+// partitioned range (L2 hits: the range was just read for its keys) to their final place with coalesced stores.
+// HBM bytes per leaf (BSphere{F32} / Int32 / UInt32): hist 16 + 4, partition 4 + 16 + 24, finish 24 + 24 = 112
+// against 4 + 4*16 + 44 (+ 48 of sector over-fetch) before.
+//
+// Stability: the partition ranks in memory order and the LDS passes are stable, so equal keys keep input order
+// (the oracle's definition of the unpinned AK.sort! tie order).
+// A bucket larger than the finish workgroup's capacity (clustered input) is sorted by its workgroup with a tiled
+// LSD through the (key, position) scratch arrays: slower, never wrong.
+#include <cstdlib>
+
+#include "ibvh_common.hpp"
+#ifdef IBVH_PHASE_STAMPS
+namespace ibvh { namespace msd { extern __device__ unsigned long long g_stamps[2][12][4096]; } }
+#define IBVH_PASS_STAMP(k)                                                                                         \
+    do {                                                                                                           \
+        if (threadIdx.x == 0 && shift == 0) ::ibvh::msd::g_stamps[1][k][blockIdx.x & 4095] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#endif
+#include "ibvh_radix.hpp"
+
+namespace ibvh {
+namespace msd {
+
+using rsort::block_exclusive_scan;
+using rsort::lds_exclusive_scan;
+using rsort::lds_exclusive_scan_pair;
+using rsort::lds_radix_pass;
+using rsort::RecordArgs;
+using rsort::wave_rank;
+
+constexpr int MSD_MAX_BITS = 12;
+
+// Diagnostic build only (-DIBVH_PHASE_STAMPS, tools/phase_stamps.sh): thread 0 of every workgroup stamps s_memtime
+// at the phase boundaries into a buffer no product code reads.  In the product build the macro is empty.
+#ifdef IBVH_PHASE_STAMPS
+__device__ unsigned long long g_stamps[2][12][4096];
+#define IBVH_STAMP(kern, k)                                                                              \
+    do {                                                                                                 \
+        if (threadIdx.x == 0) g_stamps[kern][k][blockIdx.x & 4095] = __builtin_amdgcn_s_memtime();       \
+    } while (0)
+#else
+#define IBVH_STAMP(kern, k)
+#endif
+
+// ------------------------------------------------------------------------------------------------------------
+// scan: tile_hist is TILE-major here ([num_tiles][radix]: the histogram kernel writes, and the partition kernel
+// reads, one contiguous row per tile; a digit-major matrix costs both a 128-byte line per 4-byte counter).  tile_scan
+// receives every column's (digit's) exclusive prefix over the tiles; digit_total[d] = the column sum.
+// Workgroup (db, c): 64 digits (lane = digit: a wave reads 256 contiguous bytes of a row), tile rows
+// [c*rows_per_chunk, ...).  The sum of the rows above its chunk is re-derived by the workgroup itself (rows dealt
+// round-robin to its 16 waves) — redundant reads of an L2-resident matrix instead of a second launch.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int SCAN_TPB = 1024;
+__global__ __launch_bounds__(SCAN_TPB) void scan_tiles_kernel(const uint32_t *__restrict__ tile_hist, uint32_t *__restrict__ tile_scan,
+                                                              int num_tiles, int radix, int rows_per_chunk,
+                                                              uint32_t *__restrict__ digit_total) {
+    constexpr int W = SCAN_TPB / 64;
+    __shared__ uint32_t s_part[W][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int ndb = radix >> 6;
+    const int db = blockIdx.x % ndb, c = blockIdx.x / ndb;
+    // (out of place: other workgroups are still summing the counts of this chunk's rows)
+    const uint32_t *col = tile_hist + db * 64 + lane;
+    uint32_t *out = tile_scan + db * 64 + lane;
+    const int r0 = c * rows_per_chunk;
+    const int r1 = r0 + rows_per_chunk < num_tiles ? r0 + rows_per_chunk : num_tiles;
+    if (r0 >= num_tiles) return;
+    // rows above the chunk
+    uint32_t above = 0;
+    {
+        uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int r = w;
+        for (; r + 7 * W < r0; r += 8 * W) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += col[(int64_t)(r + u * W) * radix];
+        }
+        for (; r < r0; r += W) acc[0] += col[(int64_t)r * radix];
+        s_part[w][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < W; ++i) above += s_part[i][lane];
+        __syncthreads();
+    }
+    // own rows: wave w takes the contiguous share [a, b)
+    const int share = (r1 - r0 + W - 1) / W;
+    const int a = r0 + w * share;
+    const int b = a + share < r1 ? a + share : r1;
+    uint32_t mine = 0;
+    for (int r = a; r < b; ++r) mine += col[(int64_t)r * radix];
+    s_part[w][lane] = mine;
+    __syncthreads();
+    uint32_t run = above, chunk_total = 0;
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        const uint32_t t = s_part[i][lane];
+        if (i < w) run += t;
+        chunk_total += t;
+    }
+    for (int r = a; r < b; ++r) {
+        const uint32_t v = col[(int64_t)r * radix];
+        out[(int64_t)r * radix] = run;
+        run += v;
+    }
+    if (r1 == num_tiles && w == 0) digit_total[db * 64 + lane] = above + chunk_total;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// partition: tile t (TPB * IPT consecutive source leaves) ranks its keys by the top digit and writes every
+// leaf's finished record (volume, index, key) to its bucket's range in `rec.dst`.
+// ------------------------------------------------------------------------------------------------------------
+// The record of source leaf i is assembled word by word (8-byte words; every layout is a multiple of 8 with the
+// volume first): volume words are copied, the words behind the volume carry .index and .morton.
+struct TailLayout {
+    int32_t vol_bytes, index_off, morton_off, index_bytes, morton_bytes;
+};
+IBVH_D uint64_t tail_word(const TailLayout &t, int word /* of the record */, uint64_t index, uint64_t key, uint64_t old) {
+    const int base = word * 8;
+    uint64_t w = old;
+    const int io = t.index_off - base, mo = t.morton_off - base;
+    if (io >= 0 && io < 8) {
+        const uint64_t m = t.index_bytes == 8 ? ~(uint64_t)0 : (uint64_t)0xffffffffu;
+        w = (w & ~(m << (8 * io))) | ((index & m) << (8 * io));
+    }
+    if (mo >= 0 && mo < 8) {
+        const uint64_t m = t.morton_bytes == 8 ? ~(uint64_t)0 : (t.morton_bytes == 4 ? (uint64_t)0xffffffffu : (uint64_t)0xffffu);
+        w = (w & ~(m << (8 * mo))) | ((key & m) << (8 * mo));
+    }
+    return w;
+}
+
+// Assemble the records of G rows of a wave (lane = one source leaf per row) and put them at their tile-local sorted
+// positions in the LDS stage: NW source words per leaf are loaded for all G rows before the first LDS store (NW =
+// sizeof(V)/8 for fresh volumes; the whole record for wrapped sources, whose .index is kept), the words behind the
+// volume are assembled from (index, key).  NW / OW are compile-time: the kernel switches once, wave-uniformly, on
+// the run-time layout.
+template <int NW, int OW, bool WRAPPED, class K, int G>
+IBVH_D void stage_rows(const uint64_t *__restrict__ src, uint32_t src_words, uint64_t *stage, const TailLayout &tl,
+                       int64_t first /* source leaf of row 0, lane 0 */, int64_t n, const K *key, const uint32_t *pos) {
+    const int lane = threadIdx.x & 63;
+    uint64_t v[G][NW];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        int64_t i = first + j * 64 + lane;
+        if (i >= n) i = n - 1; // (a valid address; the value is not stored)
+        const uint64_t *p = src + (uint64_t)i * src_words;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) v[j][k] = p[k];
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        const int64_t i = first + j * 64 + lane;
+        if (i < n) {
+            uint64_t *q = stage + (uint32_t)pos[j] * OW;
+#pragma unroll
+            for (int k = 0; k < OW; ++k) {
+                if constexpr (WRAPPED) q[k] = tail_word(tl, k, 0, (uint64_t)key[j], v[j][k]); // only .morton is new
+                else q[k] = k < NW ? v[j][k < NW ? k : 0] : tail_word(tl, k, (uint64_t)i + 1u, (uint64_t)key[j], 0);
+            }
+        }
+    }
+}
+
+// occupancy the LDS stage allows (24-byte records): pinned so the layout switch cannot push the VGPR count over a step
+constexpr int partition_min_waves(int tpb, int ipt) { return tpb * ipt <= 2048 ? 3 : 2; }
+
+template <class K, int TPB, int IPT>
+__global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_kernel(const K *__restrict__ keys, int64_t n, int shift, int bits,
+                                                        const uint32_t *__restrict__ tile_hist,
+                                                        const uint32_t *__restrict__ digit_total, int num_tiles,
+                                                        RecordArgs rec, uint32_t inv_words) {
+    constexpr int W = TPB / 64;
+    constexpr int TILE = TPB * IPT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int radix = 1 << bits;
+    const uint32_t mask = (uint32_t)radix - 1u;
+    // layout: local_base[radix] | delta[radix] | wave_tot[16] | { whist[W * radix] (u16), later stage[TILE records] }
+    uint32_t *local_base = (uint32_t *)smem;         // radix: tile-local start of digit d
+    uint32_t *delta = local_base + radix;            // radix: (global position) - (tile-local sorted position) of digit d
+    uint32_t *wave_tot = delta + radix;              // 2 * W <= 32
+    uint64_t *stage = (uint64_t *)(wave_tot + 32);
+    uint16_t *whist = (uint16_t *)stage;             // W * radix
+
+    const int tile = xcd_remap(blockIdx.x, num_tiles);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t tile_base = (int64_t)tile * TILE;
+    const int64_t wave_base = tile_base + (int64_t)w * (64 * IPT);
+
+    IBVH_STAMP(0, 0);
+    // this tile's row of the (scanned, tile-major) histogram: coalesced, in flight while the keys are ranked
+    constexpr int DPT = (1 << MSD_MAX_BITS) / TPB; // digits per thread, at most
+    uint32_t tile_off[DPT];
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) {
+        const int d = k * TPB + threadIdx.x;
+        tile_off[k] = d < radix ? tile_hist[(int64_t)tile * radix + d] : 0u;
+    }
+    for (int i = threadIdx.x; i < W * radix / 2; i += TPB) ((uint32_t *)whist)[i] = 0;
+    K key[IPT];
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        const int64_t i = wave_base + j * 64 + lane;
+        key[j] = i < n ? keys[i] : (K) ~(K)0;
+    }
+    __syncthreads();
+    IBVH_STAMP(0, 1);
+    uint16_t rank[IPT];
+    uint16_t *my_hist = whist + w * radix;
+    wave_rank<K, IPT>(key, shift, mask, bits, my_hist, lane, rank);
+    __syncthreads();
+    IBVH_STAMP(0, 2);
+    // per digit: exclusive prefix over the waves (in place), tile total, global start of the digit
+    for (int d = threadIdx.x; d < radix; d += TPB) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            const uint32_t c = whist[i * radix + d];
+            whist[i * radix + d] = (uint16_t)run;
+            run += c;
+        }
+        local_base[d] = run;
+        delta[d] = digit_total[d];
+    }
+    __syncthreads();
+    IBVH_STAMP(0, 3);
+    lds_exclusive_scan_pair<TPB>(local_base, delta, radix, wave_tot);
+    IBVH_STAMP(0, 4);
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) {
+        const int d = k * TPB + threadIdx.x;
+        if (d < radix) delta[d] = delta[d] + tile_off[k] - local_base[d]; // mod 2^32
+    }
+    uint32_t pos[IPT];
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        const uint32_t d = (uint32_t)(key[j] >> shift) & mask;
+        pos[j] = local_base[d] + my_hist[d] + rank[j];
+    }
+    __syncthreads(); // every wave is done with whist: its bytes become the stage
+    IBVH_STAMP(0, 5);
+    // the records: sources are read in memory order (coalesced) and land at their sorted place in the stage
+    const uint32_t src_words = (uint32_t)(rec.src_stride / 8);
+    const uint32_t words = (uint32_t)rec.lay.stride / 8u;
+    const bool wrapped = rec.src_wrapped != 0;
+    const uint64_t *src = (const uint64_t *)rec.src;
+    const TailLayout tl{rec.vol_words * 8, wrapped ? -64 : rec.lay.index_off, rec.lay.morton_off, rec.index_bytes, rec.lay.morton_bytes};
+    static_assert(IPT % 4 == 0, "rows are moved 4 or 2 at a time");
+#define IBVH_MOVE(NW, OW, WR)                                                                                           \
+    for (int j0 = 0; j0 < IPT; j0 += (NW <= 3 ? 4 : 2))                                                                 \
+        stage_rows<NW, OW, WR, K, (NW <= 3 ? 4 : 2)>(src, src_words, stage, tl, wave_base + j0 * 64, n, key + j0, pos + j0);
+    // (volume words, record words) of every layout layout_of() can produce; wrapped sources carry whole records
+    const int code = (wrapped ? 100 : 0) + rec.vol_words * 10 + (int)words;
+    switch (code) {
+    case 23: IBVH_MOVE(2, 3, false) break;  // BSphere{F32}, 24-byte record (Int32 / UInt16|UInt32)
+    case 24: IBVH_MOVE(2, 4, false) break;  // BSphere{F32}, Int64 and/or UInt64
+    case 34: IBVH_MOVE(3, 4, false) break;  // BBox{F32}
+    case 35: IBVH_MOVE(3, 5, false) break;
+    case 45: IBVH_MOVE(4, 5, false) break;  // BSphere{F64}
+    case 46: IBVH_MOVE(4, 6, false) break;
+    case 67: IBVH_MOVE(6, 7, false) break;  // BBox{F64}
+    case 68: IBVH_MOVE(6, 8, false) break;
+    case 123: IBVH_MOVE(3, 3, true) break;
+    case 124: case 134: IBVH_MOVE(4, 4, true) break;
+    case 135: case 145: IBVH_MOVE(5, 5, true) break;
+    case 146: IBVH_MOVE(6, 6, true) break;
+    case 167: IBVH_MOVE(7, 7, true) break;
+    case 168: IBVH_MOVE(8, 8, true) break;
+    default: break; // (unreachable: the host refuses other layouts)
+    }
+#undef IBVH_MOVE
+    __syncthreads();
+    IBVH_STAMP(0, 6);
+    // out: lane <-> 8-byte word of the tile's sorted records; a digit's run goes to consecutive addresses
+    const int64_t left = n - tile_base;
+    const uint32_t valid = left < (int64_t)TILE ? (uint32_t)left : (uint32_t)TILE;
+    const uint32_t total = valid * words;
+    uint64_t *__restrict__ dst = (uint64_t *)rec.dst;
+    const char *stage_bytes = (const char *)stage;
+    constexpr int U = 4; // LDS reads of U words are issued before the first global store
+    for (uint32_t g0 = threadIdx.x; g0 < total; g0 += TPB * U) {
+        uint64_t v[U];
+        uint32_t kd[U], rr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t g = g0 + u * TPB;
+            const uint32_t gc = g < total ? g : 0u;
+            rr[u] = __umulhi(gc, inv_words);
+            v[u] = stage[gc];
+            kd[u] = (uint32_t)((K)load_morton(stage_bytes + rr[u] * (uint32_t)rec.lay.stride, rec.lay) >> shift) & mask;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) kd[u] = delta[kd[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t g = g0 + u * TPB;
+            if (g < total) dst[(uint64_t)(rr[u] + kd[u]) * words + (g - rr[u] * words)] = v[u];
+        }
+    }
+    IBVH_STAMP(0, 7);
+}
+template <class K, int TPB, int IPT> inline size_t partition_smem(int bits, int stride) {
+    const size_t hist = (size_t)(TPB / 64) * ((size_t)2 << bits), st = (size_t)TPB * IPT * (size_t)stride;
+    return ((size_t)8 << bits) + 128 + (hist > st ? hist : st);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// finish: workgroup b sorts bucket b's records on the low `low_bits` bits of their keys and writes them to `out`
+// ------------------------------------------------------------------------------------------------------------
+struct FinishArgs {
+    const char *part;  // partitioned records (the partition kernel's dst)
+    char *out;         // sorted records
+    LeafLayout lay;
+    uint32_t words;    // lay.stride / 8
+    uint32_t inv_words; // ceil(2^32 / words): g / words == __umulhi(g, inv_words) for g < 2^29
+    // slow path only: (key, position) arrays of n entries each
+    void *kalt, *kpri;
+    uint32_t *valt, *vpri;
+};
+
+template <class K, int TPB, int IPT>
+__global__ __launch_bounds__(TPB) void finish_kernel(const uint32_t *__restrict__ digit_total, int low_bits, FinishArgs fa) {
+    constexpr int W = TPB / 64;
+    constexpr int CAP = TPB * IPT;
+    constexpr int RB = 8, R = 1 << RB;
+    static_assert(R <= TPB, "one digit counter per thread");
+    extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
+    // fast path: CAP keys + CAP 16-bit positions; slow path: tiles of CAP/2 keys + 32-bit positions in the same bytes
+    K *s_keys = (K *)bsm;                                 // CAP
+    uint16_t *s_idx = (uint16_t *)(s_keys + CAP);         // CAP
+    uint32_t *s_vals32 = (uint32_t *)(s_keys + CAP / 2);  // CAP / 2 (slow path)
+    uint32_t *local_base = (uint32_t *)(s_idx + CAP);     // R
+    uint32_t *gbase = local_base + R;                     // R
+    uint32_t *wave_tot = gbase + R;                       // 16
+    uint16_t *whist = (uint16_t *)(wave_tot + 16);        // W * R
+    // the bucket's range: every workgroup sums the digit totals in front of its own digit itself
+    IBVH_STAMP(1, 0);
+    const int64_t m = (int64_t)digit_total[blockIdx.x];
+    if (m == 0) return;
+    uint32_t before = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += TPB) before += digit_total[i];
+    uint32_t start32 = 0;
+    block_exclusive_scan<TPB>(before, wave_tot, &start32);
+    const int64_t start = (int64_t)start32;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int stride = fa.lay.stride;
+    const char *bucket = fa.part + start * stride;
+    const int passes = (low_bits + RB - 1) / RB;
+    IBVH_STAMP(1, 1);
+
+    if (m <= CAP) {
+        // ---- fast path: the bucket's keys live in LDS ------------------------------------------------------
+        // the m keys are dealt to the waves in equal contiguous shares of `chunk` (a multiple of 64): a bucket of
+        // CAP/4 keys keeps every wave busy with a quarter of the ranking work; (w, j, lane) order is memory order
+        const int chunk = (int)((m + W * 64 - 1) / (W * 64)) * 64;
+        const int jmax = chunk / 64; // <= IPT
+        K key[IPT];
+        uint16_t val[IPT];
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const int idx = w * chunk + j * 64 + lane;
+            const bool ok = j < jmax && idx < m;
+            // (the strided key loads touch every line of the bucket's records: they are L2 hits for the copy below)
+            key[j] = ok ? (K)load_morton(bucket + (int64_t)idx * stride, fa.lay) : (K) ~(K)0; // sentinels sort last
+            val[j] = (uint16_t)idx;
+        }
+        if (passes == 0) {
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) {
+                const int idx = w * chunk + j * 64 + lane;
+                if (j < jmax) s_idx[idx] = val[j];
+            }
+            __syncthreads();
+        }
+        int done = 0;
+        IBVH_STAMP(1, 2);
+        for (int p = 0; p < passes; ++p) {
+            const int bits = (low_bits - done + (passes - p) - 1) / (passes - p); // even split of the remaining bits
+            lds_radix_pass<K, uint16_t, TPB, IPT, RB>(key, val, done, bits, jmax, s_keys, s_idx, local_base, wave_tot, whist);
+            done += bits;
+            if (p + 1 < passes) {
+#pragma unroll
+                for (int j = 0; j < IPT; ++j) {
+                    const int idx = w * chunk + j * 64 + lane;
+                    if (j < jmax) {
+                        key[j] = s_keys[idx];
+                        val[j] = s_idx[idx];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // records: lane <-> 8-byte word of the output range (fully coalesced stores; the loads hit the bucket's
+        // partitioned range, which the key loads above have just pulled through L2)
+        IBVH_STAMP(1, 3);
+        const uint64_t *__restrict__ src = (const uint64_t *)bucket;
+        uint64_t *__restrict__ dst = (uint64_t *)(fa.out + start * stride);
+        const uint32_t total = (uint32_t)m * fa.words;
+        constexpr int U = 8;
+        for (uint32_t g0 = threadIdx.x; g0 < total; g0 += TPB * U) {
+            uint64_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t g = g0 + u * TPB;
+                const uint32_t gc = g < total ? g : 0u;
+                const uint32_t r = __umulhi(gc, fa.inv_words);
+                const uint32_t part = gc - r * fa.words;
+                v[u] = src[(uint32_t)s_idx[r] * fa.words + part];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t g = g0 + u * TPB;
+                if (g < total) dst[g] = v[u];
+            }
+        }
+        IBVH_STAMP(1, 4);
+        return;
+    }
+
+    // ---- slow path: bucket larger than the LDS capacity; tiled LSD between the two (key, position) arrays ----
+    K *src_k = (K *)fa.kalt + start, *dst_k = (K *)fa.kpri + start;
+    uint32_t *src_v = fa.valt + start, *dst_v = fa.vpri + start;
+    for (int64_t i = threadIdx.x; i < m; i += TPB) {
+        src_k[i] = (K)load_morton(bucket + i * stride, fa.lay);
+        src_v[i] = (uint32_t)i;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int p = 0; p < passes; ++p) {
+        const int shift = RB * p;
+        const int bits = low_bits - shift < RB ? low_bits - shift : RB;
+        const uint32_t mask = (1u << bits) - 1u;
+        if (threadIdx.x < R) gbase[threadIdx.x] = 0;
+        __syncthreads();
+        for (int64_t i = threadIdx.x; i < m; i += TPB) atomicAdd(&gbase[(uint32_t)(src_k[i] >> shift) & mask], 1u);
+        __syncthreads();
+        lds_exclusive_scan<TPB>(gbase, R, wave_tot);
+        constexpr int SIPT = IPT / 2, SCAP = CAP / 2;
+        for (int64_t t0 = 0; t0 < m; t0 += SCAP) {
+            const int64_t cnt = m - t0 < SCAP ? m - t0 : SCAP;
+            K key[SIPT];
+            uint32_t val[SIPT];
+#pragma unroll
+            for (int j = 0; j < SIPT; ++j) {
+                const int idx = w * 64 * SIPT + j * 64 + lane;
+                const bool ok = idx < cnt;
+                key[j] = ok ? src_k[t0 + idx] : (K) ~(K)0;
+                val[j] = ok ? src_v[t0 + idx] : 0u;
+            }
+            uint32_t tot_d;
+            lds_radix_pass<K, uint32_t, TPB, SIPT, RB>(key, val, shift, bits, SIPT, s_keys, s_vals32, local_base, wave_tot, whist, &tot_d);
+            for (int pos = threadIdx.x; pos < cnt; pos += TPB) {
+                const K kk = s_keys[pos];
+                const uint32_t d = (uint32_t)(kk >> shift) & mask;
+                const uint32_t dest = gbase[d] + ((uint32_t)pos - local_base[d]);
+                dst_k[dest] = kk;
+                dst_v[dest] = s_vals32[pos];
+            }
+            __syncthreads();
+            // sentinels of a partial tile were counted in the last digit: real count there = cnt - local_base
+            if (threadIdx.x < R) {
+                uint32_t real = tot_d;
+                if ((int)threadIdx.x == (int)mask && cnt < SCAP) real = (uint32_t)cnt - local_base[mask];
+                gbase[threadIdx.x] += real;
+            }
+            __syncthreads();
+        }
+        // make this pass's global writes visible to the next pass's reads (same workgroup, other lanes)
+        __threadfence_block();
+        __syncthreads();
+        K *tk = src_k;
+        src_k = dst_k;
+        dst_k = tk;
+        uint32_t *tv = src_v;
+        src_v = dst_v;
+        dst_v = tv;
+    }
+    // `src_v` holds the bucket's positions in sorted order
+    const uint64_t *src = (const uint64_t *)bucket;
+    uint64_t *dst = (uint64_t *)(fa.out + start * stride);
+    const uint64_t total = (uint64_t)m * fa.words;
+    for (uint64_t g = threadIdx.x; g < total; g += TPB) {
+        const uint64_t r = g / fa.words;
+        const uint32_t part = (uint32_t)(g - r * fa.words);
+        dst[g] = src[(uint64_t)src_v[r] * fa.words + part];
+    }
+}
+template <class K, int TPB, int IPT> constexpr size_t finish_smem() {
+    return (size_t)TPB * IPT * (sizeof(K) + 2) + 2 * 256 * 4 + 64 + (size_t)(TPB / 64) * 256 * 2 + 64;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+struct Plan {
+    int bits;            // MSD digit width; 0: this path does not apply (tiny or huge input) -> ibvh_sort.hip
+    int shift;           // key_bits - bits: the digit is key >> shift
+    int ptpb, pipt;      // partition (and histogram) tile geometry
+    int num_tiles;
+    int ftpb, fipt;      // finish workgroup: threads, keys per thread (capacity = ftpb * fipt)
+    uint32_t *tile_hist;   // [num_tiles][2^bits]: counts
+    uint32_t *tile_scan;   // [num_tiles][2^bits]: exclusive prefix over the tiles
+    uint32_t *digit_total; // [2^bits]
+};
+
+static int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+Plan make_plan(int64_t n, int key_bits, int key_bytes, int leaf_bytes, void *sort_scratch) {
+    // tuning knobs (measurement only): IBVH_MSD=0 disables the path, IBVH_MSD_BITS / _CAP / _TILE force a geometry
+    static const int enabled = env_int("IBVH_MSD", 1);
+    static const int f_bits = env_int("IBVH_MSD_BITS", 0);
+    static const int f_cap = env_int("IBVH_MSD_CAP", 0);
+    static const int f_tile = env_int("IBVH_MSD_TILE", 0);
+    static const int f_avg = env_int("IBVH_MSD_AVG", 1024);
+    Plan p{};
+    if (!enabled || n < 4096 || key_bits <= 8) return p;
+    int bits = 6; // (>= 6: the scan kernel works on blocks of 64 digits)
+    while (bits < 11 && bits < key_bits - 1 && (n >> bits) > f_avg) ++bits;
+    if (f_bits) bits = f_bits;
+    if (bits > MSD_MAX_BITS) bits = MSD_MAX_BITS;
+    if (bits >= key_bits) bits = key_bits - 1;
+    if (bits < 6) return p;
+    const int64_t avg = n >> bits;
+    // capacity of the finish workgroup: the average bucket fills at most 5/8 of it (uniform clouds vary by a few
+    // per cent; denser-than-average regions get the rest of the headroom before the slow path takes over)
+    int cap = 2048;
+    while (cap < 16384 && avg * 8 > (int64_t)cap * 5) cap *= 2;
+    if (f_cap) cap = f_cap;
+    if (avg * 8 > (int64_t)cap * 5 && !f_cap) return p; // one partition level is not enough: LSD path
+    if (key_bytes == 8 && cap > 8192) {
+        if (avg * 8 > (int64_t)8192 * 5) return p;
+        cap = 8192; // 16384 x 12 B does not fit the LDS
+    }
+    // partition tile: its records are staged in LDS (tile * leaf_bytes + 2 tables of 2^bits words <= 160 KiB)
+    int tile = (n >= (int64_t(1) << 22) && leaf_bytes <= 32) ? 4096 : 2048;
+    if (f_tile) tile = f_tile;
+    if (tile < (1 << bits)) tile = 1 << bits; // scratch sizing: radix * num_tiles <= n + radix
+    while (tile > 1024 && (size_t)tile * leaf_bytes + ((size_t)8 << bits) + 128 > 160 * 1024) tile >>= 1;
+    if (tile < (1 << bits)) return p;
+    switch (tile) {
+    case 1024: p.ptpb = 256, p.pipt = 4; break;
+    case 2048: p.ptpb = 256, p.pipt = 8; break;
+    default: p.ptpb = 512, p.pipt = 8; break;
+    }
+    // finish workgroups are small (4 or 8 waves, many keys per thread): several buckets per CU at different phases
+    static const int f_ftpb = env_int("IBVH_MSD_FTPB", 0);
+    switch (cap) {
+    case 2048: p.ftpb = 256; break;
+    case 4096: p.ftpb = 256; break;
+    case 8192: p.ftpb = 512; break;
+    default: p.ftpb = 512; break;
+    }
+    if (f_ftpb) p.ftpb = f_ftpb;
+    p.fipt = cap / p.ftpb;
+    p.bits = bits;
+    p.shift = key_bits - bits;
+    p.num_tiles = (int)ceil_div(n, (int64_t)p.ptpb * p.pipt);
+    p.tile_hist = (uint32_t *)sort_scratch;
+    const int64_t hist_bytes = align_up(((int64_t)1 << bits) * p.num_tiles * 4, 256);
+    p.tile_scan = (uint32_t *)((char *)sort_scratch + hist_bytes);
+    p.digit_total = (uint32_t *)((char *)sort_scratch + 2 * hist_bytes);
+    return p;
+}
+
+// scratch for tile histograms + digit totals (tile >= radix, so radix * num_tiles <= n + radix)
+size_t scratch_bytes(int64_t n) {
+    return 2 * (size_t)align_up((n + (1 << MSD_MAX_BITS)) * 4, 256) + ((size_t)4 << MSD_MAX_BITS) + 512;
+}
+
+template <class K, int PT, int PI>
+static int launch_partition(const Plan &p, const K *keys, int64_t n, const RecordArgs &ra, hipStream_t st) {
+    const size_t smem = partition_smem<K, PT, PI>(p.bits, ra.lay.stride);
+    if (smem > 160 * 1024) return IBVH_ERR_INVALID_ARG; // (make_plan sizes the tile for the record)
+    IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)partition_kernel<K, PT, PI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    const uint32_t words = (uint32_t)ra.lay.stride / 8u;
+    IBVH_LAUNCH((partition_kernel<K, PT, PI>), dim3(p.num_tiles), dim3(PT), smem, st, keys, n, p.shift, p.bits, p.tile_scan,
+                p.digit_total, p.num_tiles, ra, (uint32_t)((((uint64_t)1 << 32) + words - 1) / words));
+    return IBVH_OK;
+}
+template <class K, int FT, int FI>
+static int launch_finish(const Plan &p, const FinishArgs &fa, hipStream_t st) {
+    constexpr size_t smem = finish_smem<K, FT, FI>();
+    IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)finish_kernel<K, FT, FI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    IBVH_LAUNCH((finish_kernel<K, FT, FI>), dim3(1u << p.bits), dim3(FT), smem, st, p.digit_total, p.shift, fa);
+    return IBVH_OK;
+}
+
+// keys: n Morton keys (uint32 / uint64) in source order, their top-digit tile histogram already in p.tile_hist.
+// ra: source -> partitioned records (ra.dst = scratch of n records); out: the sorted records.
+// (kalt, valt, kpri, vpri): n-entry scratch arrays for oversized buckets (kpri may alias `keys`: the keys are dead
+// once the partition has run).
+int sort_records(const Plan &p, int key_bytes, const void *keys, int64_t n, const RecordArgs &ra, char *out, void *kalt,
+                 uint32_t *valt, void *kpri, uint32_t *vpri, hipStream_t st) {
+    {
+        const int radix = 1 << p.bits, ndb = radix >> 6;
+        int chunks = 512 / ndb < 1 ? 1 : 512 / ndb; // ~512 workgroups
+        if (chunks > (p.num_tiles + 15) / 16) chunks = (p.num_tiles + 15) / 16;
+        const int rows = (p.num_tiles + chunks - 1) / chunks;
+        chunks = (p.num_tiles + rows - 1) / rows;
+        IBVH_LAUNCH((scan_tiles_kernel), dim3(ndb * chunks), dim3(SCAN_TPB), 0, st, p.tile_hist, p.tile_scan, p.num_tiles, radix, rows, p.digit_total);
+    }
+    int rc = IBVH_ERR_INVALID_ARG;
+#define IBVH_PART(K, T, I) \
+    if (p.ptpb == T && p.pipt == I) rc = launch_partition<K, T, I>(p, (const K *)keys, n, ra, st);
+    if (key_bytes == 4) {
+        IBVH_PART(uint32_t, 256, 4) IBVH_PART(uint32_t, 256, 8) IBVH_PART(uint32_t, 512, 8)
+    } else {
+        IBVH_PART(uint64_t, 256, 4) IBVH_PART(uint64_t, 256, 8) IBVH_PART(uint64_t, 512, 8)
+    }
+#undef IBVH_PART
+    if (rc) return rc;
+    FinishArgs fa{};
+    fa.part = ra.dst;
+    fa.out = out;
+    fa.lay = ra.lay;
+    fa.words = (uint32_t)ra.lay.stride / 8u;
+    fa.inv_words = (uint32_t)((((uint64_t)1 << 32) + fa.words - 1) / fa.words);
+    fa.kalt = kalt;
+    fa.kpri = kpri;
+    fa.valt = valt;
+    fa.vpri = vpri;
+    rc = IBVH_ERR_INVALID_ARG;
+#define IBVH_FIN(K, T, I) \
+    if (p.ftpb == T && p.fipt == I) rc = launch_finish<K, T, I>(p, fa, st);
+    if (key_bytes == 4) {
+        IBVH_FIN(uint32_t, 256, 8) IBVH_FIN(uint32_t, 256, 16) IBVH_FIN(uint32_t, 256, 32) IBVH_FIN(uint32_t, 512, 8)
+        IBVH_FIN(uint32_t, 512, 16) IBVH_FIN(uint32_t, 512, 32) IBVH_FIN(uint32_t, 1024, 8) IBVH_FIN(uint32_t, 1024, 16)
+    } else {
+        IBVH_FIN(uint64_t, 256, 8) IBVH_FIN(uint64_t, 256, 16) IBVH_FIN(uint64_t, 256, 32) IBVH_FIN(uint64_t, 512, 8)
+        IBVH_FIN(uint64_t, 512, 16) IBVH_FIN(uint64_t, 1024, 8)
+    }
+#undef IBVH_FIN
+    if (rc) return rc;
+    IBVH_LAUNCH_CHECK();
+    return IBVH_OK;
+}
+
+} // namespace msd
+} // namespace ibvh
+
+#ifdef IBVH_PHASE_STAMPS
+extern "C" int ibvh_debug_stamps(unsigned long long *out /* 2 * 12 * 4096 */) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ibvh::msd::g_stamps), sizeof(ibvh::msd::g_stamps));
+}
+#endif

@@ -15,34 +15,13 @@
 #include <cstdlib>
 
 #include "ibvh_common.hpp"
+#include "ibvh_radix.hpp"
 
 namespace ibvh {
 namespace rsort {
 
 constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;
-
-template <int TPB> IBVH_D uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_tot /* TPB/64 */, uint32_t *total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += t;
-    }
-    if (lane == 63) wave_tot[w] = inc;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-#pragma unroll
-    for (int i = 0; i < TPB / 64; ++i) {
-        uint32_t t = wave_tot[i];
-        if (i < w) base += t;
-        tot += t;
-    }
-    if (total) *total = tot;
-    __syncthreads();
-    return base + inc - v;
-}
 
 // ---- hist ---------------------------------------------------------------------------------
 template <class K, int TPB, int IPT>
@@ -76,41 +55,11 @@ __global__ __launch_bounds__(TPB) void hist_kernel(const K *__restrict__ keys, i
     }
 }
 
-// ---- scan ---------------------------------------------------------------------------------
-// grid = RADIX workgroups; workgroup d turns row d of tile_hist into its exclusive prefix over
-// tiles and writes the row sum to digit_total[d].
-template <int TPB>
-__global__ __launch_bounds__(TPB) void scan_kernel(uint32_t *__restrict__ tile_hist, int num_tiles,
-                                                   uint32_t *__restrict__ digit_total) {
-    __shared__ uint32_t wave_tot[TPB / 64];
-    uint32_t *row = tile_hist + (int64_t)blockIdx.x * num_tiles;
-    uint32_t carry = 0;
-    for (int base = 0; base < num_tiles; base += TPB) {
-        int i = base + threadIdx.x;
-        uint32_t v = i < num_tiles ? row[i] : 0u;
-        uint32_t tot;
-        uint32_t ex = block_exclusive_scan<TPB>(v, wave_tot, &tot);
-        if (i < num_tiles) row[i] = carry + ex;
-        carry += tot;
-    }
-    if (threadIdx.x == 0) digit_total[blockIdx.x] = carry;
-}
-
 // ---- scatter ------------------------------------------------------------------------------
 // RECORDS = true (last pass of a BVH build): instead of writing (key, position) and gathering later, the
 // pass fetches the source volume at `position` and writes the finished BoundingVolume record straight to
 // its sorted place — the separate gather kernel and one (key, position) round trip through HBM disappear.
 // Type-generic at run time (volumes move as 8-byte words), so no extra template axis.
-struct RecordArgs {
-    const char *src;      // raw volumes or BoundingVolume records
-    char *dst;            // sorted BoundingVolume records
-    int64_t src_stride;
-    int32_t src_wrapped;  // 1: keep the source record's .index, 0: index = position + 1
-    int32_t vol_words;    // sizeof(V) / 8
-    int32_t index_bytes;  // 4 or 8
-    LeafLayout lay;
-};
-
 // Occupancy the LDS budget allows, pinned so that co-compiled instantiations cannot push the VGPR count over a
 // waves-per-SIMD step (observed: 128 -> 132 VGPRs, 4 -> 3 waves/SIMD, scatter 48 -> 66 us at 1e7 keys).
 constexpr int scatter_min_waves(int tpb, int ipt, int key_bytes) {
@@ -252,47 +201,6 @@ __global__ __launch_bounds__(TPB, scatter_min_waves(TPB, IPT, sizeof(K))) void s
 // =============================================================================================
 constexpr int MSD_MAX_BITS = 11;
 
-// wave64 "match" ranking of IPT keys per lane on a digit of `bits` bits: rank[j] = number of keys of
-// the same digit that precede key j in (j, lane) order within this wave, counted through my_hist
-template <class K, int IPT>
-IBVH_D void wave_rank(const K (&key)[IPT], int shift, uint32_t mask, int bits, uint16_t *my_hist, int lane,
-                      uint16_t (&rank)[IPT], int jmax = IPT) {
-    const uint64_t lt_mask = ((uint64_t)1 << lane) - 1;
-#pragma unroll
-    for (int j = 0; j < IPT; ++j) {
-        if (j >= jmax) break; // (wave-uniform) rows beyond the wave's share hold nothing
-        const uint32_t d = (uint32_t)(key[j] >> shift) & mask;
-        uint64_t peers = ~(uint64_t)0;
-        for (int b = 0; b < bits; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t bal = __ballot(bit);
-            peers &= bit ? bal : ~bal;
-        }
-        const uint32_t prev = my_hist[d];
-        rank[j] = (uint16_t)(prev + (uint32_t)__popcll(peers & lt_mask));
-        if ((peers & lt_mask) == 0) my_hist[d] = (uint16_t)(prev + (uint32_t)__popcll(peers));
-    }
-}
-
-// in-place exclusive scan of an LDS array of `count` (<= 2048) values by the whole workgroup; returns the total
-template <int TPB> IBVH_D uint32_t lds_exclusive_scan(uint32_t *arr, int count, uint32_t *wave_tot) {
-    const int per = (count + TPB - 1) / TPB;
-    const int lo = threadIdx.x * per;
-    uint32_t sum = 0;
-    for (int k = 0; k < per; ++k)
-        if (lo + k < count) sum += arr[lo + k];
-    uint32_t total;
-    uint32_t run = block_exclusive_scan<TPB>(sum, wave_tot, &total);
-    for (int k = 0; k < per; ++k)
-        if (lo + k < count) {
-            const uint32_t v = arr[lo + k];
-            arr[lo + k] = run;
-            run += v;
-        }
-    __syncthreads();
-    return total;
-}
-
 // per-tile histogram of a digit of up to MSD_MAX_BITS bits (the build fuses this into the key encoder)
 template <class K, int TPB, int IPT>
 __global__ __launch_bounds__(TPB) void hist_wide_kernel(const K *__restrict__ keys, int64_t n, int shift, int bits,
@@ -391,21 +299,6 @@ __global__ __launch_bounds__(TPB) void scatter_wide_kernel(const K *__restrict__
 }
 template <class K, int TPB, int IPT> inline size_t scatter_wide_smem(int bits) {
     return (size_t)TPB * IPT * (sizeof(K) + 4) + ((size_t)2 << bits) * 4 + 64 + (size_t)(TPB / 64) * ((size_t)1 << bits) * 2 + 64;
-}
-
-IBVH_D void write_record(const RecordArgs &rec, uint32_t p, uint64_t dest, uint64_t key) {
-    const char *sp = rec.src + (int64_t)p * rec.src_stride;
-    char *dp = rec.dst + (int64_t)dest * rec.lay.stride;
-    const uint64_t *sw = (const uint64_t *)sp;
-    uint64_t *dw = (uint64_t *)dp;
-#pragma unroll
-    for (int wd = 0; wd < 6; ++wd)
-        if (wd < rec.vol_words) dw[wd] = sw[wd];
-    if (rec.index_bytes == 4)
-        *(int32_t *)(dp + rec.lay.index_off) = rec.src_wrapped ? *(const int32_t *)(sp + rec.lay.index_off) : (int32_t)(p + 1u);
-    else
-        *(int64_t *)(dp + rec.lay.index_off) = rec.src_wrapped ? *(const int64_t *)(sp + rec.lay.index_off) : (int64_t)p + 1;
-    store_morton(dp, rec.lay, key);
 }
 
 // one workgroup per bucket: sort the bucket's pairs on the low `low_bits` bits and write them out

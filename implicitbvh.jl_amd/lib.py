@@ -10,7 +10,8 @@ import os
 from . import abi
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libibvh.so")
+# IBVH_LIB: load another build of the same library (diagnostic builds, tools/phase_stamps.sh); default: the in-tree one
+LIB_PATH = os.environ.get("IBVH_LIB") or os.path.join(_PKG, "libibvh.so")
 
 _vp, _i64, _i32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_size_t
 _P = C.POINTER
