@@ -7,10 +7,12 @@ on `--n` BSphere{Float32} leaves (default 1e6: BASELINE.json configs[1]), UInt32
 indices.  Protocol follows the reference's benchmark scripts (benchmark/bvh_build.jl:38-45,
 bvh_contact.jl:40-45): warm-up, then timed repetitions on resident data with buffer reuse.
 
-N > 1 (launched by torch.distributed.run): the leaves are sharded over the ranks; the build's
-global centre AABB is an RCCL all-reduce and the Morton sort a distributed radix-sort exchange
-(implicitbvh_amd.dist); each rank then builds and self-traverses its slice.  Weak scaling: --n is the
-per-GPU leaf count, value = all ranks' leaves / max-over-ranks time.
+N > 1: one process per GPU (launched by torch.distributed.run, or — `python bench.py --gpus N` with no
+WORLD_SIZE in the environment — started by this script itself before anything touches a GPU): the leaves
+are sharded over the ranks; the build's global centre AABB is an RCCL all-reduce and the Morton sort a
+distributed radix-sort exchange (implicitbvh_amd.dist); each rank then builds and self-traverses its slice
+(BASELINE.json configs[4]: 1e8 leaves over 8 GPUs = 12.5 M leaves per GPU, the default for N > 1).  Weak
+scaling: --n is the per-GPU leaf count, value = all ranks' leaves / max-over-ranks time.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed inside the library)
 and `cpu_baseline` (the CPU oracle's multi-threaded restatement, timed on this box's host cores).
@@ -99,12 +101,51 @@ def collect_profile(lib):
     return out
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (children of a parent that never
+    touches a GPU), wait for them, pass rank 0's JSON line through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    # wait for all ranks; a rank that dies takes the others with it (they would wait for it until the RCCL timeout)
+    import threading
+    import time as _time
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()  # our own children, by handle
+            break
+        _time.sleep(0.05)
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    sys.stdout.write("".join(c for c in chunks if c))
+    sys.stdout.flush()
+    raise SystemExit(1 if failed else max(abs(rc) for rc in rcs))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1_000_000, help="leaves per GPU")
+    ap.add_argument("--n", type=int, default=0,
+                    help="leaves per GPU (default: 1e6 at one GPU = BASELINE.json configs[1]; 12.5e6 at N > 1 = configs[4], "
+                         "1e8 leaves over 8 GPUs)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="use the multi-GPU build path even with one rank")
@@ -112,6 +153,8 @@ def main():
                     help="also report the north-star size (1e7 leaves) at N=1; 0 disables")
     ap.add_argument("--cpu-n", type=int, default=0, help="leaves of the CPU baseline sample (0 = same as --n, capped)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)  # (does not return)
 
     import numpy as np
     import torch
@@ -134,7 +177,9 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=300))
     lib.load()
 
-    n = args.n
+    if world != max(args.gpus, 1) and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); running with {world}", file=sys.stderr)
+    n = args.n or (1_000_000 if world == 1 else 12_500_000)
     n_global = n * world
     # SURVEY.md §8(d) config 2 law: r = r0*(0.5+0.5u), r0 = 0.5*(3k/(4 pi N))^(1/3), k = 8 -> ~1.8 contacts / leaf
     r0 = 0.5 * (3 * 8 / (4 * math.pi * n_global)) ** (1 / 3)
@@ -315,7 +360,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n} random BSphere{{Float32}} leaves per GPU, BBox{{Float32}} nodes, UInt32 Morton, "
-                                   f"Int32 index, build + LVT self-traverse (BASELINE.json configs[1])",
+                                   f"Int32 index, build + LVT self-traverse "
+                                   + ("(BASELINE.json configs[1])" if world == 1 and n == 1_000_000 else
+                                      f"(BASELINE.json configs[4] law: {n_global} leaves sharded over {world} GPU(s), distributed "
+                                      f"Morton + radix-sort exchange, global-AABB RCCL all-reduce, per-GPU self-traverse)"
+                                      if dist is not None else "(configs[1] law at another size)"),
                        "leaves_per_gpu": n, "leaves_total": leaves_total, "contacts_total": contacts_total,
                        "parallelism": "single GPU" if world == 1 else f"leaves sharded over {world} GPUs (RCCL build), per-GPU traversal"},
             "mcontacts_per_s": round(contacts_total * args.steps / elapsed / 1e6, 3),

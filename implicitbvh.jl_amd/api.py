@@ -442,7 +442,7 @@ class BVHTraversal:
         self._cache1 = cache1
         self.cache2 = cache2
         self._scratch = _scratch
-        self._pending = _pending  # (total: 1-element device tensor, capacity, finish(total) -> contacts tensor)
+        self._pending = _pending  # (total: _PendingTotal, capacity, finish(total) -> contacts tensor)
         self._donated = False
 
     def _resolve(self):
@@ -524,53 +524,57 @@ def _speculative_buffer(cache, idt):
 
 
 class _LvtScratch:
-    """The LVT scratch buffer of a chain of traversals that hand each other their buffers through `cache=`.
+    """The LVT scratch buffer of a chain of traversals that hand each other their buffers through `cache=`, plus a ring
+    of device-side totals.
 
-    The library keeps the total contact count in the first 8 bytes of the scratch it is given.  A traversal that was
-    enqueued without a host read (`*_enqueue`) fetches that total later, possibly after the next traversal has already
-    reused the buffer, so every call gets its OWN 64-byte header: the buffer carries a 4 KiB prefix of 64 header slots and
-    call k hands the library `base + 64 * (k mod 64)` as its scratch pointer (count and write of one traversal use the
-    same pointer, which is all the layout requires).  No copy of the total is needed, and a traversal's header survives
-    the next 63 calls on the same buffer."""
-    SLOTS, SLOT_BYTES = 64, 64
+    A traversal that was enqueued without a host read (`*_enqueue`) fetches its total contact count later, possibly
+    after later traversals have reused — and rewritten — the scratch buffer (header, tile sums and contact cache
+    alike).  So the totals do NOT live in the scratch: every call hands the library its own int64 word of a separate
+    64-entry ring (`total_dev` of include/ibvh.h), which nothing else writes until the ring wraps, 64 calls later; a
+    total that was never read by then raises instead of returning another call's number.  An event recorded on the
+    launch stream orders the late read against the launch even when the current stream has changed."""
+    SLOTS = 64
 
     def __init__(self, nbytes):
-        self.buf = _torch().empty(nbytes + self.SLOTS * self.SLOT_BYTES, dtype=_torch().uint8, device="cuda")
+        torch = _torch()
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        self.totals = torch.zeros(self.SLOTS, dtype=torch.int64, device="cuda")
         self.calls = 0
-        self.slot = 0
 
     def capacity(self):
-        return self.buf.numel() - self.SLOTS * self.SLOT_BYTES
+        return self.buf.numel()
 
-    def next_call(self):
-        self.slot = self.calls % self.SLOTS
-        self.calls += 1
-        return self
-
-    # what _ptr() and the call sites use: the pointer / size handed to the library for the CURRENT call
     def data_ptr(self):
-        return self.buf.data_ptr() + self.slot * self.SLOT_BYTES
+        return self.buf.data_ptr()
 
     def numel(self):
-        return self.capacity()
+        return self.buf.numel()
 
-    def header(self):
-        """(view of this call's header words [total, -, -], token to detect that the slot was recycled)"""
-        off = self.slot * self.SLOT_BYTES
-        return self.buf[off:off + 8].view(_torch().int64), (self, self.slot, self.calls)
+    def next_total(self):
+        """(device pointer of this call's total word, handle to read it later)"""
+        slot = self.calls % self.SLOTS
+        self.calls += 1
+        return C.c_void_p(self.totals.data_ptr() + 8 * slot), _PendingTotal(self, slot, self.calls)
 
 
-def _keep_total(scratch):
-    """The device-side total of the call just enqueued on `scratch` (no copy: the call owns its header slot)."""
-    view, (owner, slot, calls) = scratch.header()
+class _PendingTotal:
+    def __init__(self, owner, slot, calls):
+        self.owner, self.slot, self.calls = owner, slot, calls
+        self.event = None
 
-    class _Total:
-        def item(self_inner):
-            if owner.calls - calls >= owner.SLOTS:
-                raise RuntimeError("this traversal's contact count was never read and its scratch header has been recycled "
-                                   f"by {owner.SLOTS} later traversals on the same cache")
-            return view.item()
-    return _Total()
+    def launched(self):
+        torch = _torch()
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream())
+        return self
+
+    def item(self):
+        if self.owner.calls - self.calls >= self.owner.SLOTS:
+            raise RuntimeError("this traversal's contact count was never read and its slot in the totals ring has been "
+                               f"recycled by {self.owner.SLOTS} later traversals on the same cache")
+        if self.event is not None:
+            self.event.synchronize()
+        return int(self.owner.totals[self.slot].item())
 
 
 def _cache_slots(cache, n_items, default):
@@ -595,7 +599,7 @@ def _lvt_scratch(cache, types, n_items, slots=None):
     s = cache._scratch if cache is not None else None
     if not isinstance(s, _LvtScratch) or s.capacity() < need.value:
         s = _LvtScratch(need.value)
-    return s.next_call()
+    return s
 
 
 def _traverse_lvt_single(bvh, start_level, narrow, cache):
@@ -609,19 +613,21 @@ def _traverse_lvt_single(bvh, start_level, narrow, cache):
     n = len(bvh.leaves)
     counts = _cache_tensor(cache.cache2 if cache else None, n, 0, idt, "cache2")
     scratch = _lvt_scratch(cache, bvh.types, n)
-    sp, sn = _ptr(scratch), scratch.numel()  # frozen now: the object hands out a new header slot per call
+    sp, sn = _ptr(scratch), scratch.numel()
     s = bvh.struct()
     spec = _speculative_buffer(cache, idt)
     if spec is not None:
+        tdev, pending = scratch.next_total()
         lib.call("ibvh_traverse_lvt_enqueue", C.byref(s), start_level, narrow, _ptr(counts), _ptr(spec), spec.shape[0],
-                 sp, sn, _stream())
+                 tdev, sp, sn, _stream())
+        pending.launched()
 
         def finish(total):
             contacts = torch.empty((total, 2), dtype=idt, device="cuda")
             lib.call("ibvh_traverse_lvt_write", C.byref(s), start_level, narrow, _ptr(counts), _ptr(contacts), sp,
                      sn, _stream())
             return contacts
-        return BVHTraversal(start_level, 0, 0, None, spec, counts, scratch, _pending=(_keep_total(scratch), spec.shape[0], finish))
+        return BVHTraversal(start_level, 0, 0, None, spec, counts, scratch, _pending=(pending, spec.shape[0], finish))
     total = C.c_int64()
     lib.call("ibvh_traverse_lvt_count", C.byref(s), start_level, narrow, _ptr(counts), C.byref(total), sp,
              sn, _stream())
@@ -643,19 +649,21 @@ def _traverse_lvt_pair(bvh1, bvh2, sl1, sl2, narrow, cache):
     n = max(len(bvh1.leaves), len(bvh2.leaves))
     counts = _cache_tensor(cache.cache2 if cache else None, n, 0, idt, "cache2")
     scratch = _lvt_scratch(cache, bvh1.types, n)
-    sp, sn = _ptr(scratch), scratch.numel()  # frozen now: the object hands out a new header slot per call
+    sp, sn = _ptr(scratch), scratch.numel()
     s1, s2 = bvh1.struct(), bvh2.struct()
     spec = _speculative_buffer(cache, idt)
     if spec is not None:
+        tdev, pending = scratch.next_total()
         lib.call("ibvh_traverse_pair_lvt_enqueue", C.byref(s1), C.byref(s2), sl1, sl2, narrow, _ptr(counts), _ptr(spec),
-                 spec.shape[0], sp, sn, _stream())
+                 spec.shape[0], tdev, sp, sn, _stream())
+        pending.launched()
 
         def finish(total):
             contacts = torch.empty((total, 2), dtype=idt, device="cuda")
             lib.call("ibvh_traverse_pair_lvt_write", C.byref(s1), C.byref(s2), sl1, sl2, narrow, _ptr(counts), _ptr(contacts),
                      sp, sn, _stream())
             return contacts
-        return BVHTraversal(sl1, sl2, 0, None, spec, counts, scratch, _pending=(_keep_total(scratch), spec.shape[0], finish))
+        return BVHTraversal(sl1, sl2, 0, None, spec, counts, scratch, _pending=(pending, spec.shape[0], finish))
     total = C.c_int64()
     lib.call("ibvh_traverse_pair_lvt_count", C.byref(s1), C.byref(s2), sl1, sl2, narrow, _ptr(counts), C.byref(total),
              sp, sn, _stream())
@@ -776,11 +784,13 @@ def traverse_rays(bvh, points, directions, alg=None, start_level=1, narrow=None,
     if lvt:
         counts = _cache_tensor(cache.cache2 if cache else None, nr, 0, idt, "cache2")
         scratch = _lvt_scratch(cache, bvh.types, nr, slots=RAY_CACHE_SLOTS)
-        sp, sn = _ptr(scratch), scratch.numel()  # frozen now: the object hands out a new header slot per call
+        sp, sn = _ptr(scratch), scratch.numel()
         spec = _speculative_buffer(cache, idt)
         if spec is not None:
+            tdev, pending = scratch.next_total()
             lib.call("ibvh_traverse_rays_lvt_enqueue", C.byref(s), _ptr(p), _ptr(d), nr, start_level, _ptr(counts), _ptr(spec),
-                     spec.shape[0], sp, sn, _stream())
+                     spec.shape[0], tdev, sp, sn, _stream())
+            pending.launched()
 
             def finish(total):
                 contacts = torch.empty((total, 2), dtype=idt, device="cuda")
@@ -788,7 +798,7 @@ def traverse_rays(bvh, points, directions, alg=None, start_level=1, narrow=None,
                          _ptr(contacts), sp, sn, _stream())
                 return contacts
             return BVHTraversal(start_level, 0, 0, None, spec, counts, scratch,
-                                _pending=(_keep_total(scratch), spec.shape[0], finish))
+                                _pending=(pending, spec.shape[0], finish))
         total = C.c_int64()
         lib.call("ibvh_traverse_rays_lvt_count", C.byref(s), _ptr(p), _ptr(d), nr, start_level, _ptr(counts),
                  C.byref(total), sp, sn, _stream())

@@ -1002,10 +1002,10 @@ inline int cache_slots_for(size_t scratch_bytes, int64_t n_items, int64_t pair_b
 }
 
 // inclusive scan in place + (total_out != nullptr) blocking read of the total (the reference's @allowscalar, :60)
-template <class I> int scan_counts(I *counts, int64_t n, int64_t *total_out, void *scratch, hipStream_t st) {
+template <class I> int scan_counts(I *counts, int64_t n, int64_t *total_out, void *scratch, hipStream_t st, int64_t *total_dev = nullptr) {
     int64_t nparts = ceil_div(n, SCAN_TILE);
-    int64_t *totals = (int64_t *)scratch;
-    int64_t *partials = totals + 8;
+    int64_t *totals = total_dev ? total_dev : (int64_t *)scratch; // where the device-side total goes
+    int64_t *partials = (int64_t *)scratch + 8;
     IBVH_LAUNCH((scan_reduce_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, partials);
     IBVH_LAUNCH((scan_apply_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, partials, totals);
     IBVH_LAUNCH_CHECK();
@@ -1097,7 +1097,7 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
 template <int MODE>
 int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const void *dirs, int64_t n_items,
         int64_t start_level, int32_t narrow, int32_t flip, void *counts, int64_t *total_out, void *contacts, void *scratch,
-        size_t scratch_bytes, hipStream_t st, bool enqueue = false, int64_t capacity = 0) {
+        size_t scratch_bytes, hipStream_t st, bool enqueue = false, int64_t capacity = 0, int64_t *total_dev = nullptr) {
     // three shapes: count (contacts == nullptr), write (contacts, !enqueue), enqueue = count + scan + guarded write
     const bool write = contacts != nullptr && !enqueue;
     ibvh_layout lay;
@@ -1141,9 +1141,9 @@ int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const voi
                 PairCache<I> cache{K ? (IndexPair<I> *)((char *)scratch + scan_scratch_bytes(n_items)) : nullptr, K};
                 if (int e = launch<L, N, I, MODE>(a, cache, write, st)) return e;
                 if (write) return (int)IBVH_OK;
-                if (int e = scan_counts<I>((I *)counts, n_items, enqueue ? nullptr : total_out, scratch, st)) return e;
+                if (int e = scan_counts<I>((I *)counts, n_items, enqueue ? nullptr : total_out, scratch, st, enqueue ? total_dev : nullptr)) return e;
                 if (enqueue && capacity > 0) {
-                    a.guard_total = (const int64_t *)scratch; // header [0]: total contacts
+                    a.guard_total = total_dev ? (const int64_t *)total_dev : (const int64_t *)scratch; // the total contacts
                     a.guard_capacity = sizeof(I) == 4 && capacity > (int64_t)INT32_MAX ? (int64_t)INT32_MAX : capacity;
                     return launch<L, N, I, MODE>(a, cache, true, st);
                 }
@@ -1200,17 +1200,18 @@ ibvh_status ibvh_traverse_lvt_write(const ibvh_bvh *bvh, int64_t start_level, in
 // fits `capacity` pairs.  The total stays in the scratch header: read it with ibvh_lvt_total whenever convenient;
 // if it exceeds `capacity`, call ibvh_traverse_lvt_write with a larger buffer (counts and scratch are ready for it).
 ibvh_status ibvh_traverse_lvt_enqueue(const ibvh_bvh *bvh, int64_t start_level, int32_t narrow, void *counts, void *contacts,
-                                      int64_t capacity, void *scratch, size_t scratch_bytes, void *stream) {
+                                      int64_t capacity, void *total_dev, void *scratch, size_t scratch_bytes, void *stream) {
     if (!bvh || capacity < 0) return IBVH_ERR_INVALID_ARG;
     if (int e = check_levels(*bvh, start_level)) return (ibvh_status)e;
     if (!scratch || scratch_bytes < scan_scratch_bytes(bvh->tree.real_leaves)) return IBVH_ERR_SCRATCH;
     if (bvh->tree.real_nodes <= 1) { // traverse_single.jl:17-21: no contacts
-        if (hipMemsetAsync(scratch, 0, 8, (hipStream_t)stream) != hipSuccess) return IBVH_ERR_HIP;
+        if (hipMemsetAsync(total_dev ? total_dev : scratch, 0, 8, (hipStream_t)stream) != hipSuccess) return IBVH_ERR_HIP;
         return IBVH_OK;
     }
     if (!counts || (capacity > 0 && !contacts)) return IBVH_ERR_INVALID_ARG;
     return (ibvh_status)run<MODE_SELF>(bvh, bvh, nullptr, nullptr, bvh->tree.real_leaves, start_level, narrow, 0, counts,
-                                       nullptr, contacts, scratch, scratch_bytes, (hipStream_t)stream, true, capacity);
+                                       nullptr, contacts, scratch, scratch_bytes, (hipStream_t)stream, true, capacity,
+                                       (int64_t *)total_dev);
 }
 // blocking read of the total contact count a *_count / *_enqueue call left in the scratch header
 ibvh_status ibvh_lvt_total(const void *scratch, int64_t *total_out, void *stream) {
@@ -1223,7 +1224,7 @@ ibvh_status ibvh_lvt_total(const void *scratch, int64_t *total_out, void *stream
 // traverse(bvh1, bvh2, LVTTraversal()) — lvt/traverse_pair.jl:1-116
 static ibvh_status pair_common(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, int64_t sl1, int64_t sl2, int32_t narrow,
                                void *counts, int64_t *total_out, void *contacts, void *scratch, size_t scratch_bytes,
-                               void *stream, bool enqueue = false, int64_t capacity = 0) {
+                               void *stream, bool enqueue = false, int64_t capacity = 0, void *total_dev = nullptr) {
     if (!bvh1 || !bvh2) return IBVH_ERR_INVALID_ARG;
     if (int e = check_levels(*bvh1, sl1)) return (ibvh_status)e;
     if (int e = check_levels(*bvh2, sl2)) return (ibvh_status)e;
@@ -1234,7 +1235,7 @@ static ibvh_status pair_common(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, int64
     const ibvh_bvh *drv = flip ? bvh2 : bvh1, *oth = flip ? bvh1 : bvh2;
     return (ibvh_status)run<MODE_PAIR>(drv, oth, nullptr, nullptr, drv->tree.real_leaves, flip ? sl1 : sl2, narrow,
                                        flip ? 1 : 0, counts, total_out, contacts, scratch, scratch_bytes,
-                                       (hipStream_t)stream, enqueue, capacity);
+                                       (hipStream_t)stream, enqueue, capacity, (int64_t *)total_dev);
 }
 ibvh_status ibvh_traverse_pair_lvt_count(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, int64_t sl1, int64_t sl2,
                                          int32_t narrow, void *counts, int64_t *total_out, void *scratch,
@@ -1252,26 +1253,28 @@ ibvh_status ibvh_traverse_pair_lvt_write(const ibvh_bvh *bvh1, const ibvh_bvh *b
 }
 
 ibvh_status ibvh_traverse_pair_lvt_enqueue(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, int64_t sl1, int64_t sl2,
-                                           int32_t narrow, void *counts, void *contacts, int64_t capacity, void *scratch,
-                                           size_t scratch_bytes, void *stream) {
+                                           int32_t narrow, void *counts, void *contacts, int64_t capacity, void *total_dev,
+                                           void *scratch, size_t scratch_bytes, void *stream) {
     if (!scratch || capacity < 0 || (capacity > 0 && !contacts)) return IBVH_ERR_INVALID_ARG;
-    return pair_common(bvh1, bvh2, sl1, sl2, narrow, counts, nullptr, contacts, scratch, scratch_bytes, stream, true, capacity);
+    return pair_common(bvh1, bvh2, sl1, sl2, narrow, counts, nullptr, contacts, scratch, scratch_bytes, stream, true, capacity,
+                       total_dev);
 }
 
 // traverse_rays(bvh, points, directions, LVTTraversal()) — raytrace/leaf_vs_tree/leaf_vs_tree.jl:1-90
 static ibvh_status rays_common(const ibvh_bvh *bvh, const void *points, const void *dirs, int64_t num_rays, int64_t sl,
                                void *counts, int64_t *total_out, void *contacts, void *scratch, size_t scratch_bytes,
-                               void *stream, bool enqueue = false, int64_t capacity = 0) {
+                               void *stream, bool enqueue = false, int64_t capacity = 0, void *total_dev = nullptr) {
     if (!bvh || num_rays < 0) return IBVH_ERR_INVALID_ARG;
     if (int e = check_levels(*bvh, sl)) return (ibvh_status)e;
     if (bvh->types.leaf_float != bvh->types.node_float) return IBVH_ERR_UNSUPPORTED;
     if (num_rays == 0) { // :22-26
-        if (enqueue && scratch && hipMemsetAsync(scratch, 0, 8, (hipStream_t)stream) != hipSuccess) return IBVH_ERR_HIP;
+        if (enqueue && (total_dev || scratch) && hipMemsetAsync(total_dev ? total_dev : scratch, 0, 8, (hipStream_t)stream) != hipSuccess)
+            return IBVH_ERR_HIP;
         return IBVH_OK;
     }
     if (!points || !dirs || !counts) return IBVH_ERR_INVALID_ARG;
     return (ibvh_status)run<MODE_RAYS>(nullptr, bvh, points, dirs, num_rays, sl, 0, 0, counts, total_out, contacts,
-                                       scratch, scratch_bytes, (hipStream_t)stream, enqueue, capacity);
+                                       scratch, scratch_bytes, (hipStream_t)stream, enqueue, capacity, (int64_t *)total_dev);
 }
 ibvh_status ibvh_traverse_rays_lvt_count(const ibvh_bvh *bvh, const void *points, const void *dirs, int64_t num_rays,
                                          int64_t sl, void *counts, int64_t *total_out, void *scratch,
@@ -1289,10 +1292,11 @@ ibvh_status ibvh_traverse_rays_lvt_write(const ibvh_bvh *bvh, const void *points
     return rays_common(bvh, points, dirs, num_rays, sl, (void *)counts, &dummy, contacts, scratch, scratch_bytes, stream);
 }
 ibvh_status ibvh_traverse_rays_lvt_enqueue(const ibvh_bvh *bvh, const void *points, const void *dirs, int64_t num_rays,
-                                           int64_t sl, void *counts, void *contacts, int64_t capacity, void *scratch,
-                                           size_t scratch_bytes, void *stream) {
+                                           int64_t sl, void *counts, void *contacts, int64_t capacity, void *total_dev,
+                                           void *scratch, size_t scratch_bytes, void *stream) {
     if (!scratch || capacity < 0 || (capacity > 0 && !contacts)) return IBVH_ERR_INVALID_ARG;
-    return rays_common(bvh, points, dirs, num_rays, sl, counts, nullptr, contacts, scratch, scratch_bytes, stream, true, capacity);
+    return rays_common(bvh, points, dirs, num_rays, sl, counts, nullptr, contacts, scratch, scratch_bytes, stream, true, capacity,
+                       total_dev);
 }
 
 } // extern "C"

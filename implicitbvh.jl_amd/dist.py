@@ -388,8 +388,19 @@ class DistributedBuilder:
         else:
             recv = records
         n_recv = int(sum(recv_counts))
-        if n_recv < 1:
-            raise abi.DomainError("a rank received no leaves (degenerate key distribution)")
+        # A rank left without leaves (all its keys' neighbours are duplicates of one splitter key, or the cloud is
+        # heavily clustered) cannot build a tree.  EVERY rank must learn that and raise together: a rank that
+        # carried on alone would hang in the next collective until the RCCL timeout.
+        if send_matrix is not None:
+            min_recv = int(send_matrix.sum(axis=0).min())
+        elif comm.size > 1:
+            flag = eng.tensor([n_recv], torch.int64)
+            comm.all_reduce(flag, "min")
+            min_recv = int(eng.to_host(flag)[0])
+        else:
+            min_recv = n_recv
+        if min_recv < 1:
+            raise abi.DomainError("a rank received no leaves (degenerate key distribution): every rank stops here")
         self.last = {"splitters": splitters, "send_counts": send_counts, "recv_counts": recv_counts, "base": base,
                      "n_global": n_global, "extrema": ext_host}
         # 4. local build over the received slice

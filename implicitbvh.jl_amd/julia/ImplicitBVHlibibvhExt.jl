@@ -6,13 +6,24 @@
 #   [extensions] ImplicitBVHlibibvhExt = "AMDGPU"
 # and ENV["LIBIBVH"] (or a JLL) pointing at libibvh.so.  The C ABI is include/ibvh.h.
 #
-# The extension only adds MORE SPECIFIC METHODS for the three user entry points; keyword surface, return
-# types (BVH, BVHTraversal) and error behaviour are the reference's.  All buffers are ROCArrays owned by Julia
-# (cache= reuse keeps working); the library never allocates.
+# The extension only adds MORE SPECIFIC METHODS for the user entry points of the hot path:
+#     BVH(::ROCVector, ...)                                            build.jl:198-271
+#     traverse(bvh, ::LVTTraversal | ::BFSTraversal; ...)              lvt/traverse_single.jl, bfs/traverse_single.jl
+#     traverse(bvh1, bvh2, ::LVTTraversal | ::BFSTraversal; ...)       lvt/traverse_pair.jl, bfs/traverse_pair.jl
+#     traverse_rays(bvh, points, directions, ::LVTTraversal | ::BFSTraversal; ...)   raytrace/*
+# Keyword surface, return types (BVH, BVHTraversal) and error behaviour are the reference's.  All buffers are
+# ROCArrays owned by Julia (cache= reuse keeps working); the library never allocates.
 #
-# NOTE: written against include/ibvh.h; Julia is not available in the build environment of libibvh, so this
-# file is delivered as source and the identical call sequence is exercised by the Python mirror
-# (implicitbvh.jl_amd/api.py) and its GPU parity tests.
+# `narrow`: an arbitrary Julia closure cannot cross a C ABI.  The reference's default and two callable structs defined
+# here (MortonLess, IndexLess: the predicates its tests use, runtests.jl:1239) run on the device; ANY other `narrow`
+# falls back to the reference's own generic method through `invoke` — it is never silently dropped.
+#
+# One `ccall` per C entry point lives in the `c_*` wrappers below; tests/test_host_cpu.py parses their argument-type
+# tuples and the POD structs and checks them against the ctypes binding (implicitbvh.jl_amd/lib.py, abi.py) the GPU
+# parity tests run on, so the two bindings cannot drift apart.
+#
+# NOTE: written against include/ibvh.h; Julia is not available in the build environment of libibvh, so this file is
+# delivered as source and the identical call sequences are exercised by the Python mirror (implicitbvh.jl_amd/api.py).
 module ImplicitBVHlibibvhExt
 
 using ImplicitBVH
@@ -51,6 +62,9 @@ morcode(::Type{UInt16}) = Int32(0);  morcode(::Type{UInt32}) = Int32(1); morcode
 ibvh_types(::Type{L}, ::Type{N}, ::Type{I}, ::Type{M}) where {L, N, I, M} =
     IbvhTypes(kind(L), fltcode(eltype(L)), kind(N), fltcode(eltype(N)), idxcode(I), morcode(M))
 
+const IBVH_ERR_UNSUPPORTED = Cint(3)
+const IBVH_ERR_CAPACITY = Cint(4)
+
 # status -> the exception the reference throws in the same situation
 function check(status::Cint, what)
     status == 0 && return
@@ -62,14 +76,130 @@ function check(status::Cint, what)
 end
 
 stream_ptr() = Ptr{Cvoid}(UInt(AMDGPU.stream().stream))   # hipStream_t of the task-local stream
-devptr(a::ROCArray) = Ptr{Cvoid}(UInt(pointer(a)))
+devptr(a::ROCArray) = length(a) == 0 ? Ptr{Cvoid}(C_NULL) : Ptr{Cvoid}(UInt(pointer(a)))
+devptr(::Nothing) = Ptr{Cvoid}(C_NULL)
 
 tree_of(t::ImplicitTree) = IbvhTree(t.levels, t.real_leaves, t.real_nodes, t.virtual_leaves, t.virtual_nodes)
+
+const RocBVH{I} = BVH{I, <:ROCVector, <:ROCVector, <:ROCVector}
 
 function bvh_desc(bvh::BVH{I, <:ROCVector, <:ROCVector{N}, <:ROCVector{BoundingVolume{L, I, M}}}) where {I, N, L, M}
     IbvhBvh(ibvh_types(L, N, I, M), tree_of(bvh.tree), Int64(bvh.built_level),
             devptr(bvh.leaves), devptr(bvh.nodes), devptr(bvh.skips))
 end
+
+# ---- narrow --------------------------------------------------------------------------------------------
+const DEFAULT_NARROW = (bv1, bv2) -> true          # the default of every method below (=== comparable)
+const DEFAULT_RAY_NARROW = (bv, p, d) -> true
+"`narrow=MortonLess()`: (a, b) -> a.morton < b.morton, evaluated on the device (IBVH_NARROW_MORTON_LT)."
+struct MortonLess end
+(::MortonLess)(a, b) = a.morton < b.morton
+"`narrow=IndexLess()`: (a, b) -> a.index < b.index, evaluated on the device (IBVH_NARROW_INDEX_LT)."
+struct IndexLess end
+(::IndexLess)(a, b) = a.index < b.index
+# the device-side menu, or `nothing`: the caller then hands the whole call to the reference's generic method
+narrow_code(f) = f === DEFAULT_NARROW ? Int32(0) : f isa MortonLess ? Int32(1) : f isa IndexLess ? Int32(2) : nothing
+
+# ---- scratch: one growing ROCVector{UInt8} per (task, purpose) instead of an allocation per call -------------
+function scratch!(purpose::Symbol, nbytes::Integer)
+    pool = get!(() -> Dict{Symbol, Any}(), task_local_storage(), :libibvh_scratch)::Dict{Symbol, Any}
+    buf = get(pool, purpose, nothing)
+    if buf === nothing || length(buf) < nbytes
+        buf = ROCVector{UInt8}(undef, nbytes)
+        pool[purpose] = buf
+    end
+    buf::ROCVector{UInt8}
+end
+# the device-side totals of enqueued LVT traversals: a ring of 64 words, one per call (include/ibvh.h, `total_dev`)
+function next_total_word()
+    ring = get!(() -> (AMDGPU.zeros(Int64, 64), Ref(0)), task_local_storage(), :libibvh_totals)
+    words, calls = ring
+    slot = calls[] % 64
+    calls[] += 1
+    Ptr{Cvoid}(UInt(pointer(words)) + 8 * slot)
+end
+
+# ---- one ccall per C entry point (include/ibvh.h) ---------------------------------------------------------
+c_build_scratch_bytes(types, n, out) =
+    ccall((:ibvh_build_scratch_bytes, libibvh), Cint,
+          (Ref{IbvhTypes}, Int64, Ref{Csize_t}),
+          types, n, out)
+c_build(desc, volumes, leaves, nodes, skips, extrema_out, scratch, scratch_bytes, stream) =
+    ccall((:ibvh_build, libibvh), Cint,
+          (Ref{IbvhBuildDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+          desc, volumes, leaves, nodes, skips, extrema_out, scratch, scratch_bytes, stream)
+c_lvt_scratch_bytes(types, n_items, cache_slots, out) =
+    ccall((:ibvh_lvt_scratch_bytes, libibvh), Cint,
+          (Ref{IbvhTypes}, Int64, Int32, Ref{Csize_t}),
+          types, n_items, cache_slots, out)
+c_lvt_total(total_dev, out, stream) =
+    ccall((:ibvh_lvt_total, libibvh), Cint,
+          (Ptr{Cvoid}, Ref{Int64}, Ptr{Cvoid}),
+          total_dev, out, stream)
+c_traverse_lvt_count(bvh, sl, narrow, counts, total, scratch, sb, stream) =
+    ccall((:ibvh_traverse_lvt_count, libibvh), Cint,
+          (Ref{IbvhBvh}, Int64, Int32, Ptr{Cvoid}, Ref{Int64}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+          bvh, sl, narrow, counts, total, scratch, sb, stream)
+c_traverse_lvt_write(bvh, sl, narrow, counts, contacts, scratch, sb, stream) =
+    ccall((:ibvh_traverse_lvt_write, libibvh), Cint,
+          (Ref{IbvhBvh}, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+          bvh, sl, narrow, counts, contacts, scratch, sb, stream)
+c_traverse_lvt_enqueue(bvh, sl, narrow, counts, contacts, capacity, total_dev, scratch, sb, stream) =
+    ccall((:ibvh_traverse_lvt_enqueue, libibvh), Cint,
+          (Ref{IbvhBvh}, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+          bvh, sl, narrow, counts, contacts, capacity, total_dev, scratch, sb, stream)
+c_traverse_pair_lvt_count(bvh1, bvh2, sl1, sl2, narrow, counts, total, scratch, sb, stream) =
+    ccall((:ibvh_traverse_pair_lvt_count, libibvh), Cint,
+          (Ref{IbvhBvh}, Ref{IbvhBvh}, Int64, Int64, Int32, Ptr{Cvoid}, Ref{Int64}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+          bvh1, bvh2, sl1, sl2, narrow, counts, total, scratch, sb, stream)
+c_traverse_pair_lvt_write(bvh1, bvh2, sl1, sl2, narrow, counts, contacts, scratch, sb, stream) =
+    ccall((:ibvh_traverse_pair_lvt_write, libibvh), Cint,
+          (Ref{IbvhBvh}, Ref{IbvhBvh}, Int64, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+          bvh1, bvh2, sl1, sl2, narrow, counts, contacts, scratch, sb, stream)
+c_traverse_pair_lvt_enqueue(bvh1, bvh2, sl1, sl2, narrow, counts, contacts, capacity, total_dev, scratch, sb, stream) =
+    ccall((:ibvh_traverse_pair_lvt_enqueue, libibvh), Cint,
+          (Ref{IbvhBvh}, Ref{IbvhBvh}, Int64, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+          bvh1, bvh2, sl1, sl2, narrow, counts, contacts, capacity, total_dev, scratch, sb, stream)
+c_traverse_rays_lvt_count(bvh, points, dirs, num_rays, sl, counts, total, scratch, sb, stream) =
+    ccall((:ibvh_traverse_rays_lvt_count, libibvh), Cint,
+          (Ref{IbvhBvh}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ref{Int64}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+          bvh, points, dirs, num_rays, sl, counts, total, scratch, sb, stream)
+c_traverse_rays_lvt_write(bvh, points, dirs, num_rays, sl, counts, contacts, scratch, sb, stream) =
+    ccall((:ibvh_traverse_rays_lvt_write, libibvh), Cint,
+          (Ref{IbvhBvh}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+          bvh, points, dirs, num_rays, sl, counts, contacts, scratch, sb, stream)
+c_traverse_rays_lvt_enqueue(bvh, points, dirs, num_rays, sl, counts, contacts, capacity, total_dev, scratch, sb, stream) =
+    ccall((:ibvh_traverse_rays_lvt_enqueue, libibvh), Cint,
+          (Ref{IbvhBvh}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+          bvh, points, dirs, num_rays, sl, counts, contacts, capacity, total_dev, scratch, sb, stream)
+c_bfs_initial_capacity(bvh, sl, out) =
+    ccall((:ibvh_bfs_initial_capacity, libibvh), Cint,
+          (Ref{IbvhBvh}, Int64, Ref{Int64}),
+          bvh, sl, out)
+c_bfs_pair_initial_capacity(bvh1, bvh2, sl1, sl2, out) =
+    ccall((:ibvh_bfs_pair_initial_capacity, libibvh), Cint,
+          (Ref{IbvhBvh}, Ref{IbvhBvh}, Int64, Int64, Ref{Int64}),
+          bvh1, bvh2, sl1, sl2, out)
+c_bfs_rays_initial_capacity(bvh, num_rays, sl, out) =
+    ccall((:ibvh_bfs_rays_initial_capacity, libibvh), Cint,
+          (Ref{IbvhBvh}, Int64, Int64, Ref{Int64}),
+          bvh, num_rays, sl, out)
+c_bfs_counters_bytes(total_levels, out) =
+    ccall((:ibvh_bfs_counters_bytes, libibvh), Cint,
+          (Int64, Ref{Csize_t}),
+          total_levels, out)
+c_traverse_bfs(bvh, sl, narrow, bvtt1, bvtt2, capacity, counters, result, stream) =
+    ccall((:ibvh_traverse_bfs, libibvh), Cint,
+          (Ref{IbvhBvh}, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ref{IbvhBfsResult}, Ptr{Cvoid}),
+          bvh, sl, narrow, bvtt1, bvtt2, capacity, counters, result, stream)
+c_traverse_pair_bfs(bvh1, bvh2, sl1, sl2, narrow, bvtt1, bvtt2, capacity, counters, result, stream) =
+    ccall((:ibvh_traverse_pair_bfs, libibvh), Cint,
+          (Ref{IbvhBvh}, Ref{IbvhBvh}, Int64, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ref{IbvhBfsResult}, Ptr{Cvoid}),
+          bvh1, bvh2, sl1, sl2, narrow, bvtt1, bvtt2, capacity, counters, result, stream)
+c_traverse_rays_bfs(bvh, points, dirs, num_rays, sl, bvtt1, bvtt2, capacity, counters, result, stream) =
+    ccall((:ibvh_traverse_rays_bfs, libibvh), Cint,
+          (Ref{IbvhBvh}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ref{IbvhBfsResult}, Ptr{Cvoid}),
+          bvh, points, dirs, num_rays, sl, bvtt1, bvtt2, capacity, counters, result, stream)
 
 # ---- BVH(...) — build.jl:198-271 ------------------------------------------------------------------------
 function ImplicitBVH.BVH(
@@ -102,124 +232,269 @@ function ImplicitBVH.BVH(
 
     types = ibvh_types(V, N, I, M)
     need = Ref{Csize_t}(0)
-    check(ccall((:ibvh_build_scratch_bytes, libibvh), Cint, (Ref{IbvhTypes}, Int64, Ref{Csize_t}), types, numbv, need),
-          "ibvh_build_scratch_bytes")
-    scratch = ROCVector{UInt8}(undef, need[])           # a real shim keeps this in a task-local pool
+    st = c_build_scratch_bytes(types, numbv, need)
+    if st == IBVH_ERR_UNSUPPORTED   # e.g. Float16 volumes, F32 leaves under F64 nodes: the reference's own path
+        return invoke(ImplicitBVH.BVH, Tuple{AbstractVector, Type}, bounding_volumes, node_type;
+                      built_level=built_level, cache=cache, options=options)
+    end
+    check(st, "ibvh_build_scratch_bytes")
+    scratch = scratch!(:build, need[])
 
     alg = options.morton
     desc = IbvhBuildDesc(types, numbv, Int64(built_ilevel), wrapped ? 1 : 0, alg.compute_extrema ? 1 : 0,
                          Float64.(alg.mins), Float64.(alg.maxs))   # NB alg.mins/maxs, not options.mins (default.jl:55-56)
-    check(ccall((:ibvh_build, libibvh), Cint,
-                (Ref{IbvhBuildDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
-                desc, wrapped ? C_NULL : devptr(bounding_volumes), devptr(leaves), devptr(nodes), devptr(skips),
-                C_NULL, devptr(scratch), need[], stream_ptr()), "ibvh_build")
+    check(c_build(desc, wrapped ? C_NULL : devptr(bounding_volumes), devptr(leaves), devptr(nodes), devptr(skips),
+                  C_NULL, devptr(scratch), need[], stream_ptr()), "ibvh_build")
     BVH(I(built_ilevel), tree, skips, nodes, leaves)
 end
 
-# ---- traverse(bvh, LVTTraversal()) — lvt/traverse_single.jl:1-79 ----------------------------------------
+# ---- leaf-vs-tree: count -> (cache) -> write, or enqueue against a cached contact buffer ------------------------
 const LVT_CACHE_SLOTS = Int32(8)
-narrow_code(narrow) = Int32(0)   # default (a, b) -> true; map known closures to IBVH_NARROW_* here, otherwise
-                                 # fall back to the generic method (invoke) or post-filter `.contacts`
+const RAY_CACHE_SLOTS = Int32(32)
 
-function ImplicitBVH.traverse(
-    bvh::BVH{I, <:ROCVector, <:ROCVector, <:ROCVector}, alg::LVTTraversal;
-    start_level::Int=default_start_level(bvh, alg),
-    narrow=(bv1, bv2) -> true,
-    cache::Union{Nothing, BVHTraversal}=nothing,
-    options=BVHOptions(),
-) where {I}
-    bvh.built_level <= start_level <= bvh.tree.levels <= 32 || throw(ArgumentError("start_level out of range"))
-    if bvh.tree.real_nodes <= 1
-        return BVHTraversal(Int(start_level), 0, 0, similar(bvh.nodes, IndexPair{I}, 0), similar(bvh.nodes, I, 0))
+cached(cache, field::Symbol, ::Type{T}, n, like) where {T} =
+    if isnothing(cache)
+        similar(like, T, n)
+    else
+        buf = getfield(cache, field)
+        eltype(buf) === T || throw(ArgumentError("eltype(cache.$field) === $T must hold"))
+        length(buf) < n && resize!(buf, n)
+        buf
     end
-    n = length(bvh.leaves)
-    counts = isnothing(cache) ? similar(bvh.nodes, I, n) : begin
-        eltype(cache.cache2) === I || throw(ArgumentError("eltype(cache.cache2) === I must hold"))
-        length(cache.cache2) < n && resize!(cache.cache2, n); cache.cache2 end
-    d = bvh_desc(bvh)
+
+# `count`, `write`, `enqueue`: closures over the entry points of one traversal shape; they take the buffers only.
+function lvt_two_pass(::Type{I}, like, n_items, types, slots, cache, count, write, enqueue) where {I}
+    counts = cached(cache, :cache2, I, n_items, like)
     need = Ref{Csize_t}(0)
-    check(ccall((:ibvh_lvt_scratch_bytes, libibvh), Cint, (Ref{IbvhTypes}, Int64, Int32, Ref{Csize_t}),
-                d.types, n, LVT_CACHE_SLOTS, need), "ibvh_lvt_scratch_bytes")
-    scratch = ROCVector{UInt8}(undef, need[])
+    check(c_lvt_scratch_bytes(types, n_items, slots, need), "ibvh_lvt_scratch_bytes")
+    scratch = scratch!(:lvt, need[])
     total = Ref{Int64}(0)
     if !isnothing(cache) && length(cache.cache1) > 0
-        # cache reuse: enqueue pass 1 + scan + a guarded pass 2 against the cached buffer without a host read in between
-        # (the GPU never idles); read the total afterwards and fall through to the ordinary _write only if it did not fit.
+        # cache reuse: pass 1 + scan + a guarded pass 2 against the cached buffer are enqueued without a host read in
+        # between (the GPU never idles); the total is read afterwards — the reference's @allowscalar (:60), after the
+        # work is queued — and the ordinary _write runs only if the cached buffer turned out too small.
         eltype(cache.cache1) === IndexPair{I} || throw(ArgumentError("eltype(cache.cache1) === IndexPair{I} must hold"))
-        check(ccall((:ibvh_traverse_lvt_enqueue, libibvh), Cint,
-                    (Ref{IbvhBvh}, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
-                    d, start_level, narrow_code(narrow), devptr(counts), devptr(cache.cache1), length(cache.cache1),
-                    devptr(scratch), need[], stream_ptr()), "ibvh_traverse_lvt_enqueue")
-        check(ccall((:ibvh_lvt_total, libibvh), Cint, (Ptr{Cvoid}, Ref{Int64}, Ptr{Cvoid}), devptr(scratch), total, stream_ptr()),
-              "ibvh_lvt_total")                             # the reference's @allowscalar (:60), after the work is queued
-        if total[] <= length(cache.cache1)
-            return BVHTraversal(Int(start_level), 0, Int(total[]), cache.cache1, counts)
+        tdev = next_total_word()
+        check(enqueue(counts, cache.cache1, length(cache.cache1), tdev, scratch, need[]), "ibvh_traverse_*_lvt_enqueue")
+        check(c_lvt_total(tdev, total, stream_ptr()), "ibvh_lvt_total")
+        if total[] > length(cache.cache1)
+            resize!(cache.cache1, total[])
+            check(write(counts, cache.cache1, scratch, need[]), "ibvh_traverse_*_lvt_write")
         end
-        resize!(cache.cache1, total[])
-        check(ccall((:ibvh_traverse_lvt_write, libibvh), Cint,
-                    (Ref{IbvhBvh}, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
-                    d, start_level, narrow_code(narrow), devptr(counts), devptr(cache.cache1), devptr(scratch), need[],
-                    stream_ptr()), "ibvh_traverse_lvt_write")
-        return BVHTraversal(Int(start_level), 0, Int(total[]), cache.cache1, counts)
+        return Int(total[]), cache.cache1, counts
     end
-    check(ccall((:ibvh_traverse_lvt_count, libibvh), Cint,
-                (Ref{IbvhBvh}, Int64, Int32, Ptr{Cvoid}, Ref{Int64}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
-                d, start_level, narrow_code(narrow), devptr(counts), total, devptr(scratch), need[], stream_ptr()),
-          "ibvh_traverse_lvt_count")                        # synchronises: the reference's @allowscalar (:60)
-    contacts = isnothing(cache) ? similar(bvh.nodes, IndexPair{I}, total[]) : begin
-        eltype(cache.cache1) === IndexPair{I} || throw(ArgumentError("eltype(cache.cache1) === IndexPair{I} must hold"))
-        length(cache.cache1) < total[] && resize!(cache.cache1, total[]); cache.cache1 end
-    if total[] > 0
-        check(ccall((:ibvh_traverse_lvt_write, libibvh), Cint,
-                    (Ref{IbvhBvh}, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
-                    d, start_level, narrow_code(narrow), devptr(counts), devptr(contacts), devptr(scratch), need[],
-                    stream_ptr()), "ibvh_traverse_lvt_write")
-    end
-    BVHTraversal(Int(start_level), 0, Int(total[]), contacts, counts)
+    check(count(counts, total, scratch, need[]), "ibvh_traverse_*_lvt_count")   # synchronises: @allowscalar (:60)
+    contacts = cached(cache, :cache1, IndexPair{I}, total[], like)
+    total[] > 0 && check(write(counts, contacts, scratch, need[]), "ibvh_traverse_*_lvt_write")
+    Int(total[]), contacts, counts
 end
 
-# traverse(bvh1, bvh2, LVTTraversal()) and traverse_rays(bvh, points, directions, LVTTraversal()) follow the same
-# count -> allocate -> write shape with ibvh_traverse_pair_lvt_* / ibvh_traverse_rays_lvt_*; `points` and
-# `directions` are (3, N) ROCMatrix{T} (converted to the leaf eltype first, raytrace/lvt:116-125) and are passed as is:
-# Julia's column-major (3, N) is the layout the library expects.
-
-# ---- traverse(bvh, BFSTraversal()) — bfs/traverse_single.jl:1-61 ----------------------------------------
+# traverse(bvh, LVTTraversal()) — lvt/traverse_single.jl:1-79
 function ImplicitBVH.traverse(
-    bvh::BVH{I, <:ROCVector, <:ROCVector, <:ROCVector}, alg::BFSTraversal;
+    bvh::RocBVH{I}, alg::LVTTraversal;
     start_level::Int=default_start_level(bvh, alg),
+    narrow=DEFAULT_NARROW,
     cache::Union{Nothing, BVHTraversal}=nothing,
-    narrow=(bv1, bv2) -> true,
     options=BVHOptions(),
 ) where {I}
-    bvh.tree.levels >= start_level >= bvh.built_level || throw(ArgumentError("start_level out of range"))
+    code = narrow_code(narrow)
+    if isnothing(code)   # an arbitrary closure: the reference's generic (KernelAbstractions) method evaluates it
+        return invoke(ImplicitBVH.traverse, Tuple{BVH, LVTTraversal}, bvh, alg;
+                      start_level=start_level, narrow=narrow, cache=cache, options=options)
+    end
+    bvh.built_level <= start_level <= bvh.tree.levels <= 32 ||
+        throw(ArgumentError("bvh.built_level <= start_level <= bvh.tree.levels <= 32 must hold"))
+    if bvh.tree.real_nodes <= 1   # :17-21
+        return BVHTraversal(Int(start_level), 0, 0, similar(bvh.nodes, IndexPair{I}, 0), similar(bvh.nodes, I, 0))
+    end
+    d = bvh_desc(bvh)
+    s = stream_ptr()
+    total, contacts, counts = lvt_two_pass(I, bvh.nodes, length(bvh.leaves), d.types, LVT_CACHE_SLOTS, cache,
+        (cn, tot, sc, sb) -> c_traverse_lvt_count(d, start_level, code, devptr(cn), tot, devptr(sc), sb, s),
+        (cn, ct, sc, sb) -> c_traverse_lvt_write(d, start_level, code, devptr(cn), devptr(ct), devptr(sc), sb, s),
+        (cn, ct, cap, td, sc, sb) -> c_traverse_lvt_enqueue(d, start_level, code, devptr(cn), devptr(ct), cap, td, devptr(sc), sb, s))
+    BVHTraversal(Int(start_level), 0, total, contacts, counts)
+end
+
+# traverse(bvh1, bvh2, LVTTraversal()) — lvt/traverse_pair.jl:1-116 (the library picks the BVH with more leaves as
+# the driver and flips the pairs back: contacts are always (index in bvh1, index in bvh2))
+function ImplicitBVH.traverse(
+    bvh1::RocBVH{I}, bvh2::RocBVH, alg::LVTTraversal;
+    start_level1::Int=default_start_level(bvh1, alg),
+    start_level2::Int=default_start_level(bvh2, alg),
+    narrow=DEFAULT_NARROW,
+    cache::Union{Nothing, BVHTraversal}=nothing,
+    options=BVHOptions(),
+) where {I}
+    code = narrow_code(narrow)
+    d1, d2 = bvh_desc(bvh1), bvh_desc(bvh2)
+    if isnothing(code) || d1.types != d2.types   # closures, and pairs of different leaf / node types: generic method
+        return invoke(ImplicitBVH.traverse, Tuple{BVH, BVH, LVTTraversal}, bvh1, bvh2, alg;
+                      start_level1=start_level1, start_level2=start_level2, narrow=narrow, cache=cache, options=options)
+    end
+    bvh1.built_level <= start_level1 <= bvh1.tree.levels <= 32 ||
+        throw(ArgumentError("bvh1.built_level <= start_level1 <= bvh1.tree.levels <= 32 must hold"))
+    bvh2.built_level <= start_level2 <= bvh2.tree.levels <= 32 ||
+        throw(ArgumentError("bvh2.built_level <= start_level2 <= bvh2.tree.levels <= 32 must hold"))
+    get_index_type(bvh2) === I || throw(ArgumentError("get_index_type(bvh2) === I must hold"))   # :50-52
+    s = stream_ptr()
+    n_items = max(length(bvh1.leaves), length(bvh2.leaves))
+    total, contacts, counts = lvt_two_pass(I, bvh1.nodes, n_items, d1.types, LVT_CACHE_SLOTS, cache,
+        (cn, tot, sc, sb) -> c_traverse_pair_lvt_count(d1, d2, start_level1, start_level2, code, devptr(cn), tot, devptr(sc), sb, s),
+        (cn, ct, sc, sb) -> c_traverse_pair_lvt_write(d1, d2, start_level1, start_level2, code, devptr(cn), devptr(ct), devptr(sc), sb, s),
+        (cn, ct, cap, td, sc, sb) -> c_traverse_pair_lvt_enqueue(d1, d2, start_level1, start_level2, code, devptr(cn), devptr(ct), cap, td, devptr(sc), sb, s))
+    BVHTraversal(Int(start_level1), Int(start_level2), 0, total, contacts, counts)
+end
+
+# rays as the library wants them: (3, N) column-major matrices of the leaf float type (raytrace/lvt:116-125 converts
+# every coordinate with T.(...) too)
+function ray_matrices(bvh::BVH{I, <:ROCVector, <:ROCVector, <:ROCVector{BoundingVolume{L, I, M}}}, points, directions) where {I, L, M}
+    size(points, 1) == size(directions, 1) == 3 || throw(ArgumentError("size(points, 1) == size(directions, 1) == 3 must hold"))
+    size(points, 2) == size(directions, 2) || throw(ArgumentError("size(points, 2) == size(directions, 2) must hold"))
+    T = eltype(L)
+    p = points isa ROCMatrix{T} ? points : ROCMatrix{T}(points)
+    d = directions isa ROCMatrix{T} ? directions : ROCMatrix{T}(directions)
+    p, d
+end
+
+# traverse_rays(bvh, points, directions, LVTTraversal()) — raytrace/leaf_vs_tree/leaf_vs_tree.jl:1-90
+function ImplicitBVH.traverse_rays(
+    bvh::RocBVH{I},
+    points::AbstractMatrix, directions::AbstractMatrix,
+    alg::LVTTraversal;
+    start_level::Int=1,
+    narrow=DEFAULT_RAY_NARROW,
+    cache::Union{Nothing, BVHTraversal}=nothing,
+    options=BVHOptions(),
+) where {I}
+    d = bvh_desc(bvh)
+    if narrow !== DEFAULT_RAY_NARROW || d.types.leaf_float != d.types.node_float   # (isintersection needs one T)
+        return invoke(ImplicitBVH.traverse_rays, Tuple{BVH, AbstractMatrix, AbstractMatrix, LVTTraversal},
+                      bvh, points, directions, alg; start_level=start_level, narrow=narrow, cache=cache, options=options)
+    end
+    bvh.built_level <= start_level <= bvh.tree.levels <= 32 ||
+        throw(ArgumentError("bvh.built_level <= start_level <= bvh.tree.levels <= 32 must hold"))
+    p, dr = ray_matrices(bvh, points, directions)
+    nr = size(p, 2)
+    if nr == 0   # :22-26
+        return BVHTraversal(start_level, 0, 0, similar(bvh.nodes, IndexPair{I}, 0), similar(bvh.nodes, IndexPair{I}, 0))
+    end
+    s = stream_ptr()
+    total, contacts, counts = lvt_two_pass(I, bvh.nodes, nr, d.types, RAY_CACHE_SLOTS, cache,
+        (cn, tot, sc, sb) -> c_traverse_rays_lvt_count(d, devptr(p), devptr(dr), nr, start_level, devptr(cn), tot, devptr(sc), sb, s),
+        (cn, ct, sc, sb) -> c_traverse_rays_lvt_write(d, devptr(p), devptr(dr), nr, start_level, devptr(cn), devptr(ct), devptr(sc), sb, s),
+        (cn, ct, cap, td, sc, sb) -> c_traverse_rays_lvt_enqueue(d, devptr(p), devptr(dr), nr, start_level, devptr(cn), devptr(ct), cap, td, devptr(sc), sb, s))
+    BVHTraversal(Int(start_level), 0, total, contacts, counts)
+end
+
+# ---- breadth-first: two caller-owned pair queues, grown when the library reports the capacity it needs ------------
+# `run(bvtt1, bvtt2, capacity, counters, result)` issues the entry point of one traversal shape.
+function bfs_run(::Type{I}, like, initial_pairs, total_levels, cache, run, what) where {I}
+    capacity = 4 * max(initial_pairs, 1)                    # the reference's initial sizing (bfs/traverse_single.jl:73)
+    bvtt1 = cached(cache, :cache1, IndexPair{I}, capacity, like)
+    bvtt2 = cached(cache, :cache2, IndexPair{I}, capacity, like)
+    nb = Ref{Csize_t}(0)
+    check(c_bfs_counters_bytes(total_levels, nb), "ibvh_bfs_counters_bytes")
+    counters = scratch!(:bfs_counters, nb[])
+    fill!(counters, 0x00)
+    res = IbvhBfsResult(0, 0, 1, 0)
+    while true
+        st = run(bvtt1, bvtt2, min(length(bvtt1), length(bvtt2)), counters, res)
+        if st == IBVH_ERR_CAPACITY                          # the reference's resize! (bfs/traverse_single.jl:40)
+            resize!(bvtt1, res.required_capacity); resize!(bvtt2, res.required_capacity)
+            continue
+        end
+        check(st, what); break
+    end
+    contacts, other = res.contacts_in == 1 ? (bvtt1, bvtt2) : (bvtt2, bvtt1)
+    Int(res.num_checks), Int(res.num_contacts), contacts, other
+end
+
+# traverse(bvh, BFSTraversal()) — bfs/traverse_single.jl:1-61
+function ImplicitBVH.traverse(
+    bvh::RocBVH{I}, alg::BFSTraversal;
+    start_level::Int=default_start_level(bvh, alg),
+    narrow=DEFAULT_NARROW,
+    cache::Union{Nothing, BVHTraversal}=nothing,
+    options=BVHOptions(),
+) where {I}
+    code = narrow_code(narrow)
+    if isnothing(code)
+        return invoke(ImplicitBVH.traverse, Tuple{BVH, BFSTraversal}, bvh, alg;
+                      start_level=start_level, narrow=narrow, cache=cache, options=options)
+    end
+    bvh.tree.levels >= start_level >= bvh.built_level ||
+        throw(ArgumentError("bvh.tree.levels >= start_level >= bvh.built_level must hold"))
     if bvh.tree.real_nodes <= 1
         return BVHTraversal(start_level, 0, 0, similar(bvh.nodes, IndexPair{I}, 0), similar(bvh.nodes, IndexPair{I}, 0))
     end
     d = bvh_desc(bvh)
+    s = stream_ptr()
     cap = Ref{Int64}(0)
-    check(ccall((:ibvh_bfs_initial_capacity, libibvh), Cint, (Ref{IbvhBvh}, Int64, Ref{Int64}), d, start_level, cap),
-          "ibvh_bfs_initial_capacity")
-    capacity = 4 * cap[]                                    # the reference's initial_number (bfs/traverse_single.jl:73)
-    bvtt1 = isnothing(cache) ? similar(bvh.nodes, IndexPair{I}, capacity) : cache.cache1
-    bvtt2 = isnothing(cache) ? similar(bvh.nodes, IndexPair{I}, capacity) : cache.cache2
-    nb = Ref{Csize_t}(0)
-    ccall((:ibvh_bfs_counters_bytes, libibvh), Cint, (Int64, Ref{Csize_t}), bvh.tree.levels, nb)
-    counters = AMDGPU.zeros(UInt8, nb[])
-    res = IbvhBfsResult(0, 0, 1, 0)
-    while true
-        capacity = min(length(bvtt1), length(bvtt2))
-        st = ccall((:ibvh_traverse_bfs, libibvh), Cint,
-                   (Ref{IbvhBvh}, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ref{IbvhBfsResult}, Ptr{Cvoid}),
-                   d, start_level, narrow_code(narrow), devptr(bvtt1), devptr(bvtt2), capacity, devptr(counters), res,
-                   stream_ptr())
-        if st == 4                                          # IBVH_ERR_CAPACITY: the reference's resize! (:40)
-            resize!(bvtt1, res.required_capacity); resize!(bvtt2, res.required_capacity)
-            continue
-        end
-        check(st, "ibvh_traverse_bfs"); break
+    check(c_bfs_initial_capacity(d, start_level, cap), "ibvh_bfs_initial_capacity")
+    checks, total, contacts, other = bfs_run(I, bvh.nodes, cap[], bvh.tree.levels, cache,
+        (q1, q2, c, ctr, res) -> c_traverse_bfs(d, start_level, code, devptr(q1), devptr(q2), c, devptr(ctr), res, s),
+        "ibvh_traverse_bfs")
+    BVHTraversal(start_level, checks, total, contacts, other)
+end
+
+# traverse(bvh1, bvh2, BFSTraversal()) — bfs/traverse_pair.jl:1-151 (six-phase descent)
+function ImplicitBVH.traverse(
+    bvh1::RocBVH{I}, bvh2::RocBVH, alg::BFSTraversal;
+    start_level1::Int=default_start_level(bvh1, alg),
+    start_level2::Int=default_start_level(bvh2, alg),
+    narrow=DEFAULT_NARROW,
+    cache::Union{Nothing, BVHTraversal}=nothing,
+    options=BVHOptions(),
+) where {I}
+    code = narrow_code(narrow)
+    d1, d2 = bvh_desc(bvh1), bvh_desc(bvh2)
+    if isnothing(code) || d1.types != d2.types
+        return invoke(ImplicitBVH.traverse, Tuple{BVH, BVH, BFSTraversal}, bvh1, bvh2, alg;
+                      start_level1=start_level1, start_level2=start_level2, narrow=narrow, cache=cache, options=options)
     end
-    contacts, other = res.contacts_in == 1 ? (bvtt1, bvtt2) : (bvtt2, bvtt1)
-    BVHTraversal(start_level, Int(res.num_checks), Int(res.num_contacts), contacts, other)
+    bvh1.tree.levels >= start_level1 >= bvh1.built_level ||
+        throw(ArgumentError("bvh1.tree.levels >= start_level1 >= bvh1.built_level must hold"))
+    bvh2.tree.levels >= start_level2 >= bvh2.built_level ||
+        throw(ArgumentError("bvh2.tree.levels >= start_level2 >= bvh2.built_level must hold"))
+    s = stream_ptr()
+    cap = Ref{Int64}(0)
+    check(c_bfs_pair_initial_capacity(d1, d2, start_level1, start_level2, cap), "ibvh_bfs_pair_initial_capacity")
+    checks, total, contacts, other = bfs_run(I, bvh1.nodes, cap[], bvh1.tree.levels + bvh2.tree.levels, cache,
+        (q1, q2, c, ctr, res) -> c_traverse_pair_bfs(d1, d2, start_level1, start_level2, code, devptr(q1), devptr(q2), c, devptr(ctr), res, s),
+        "ibvh_traverse_pair_bfs")
+    BVHTraversal(start_level1, start_level2, checks, total, contacts, other)
+end
+
+# traverse_rays(bvh, points, directions, BFSTraversal()) — raytrace/breadth_first/breadth_first.jl:1-66
+function ImplicitBVH.traverse_rays(
+    bvh::RocBVH{I},
+    points::AbstractMatrix, directions::AbstractMatrix,
+    alg::BFSTraversal;
+    start_level::Int=1,
+    narrow=DEFAULT_RAY_NARROW,
+    cache::Union{Nothing, BVHTraversal}=nothing,
+    options=BVHOptions(),
+) where {I}
+    d = bvh_desc(bvh)
+    if narrow !== DEFAULT_RAY_NARROW || d.types.leaf_float != d.types.node_float
+        return invoke(ImplicitBVH.traverse_rays, Tuple{BVH, AbstractMatrix, AbstractMatrix, BFSTraversal},
+                      bvh, points, directions, alg; start_level=start_level, narrow=narrow, cache=cache, options=options)
+    end
+    bvh.tree.levels >= start_level >= bvh.built_level ||
+        throw(ArgumentError("bvh.tree.levels >= start_level >= bvh.built_level must hold"))
+    p, dr = ray_matrices(bvh, points, directions)
+    nr = size(p, 2)
+    if nr == 0
+        return BVHTraversal(start_level, 0, 0, similar(bvh.nodes, IndexPair{I}, 0), similar(bvh.nodes, IndexPair{I}, 0))
+    end
+    s = stream_ptr()
+    cap = Ref{Int64}(0)
+    check(c_bfs_rays_initial_capacity(d, nr, start_level, cap), "ibvh_bfs_rays_initial_capacity")
+    checks, total, contacts, other = bfs_run(I, bvh.nodes, cap[], bvh.tree.levels, cache,
+        (q1, q2, c, ctr, res) -> c_traverse_rays_bfs(d, devptr(p), devptr(dr), nr, start_level, devptr(q1), devptr(q2), c, devptr(ctr), res, s),
+        "ibvh_traverse_rays_bfs")
+    BVHTraversal(start_level, checks, total, contacts, other)
 end
 
 end # module

@@ -39,9 +39,9 @@ SIGNATURES = {
     "ibvh_traverse_pair_lvt_write": [_P(abi.Bvh), _P(abi.Bvh), _i64, _i64, _i32, _vp, _vp, _vp, _sz, _vp],
     "ibvh_traverse_rays_lvt_count": [_P(abi.Bvh), _vp, _vp, _i64, _i64, _vp, _P(_i64), _vp, _sz, _vp],
     "ibvh_traverse_rays_lvt_write": [_P(abi.Bvh), _vp, _vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp],
-    "ibvh_traverse_lvt_enqueue": [_P(abi.Bvh), _i64, _i32, _vp, _vp, _i64, _vp, _sz, _vp],
-    "ibvh_traverse_pair_lvt_enqueue": [_P(abi.Bvh), _P(abi.Bvh), _i64, _i64, _i32, _vp, _vp, _i64, _vp, _sz, _vp],
-    "ibvh_traverse_rays_lvt_enqueue": [_P(abi.Bvh), _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _sz, _vp],
+    "ibvh_traverse_lvt_enqueue": [_P(abi.Bvh), _i64, _i32, _vp, _vp, _i64, _vp, _vp, _sz, _vp],
+    "ibvh_traverse_pair_lvt_enqueue": [_P(abi.Bvh), _P(abi.Bvh), _i64, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _sz, _vp],
+    "ibvh_traverse_rays_lvt_enqueue": [_P(abi.Bvh), _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _sz, _vp],
     "ibvh_lvt_total": [_vp, _P(_i64), _vp],
     "ibvh_bfs_initial_capacity": [_P(abi.Bvh), _i64, _P(_i64)],
     "ibvh_bfs_pair_initial_capacity": [_P(abi.Bvh), _P(abi.Bvh), _i64, _i64, _P(_i64)],

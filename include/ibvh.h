@@ -236,24 +236,27 @@ ibvh_status ibvh_traverse_rays_lvt_write(const ibvh_bvh *bvh, const void *points
 /* _enqueue : _count + _write without the host read in between, for callers that already own a contact
  *   buffer (the reference's `cache=` reuse, traverse.jl:54-107): pass 1, the scan and pass 2 are enqueued
  *   back to back and NOTHING synchronises the stream; pass 2 does nothing unless the total fits
- *   `capacity` pairs.  The total stays in the first 8 bytes of `scratch` (int64): fetch it with
- *   ibvh_lvt_total() when it is needed; if it exceeds `capacity`, grow the buffer and call the matching
- *   _write (counts and scratch are ready for it).  Replaces the same reference lines as _count/_write;
- *   only the place of the blocking read (`@allowscalar`, lvt/traverse_single.jl:60) moves. */
+ *   `capacity` pairs.  The total is written to `total_dev`, a DEVICE pointer to one int64 owned by the caller
+ *   (NULL: the first 8 bytes of `scratch`): fetch it with ibvh_lvt_total() when it is needed; if it exceeds
+ *   `capacity`, grow the buffer and call the matching _write (counts and scratch are ready for it).  A caller that
+ *   chains traversals through one scratch buffer and reads the totals late gives every call its own `total_dev`
+ *   word: the scratch (header included) is rewritten by the next call.  Replaces the same reference lines as
+ *   _count/_write; only the place of the blocking read (`@allowscalar`, lvt/traverse_single.jl:60) moves. */
 ibvh_status ibvh_traverse_lvt_enqueue(const ibvh_bvh *bvh, int64_t start_level, int32_t narrow,
-                                      void *counts, void *contacts, int64_t capacity, void *scratch,
-                                      size_t scratch_bytes, void *stream);
+                                      void *counts, void *contacts, int64_t capacity, void *total_dev,
+                                      void *scratch, size_t scratch_bytes, void *stream);
 ibvh_status ibvh_traverse_pair_lvt_enqueue(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2,
                                            int64_t start_level1, int64_t start_level2, int32_t narrow,
-                                           void *counts, void *contacts, int64_t capacity,
+                                           void *counts, void *contacts, int64_t capacity, void *total_dev,
                                            void *scratch, size_t scratch_bytes, void *stream);
 ibvh_status ibvh_traverse_rays_lvt_enqueue(const ibvh_bvh *bvh, const void *points,
                                            const void *directions, int64_t num_rays,
                                            int64_t start_level, void *counts, void *contacts,
-                                           int64_t capacity, void *scratch, size_t scratch_bytes,
-                                           void *stream);
-/* blocking read of the total a _count / _enqueue call left in the scratch header */
-ibvh_status ibvh_lvt_total(const void *scratch, int64_t *total_out, void *stream);
+                                           int64_t capacity, void *total_dev, void *scratch,
+                                           size_t scratch_bytes, void *stream);
+/* blocking read of the total a _count / _enqueue call left behind: pass the call's `total_dev`, or its `scratch`
+ * when total_dev was NULL */
+ibvh_status ibvh_lvt_total(const void *total_dev_or_scratch, int64_t *total_out, void *stream);
 
 /* ----------------------------------------------------------------------------------- */
 /* breadth-first traversal (BFSTraversal): level-synchronous pair queues                 */

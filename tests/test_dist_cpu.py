@@ -245,3 +245,22 @@ def test_heavy_duplicates_and_uneven_shards():
         return builder.build(torch.from_numpy(vols[bounds[comm.rank]:bounds[comm.rank + 1]].copy())).leaves
     out = ibd.run_virtual_ranks(3, fn)
     check_against_single_build(vols, abi.make_types(), out)
+
+
+def test_starved_rank_raises_on_every_rank():
+    """All leaves share one Morton key: every splitter coincides, one rank would receive everything and the others
+    nothing.  Every rank must raise (a rank that carried on alone would hang in the next collective)."""
+    one = cloud(1, 3)
+    vols = np.repeat(one, 600, axis=0)
+    seen = []
+
+    def fn(comm):
+        builder = ibd.DistributedBuilder(comm, engine=OracleEngine())
+        try:
+            builder.build(torch.from_numpy(vols[comm.rank * 200:(comm.rank + 1) * 200].copy()))
+        except abi.DomainError:
+            seen.append(comm.rank)
+            return "raised"
+        return "built"
+    out = ibd.run_virtual_ranks(3, fn)
+    assert out == ["raised"] * 3 and sorted(seen) == [0, 1, 2]

@@ -423,8 +423,8 @@ def test_lvt_enqueue_without_host_sync_matches_the_two_call_protocol():
     # large enough
     cap = len(exp) + 100
     contacts = torch.full((cap, 2), -7, dtype=torch.int32, device="cuda")
-    lib.call("ibvh_traverse_lvt_enqueue", C.byref(s), 1, 0, counts.data_ptr(), contacts.data_ptr(), cap, scratch.data_ptr(),
-             scratch.numel(), stream)
+    lib.call("ibvh_traverse_lvt_enqueue", C.byref(s), 1, 0, counts.data_ptr(), contacts.data_ptr(), cap, None, scratch.data_ptr(),
+             scratch.numel(), stream)  # total_dev = NULL: the total stays in the scratch header
     total = C.c_int64()
     lib.call("ibvh_lvt_total", scratch.data_ptr(), C.byref(total), stream)
     assert total.value == len(exp)
@@ -434,9 +434,11 @@ def test_lvt_enqueue_without_host_sync_matches_the_two_call_protocol():
     # exactly enough, then one too few: the guarded pass must not touch the buffer
     for cap, written in ((len(exp), True), (len(exp) - 1, False)):
         contacts = torch.full((len(exp), 2), -7, dtype=torch.int32, device="cuda")
+        tdev = torch.full((3,), -1, dtype=torch.int64, device="cuda")  # the caller's own total word (middle one)
         lib.call("ibvh_traverse_lvt_enqueue", C.byref(s), 1, 0, counts.data_ptr(), contacts.data_ptr(), cap,
-                 scratch.data_ptr(), scratch.numel(), stream)
-        lib.call("ibvh_lvt_total", scratch.data_ptr(), C.byref(total), stream)
+                 tdev.data_ptr() + 8, scratch.data_ptr(), scratch.numel(), stream)
+        lib.call("ibvh_lvt_total", tdev.data_ptr() + 8, C.byref(total), stream)
+        assert tdev.cpu().tolist() == [-1, len(exp), -1]
         assert total.value == len(exp)
         got = contacts.cpu().numpy()
         assert (got == exp).all() if written else (got == -7).all()
@@ -444,7 +446,7 @@ def test_lvt_enqueue_without_host_sync_matches_the_two_call_protocol():
              scratch.numel(), stream)
     assert (contacts.cpu().numpy() == exp).all()
     # capacity 0: counting only
-    lib.call("ibvh_traverse_lvt_enqueue", C.byref(s), 1, 0, counts.data_ptr(), None, 0, scratch.data_ptr(), scratch.numel(), stream)
+    lib.call("ibvh_traverse_lvt_enqueue", C.byref(s), 1, 0, counts.data_ptr(), None, 0, None, scratch.data_ptr(), scratch.numel(), stream)
     lib.call("ibvh_lvt_total", scratch.data_ptr(), C.byref(total), stream)
     assert total.value == len(exp)
 
@@ -476,6 +478,47 @@ def test_lvt_cache_reuse_is_lazy_and_grows_when_the_cached_buffer_is_too_small()
     with pytest.raises(RuntimeError):
         t6.num_contacts
     assert (contacts_np(t7) == exp_b).all()
+
+
+def test_lvt_pending_count_survives_later_traversals_on_the_same_cache():
+    """A traversal enqueued with `cache=` keeps its total in a ring of per-call device words, NOT in the scratch the
+    next calls rewrite (round-1 advisor finding: header slots inside the scratch were overwritten by the tile sums of
+    later calls).  Chains of more than 64 calls on one cache, a late read just before and just after the ring wraps,
+    and — with more than 2 M items, where the tile sums alone exceed 4 KiB — a read one call late."""
+    rng = np.random.default_rng(16)
+    types = abi.make_types()
+    small = random_volumes(rng, 4000, abi.BSPHERE, abi.F32, scale=20.0)
+    other = random_volumes(rng, 5000, abi.BSPHERE, abi.F32, scale=20.0)
+    (o1, g1), (o2, g2) = build_both(small, types), build_both(other, types)
+    n1, n2 = len(orc.traverse_lvt(o1)[0]), len(orc.traverse_lvt(o2)[0])
+    assert n1 != n2 and n1 > 0 and n2 > 0
+    t = ibvh.traverse(g2)                       # sizes the cached buffers for the larger list
+    kept = []
+    for k in range(130):                        # two wraps of the 64-entry ring
+        t = ibvh.traverse(g1 if k % 2 == 0 else g2, cache=t)
+        assert t._pending is not None
+        kept.append((k, t))
+        if len(kept) == 60:                     # read 59 ... 1 calls late: all still valid
+            for kk, tt in kept:
+                assert tt._pending[0].item() == (n1 if kk % 2 == 0 else n2)
+            kept = []
+    stale = kept[0][1]                          # enqueued 70 - 1 calls ago by now? make it so
+    for _ in range(70):
+        t = ibvh.traverse(g2, cache=t)
+    with pytest.raises(RuntimeError):
+        stale._pending[0].item()                # recycled: refuses instead of returning another call's number
+    assert t.num_contacts == n2
+    # > 2 M items: the scan's tile sums reach beyond the first 4 KiB of the scratch
+    nbig = 2_200_000
+    big = ibvh.generate_spheres(nbig, 5, r0=0.5 * (3 * 8 / (4 * np.pi * nbig)) ** (1 / 3))
+    gb = ibvh.BVH(big)
+    ref = ibvh.traverse(gb)
+    want = ref.num_contacts
+    tb = ibvh.traverse(gb, cache=ref)
+    for _ in range(66):                          # across the wrap of the ring
+        prev = tb
+        tb = ibvh.traverse(gb, cache=tb)
+        assert prev._pending[0].item() == want   # read one call late
 
 
 def test_lvt_pair_and_rays_cache_reuse_enqueue_paths():

@@ -131,3 +131,62 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".jl")) or f == "Makefile":
                 text = open(os.path.join(base, f), errors="ignore").read()
                 assert "oracle/" not in text and "ibvh_oracle" not in text and "oracle_lib" not in text, f
+
+
+# ---------------------------------------------------------------------------------------------
+# the Julia binding (source only: no Julia here) must agree with the ctypes binding the GPU tests run on
+# ---------------------------------------------------------------------------------------------
+def _julia_ext():
+    import os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return open(os.path.join(here, "implicitbvh.jl_amd", "julia", "ImplicitBVHlibibvhExt.jl")).read()
+
+
+def test_julia_ccall_signatures_match_the_ctypes_binding():
+    """Every `ccall((:ibvh_x, libibvh), Cint, (argtypes...), ...)` of the Julia extension has the argument kinds
+    lib.SIGNATURES declares for ibvh_x (same count, same order, same width), so the two bindings cannot drift."""
+    import ctypes as C
+    import re
+    from implicitbvh_amd import abi, lib
+    src = _julia_ext()
+    calls = re.findall(r"ccall\(\(:(\w+), libibvh\), (\w+),\s*\(([^)]*)\)", src)
+    assert len(calls) >= 20
+    jl = {"Ptr{Cvoid}": C.c_void_p, "Int64": C.c_int64, "Int32": C.c_int32, "Csize_t": C.c_size_t, "Float64": C.c_double,
+          "Ref{Int64}": C.POINTER(C.c_int64), "Ref{Int32}": C.POINTER(C.c_int32), "Ref{Csize_t}": C.POINTER(C.c_size_t),
+          "Ref{IbvhTypes}": C.POINTER(abi.Types), "Ref{IbvhTree}": C.POINTER(abi.Tree), "Ref{IbvhBvh}": C.POINTER(abi.Bvh),
+          "Ref{IbvhBuildDesc}": C.POINTER(abi.BuildDesc), "Ref{IbvhBfsResult}": C.POINTER(abi.BfsResult)}
+    seen = set()
+    for name, ret, args in calls:
+        assert ret == "Cint", name
+        got = [jl[a.strip()] for a in args.split(",") if a.strip()]
+        assert got == lib.SIGNATURES[name], (name, args)
+        seen.add(name)
+    # the whole hot-path surface is bound: build + 3 LVT shapes x (count, write, enqueue) + 3 BFS shapes
+    want = {"ibvh_build", "ibvh_build_scratch_bytes", "ibvh_lvt_scratch_bytes", "ibvh_lvt_total", "ibvh_bfs_counters_bytes"}
+    for shape in ("", "_pair", "_rays"):
+        want |= {f"ibvh_traverse{shape}_lvt_{k}" for k in ("count", "write", "enqueue")}
+        want |= {f"ibvh_traverse{shape}_bfs", f"ibvh_bfs{shape}_initial_capacity"}
+    assert want <= seen, want - seen
+
+
+def test_julia_pod_structs_match_the_header_mirror():
+    """Field names, order and widths of the POD descriptors in the Julia extension == abi.py's ctypes mirror of ibvh.h."""
+    import ctypes as C
+    import re
+    from implicitbvh_amd import abi
+    src = _julia_ext()
+    width = {"Int32": 4, "Int64": 8, "Ptr{Cvoid}": 8, "NTuple{3, Float64}": 24, "IbvhTypes": C.sizeof(abi.Types), "IbvhTree": C.sizeof(abi.Tree)}
+    for jname, ctype in (("IbvhTypes", abi.Types), ("IbvhTree", abi.Tree), ("IbvhBvh", abi.Bvh), ("IbvhBuildDesc", abi.BuildDesc),
+                         ("IbvhBfsResult", abi.BfsResult)):
+        body = re.search(r"struct " + jname + r"\n(.*?)\nend", src, re.S).group(1)
+        fields = [(m.group(1), m.group(2).strip()) for m in re.finditer(r"(\w+)::([^;\n]+)", body)]
+        assert [f for f, _ in fields] == [f for f, _ in ctype._fields_], jname
+        assert [width[t] for _, t in fields] == [C.sizeof(t) for _, t in ctype._fields_], jname
+
+
+def test_julia_extension_never_drops_narrow():
+    """Round-1 finding: narrow_code(narrow) = 0 ignored user predicates.  Now unknown closures go to the generic method."""
+    src = _julia_ext()
+    assert "narrow_code(narrow) = Int32(0)" not in src
+    assert src.count("isnothing(code)") >= 4 and src.count("invoke(ImplicitBVH.traverse") >= 4
+    assert src.count("invoke(ImplicitBVH.traverse_rays") == 2
