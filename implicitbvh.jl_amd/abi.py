@@ -68,7 +68,7 @@ class BuildDesc(C.Structure):
 
 class BfsResult(C.Structure):
     _fields_ = [("num_contacts", C.c_int64), ("num_checks", C.c_int64), ("contacts_in", C.c_int64),
-                ("required_capacity", C.c_int64)]
+                ("required_capacity", C.c_int64), ("resume_step", C.c_int64), ("resume_num", C.c_int64)]
 
 
 def volume_dtype(kind, flt):

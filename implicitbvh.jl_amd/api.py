@@ -674,25 +674,39 @@ def _traverse_lvt_pair(bvh1, bvh2, sl1, sl2, narrow, cache):
     return BVHTraversal(sl1, sl2, 0, total.value, contacts, counts, scratch)
 
 
+BFS_INITIAL_FACTOR = 4  # queues start at 4x the initial pair count (bfs/traverse_single.jl:73)
+BFS_GROWTH = 2          # and at least double when a level does not fit
+
+
 def _bfs_run(entry, types, initial_capacity, cache, levels_hint, *args):
-    """Shared BFS driver: grow both queues to the reported capacity and retry (the reference's resize!)."""
+    """Shared BFS driver.  Queues start at 4x the initial pair count (the reference's sizing, bfs/traverse_single.jl:73)
+    or at the size of the cached buffers; when the library reports IBVH_ERR_CAPACITY both queues are grown (the pairs of
+    the level that overflowed are kept) and the SAME traversal continues from that level — the reference's resize!
+    between two levels (bfs/traverse_single.jl:38-53) — instead of starting over."""
     torch = _require_gpu()
     idt = _torch_index(types.index_type)
-    cap = max(int(initial_capacity), 1)
+    cap = BFS_INITIAL_FACTOR * max(int(initial_capacity), 1)
     q1 = cache.cache1 if cache else None
     q2 = cache.cache2 if cache else None
     need = C.c_size_t()
     lib.call("ibvh_bfs_counters_bytes", int(levels_hint), C.byref(need))
     counters = torch.zeros(need.value, dtype=torch.uint8, device="cuda")
+    q1 = _cache_tensor(q1, cap, 2, idt, "cache1")
+    q2 = _cache_tensor(q2, cap, 2, idt, "cache2")
+    res = abi.BfsResult()
     while True:
-        q1 = _cache_tensor(q1, cap, 2, idt, "cache1")
-        q2 = _cache_tensor(q2, cap, 2, idt, "cache2")
         cap = min(q1.shape[0], q2.shape[0])
-        res = abi.BfsResult()
         st = getattr(lib.load(), entry)(*args, _ptr(q1), _ptr(q2), cap, _ptr(counters), C.byref(res), _stream())
         if st == abi.ERR_CAPACITY:
-            cap = int(res.required_capacity)
-            q1 = q2 = None
+            new_cap = max(int(res.required_capacity), BFS_GROWTH * cap)
+            keep = int(res.resume_num) if res.resume_step > 0 else 0
+            grown = []
+            for k, q in enumerate((q1, q2), start=1):
+                g = torch.empty((new_cap, 2), dtype=idt, device="cuda")
+                if keep and k == res.contacts_in:
+                    g[:keep].copy_(q[:keep])  # the pairs the overflowed level still has to expand
+                grown.append(g)
+            q1, q2 = grown
             continue
         abi.check(st, entry)
         if res.contacts_in == 2:

@@ -207,49 +207,61 @@ template <class L, class N, class I, bool LEAF> struct RayStep {
 // ------------------------------------------------------------------------------------------
 // the level kernel: expand + wave64 ballot compaction + one global atomic per workgroup
 // ------------------------------------------------------------------------------------------
-// counters[0] = overflow flag, counters[slot] = tail of this step's destination queue
+// counters[0]      overflow flag: 0, or 1 + the index of the first step whose destination queue was too small
+// counters[1 + s]  entries in the SOURCE queue of step s (counters[1] = the initial queue; step s produces
+//                  counters[2 + s], counting on past `capacity` so that the exact need is known)
+// No host read between the levels: a step takes its source count from the device word the previous step
+// accumulated, so the grid is a fixed number of workgroups that stride over the source queue; once a step has
+// overflowed, the later steps (already enqueued) return at once and the caller resumes from that step with larger
+// queues (the source queue of the overflowed step is intact).
 template <class I, class Policy>
-__global__ __launch_bounds__(TPB) void level_kernel(const IndexPair<I> *__restrict__ src, int64_t num_src,
-                                                    IndexPair<I> *__restrict__ dst, int64_t capacity,
-                                                    unsigned long long *__restrict__ counters, int slot, Policy pol) {
+__global__ __launch_bounds__(TPB) void level_kernel(const IndexPair<I> *__restrict__ src, IndexPair<I> *__restrict__ dst,
+                                                    int64_t capacity, unsigned long long *__restrict__ counters, int step,
+                                                    Policy pol) {
     constexpr int MAXOUT = Policy::MAXOUT;
     __shared__ IndexPair<I> staged[MAXOUT * TPB];
     __shared__ int wave_tot[TPB / 64];
     __shared__ unsigned long long s_base;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
-
-    IndexPair<I> out[MAXOUT];
-    int k = 0;
-    if (i < num_src) k = pol.expand(src[i], out);
-
-    // exclusive offset inside the wave from ballots over the bit planes of k (k <= 4)
+    if (counters[0] != 0ull) return; // an earlier step overflowed: its destination (our source) is incomplete
+    const int64_t num_src = (int64_t)counters[1 + step];
+    if (num_src > capacity) return;   // (defensive: the flag covers this)
     const uint64_t lt = ((uint64_t)1 << lane) - 1;
-    uint64_t b0 = __ballot(k & 1), b1 = __ballot(k & 2), b2 = __ballot(k & 4);
-    int wave_prefix = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
-    int wave_sum = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
-    if (lane == 0) wave_tot[w] = wave_sum;
-    __syncthreads();
-    int block_prefix = 0, total = 0;
+    for (int64_t chunk = blockIdx.x; chunk * TPB < num_src; chunk += gridDim.x) {
+        const int64_t i = chunk * TPB + threadIdx.x;
+        IndexPair<I> out[MAXOUT];
+        int k = 0;
+        if (i < num_src) k = pol.expand(src[i], out);
+
+        // exclusive offset inside the wave from ballots over the bit planes of k (k <= 4)
+        uint64_t b0 = __ballot(k & 1), b1 = __ballot(k & 2), b2 = __ballot(k & 4);
+        int wave_prefix = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
+        int wave_sum = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+        if (lane == 0) wave_tot[w] = wave_sum;
+        __syncthreads();
+        int block_prefix = 0, total = 0;
 #pragma unroll
-    for (int j = 0; j < TPB / 64; ++j) {
-        int t = wave_tot[j];
-        if (j < w) block_prefix += t;
-        total += t;
-    }
-    const int at = block_prefix + wave_prefix;
+        for (int j = 0; j < TPB / 64; ++j) {
+            int t = wave_tot[j];
+            if (j < w) block_prefix += t;
+            total += t;
+        }
+        const int at = block_prefix + wave_prefix;
 #pragma unroll
-    for (int j = 0; j < MAXOUT; ++j)
-        if (j < k) staged[at + j] = out[j];
-    if (threadIdx.x == 0) s_base = total ? atomicAdd(&counters[slot], (unsigned long long)total) : 0ull;
-    __syncthreads();
-    if (total == 0) return;
-    const unsigned long long base = s_base;
-    if (base + (unsigned long long)total > (unsigned long long)capacity) {
-        if (threadIdx.x == 0) counters[0] = 1ull; // overflow: the tail keeps counting so the need is known
-        return;
+        for (int j = 0; j < MAXOUT; ++j)
+            if (j < k) staged[at + j] = out[j];
+        if (threadIdx.x == 0) s_base = total ? atomicAdd(&counters[2 + step], (unsigned long long)total) : 0ull;
+        __syncthreads();
+        const unsigned long long base = s_base;
+        if (total > 0) {
+            if (base + (unsigned long long)total > (unsigned long long)capacity) {
+                if (threadIdx.x == 0) atomicMax(&counters[0], (unsigned long long)(1 + step)); // the tail keeps counting
+            } else {
+                for (int p = threadIdx.x; p < total; p += TPB) dst[base + p] = staged[p];
+            }
+        }
+        __syncthreads(); // staged / wave_tot / s_base are reused by the next chunk
     }
-    for (int p = threadIdx.x; p < total; p += TPB) dst[base + p] = staged[p];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -287,65 +299,107 @@ __global__ __launch_bounds__(TPB) void fill_product_kernel(IndexPair<I> *q, int6
 // ------------------------------------------------------------------------------------------
 // host drivers
 // ------------------------------------------------------------------------------------------
+// A traversal is a fixed sequence of steps (one level kernel each).  All steps are enqueued back to back; ONE host
+// read at the end fetches the overflow flag and every step's count.
 struct Run {
     hipStream_t st;
     unsigned long long *counters;
     int64_t capacity;
-    int slot = 1;
-    int64_t num = 0; // entries in the current source queue
-    int64_t checks = 0;
-    int64_t need = 0;
-    bool swapped = false;
+    int64_t total_levels;
+    int step = 0;          // index of the next step
+    int first = 0;         // steps below `first` were completed by an earlier call (resume): they are not launched
+    bool swapped = false;  // false: step `step` reads q[0]
     void *q[2];
     void *src() const { return q[swapped ? 1 : 0]; }
     void *dst() const { return q[swapped ? 0 : 1]; }
 };
 
+inline int level_grid() {
+    static const int g = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return cus * 8;
+    }();
+    return g;
+}
+
 template <class I, class Policy> int step(Run &r, const Policy &pol) {
-    unsigned long long tail = 0, ovf = 0;
-    if (r.num > 0) {
-        unsigned blocks = (unsigned)ceil_div(r.num, TPB);
-        IBVH_LAUNCH((level_kernel<I, Policy>), dim3(blocks), dim3(TPB), 0, r.st, (const IndexPair<I> *)r.src(), r.num,
-                           (IndexPair<I> *)r.dst(), r.capacity, r.counters, r.slot, pol);
+    if (r.step >= r.first) {
+        IBVH_LAUNCH((level_kernel<I, Policy>), dim3(level_grid()), dim3(TPB), 0, r.st, (const IndexPair<I> *)r.src(),
+                    (IndexPair<I> *)r.dst(), r.capacity, r.counters, r.step, pol);
         IBVH_LAUNCH_CHECK();
-        // one blocking read per level, as the reference (bfs/traverse_single_gpu.jl:24)
-        IBVH_HIP_CHECK(hipMemcpyAsync(&tail, r.counters + r.slot, 8, hipMemcpyDeviceToHost, r.st));
-        IBVH_HIP_CHECK(hipMemcpyAsync(&ovf, r.counters, 8, hipMemcpyDeviceToHost, r.st));
-        IBVH_HIP_CHECK(hipStreamSynchronize(r.st));
     }
-    r.slot += 1;
-    if (ovf || (int64_t)tail > r.capacity) {
-        r.need = (int64_t)tail;
-        return IBVH_ERR_CAPACITY;
-    }
-    r.num = (int64_t)tail;
+    r.step += 1;
     r.swapped = !r.swapped;
     return IBVH_OK;
 }
 
 inline size_t counters_bytes(int64_t total_levels) { return (size_t)(total_levels + 8) * 8; }
 
-inline int begin(Run &r, void *bvtt1, void *bvtt2, int64_t capacity, void *counters, int64_t total_levels, hipStream_t st) {
+// fresh run: counters zeroed, counters[1] = initial queue size.  Resume (res->resume_step > 0): the queue the
+// overflowed step reads — res->contacts_in says which buffer — still holds res->resume_num entries; the flag and
+// the counts from that step on are cleared, the earlier counts stay (they are part of num_checks).
+inline int begin(Run &r, void *bvtt1, void *bvtt2, int64_t capacity, void *counters, int64_t total_levels, hipStream_t st,
+                 const ibvh_bfs_result *res, int64_t initial) {
     r.st = st;
     r.counters = (unsigned long long *)counters;
     r.capacity = capacity;
+    r.total_levels = total_levels;
     r.q[0] = bvtt1;
     r.q[1] = bvtt2;
+    if (res->resume_step > 0) {
+        if (res->resume_step > total_levels + 4) return IBVH_ERR_INVALID_ARG;
+        r.first = (int)res->resume_step;
+        const size_t keep = (size_t)(2 + r.first) * 8; // flag + counts of the sources of steps 0 .. first
+        IBVH_HIP_CHECK(hipMemsetAsync(counters, 0, 8, st));
+        IBVH_HIP_CHECK(hipMemsetAsync((char *)counters + keep, 0, counters_bytes(total_levels) - keep, st));
+        return IBVH_OK;
+    }
     IBVH_HIP_CHECK(hipMemsetAsync(counters, 0, counters_bytes(total_levels), st));
+    unsigned long long init = (unsigned long long)initial;
+    IBVH_HIP_CHECK(hipMemcpyAsync((char *)counters + 8, &init, 8, hipMemcpyHostToDevice, st)); // (pageable: copied before return)
     return IBVH_OK;
 }
 
-inline void finish(const Run &r, ibvh_bfs_result *res) {
-    res->num_contacts = r.num;
-    res->num_checks = r.checks;
+// the one blocking read: flag + all counts
+inline int finish(const Run &r, ibvh_bfs_result *res) {
+    unsigned long long host[80];
+    const int nsteps = r.step;
+    if (nsteps + 2 > 80) return IBVH_ERR_INVALID_ARG;
+    IBVH_HIP_CHECK(hipMemcpyAsync(host, r.counters, (size_t)(nsteps + 2) * 8, hipMemcpyDeviceToHost, r.st));
+    IBVH_HIP_CHECK(hipStreamSynchronize(r.st));
+    const unsigned long long flag = host[0];
+    if (flag != 0ull) {
+        const int s = (int)flag - 1; // the first step whose destination was too small
+        const int64_t need = (int64_t)host[2 + s];
+        res->num_contacts = 0;
+        res->num_checks = 0;
+        // the source queue of step s: buffer 1 if s is even (nothing swapped yet), buffer 2 otherwise
+        res->contacts_in = (s % 2 == 0) ? 1 : 2;
+        res->required_capacity = need + need / 4 + 1024; // exact need of the step that overflowed + headroom
+        res->resume_step = s;
+        res->resume_num = (int64_t)host[1 + s];
+        return IBVH_ERR_CAPACITY;
+    }
+    // num_checks (bfs/traverse_single.jl:25,48, traverse_pair.jl:146-150): every entry of every SOURCE queue is one
+    // check — the initial queue plus each node-level result; the result of the last (leaf) step is the contact list
+    int64_t checks = 0;
+    for (int s = 0; s < nsteps; ++s) checks += (int64_t)host[1 + s];
+    res->num_contacts = (int64_t)host[1 + nsteps];
+    res->num_checks = checks;
     res->contacts_in = r.swapped ? 2 : 1;
     res->required_capacity = 0;
+    res->resume_step = 0;
+    res->resume_num = 0;
+    return IBVH_OK;
 }
-inline int capacity_error(const Run &r, ibvh_bfs_result *res, int64_t need) {
+inline int capacity_error(ibvh_bfs_result *res, int64_t need) {
     res->num_contacts = 0;
     res->num_checks = 0;
     res->contacts_in = 1;
-    res->required_capacity = need + need / 4 + 1024; // exact need of the level that overflowed + headroom
+    res->required_capacity = need + need / 4 + 1024;
+    res->resume_step = 0; // nothing to keep: the initial queue itself did not fit
+    res->resume_num = 0;
     return IBVH_ERR_CAPACITY;
 }
 
@@ -366,25 +420,21 @@ int run_self(const ibvh_bvh &b, int64_t start_level, int narrow, void *bvtt1, vo
     LeafLayout dl;
     layout_of(b.types, lay, &dl);
     Run r;
-    if (int e = begin(r, bvtt1, bvtt2, capacity, counters, b.tree.levels, st)) return e;
     const int64_t levels = b.tree.levels;
     const int64_t n0 = level_num_real(levels, b.tree.virtual_leaves, start_level);
     const int64_t total0 = self_initial(b, start_level);
-    if (total0 > capacity) return capacity_error(r, res, total0);
-    if (total0 > 0)
+    if (res->resume_step == 0 && total0 > capacity) return capacity_error(res, total0);
+    if (int e = begin(r, bvtt1, bvtt2, capacity, counters, levels, st, res, total0)) return e;
+    if (r.first == 0 && total0 > 0)
         IBVH_LAUNCH((fill_self_kernel<I>), dim3((unsigned)ceil_div(total0, TPB)), dim3(TPB), 0, st, (IndexPair<I> *)bvtt1,
                            n0, int64_t(1) << (start_level - 1), start_level != levels ? 1 : 0, total0);
-    r.num = total0;
-    r.checks = total0;
     for (int64_t level = start_level; level < levels; ++level) {
         SelfNodes<L, N, I> pol{make_ref<L, N>(b, dl, level), level < levels - 1 ? 1 : 0}; // self_checks (:44)
-        if (int e = step<I>(r, pol)) return e == IBVH_ERR_CAPACITY ? capacity_error(r, res, r.need) : e;
-        r.checks += r.num;
+        if (int e = step<I>(r, pol)) return e;
     }
     SelfLeaves<L, N, I> leaves{make_ref<L, N>(b, dl, levels), narrow};
-    if (int e = step<I>(r, leaves)) return e == IBVH_ERR_CAPACITY ? capacity_error(r, res, r.need) : e;
-    finish(r, res);
-    return IBVH_OK;
+    if (int e = step<I>(r, leaves)) return e;
+    return finish(r, res);
 }
 
 template <class L, class N, class I>
@@ -395,14 +445,13 @@ int run_pair(const ibvh_bvh &b1, const ibvh_bvh &b2, int64_t sl1, int64_t sl2, i
     layout_of(b1.types, lay, &dl);
     Run r;
     const int64_t L1 = b1.tree.levels, L2 = b2.tree.levels;
-    if (int e = begin(r, bvtt1, bvtt2, capacity, counters, L1 + L2, st)) return e;
     const int64_t nr1 = level_num_real(L1, b1.tree.virtual_leaves, sl1), nr2 = level_num_real(L2, b2.tree.virtual_leaves, sl2);
     const int64_t total0 = nr1 * nr2;
-    if (total0 > capacity) return capacity_error(r, res, total0);
-    IBVH_LAUNCH((fill_product_kernel<I>), dim3((unsigned)ceil_div(total0, TPB)), dim3(TPB), 0, st, (IndexPair<I> *)bvtt1,
-                       nr1, nr2, int64_t(1) << (sl1 - 1), int64_t(1) << (sl2 - 1));
-    r.num = total0;
-    r.checks = total0;
+    if (res->resume_step == 0 && total0 > capacity) return capacity_error(res, total0);
+    if (int e = begin(r, bvtt1, bvtt2, capacity, counters, L1 + L2, st, res, total0)) return e;
+    if (r.first == 0)
+        IBVH_LAUNCH((fill_product_kernel<I>), dim3((unsigned)ceil_div(total0, TPB)), dim3(TPB), 0, st, (IndexPair<I> *)bvtt1,
+                           nr1, nr2, int64_t(1) << (sl1 - 1), int64_t(1) << (sl2 - 1));
     int64_t l1 = sl1, l2 = sl2;
     int rc = IBVH_OK;
     auto do_step = [&](auto pol) {
@@ -410,44 +459,36 @@ int run_pair(const ibvh_bvh &b1, const ibvh_bvh &b2, int64_t sl1, int64_t sl2, i
         pol.t2 = make_ref<L, N>(b2, dl, l2);
         pol.narrow = narrow;
         rc = step<I>(r, pol);
-        if (rc == IBVH_OK) r.checks += r.num;
         return rc == IBVH_OK;
     };
     // the six-phase descent of bfs/traverse_pair.jl:50-143
     while (l1 < L1 - 1 && l2 < L2 - 1) {
-        if (!do_step(PairStep<L, N, I, false, false, true, true>{})) goto fail;
+        if (!do_step(PairStep<L, N, I, false, false, true, true>{})) return rc;
         ++l1, ++l2;
     }
     while (l1 < L1 - 1 && l2 == L2 - 1) {
-        if (!do_step(PairStep<L, N, I, false, false, true, false>{})) goto fail;
+        if (!do_step(PairStep<L, N, I, false, false, true, false>{})) return rc;
         ++l1;
     }
     while (l2 < L2 - 1 && l1 == L1 - 1) {
-        if (!do_step(PairStep<L, N, I, false, false, false, true>{})) goto fail;
+        if (!do_step(PairStep<L, N, I, false, false, false, true>{})) return rc;
         ++l2;
     }
     while (l2 == L2 && l1 < L1) {
-        if (!do_step(PairStep<L, N, I, false, true, true, false>{})) goto fail;
+        if (!do_step(PairStep<L, N, I, false, true, true, false>{})) return rc;
         ++l1;
     }
     while (l1 == L1 && l2 < L2) {
-        if (!do_step(PairStep<L, N, I, true, false, false, true>{})) goto fail;
+        if (!do_step(PairStep<L, N, I, true, false, false, true>{})) return rc;
         ++l2;
     }
     if (l1 == L1 - 1 && l2 == L2 - 1) {
-        if (!do_step(PairStep<L, N, I, false, false, true, true>{})) goto fail;
+        if (!do_step(PairStep<L, N, I, false, false, true, true>{})) return rc;
         ++l1, ++l2;
     }
-    {
-        // leaf-leaf: num_checks is not incremented after the final step (bfs/traverse_pair.jl:146-150)
-        int64_t checks = r.checks;
-        if (!do_step(PairStep<L, N, I, true, true, false, false>{})) goto fail;
-        r.checks = checks;
-    }
-    finish(r, res);
-    return IBVH_OK;
-fail:
-    return rc == IBVH_ERR_CAPACITY ? capacity_error(r, res, r.need) : rc;
+    // leaf-leaf: its result is the contact list (num_checks is not incremented after it, bfs/traverse_pair.jl:146-150)
+    if (!do_step(PairStep<L, N, I, true, true, false, false>{})) return rc;
+    return finish(r, res);
 }
 
 template <class L, class N, class I>
@@ -459,23 +500,20 @@ int run_rays(const ibvh_bvh &b, const void *points, const void *dirs, int64_t nu
     layout_of(b.types, lay, &dl);
     Run r;
     const int64_t levels = b.tree.levels;
-    if (int e = begin(r, bvtt1, bvtt2, capacity, counters, levels, st)) return e;
     const int64_t nr = level_num_real(levels, b.tree.virtual_leaves, start_level);
     const int64_t total0 = nr * num_rays;
-    if (total0 > capacity) return capacity_error(r, res, total0);
-    IBVH_LAUNCH((fill_product_kernel<I>), dim3((unsigned)ceil_div(total0, TPB)), dim3(TPB), 0, st, (IndexPair<I> *)bvtt1, nr,
-                       num_rays, int64_t(1) << (start_level - 1), int64_t(1));
-    r.num = total0;
-    r.checks = total0;
+    if (res->resume_step == 0 && total0 > capacity) return capacity_error(res, total0);
+    if (int e = begin(r, bvtt1, bvtt2, capacity, counters, levels, st, res, total0)) return e;
+    if (r.first == 0)
+        IBVH_LAUNCH((fill_product_kernel<I>), dim3((unsigned)ceil_div(total0, TPB)), dim3(TPB), 0, st, (IndexPair<I> *)bvtt1, nr,
+                           num_rays, int64_t(1) << (start_level - 1), int64_t(1));
     for (int64_t level = start_level; level < levels; ++level) {
         RayStep<L, N, I, false> pol{make_ref<L, N>(b, dl, level), (const T *)points, (const T *)dirs};
-        if (int e = step<I>(r, pol)) return e == IBVH_ERR_CAPACITY ? capacity_error(r, res, r.need) : e;
-        r.checks += r.num;
+        if (int e = step<I>(r, pol)) return e;
     }
     RayStep<L, N, I, true> leaves{make_ref<L, N>(b, dl, levels), (const T *)points, (const T *)dirs};
-    if (int e = step<I>(r, leaves)) return e == IBVH_ERR_CAPACITY ? capacity_error(r, res, r.need) : e;
-    finish(r, res);
-    return IBVH_OK;
+    if (int e = step<I>(r, leaves)) return e;
+    return finish(r, res);
 }
 
 inline int check_levels(const ibvh_bvh &b, int64_t sl) {
@@ -530,7 +568,9 @@ ibvh_status ibvh_bfs_rays_initial_capacity(const ibvh_bvh *bvh, int64_t num_rays
 ibvh_status ibvh_traverse_bfs(const ibvh_bvh *bvh, int64_t start_level, int32_t narrow, void *bvtt1, void *bvtt2,
                               int64_t capacity, void *counters, ibvh_bfs_result *result, void *stream) {
     if (!bvh || !result) return IBVH_ERR_INVALID_ARG;
-    *result = {0, 0, 1, 0};
+    const ibvh_bfs_result in = *result;
+    *result = {0, 0, 1, 0, in.resume_step, in.resume_num};
+    if (in.resume_step < 0 || in.resume_num < 0) return IBVH_ERR_INVALID_ARG;
     if (int e = check_levels(*bvh, start_level)) return (ibvh_status)e;
     if (bvh->tree.real_nodes <= 1) return IBVH_OK; // bfs/traverse_single.jl:17-21
     if (!bvtt1 || !bvtt2 || !counters || capacity < 1) return IBVH_ERR_INVALID_ARG;
@@ -545,7 +585,9 @@ ibvh_status ibvh_traverse_pair_bfs(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, i
                                    void *bvtt1, void *bvtt2, int64_t capacity, void *counters, ibvh_bfs_result *result,
                                    void *stream) {
     if (!bvh1 || !bvh2 || !result) return IBVH_ERR_INVALID_ARG;
-    *result = {0, 0, 1, 0};
+    const ibvh_bfs_result in = *result;
+    *result = {0, 0, 1, 0, in.resume_step, in.resume_num};
+    if (in.resume_step < 0 || in.resume_num < 0) return IBVH_ERR_INVALID_ARG;
     if (int e = check_levels(*bvh1, sl1)) return (ibvh_status)e;
     if (int e = check_levels(*bvh2, sl2)) return (ibvh_status)e;
     if (!same_types(bvh1->types, bvh2->types)) return IBVH_ERR_UNSUPPORTED;
@@ -561,7 +603,9 @@ ibvh_status ibvh_traverse_rays_bfs(const ibvh_bvh *bvh, const void *points, cons
                                    int64_t start_level, void *bvtt1, void *bvtt2, int64_t capacity, void *counters,
                                    ibvh_bfs_result *result, void *stream) {
     if (!bvh || !result || num_rays < 0) return IBVH_ERR_INVALID_ARG;
-    *result = {0, 0, 1, 0};
+    const ibvh_bfs_result in = *result;
+    *result = {0, 0, 1, 0, in.resume_step, in.resume_num};
+    if (in.resume_step < 0 || in.resume_num < 0) return IBVH_ERR_INVALID_ARG;
     if (int e = check_levels(*bvh, start_level)) return (ibvh_status)e;
     if (bvh->types.leaf_float != bvh->types.node_float) return IBVH_ERR_UNSUPPORTED;
     if (num_rays == 0) return IBVH_OK;

@@ -4,6 +4,7 @@
 
 #include "ibvh_common.hpp"
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -19,6 +20,8 @@ struct Rec {
 };
 static std::vector<Rec> recs;
 static std::vector<hipEvent_t> pool;
+static std::mutex mu; // launches may come from several host threads (one stream each)
+static thread_local size_t last = 0; // the record begin() of THIS thread opened
 static hipEvent_t take() {
     hipEvent_t e;
     if (!pool.empty()) {
@@ -30,12 +33,18 @@ static hipEvent_t take() {
     return e;
 }
 void begin(const char *name, hipStream_t st) {
+    std::lock_guard<std::mutex> g(mu);
     Rec r{name, take(), take()};
     (void)hipEventRecord(r.a, st);
     recs.push_back(r);
+    last = recs.size() - 1;
 }
-void end(hipStream_t st) { (void)hipEventRecord(recs.back().b, st); }
+void end(hipStream_t st) {
+    std::lock_guard<std::mutex> g(mu);
+    if (last < recs.size()) (void)hipEventRecord(recs[last].b, st);
+}
 static void reset() {
+    std::lock_guard<std::mutex> g(mu);
     for (auto &r : recs) {
         pool.push_back(r.a);
         pool.push_back(r.b);

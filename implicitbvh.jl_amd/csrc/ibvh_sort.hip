@@ -573,15 +573,12 @@ int run_passes(K *keys, uint32_t *vals, K *keys_alt, uint32_t *vals_alt, int64_t
     const int num_tiles = (int)ceil_div(n, TPB * IPT);
     uint32_t *tile_hist = (uint32_t *)scratch;
     uint32_t *digit_total = (uint32_t *)((char *)scratch + align_up((int64_t)RADIX * num_tiles * 4, 256));
-    static bool attr_set = false;
     constexpr size_t smem = scatter_smem<K, TPB, IPT>();
-    if (!attr_set) {
-        IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)scatter_kernel<K, TPB, IPT, false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)scatter_kernel<K, TPB, IPT, true>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
+    // (per call, not once per process: the attribute is per DEVICE, and a host may drive several GPUs from one process)
+    IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)scatter_kernel<K, TPB, IPT, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)scatter_kernel<K, TPB, IPT, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     K *kin = keys, *kout = keys_alt;
     uint32_t *vin = vals, *vout = vals_alt;
     int flips = 0;
@@ -623,16 +620,12 @@ int run_msd(K *keys, uint32_t *vals, K *keys_alt, uint32_t *vals_alt, int64_t n,
     uint32_t *digit_total = (uint32_t *)((char *)scratch + align_up((int64_t)radix * num_tiles * 4, 256));
     const size_t ssm = scatter_wide_smem<K, TPB, IPT>(msd_bits);
     constexpr size_t bsm = bucket_smem<K, BT, BI>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)scatter_wide_kernel<K, TPB, IPT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_wide_smem<K, TPB, IPT>(MSD_MAX_BITS)));
-        IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)bucket_sort_kernel<K, BT, BI, false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bsm));
-        IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)bucket_sort_kernel<K, BT, BI, true>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bsm));
-        attr_set = true;
-    }
+    IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)scatter_wide_kernel<K, TPB, IPT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_wide_smem<K, TPB, IPT>(MSD_MAX_BITS)));
+    IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)bucket_sort_kernel<K, BT, BI, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bsm));
+    IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)bucket_sort_kernel<K, BT, BI, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bsm));
     if (!first_hist_done)
         IBVH_LAUNCH((hist_wide_kernel<K, TPB, IPT>), dim3(num_tiles), dim3(TPB), (size_t)radix * 4, st, keys, n, shift, msd_bits,
                     tile_hist, num_tiles);

@@ -52,6 +52,7 @@ struct IbvhBuildDesc
 end
 mutable struct IbvhBfsResult
     num_contacts::Int64; num_checks::Int64; contacts_in::Int64; required_capacity::Int64
+    resume_step::Int64; resume_num::Int64
 end
 
 kind(::Type{<:BSphere}) = Int32(0);  kind(::Type{<:BBox}) = Int32(1)
@@ -397,11 +398,14 @@ function bfs_run(::Type{I}, like, initial_pairs, total_levels, cache, run, what)
     check(c_bfs_counters_bytes(total_levels, nb), "ibvh_bfs_counters_bytes")
     counters = scratch!(:bfs_counters, nb[])
     fill!(counters, 0x00)
-    res = IbvhBfsResult(0, 0, 1, 0)
+    res = IbvhBfsResult(0, 0, 1, 0, 0, 0)
     while true
         st = run(bvtt1, bvtt2, min(length(bvtt1), length(bvtt2)), counters, res)
         if st == IBVH_ERR_CAPACITY                          # the reference's resize! (bfs/traverse_single.jl:40)
-            resize!(bvtt1, res.required_capacity); resize!(bvtt2, res.required_capacity)
+            # resize! keeps the contents: the queue res.contacts_in still holds the res.resume_num pairs of the level
+            # that overflowed, and the next call (same `res`, same counters) resumes there instead of starting over
+            newcap = max(res.required_capacity, 2 * min(length(bvtt1), length(bvtt2)))
+            resize!(bvtt1, newcap); resize!(bvtt2, newcap)
             continue
         end
         check(st, what); break

@@ -264,8 +264,16 @@ ibvh_status ibvh_lvt_total(const void *total_dev_or_scratch, int64_t *total_out,
 typedef struct ibvh_bfs_result {
     int64_t num_contacts;
     int64_t num_checks;        /* BVHTraversal.num_checks (bfs/traverse_single.jl:25,48)          */
-    int64_t contacts_in;       /* 1: contacts are in bvtt1, 2: in bvtt2                            */
+    int64_t contacts_in;       /* 1: contacts are in bvtt1, 2: in bvtt2; with IBVH_ERR_CAPACITY: the queue that
+                                  holds the pairs still to be expanded (keep its first resume_num entries)     */
     int64_t required_capacity; /* pairs each queue must hold; set when IBVH_ERR_CAPACITY          */
+    /* IN/OUT — resuming after IBVH_ERR_CAPACITY instead of starting over (the reference grows its queue between two
+     * levels, bfs/traverse_single.jl:38-53): zero both for a fresh traversal.  With IBVH_ERR_CAPACITY the library
+     * reports the step whose destination queue was too small; call again with the SAME result struct, both queues
+     * grown to required_capacity (contents of the `contacts_in` queue preserved, e.g. Julia's resize!) and the same
+     * `counters` buffer: the traversal continues from that step.                                                   */
+    int64_t resume_step;
+    int64_t resume_num;
 } ibvh_bfs_result;
 
 /* Pairs the initial queue needs: initial_bvtt (bfs/traverse_single.jl:64-99). */
@@ -281,9 +289,11 @@ ibvh_status ibvh_bfs_counters_bytes(int64_t total_levels, size_t *bytes_out);
 
 /* traverse(bvh, BFSTraversal()) — bfs/traverse_single.jl:1-61.  bvtt1/bvtt2: two queues of
  * `capacity` IndexPair{I} each (cache1/cache2).  counters: DEVICE scratch of
- * ibvh_bfs_counters_bytes() bytes (queue tails, one per level).  Synchronises the stream (one read per level, as the reference,
- * bfs/traverse_single_gpu.jl:24).  On IBVH_ERR_CAPACITY grow both queues to
- * result->required_capacity and call again (the reference's resize!, bfs/traverse_single.jl:40). */
+ * ibvh_bfs_counters_bytes() bytes (overflow flag + one count per level).  All levels are enqueued back to back — a
+ * level takes its queue length from the device word the previous level accumulated — and the stream is synchronised
+ * ONCE, at the end (the reference reads one count per level, bfs/traverse_single_gpu.jl:24).  On IBVH_ERR_CAPACITY
+ * grow both queues to result->required_capacity and call again with the same `result` (see ibvh_bfs_result: the
+ * traversal resumes at the level that overflowed; the reference's resize!, bfs/traverse_single.jl:40). */
 ibvh_status ibvh_traverse_bfs(const ibvh_bvh *bvh, int64_t start_level, int32_t narrow, void *bvtt1,
                               void *bvtt2, int64_t capacity, void *counters,
                               ibvh_bfs_result *result, void *stream);

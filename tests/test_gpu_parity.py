@@ -651,6 +651,69 @@ def test_bfs_large_with_capacity_growth_and_cache():
     assert sorted(map(tuple, contacts_np(lvt).tolist())) == sorted(map(tuple, contacts_np(got).tolist()))
 
 
+def test_bfs_resumes_at_the_level_that_overflowed(monkeypatch):
+    """Queues that start at exactly the initial pair count and grow only to what the overflowed level needs: nearly every
+    level overflows once, and every time the traversal must RESUME there (ibvh_bfs_result.resume_step / resume_num) — same
+    contacts and the same num_checks as the oracle for one BVH, two BVHs and rays."""
+    from implicitbvh_amd import api
+    monkeypatch.setattr(api, "BFS_INITIAL_FACTOR", 1)
+    monkeypatch.setattr(api, "BFS_GROWTH", 1)
+    calls = {"n": 0, "resumed": 0}
+    real = lib.load().ibvh_traverse_bfs
+
+    rng = np.random.default_rng(41)
+    types = abi.make_types()
+    n = 30000
+    sph = orc.generate_spheres_f32(n, 9, r0=0.5 * (3 * 8 / (4 * np.pi * n)) ** (1 / 3))
+    o, g = build_both(sph, types)
+    eb, res = orc.traverse_bfs(o)
+    got = ibvh.traverse(g, ibvh.BFSTraversal())
+    assert got.num_checks == res.num_checks and got.num_contacts == res.num_contacts
+    assert sorted(map(tuple, contacts_np(got).tolist())) == sorted(map(tuple, oracle_pairs(eb).tolist()))
+    # the raw ABI: count the resumes of one traversal
+    s = g.struct()
+    cap = C.c_int64()
+    lib.call("ibvh_bfs_initial_capacity", C.byref(s), 8, C.byref(cap))
+    q = [torch.empty((cap.value, 2), dtype=torch.int32, device="cuda") for _ in range(2)]
+    need = C.c_size_t()
+    lib.call("ibvh_bfs_counters_bytes", g.tree.levels, C.byref(need))
+    counters = torch.zeros(need.value, dtype=torch.uint8, device="cuda")
+    r = abi.BfsResult()
+    resumes = 0
+    while True:
+        st = real(C.byref(s), 8, 0, q[0].data_ptr(), q[1].data_ptr(), min(q[0].shape[0], q[1].shape[0]), counters.data_ptr(),
+                  C.byref(r), torch.cuda.current_stream().cuda_stream)
+        if st != abi.ERR_CAPACITY:
+            break
+        assert r.resume_step >= resumes - 1 and r.resume_num > 0  # never back to the start
+        resumes += 1
+        grown = []
+        for k in (1, 2):
+            t_ = torch.empty((int(r.required_capacity), 2), dtype=torch.int32, device="cuda")
+            if k == r.contacts_in:
+                t_[: r.resume_num].copy_(q[k - 1][: r.resume_num])
+            grown.append(t_)
+        q = grown
+    assert st == 0 and resumes >= 3
+    e8, r8 = orc.traverse_bfs(o, 8)
+    assert r.num_checks == r8.num_checks and r.num_contacts == r8.num_contacts
+    # two BVHs and rays through the Python driver (same resume loop)
+    b2 = random_volumes(rng, 5000, abi.BSPHERE, abi.F32, scale=10.0)
+    o2, g2 = build_both(b2, types)
+    b3 = random_volumes(rng, 7000, abi.BSPHERE, abi.F32, scale=10.0)
+    o3, g3 = build_both(b3, types)
+    ep, rp = orc.traverse_pair_bfs(o2, o3, 3, 4)
+    gp = ibvh.traverse(g2, g3, ibvh.BFSTraversal(), start_level1=3, start_level2=4)
+    assert gp.num_checks == rp.num_checks
+    assert sorted(map(tuple, contacts_np(gp).tolist())) == sorted(map(tuple, oracle_pairs(ep).tolist()))
+    p = rng.random((3000, 3)).astype(np.float32) * 10
+    d = (rng.random((3000, 3)) - 0.5).astype(np.float32)
+    er, rr = orc.traverse_rays_bfs(o2, p, d, 2)
+    gr = ibvh.traverse_rays(g2, torch.from_numpy(p).cuda().t(), torch.from_numpy(d).cuda().t(), ibvh.BFSTraversal(), start_level=2)
+    assert gr.num_checks == rr.num_checks
+    assert sorted(map(tuple, contacts_np(gr).tolist())) == sorted(map(tuple, oracle_pairs(er).tolist()))
+
+
 # ---------------------------------------------------------------------------------------------
 # multi-GPU build, emulated with virtual ranks on this one GPU (HipEngine + in-process collectives)
 # ---------------------------------------------------------------------------------------------
@@ -822,3 +885,44 @@ def test_config2_one_million_properties():
     assert (c == exp).all()
     idem = ibvh.traverse(g, cache=t)
     assert (contacts_np(idem) == c).all()  # idempotence with cache reuse
+
+
+def test_concurrent_builds_and_traversals_on_two_streams_from_two_threads():
+    """Re-entrancy (include/ibvh.h: 'no global state'): two host threads, one HIP stream each, build and traverse
+    different clouds at the same time, per-launch profiling switched on (its record list is shared); each thread's
+    results must equal the oracle's."""
+    import threading
+    rng = np.random.default_rng(77)
+    types = abi.make_types()
+    clouds = [random_volumes(rng, n, abi.BSPHERE, abi.F32, scale=s) for n, s in ((30011, 25.0), (50021, 30.0))]
+    oracles = [orc.build(c, types) for c in clouds]
+    expect = [oracle_pairs(orc.traverse_lvt(o)[0]) for o in oracles]
+    errors = []
+
+    def work(k):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                dev = torch.from_numpy(clouds[k]).cuda()
+                for _ in range(6):
+                    g = ibvh.BVH(dev)
+                    t = ibvh.traverse(g)
+                    assert g.leaves.to_numpy().tobytes() == oracles[k].leaves.tobytes()
+                    assert (contacts_np(t) == expect[k]).all()
+            st.synchronize()
+        except BaseException as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    lib.call("ibvh_profile_enable", 1)
+    try:
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        cnt = C.c_int64()
+        lib.call("ibvh_profile_count", C.byref(cnt))
+        lib.call("ibvh_profile_enable", 0)
+    assert not errors, errors
+    assert cnt.value > 0
