@@ -63,7 +63,8 @@ class Bvh(C.Structure):
 class BuildDesc(C.Structure):
     _fields_ = [("types", Types), ("n", C.c_int64), ("built_level", C.c_int64),
                 ("already_wrapped", C.c_int32), ("compute_extrema", C.c_int32),
-                ("mins", C.c_double * 3), ("maxs", C.c_double * 3)]
+                ("mins", C.c_double * 3), ("maxs", C.c_double * 3),
+                ("two_level", C.c_int32), ("reserved_", C.c_int32), ("skew_flag", C.c_void_p)]
 
 
 class BfsResult(C.Structure):

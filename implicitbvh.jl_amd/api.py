@@ -366,6 +366,12 @@ class BVH:
             bounding_volumes = bounding_volumes.contiguous()
             vol_ptr = _ptr(bounding_volumes)
         self.extrema = torch.empty(6, dtype=_torch_float(flt), device="cuda")
+        # skewed inputs: a cold build always runs the sort's second partition level; a build that reuses `cache=` runs it
+        # only if the previous build of the chain met a crowded cell.  The GPU leaves that fact in a pinned host word
+        # (mapped into the device's address space), which is read here WITHOUT synchronising: the latest value that has
+        # arrived is good enough for a hint (include/ibvh.h, ibvh_build_desc.two_level / skew_flag).
+        self._skew = cache._skew if cache is not None and getattr(cache, "_skew", None) is not None else \
+            torch.ones(1, dtype=torch.int32).pin_memory()
         d = abi.BuildDesc()
         d.types = types
         d.n = n
@@ -376,6 +382,8 @@ class BVH:
         if not alg.compute_extrema:
             d.mins[:] = [float(v) for v in alg.mins]
             d.maxs[:] = [float(v) for v in alg.maxs]
+        d.two_level = 1 if (cache is None or int(self._skew[0]) != 0) else 0
+        d.skew_flag = self._skew.data_ptr()
         lib.call("ibvh_build", C.byref(d), vol_ptr, _ptr(self.leaves.buf), _ptr(self.nodes), _ptr(self.skips),
                  _ptr(self.extrema), _ptr(self._scratch), self._scratch.numel(), _stream())
 
@@ -395,6 +403,7 @@ class BVH:
         self.skips = torch.tensor(list(sk), dtype=_torch_index(types.index_type), device="cuda")
         self.extrema = None
         self._scratch = None
+        self._skew = None
         return self
 
     def struct(self):

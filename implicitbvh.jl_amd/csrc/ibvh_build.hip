@@ -10,6 +10,7 @@
 //   aggregate         read records [24 stride, 16 used], write nodes [24 * ~1]
 #include "ibvh_common.hpp"
 #include "ibvh_radix.hpp"
+#include "ibvh_msd.hpp"
 
 namespace ibvh {
 namespace rsort { // ibvh_sort.hip: LSD passes over (key, position) pairs (+ the MSD / in-LDS hybrid on pairs)
@@ -26,16 +27,6 @@ int sort_pairs(int key_bytes, int key_bits, int64_t n, void *keys, void *vals, v
                bool first_hist_done, const RecordArgs *records);
 size_t scratch_bytes(int64_t n);
 } // namespace rsort
-namespace msd { // ibvh_msd.hip: MSD partition of whole records + in-LDS finish per bucket (the default path)
-struct Plan {
-    int bits, shift, ptpb, pipt, num_tiles, ftpb, fipt;
-    uint32_t *tile_hist, *tile_scan, *digit_total;
-};
-Plan make_plan(int64_t n, int key_bits, int key_bytes, int leaf_bytes, void *sort_scratch);
-size_t scratch_bytes(int64_t n);
-int sort_records(const Plan &p, int key_bytes, const void *keys, int64_t n, const rsort::RecordArgs &ra, char *out, void *kalt,
-                 uint32_t *valt, void *kpri, uint32_t *vpri, hipStream_t st);
-} // namespace msd
 
 namespace build {
 
@@ -403,10 +394,12 @@ struct Scratch {
     char *keys, *keys_alt; // n * key_bytes
     char *vals, *vals_alt; // n * 4
     char *records;   // n * leaf_bytes: the partitioned records (and the staging of an in-place LSD build)
+    char *records2;  // n * leaf_bytes: second partition level (oversized cells only)
     char *sort;      // rsort::scratch_bytes(n)
     size_t total;
 };
-inline Scratch carve(char *base, int64_t n, int key_bytes, int64_t leaf_bytes, bool wrapped) {
+inline int morton_key_bits(int morton_type);
+inline Scratch carve(char *base, int64_t n, int key_bytes, int64_t leaf_bytes, int morton_type) {
     Scratch s;
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -421,7 +414,8 @@ inline Scratch carve(char *base, int64_t n, int key_bytes, int64_t leaf_bytes, b
     s.vals = take((size_t)n * 4);
     s.vals_alt = take((size_t)n * 4);
     s.records = take((size_t)n * leaf_bytes);
-    const size_t a = rsort::scratch_bytes(n), b = msd::scratch_bytes(n);
+    s.records2 = take((size_t)n * leaf_bytes);
+    const size_t a = rsort::scratch_bytes(n), b = msd::scratch_bytes(n, morton_key_bits(morton_type), key_bytes, (int)leaf_bytes);
     s.sort = take(a > b ? a : b);
     s.total = off;
     return s;
@@ -467,7 +461,7 @@ ibvh_status ibvh_build_scratch_bytes(const ibvh_types *types, int64_t n, size_t 
     if (!layout_of(*types, lay)) return IBVH_ERR_UNSUPPORTED;
     if (n < 1) return IBVH_ERR_DOMAIN;
     int kb = types->morton_type == IBVH_U64 ? 8 : 4;
-    *bytes_out = carve(nullptr, n, kb, lay.leaf_bytes, true).total;
+    *bytes_out = carve(nullptr, n, kb, lay.leaf_bytes, types->morton_type).total;
     return IBVH_OK;
 }
 
@@ -531,7 +525,7 @@ ibvh_status ibvh_build(const ibvh_build_desc *desc, const void *volumes, void *l
     const int64_t n = desc->n;
     const int key_bytes = ty.morton_type == IBVH_U64 ? 8 : 4;
     const bool wrapped = desc->already_wrapped != 0;
-    Scratch sc = carve((char *)scratch, n, key_bytes, lay.leaf_bytes, wrapped);
+    Scratch sc = carve((char *)scratch, n, key_bytes, lay.leaf_bytes, ty.morton_type);
     if (scratch_bytes < sc.total) return IBVH_ERR_SCRATCH;
     hipStream_t st = (hipStream_t)stream;
 
@@ -560,7 +554,7 @@ ibvh_status ibvh_build(const ibvh_build_desc *desc, const void *volumes, void *l
         const int key_bits = morton_key_bits(ty.morton_type);
         const msd::Plan mp = msd::make_plan(n, key_bits, key_bytes, (int)lay.leaf_bytes, sc.sort);
         rsort::FirstPassPlan plan;
-        if (mp.bits) plan = rsort::FirstPassPlan{mp.ptpb, mp.pipt, mp.num_tiles, mp.tile_hist, (1u << mp.bits) - 1u, mp.shift, mp.bits};
+        if (mp.bits) plan = rsort::FirstPassPlan{mp.ptpb, mp.pipt, mp.num_tiles, mp.tb.tile_hist, (1u << mp.bits) - 1u, mp.shift, mp.bits};
         else plan = rsort::first_pass_plan(n, key_bits, key_bytes, sc.sort);
         if (key_bytes == 8)
             IBVH_LAUNCH((encode_hist_kernel<L, uint64_t>), dim3(plan.num_tiles), dim3(plan.tpb), ((size_t)plan.mask + 1) * 4, st,
@@ -577,11 +571,12 @@ ibvh_status ibvh_build(const ibvh_build_desc *desc, const void *volumes, void *l
             // index (:220-222); in-place builds read `leaves`, stage in scratch and write `leaves`: no extra copy.
             rsort::RecordArgs ra{src, sc.records, src_stride, wrapped ? 1 : 0, (int32_t)(lay.volume_bytes / 8),
                                  ty.index_type == IBVH_I32 ? 4 : 8, dlay};
-            if (int e = msd::sort_records(mp, key_bytes, sc.keys, n, ra, (char *)leaves, sc.keys_alt, (uint32_t *)sc.vals_alt, sc.keys,
-                                          (uint32_t *)sc.vals, st))
+            if (int e = msd::sort_records(mp, key_bytes, sc.keys, n, ra, sc.records2, (char *)leaves, sc.keys_alt, (uint32_t *)sc.vals_alt, sc.keys,
+                                          (uint32_t *)sc.vals, desc->two_level != 0, desc->skew_flag, st))
                 return e;
             return aggregate<L, N>((const char *)leaves, lay.leaf_bytes, tree, desc->built_level, (N *)nodes, st);
         }
+        if (desc->skew_flag) IBVH_HIP_CHECK(hipMemsetAsync(desc->skew_flag, 0, 4, st)); // (LSD passes do not care about skew)
         // stable LSB radix sort of (key, position), then the records in Morton order
         // (index = position + 1 for fresh volumes, build.jl:345-349, or the source record's own index, :220-222).
         // In-place (already wrapped) builds go through scratch records.

@@ -1,5 +1,5 @@
-// ibvh_msd.hip — the build's sort: ONE most-significant-digit partition of whole BoundingVolume records, then an
-// in-LDS finish per bucket.  gfx950 only.
+// ibvh_msd.hip — the build's sort: a most-significant-digit partition of whole BoundingVolume records, then an
+// in-LDS finish per cell of the Morton grid.  gfx950 only.
 //
 // Replaces AK.sort!(leaves, by = bv -> bv.morton) + wrap_bounding_volumes (reference src/build.jl:248-253, 328-352).
 //
@@ -7,18 +7,23 @@
 // source position of sorted element i is random, so the gather pays one 64-byte HBM sector per 16-byte volume
 // (measured at 1e7 leaves: 2 x FETCH + WRITE = 1.58 GB for 0.48 GB of algorithmic bytes, 0.23 ms of the phase's
 // 0.54).  Morton codes of a cloud spread over their top bits, so here the records themselves are partitioned ONCE
-// by the top `bits` (<= 12) bits of their key — source volumes are read in order (streaming), a tile's records of
-// one bucket land next to the previous tile's (XCD-contiguous tile ranges, so the partial lines of neighbouring
-// tiles meet in one L2) — and every bucket (a few thousand records, L2-sized) is then finished by one workgroup:
-// keys -> LDS, stable LSD passes on the remaining bits entirely in LDS, records copied from the bucket's
-// partitioned range (L2 hits: the range was just read for its keys) to their final place with coalesced stores.
+// by the top `bits` (<= 12) bits of their key — a CELL of the Morton grid per digit; source volumes are read in
+// order (streaming), a tile's records are staged in LDS and leave as coalesced per-cell runs — and every cell (a
+// few thousand records, L2-sized) is then finished by one workgroup: keys -> LDS, stable LSD passes on the remaining
+// bits entirely in LDS, records copied from the cell's partitioned range to their final place with coalesced stores.
 // HBM bytes per leaf (BSphere{F32} / Int32 / UInt32): hist 16 + 4, partition 4 + 16 + 24, finish 24 + 24 = 112
 // against 4 + 4*16 + 44 (+ 48 of sector over-fetch) before.
 //
-// Stability: the partition ranks in memory order and the LDS passes are stable, so equal keys keep input order
-// (the oracle's definition of the unpinned AK.sort! tie order).
-// A bucket larger than the finish workgroup's capacity (clustered input) is sorted by its workgroup with a tiled
-// LSD through the (key, position) scratch arrays: slower, never wrong.
+// Skew: a cell that holds more records than a finish workgroup sorts in LDS (clustered clouds, surfaces: a mesh
+// fills a fraction of the grid's cells) is split again, by its next 8 key bits, by a SECOND partition level that
+// touches only such cells: plan (which cells, which tiles) -> hist2 -> scan2 -> partition2, tiles of ALL oversized
+// cells side by side in one grid, so a single huge cell is still shared by many workgroups.  The same finish
+// kernel then sorts windows of consecutive sub-cells.  For a uniform cloud the three level-2 launches find nothing
+// to do and return at once.  A sub-cell that is still too large (> 2^19 duplicates of one key prefix) is sorted by
+// one workgroup with a tiled LSD through scratch arrays: slower, never wrong.
+//
+// Stability: partitions rank in memory order and the LDS passes are stable, so equal keys keep input order (the
+// oracle's definition of the unpinned AK.sort! tie order).
 #include <cstdlib>
 
 #include "ibvh_common.hpp"
@@ -30,18 +35,19 @@ namespace ibvh { namespace msd { extern __device__ unsigned long long g_stamps[2
     } while (0)
 #endif
 #include "ibvh_radix.hpp"
+#include "ibvh_msd.hpp"
 
 namespace ibvh {
 namespace msd {
 
 using rsort::block_exclusive_scan;
 using rsort::lds_exclusive_scan;
-using rsort::lds_exclusive_scan_pair;
 using rsort::lds_radix_pass;
 using rsort::RecordArgs;
 using rsort::wave_rank;
 
 constexpr int MSD_MAX_BITS = 12;
+constexpr int L2_BITS = 8; // sub-cells per oversized cell: 2^8
 
 // Diagnostic build only (-DIBVH_PHASE_STAMPS, tools/phase_stamps.sh): thread 0 of every workgroup stamps s_memtime
 // at the phase boundaries into a buffer no product code reads.  In the product build the macro is empty.
@@ -56,8 +62,8 @@ __device__ unsigned long long g_stamps[2][12][4096];
 #endif
 
 // ------------------------------------------------------------------------------------------------------------
-// scan: tile_hist is TILE-major here ([num_tiles][radix]: the histogram kernel writes, and the partition kernel
-// reads, one contiguous row per tile; a digit-major matrix costs both a 128-byte line per 4-byte counter).  tile_scan
+// scan: tile_hist is TILE-major ([num_tiles][radix]: the histogram kernel writes, and the partition kernel reads,
+// one contiguous row per tile; a digit-major matrix costs both a 128-byte line per 4-byte counter).  tile_scan
 // receives every column's (digit's) exclusive prefix over the tiles; digit_total[d] = the column sum.
 // Workgroup (db, c): 64 digits (lane = digit: a wave reads 256 contiguous bytes of a row), tile rows
 // [c*rows_per_chunk, ...).  The sum of the rows above its chunk is re-derived by the workgroup itself (rows dealt
@@ -118,8 +124,129 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_tiles_kernel(const uint32_t *__
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// partition: tile t (TPB * IPT consecutive source leaves) ranks its keys by the top digit and writes every
-// leaf's finished record (volume, index, key) to its bucket's range in `rec.dst`.
+// plan (one workgroup): cell starts (every later kernel reads them instead of re-deriving them), the oversized cells
+// (more than `cap` records), their level-2 tiles (`tile` records each) and the tile -> cell map.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int PLAN_TPB = 1024;
+__global__ __launch_bounds__(PLAN_TPB) void plan_kernel(Tables tb, int radix, uint32_t cap, uint32_t tile, int two_level,
+                                                        int32_t *__restrict__ skew_flag) {
+    constexpr int PER = (1 << MSD_MAX_BITS) / PLAN_TPB; // cells per thread, at most
+    __shared__ uint32_t wave_tot[PLAN_TPB / 64];
+    __shared__ uint32_t s_tbase[(1 << MSD_MAX_BITS) + 1]; // over_tile_base, for the tile -> cell search
+    __shared__ uint32_t s_nover, s_ntiles;
+    const int lo = threadIdx.x * PER;
+    uint32_t tot[PER], sum = 0, nov = 0, nt = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int d = lo + k;
+        tot[k] = d < radix ? tb.cell_total[d] : 0u;
+        sum += tot[k];
+        if (tot[k] > cap) {
+            nov += 1;
+            nt += (tot[k] + tile - 1) / tile;
+        }
+    }
+    uint32_t total_n = 0, total_over = 0, total_tiles = 0;
+    uint32_t run = block_exclusive_scan<PLAN_TPB>(sum, wave_tot, &total_n);
+    uint32_t kk = block_exclusive_scan<PLAN_TPB>(nov, wave_tot, &total_over);
+    uint32_t tt = block_exclusive_scan<PLAN_TPB>(nt, wave_tot, &total_tiles);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int d = lo + k;
+        if (d < radix) {
+            tb.cell_start[d] = run;
+            run += tot[k];
+            if (tot[k] > cap) {
+                tb.over_cell[kk] = (uint32_t)d;
+                tb.over_tile_base[kk] = tt;
+                s_tbase[kk] = tt;
+                kk += 1;
+                tt += (tot[k] + tile - 1) / tile;
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        tb.cell_start[radix] = total_n;
+        tb.over_tile_base[total_over] = total_tiles;
+        s_tbase[total_over] = total_tiles;
+        if (skew_flag) *skew_flag = total_over > 0 ? 1 : 0; // the caller's hint for its next build
+        if (!two_level) total_over = total_tiles = 0;        // the finish kernel sorts crowded cells by itself
+        tb.hdr[0] = total_over;
+        tb.hdr[1] = total_tiles;
+        s_nover = total_over;
+        s_ntiles = total_tiles;
+    }
+    __syncthreads();
+    const uint32_t nover = s_nover, ntiles = s_ntiles;
+    for (uint32_t t = threadIdx.x; t < ntiles; t += PLAN_TPB) { // k with tbase[k] <= t < tbase[k + 1]
+        uint32_t a = 0, b = nover;
+        while (b - a > 1) {
+            const uint32_t mid = (a + b) >> 1;
+            if (s_tbase[mid] <= t) a = mid;
+            else b = mid;
+        }
+        tb.tile_cell[t] = a;
+    }
+}
+
+// level-2 histogram: tile t of an oversized cell counts the next L2 digit of its records' keys
+__global__ __launch_bounds__(256) void hist2_kernel(Tables tb, const char *__restrict__ part, LeafLayout lay, int shift2,
+                                                    uint32_t mask2, uint32_t tile) {
+    __shared__ uint32_t h[1 << L2_BITS];
+    const uint32_t t = blockIdx.x;
+    if (t >= tb.hdr[1]) return;
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t k = tb.tile_cell[t], d = tb.over_cell[k];
+    const uint32_t first = tb.cell_start[d] + (t - tb.over_tile_base[k]) * tile, end = tb.cell_start[d + 1];
+    const uint32_t cnt = end - first < tile ? end - first : tile;
+    for (uint32_t i = threadIdx.x; i < cnt; i += 256)
+        atomicAdd(&h[(uint32_t)(load_morton(part + (int64_t)(first + i) * lay.stride, lay) >> shift2) & mask2], 1u);
+    __syncthreads();
+    tb.tile_hist2[(int64_t)t * (1 << L2_BITS) + threadIdx.x] = h[threadIdx.x];
+}
+
+// level-2 scan: workgroup k = one oversized cell: per sub-digit, the exclusive prefix over the cell's tiles; the
+// sub-cell totals and their exclusive prefix (sub-cell starts inside the cell)
+__global__ __launch_bounds__(1024) void scan2_kernel(Tables tb) {
+    constexpr int C = 1 << L2_BITS, G = 1024 / C; // G row groups x C columns
+    __shared__ uint32_t part[G][C];
+    __shared__ uint32_t wave_tot[16];
+    const uint32_t k = blockIdx.x;
+    if (k >= tb.hdr[0]) return;
+    const int col = threadIdx.x % C, rg = threadIdx.x / C;
+    const uint32_t t0 = tb.over_tile_base[k], t1 = tb.over_tile_base[k + 1];
+    const uint32_t share = (t1 - t0 + G - 1) / G;
+    const uint32_t a = t0 + rg * share < t1 ? t0 + rg * share : t1, b = a + share < t1 ? a + share : t1;
+    uint32_t mine = 0;
+    for (uint32_t r = a; r < b; ++r) mine += tb.tile_hist2[(int64_t)r * C + col];
+    part[rg][col] = mine;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const uint32_t v = part[i][col];
+        if (i < rg) run += v;
+        total += v;
+    }
+    for (uint32_t r = a; r < b; ++r) {
+        const uint32_t v = tb.tile_hist2[(int64_t)r * C + col];
+        tb.tile_scan2[(int64_t)r * C + col] = run;
+        run += v;
+    }
+    const uint32_t ex = block_exclusive_scan<1024>(rg == 0 ? total : 0u, wave_tot, nullptr); // (threads 0..C-1 carry the totals)
+    if (rg == 0) {
+        tb.sub_total[(int64_t)k * C + col] = total;
+        tb.sub_start[(int64_t)k * C + col] = ex;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// partition: a tile ranks its keys by a digit and writes every leaf's finished record to its cell's range in dst.
+// Level 1 (L2 = false): tile t = TILE consecutive SOURCE leaves; digit = top `bits` bits; records assembled from the
+//   source volumes (or copied from wrapped source records).
+// Level 2 (L2 = true):  tile t = TILE consecutive records of an oversized cell in the level-1 output; digit = the
+//   next L2_BITS bits; records copied as they are.
 // ------------------------------------------------------------------------------------------------------------
 // The record of source leaf i is assembled word by word (8-byte words; every layout is a multiple of 8 with the
 // volume first): volume words are copied, the words behind the volume carry .index and .morton.
@@ -176,52 +303,70 @@ IBVH_D void stage_rows(const uint64_t *__restrict__ src, uint32_t src_words, uin
 // occupancy the LDS stage allows (24-byte records): pinned so the layout switch cannot push the VGPR count over a step
 constexpr int partition_min_waves(int tpb, int ipt) { return tpb * ipt <= 2048 ? 3 : 2; }
 
-template <class K, int TPB, int IPT>
+template <class K, int TPB, int IPT, bool L2>
 __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_kernel(const K *__restrict__ keys, int64_t n, int shift, int bits,
-                                                        const uint32_t *__restrict__ tile_hist,
-                                                        const uint32_t *__restrict__ digit_total, int num_tiles,
-                                                        RecordArgs rec, uint32_t inv_words) {
+                                                        Tables tb, int num_tiles, RecordArgs rec, uint32_t inv_words, int digit_bits) {
     constexpr int W = TPB / 64;
     constexpr int TILE = TPB * IPT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int radix = 1 << bits;
-    const uint32_t mask = (uint32_t)radix - 1u;
-    // layout: local_base[radix] | delta[radix] | wave_tot[16] | { whist[W * radix] (u16), later stage[TILE records] }
+    const int radix = 1 << bits;                             // table size (level 2: always 2^L2_BITS columns)
+    const uint32_t mask = ((uint32_t)1 << digit_bits) - 1u; // the digit itself may be narrower (few key bits left)
+    // layout: local_base[radix] | delta[radix] | wave_tot[32] | { whist[W * radix] (u16), later stage[TILE records] }
     uint32_t *local_base = (uint32_t *)smem;         // radix: tile-local start of digit d
     uint32_t *delta = local_base + radix;            // radix: (global position) - (tile-local sorted position) of digit d
-    uint32_t *wave_tot = delta + radix;              // 2 * W <= 32
+    uint32_t *wave_tot = delta + radix;              // 32
     uint64_t *stage = (uint64_t *)(wave_tot + 32);
     uint16_t *whist = (uint16_t *)stage;             // W * radix
 
-    const int tile = xcd_remap(blockIdx.x, num_tiles);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t tile_base = (int64_t)tile * TILE;
+    int64_t tile_base, end;         // the tile's records are [tile_base, min(tile_base + TILE, end))
+    const uint32_t *scan_row;       // this tile's row of the scanned histogram
+    const uint32_t *digit_start;    // where each digit's range starts in dst (relative to dst_first)
+    uint32_t dst_first = 0;
+    if constexpr (L2) {
+        const uint32_t t = blockIdx.x;
+        if (t >= tb.hdr[1]) return;
+        const uint32_t k = tb.tile_cell[t], d = tb.over_cell[k];
+        dst_first = tb.cell_start[d];
+        tile_base = (int64_t)dst_first + (int64_t)(t - tb.over_tile_base[k]) * TILE;
+        end = (int64_t)tb.cell_start[d + 1];
+        scan_row = tb.tile_scan2 + (int64_t)t * radix;
+        digit_start = tb.sub_start + (int64_t)k * radix;
+    } else {
+        const int tile = xcd_remap(blockIdx.x, num_tiles);
+        tile_base = (int64_t)tile * TILE;
+        end = n;
+        scan_row = tb.tile_scan + (int64_t)tile * radix;
+        digit_start = tb.cell_start;
+    }
     const int64_t wave_base = tile_base + (int64_t)w * (64 * IPT);
 
     IBVH_STAMP(0, 0);
-    // this tile's row of the (scanned, tile-major) histogram: coalesced, in flight while the keys are ranked
+    // this tile's row of the (scanned, tile-major) histogram and the digit starts: coalesced, in flight while the keys
+    // are ranked
     constexpr int DPT = (1 << MSD_MAX_BITS) / TPB; // digits per thread, at most
     uint32_t tile_off[DPT];
 #pragma unroll
     for (int k = 0; k < DPT; ++k) {
         const int d = k * TPB + threadIdx.x;
-        tile_off[k] = d < radix ? tile_hist[(int64_t)tile * radix + d] : 0u;
+        tile_off[k] = d < radix ? scan_row[d] + digit_start[d] + dst_first : 0u;
     }
     for (int i = threadIdx.x; i < W * radix / 2; i += TPB) ((uint32_t *)whist)[i] = 0;
     K key[IPT];
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
         const int64_t i = wave_base + j * 64 + lane;
-        key[j] = i < n ? keys[i] : (K) ~(K)0;
+        if constexpr (L2) key[j] = i < end ? (K)load_morton(rec.src + i * rec.src_stride, rec.lay) : (K) ~(K)0;
+        else key[j] = i < end ? keys[i] : (K) ~(K)0;
     }
     __syncthreads();
     IBVH_STAMP(0, 1);
     uint16_t rank[IPT];
     uint16_t *my_hist = whist + w * radix;
-    wave_rank<K, IPT>(key, shift, mask, bits, my_hist, lane, rank);
+    wave_rank<K, IPT>(key, shift, mask, digit_bits, my_hist, lane, rank);
     __syncthreads();
     IBVH_STAMP(0, 2);
-    // per digit: exclusive prefix over the waves (in place), tile total, global start of the digit
+    // per digit: exclusive prefix over the waves (in place), tile total
     for (int d = threadIdx.x; d < radix; d += TPB) {
         uint32_t run = 0;
 #pragma unroll
@@ -231,16 +376,15 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
             run += c;
         }
         local_base[d] = run;
-        delta[d] = digit_total[d];
     }
     __syncthreads();
     IBVH_STAMP(0, 3);
-    lds_exclusive_scan_pair<TPB>(local_base, delta, radix, wave_tot);
+    lds_exclusive_scan<TPB>(local_base, radix, wave_tot);
     IBVH_STAMP(0, 4);
 #pragma unroll
     for (int k = 0; k < DPT; ++k) {
         const int d = k * TPB + threadIdx.x;
-        if (d < radix) delta[d] = delta[d] + tile_off[k] - local_base[d]; // mod 2^32
+        if (d < radix) delta[d] = tile_off[k] - local_base[d]; // mod 2^32
     }
     uint32_t pos[IPT];
 #pragma unroll
@@ -259,7 +403,7 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
     static_assert(IPT % 4 == 0, "rows are moved 4 or 2 at a time");
 #define IBVH_MOVE(NW, OW, WR)                                                                                           \
     for (int j0 = 0; j0 < IPT; j0 += (NW <= 3 ? 4 : 2))                                                                 \
-        stage_rows<NW, OW, WR, K, (NW <= 3 ? 4 : 2)>(src, src_words, stage, tl, wave_base + j0 * 64, n, key + j0, pos + j0);
+        stage_rows<NW, OW, WR, K, (NW <= 3 ? 4 : 2)>(src, src_words, stage, tl, wave_base + j0 * 64, end, key + j0, pos + j0);
     // (volume words, record words) of every layout layout_of() can produce; wrapped sources carry whole records
     const int code = (wrapped ? 100 : 0) + rec.vol_words * 10 + (int)words;
     switch (code) {
@@ -283,7 +427,7 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
     __syncthreads();
     IBVH_STAMP(0, 6);
     // out: lane <-> 8-byte word of the tile's sorted records; a digit's run goes to consecutive addresses
-    const int64_t left = n - tile_base;
+    const int64_t left = end - tile_base;
     const uint32_t valid = left < (int64_t)TILE ? (uint32_t)left : (uint32_t)TILE;
     const uint32_t total = valid * words;
     uint64_t *__restrict__ dst = (uint64_t *)rec.dst;
@@ -316,52 +460,61 @@ template <class K, int TPB, int IPT> inline size_t partition_smem(int bits, int 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// finish: workgroup b sorts bucket b's records on the low `low_bits` bits of their keys and writes them to `out`
+// finish: sort a contiguous range of partitioned records — one cell of level 1, or a window of consecutive
+// sub-cells of an oversized cell — on the key bits that still vary inside it, and write the records to `out`
 // ------------------------------------------------------------------------------------------------------------
 struct FinishArgs {
-    const char *part;  // partitioned records (the partition kernel's dst)
-    char *out;         // sorted records
+    const char *part;   // level-1 partition output
+    const char *part2;  // level-2 partition output (oversized cells only)
+    char *out;          // sorted records
     LeafLayout lay;
-    uint32_t words;    // lay.stride / 8
+    uint32_t words;     // lay.stride / 8
     uint32_t inv_words; // ceil(2^32 / words): g / words == __umulhi(g, inv_words) for g < 2^29
+    uint32_t cap;       // cells above this size went through level 2
+    uint32_t tile;      // level-2 tile = window of sub-cells one workgroup finishes
+    int two_level;      // 0: no second level ran; crowded cells take the slow path of their own workgroup
+    int shift1, shift2; // key >> shift1 = cell, (key >> shift2) & 255 = sub-cell
     // slow path only: (key, position) arrays of n entries each
     void *kalt, *kpri;
     uint32_t *valt, *vpri;
 };
 
+template <class K, int TPB, int IPT> struct FinishLds {
+    static constexpr int W = TPB / 64, CAP = TPB * IPT, RB = 8, R = 1 << RB;
+    K *s_keys;            // CAP
+    uint16_t *s_idx;      // CAP
+    uint32_t *s_vals32;   // CAP / 2 (slow path: tiles of CAP / 2 keys + 32-bit positions in the same bytes)
+    uint32_t *local_base; // R
+    uint32_t *gbase;      // R
+    uint32_t *wave_tot;   // 16
+    uint16_t *whist;      // W * R
+    IBVH_D explicit FinishLds(unsigned char *p) {
+        s_keys = (K *)p;
+        s_idx = (uint16_t *)(s_keys + CAP);
+        s_vals32 = (uint32_t *)(s_keys + CAP / 2);
+        local_base = (uint32_t *)(s_idx + CAP);
+        gbase = local_base + R;
+        wave_tot = gbase + R;
+        whist = (uint16_t *)(wave_tot + 16);
+    }
+};
+
+// records [start, start + m) of `part`, whose keys are key_base + (an nbits-bit number): sorted into out[start ...)
 template <class K, int TPB, int IPT>
-__global__ __launch_bounds__(TPB) void finish_kernel(const uint32_t *__restrict__ digit_total, int low_bits, FinishArgs fa) {
+IBVH_D void finish_range(const FinishArgs &fa, const FinishLds<K, TPB, IPT> &l, const char *part, int64_t start, int64_t m, K key_base,
+                         int nbits) {
     constexpr int W = TPB / 64;
     constexpr int CAP = TPB * IPT;
     constexpr int RB = 8, R = 1 << RB;
     static_assert(R <= TPB, "one digit counter per thread");
-    extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
-    // fast path: CAP keys + CAP 16-bit positions; slow path: tiles of CAP/2 keys + 32-bit positions in the same bytes
-    K *s_keys = (K *)bsm;                                 // CAP
-    uint16_t *s_idx = (uint16_t *)(s_keys + CAP);         // CAP
-    uint32_t *s_vals32 = (uint32_t *)(s_keys + CAP / 2);  // CAP / 2 (slow path)
-    uint32_t *local_base = (uint32_t *)(s_idx + CAP);     // R
-    uint32_t *gbase = local_base + R;                     // R
-    uint32_t *wave_tot = gbase + R;                       // 16
-    uint16_t *whist = (uint16_t *)(wave_tot + 16);        // W * R
-    // the bucket's range: every workgroup sums the digit totals in front of its own digit itself
-    IBVH_STAMP(1, 0);
-    const int64_t m = (int64_t)digit_total[blockIdx.x];
-    if (m == 0) return;
-    uint32_t before = 0;
-    for (int i = threadIdx.x; i < (int)blockIdx.x; i += TPB) before += digit_total[i];
-    uint32_t start32 = 0;
-    block_exclusive_scan<TPB>(before, wave_tot, &start32);
-    const int64_t start = (int64_t)start32;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int stride = fa.lay.stride;
-    const char *bucket = fa.part + start * stride;
-    const int passes = (low_bits + RB - 1) / RB;
+    const char *bucket = part + start * stride;
+    const int passes = (nbits + RB - 1) / RB;
     IBVH_STAMP(1, 1);
-
     if (m <= CAP) {
-        // ---- fast path: the bucket's keys live in LDS ------------------------------------------------------
-        // the m keys are dealt to the waves in equal contiguous shares of `chunk` (a multiple of 64): a bucket of
+        // ---- fast path: the range's keys live in LDS -------------------------------------------------------
+        // the m keys are dealt to the waves in equal contiguous shares of `chunk` (a multiple of 64): a range of
         // CAP/4 keys keeps every wave busy with a quarter of the ranking work; (w, j, lane) order is memory order
         const int chunk = (int)((m + W * 64 - 1) / (W * 64)) * 64;
         const int jmax = chunk / 64; // <= IPT
@@ -371,38 +524,39 @@ __global__ __launch_bounds__(TPB) void finish_kernel(const uint32_t *__restrict_
         for (int j = 0; j < IPT; ++j) {
             const int idx = w * chunk + j * 64 + lane;
             const bool ok = j < jmax && idx < m;
-            // (the strided key loads touch every line of the bucket's records: they are L2 hits for the copy below)
-            key[j] = ok ? (K)load_morton(bucket + (int64_t)idx * stride, fa.lay) : (K) ~(K)0; // sentinels sort last
+            // (the strided key loads touch every line of the range's records: they are L2 hits for the copy below;
+            // sentinels sort last)
+            key[j] = ok ? (K)((K)load_morton(bucket + (int64_t)idx * stride, fa.lay) - key_base) : (K) ~(K)0;
             val[j] = (uint16_t)idx;
         }
         if (passes == 0) {
 #pragma unroll
             for (int j = 0; j < IPT; ++j) {
                 const int idx = w * chunk + j * 64 + lane;
-                if (j < jmax) s_idx[idx] = val[j];
+                if (j < jmax) l.s_idx[idx] = val[j];
             }
             __syncthreads();
         }
         int done = 0;
         IBVH_STAMP(1, 2);
         for (int p = 0; p < passes; ++p) {
-            const int bits = (low_bits - done + (passes - p) - 1) / (passes - p); // even split of the remaining bits
-            lds_radix_pass<K, uint16_t, TPB, IPT, RB>(key, val, done, bits, jmax, s_keys, s_idx, local_base, wave_tot, whist);
+            const int bits = (nbits - done + (passes - p) - 1) / (passes - p); // even split of the remaining bits
+            lds_radix_pass<K, uint16_t, TPB, IPT, RB>(key, val, done, bits, jmax, l.s_keys, l.s_idx, l.local_base, l.wave_tot, l.whist);
             done += bits;
             if (p + 1 < passes) {
 #pragma unroll
                 for (int j = 0; j < IPT; ++j) {
                     const int idx = w * chunk + j * 64 + lane;
                     if (j < jmax) {
-                        key[j] = s_keys[idx];
-                        val[j] = s_idx[idx];
+                        key[j] = l.s_keys[idx];
+                        val[j] = l.s_idx[idx];
                     }
                 }
                 __syncthreads();
             }
         }
-        // records: lane <-> 8-byte word of the output range (fully coalesced stores; the loads hit the bucket's
-        // partitioned range, which the key loads above have just pulled through L2)
+        // records: lane <-> 8-byte word of the output range (fully coalesced stores; the loads hit the range's
+        // partitioned records, which the key loads above have just pulled through L2)
         IBVH_STAMP(1, 3);
         const uint64_t *__restrict__ src = (const uint64_t *)bucket;
         uint64_t *__restrict__ dst = (uint64_t *)(fa.out + start * stride);
@@ -415,8 +569,8 @@ __global__ __launch_bounds__(TPB) void finish_kernel(const uint32_t *__restrict_
                 const uint32_t g = g0 + u * TPB;
                 const uint32_t gc = g < total ? g : 0u;
                 const uint32_t r = __umulhi(gc, fa.inv_words);
-                const uint32_t part = gc - r * fa.words;
-                v[u] = src[(uint32_t)s_idx[r] * fa.words + part];
+                const uint32_t part_w = gc - r * fa.words;
+                v[u] = src[(uint32_t)l.s_idx[r] * fa.words + part_w];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -425,27 +579,28 @@ __global__ __launch_bounds__(TPB) void finish_kernel(const uint32_t *__restrict_
             }
         }
         IBVH_STAMP(1, 4);
+        __syncthreads(); // (the LDS arrays are reused by the workgroup's next range)
         return;
     }
 
-    // ---- slow path: bucket larger than the LDS capacity; tiled LSD between the two (key, position) arrays ----
+    // ---- slow path: more records than the LDS holds; tiled LSD between the two (key, position) arrays ----
     K *src_k = (K *)fa.kalt + start, *dst_k = (K *)fa.kpri + start;
     uint32_t *src_v = fa.valt + start, *dst_v = fa.vpri + start;
     for (int64_t i = threadIdx.x; i < m; i += TPB) {
-        src_k[i] = (K)load_morton(bucket + i * stride, fa.lay);
+        src_k[i] = (K)((K)load_morton(bucket + i * stride, fa.lay) - key_base);
         src_v[i] = (uint32_t)i;
     }
     __threadfence_block();
     __syncthreads();
     for (int p = 0; p < passes; ++p) {
         const int shift = RB * p;
-        const int bits = low_bits - shift < RB ? low_bits - shift : RB;
+        const int bits = nbits - shift < RB ? nbits - shift : RB;
         const uint32_t mask = (1u << bits) - 1u;
-        if (threadIdx.x < R) gbase[threadIdx.x] = 0;
+        if (threadIdx.x < R) l.gbase[threadIdx.x] = 0;
         __syncthreads();
-        for (int64_t i = threadIdx.x; i < m; i += TPB) atomicAdd(&gbase[(uint32_t)(src_k[i] >> shift) & mask], 1u);
+        for (int64_t i = threadIdx.x; i < m; i += TPB) atomicAdd(&l.gbase[(uint32_t)(src_k[i] >> shift) & mask], 1u);
         __syncthreads();
-        lds_exclusive_scan<TPB>(gbase, R, wave_tot);
+        lds_exclusive_scan<TPB>(l.gbase, R, l.wave_tot);
         constexpr int SIPT = IPT / 2, SCAP = CAP / 2;
         for (int64_t t0 = 0; t0 < m; t0 += SCAP) {
             const int64_t cnt = m - t0 < SCAP ? m - t0 : SCAP;
@@ -459,20 +614,20 @@ __global__ __launch_bounds__(TPB) void finish_kernel(const uint32_t *__restrict_
                 val[j] = ok ? src_v[t0 + idx] : 0u;
             }
             uint32_t tot_d;
-            lds_radix_pass<K, uint32_t, TPB, SIPT, RB>(key, val, shift, bits, SIPT, s_keys, s_vals32, local_base, wave_tot, whist, &tot_d);
+            lds_radix_pass<K, uint32_t, TPB, SIPT, RB>(key, val, shift, bits, SIPT, l.s_keys, l.s_vals32, l.local_base, l.wave_tot, l.whist, &tot_d);
             for (int pos = threadIdx.x; pos < cnt; pos += TPB) {
-                const K kk = s_keys[pos];
+                const K kk = l.s_keys[pos];
                 const uint32_t d = (uint32_t)(kk >> shift) & mask;
-                const uint32_t dest = gbase[d] + ((uint32_t)pos - local_base[d]);
+                const uint32_t dest = l.gbase[d] + ((uint32_t)pos - l.local_base[d]);
                 dst_k[dest] = kk;
-                dst_v[dest] = s_vals32[pos];
+                dst_v[dest] = l.s_vals32[pos];
             }
             __syncthreads();
             // sentinels of a partial tile were counted in the last digit: real count there = cnt - local_base
             if (threadIdx.x < R) {
                 uint32_t real = tot_d;
-                if ((int)threadIdx.x == (int)mask && cnt < SCAP) real = (uint32_t)cnt - local_base[mask];
-                gbase[threadIdx.x] += real;
+                if ((int)threadIdx.x == (int)mask && cnt < SCAP) real = (uint32_t)cnt - l.local_base[mask];
+                l.gbase[threadIdx.x] += real;
             }
             __syncthreads();
         }
@@ -486,14 +641,67 @@ __global__ __launch_bounds__(TPB) void finish_kernel(const uint32_t *__restrict_
         src_v = dst_v;
         dst_v = tv;
     }
-    // `src_v` holds the bucket's positions in sorted order
+    // `src_v` holds the range's positions in sorted order
     const uint64_t *src = (const uint64_t *)bucket;
     uint64_t *dst = (uint64_t *)(fa.out + start * stride);
     const uint64_t total = (uint64_t)m * fa.words;
     for (uint64_t g = threadIdx.x; g < total; g += TPB) {
         const uint64_t r = g / fa.words;
-        const uint32_t part = (uint32_t)(g - r * fa.words);
-        dst[g] = src[(uint64_t)src_v[r] * fa.words + part];
+        const uint32_t part_w = (uint32_t)(g - r * fa.words);
+        dst[g] = src[(uint64_t)src_v[r] * fa.words + part_w];
+    }
+    __syncthreads();
+}
+
+IBVH_D int bit_length(uint32_t v) { return v == 0 ? 0 : 32 - __builtin_clz(v); }
+
+// grid = R + F2 workgroups: workgroup b < R finishes cell b (unless it went through level 2); the others stride over
+// the level-2 tiles: tile t of oversized cell k finishes the window of sub-cells that START inside records
+// [t * tile, (t + 1) * tile) of the cell (consecutive sub-cells: one LDS sort with the sub-cell number as the top bits)
+template <class K, int TPB, int IPT>
+__global__ __launch_bounds__(TPB) void finish_kernel(Tables tb, int radix, FinishArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
+    const FinishLds<K, TPB, IPT> l(bsm);
+    IBVH_STAMP(1, 0);
+    if ((int)blockIdx.x < radix) {
+        const uint32_t d = blockIdx.x;
+        const uint32_t start = tb.cell_start[d], m = tb.cell_start[d + 1] - start;
+        if (m == 0 || (m > fa.cap && fa.two_level)) return; // (with two levels, crowded cells are finished window by window below)
+        finish_range<K, TPB, IPT>(fa, l, fa.part, (int64_t)start, (int64_t)m, (K)((K)d << fa.shift1), fa.shift1);
+        return;
+    }
+    constexpr int C = 1 << L2_BITS;
+    const uint32_t ntiles = tb.hdr[1];
+    for (uint32_t t = blockIdx.x - radix; t < ntiles; t += gridDim.x - radix) {
+        const uint32_t k = tb.tile_cell[t], d = tb.over_cell[k];
+        const uint32_t *ss = tb.sub_start + (int64_t)k * C;
+        const uint32_t cell_total = tb.cell_start[d + 1] - tb.cell_start[d];
+        const uint32_t lo = (t - tb.over_tile_base[k]) * fa.tile, hi = lo + fa.tile;
+        // e0 = first sub-cell starting at or after lo, e1 = first one starting at or after hi (binary searches; the
+        // whole workgroup walks the same path)
+        uint32_t e0 = 0, e1 = 0;
+        {
+            uint32_t a = 0, b = C; // first e with ss[e] >= lo
+            while (a < b) {
+                const uint32_t mid = (a + b) >> 1;
+                if (ss[mid] < lo) a = mid + 1;
+                else b = mid;
+            }
+            e0 = a;
+            a = e0, b = C;
+            while (a < b) {
+                const uint32_t mid = (a + b) >> 1;
+                if (ss[mid] < hi) a = mid + 1;
+                else b = mid;
+            }
+            e1 = a;
+        }
+        if (e0 == e1) continue; // no sub-cell starts in this window (a large one covers it)
+        const uint32_t rs = ss[e0], re = e1 < C ? ss[e1] : cell_total;
+        if (re == rs) continue; // empty sub-cells only
+        const K key_base = (K)(((K)d << fa.shift1) + ((K)e0 << fa.shift2));
+        const int nbits = fa.shift2 + bit_length(e1 - e0 - 1);
+        finish_range<K, TPB, IPT>(fa, l, fa.part2, (int64_t)tb.cell_start[d] + rs, (int64_t)(re - rs), key_base, nbits);
     }
 }
 template <class K, int TPB, int IPT> constexpr size_t finish_smem() {
@@ -503,20 +711,35 @@ template <class K, int TPB, int IPT> constexpr size_t finish_smem() {
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
-struct Plan {
-    int bits;            // MSD digit width; 0: this path does not apply (tiny or huge input) -> ibvh_sort.hip
-    int shift;           // key_bits - bits: the digit is key >> shift
-    int ptpb, pipt;      // partition (and histogram) tile geometry
-    int num_tiles;
-    int ftpb, fipt;      // finish workgroup: threads, keys per thread (capacity = ftpb * fipt)
-    uint32_t *tile_hist;   // [num_tiles][2^bits]: counts
-    uint32_t *tile_scan;   // [num_tiles][2^bits]: exclusive prefix over the tiles
-    uint32_t *digit_total; // [2^bits]
-};
-
 static int env_int(const char *name, int dflt) {
     const char *e = getenv(name);
     return e ? atoi(e) : dflt;
+}
+
+static size_t carve_tables(Tables *tb, char *base, int64_t n, int radix, int num_tiles, int max_tiles2) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        uint32_t *p = base ? (uint32_t *)(base + off) : nullptr;
+        off += (size_t)align_up((int64_t)bytes, 256);
+        return p;
+    };
+    Tables t;
+    t.tile_hist = take((size_t)radix * num_tiles * 4);
+    t.tile_scan = take((size_t)radix * num_tiles * 4);
+    t.cell_total = take((size_t)radix * 4);
+    t.cell_start = take((size_t)(radix + 1) * 4);
+    t.hdr = take(64);
+    t.over_cell = take((size_t)radix * 4);
+    t.over_tile_base = take((size_t)(radix + 1) * 4);
+    t.tile_cell = take((size_t)max_tiles2 * 4);
+    t.tile_hist2 = take((size_t)max_tiles2 * 4 << L2_BITS);
+    t.tile_scan2 = take((size_t)max_tiles2 * 4 << L2_BITS);
+    // at most n / cap + 1 cells can be oversized; cap >= 2048
+    const size_t max_over = (size_t)(n / 2048 + 1 < radix ? n / 2048 + 1 : radix);
+    t.sub_total = take(max_over * 4 << L2_BITS);
+    t.sub_start = take(max_over * 4 << L2_BITS);
+    if (tb) *tb = t;
+    return off;
 }
 
 Plan make_plan(int64_t n, int key_bits, int key_bytes, int leaf_bytes, void *sort_scratch) {
@@ -526,8 +749,9 @@ Plan make_plan(int64_t n, int key_bits, int key_bytes, int leaf_bytes, void *sor
     static const int f_cap = env_int("IBVH_MSD_CAP", 0);
     static const int f_tile = env_int("IBVH_MSD_TILE", 0);
     static const int f_avg = env_int("IBVH_MSD_AVG", 1024);
+    static const int f_ftpb = env_int("IBVH_MSD_FTPB", 0);
     Plan p{};
-    if (!enabled || n < 4096 || key_bits <= 8) return p;
+    if (!enabled || n < 4096 || key_bits <= 8 || n >= ((int64_t)1 << 32) - 65536) return p;
     int bits = 6; // (>= 6: the scan kernel works on blocks of 64 digits)
     while (bits < 11 && bits < key_bits - 1 && (n >> bits) > f_avg) ++bits;
     if (f_bits) bits = f_bits;
@@ -535,29 +759,25 @@ Plan make_plan(int64_t n, int key_bits, int key_bytes, int leaf_bytes, void *sor
     if (bits >= key_bits) bits = key_bits - 1;
     if (bits < 6) return p;
     const int64_t avg = n >> bits;
-    // capacity of the finish workgroup: the average bucket fills at most 5/8 of it (uniform clouds vary by a few
-    // per cent; denser-than-average regions get the rest of the headroom before the slow path takes over)
+    // capacity of the finish workgroup: the average cell fills at most 5/8 of it (uniform clouds vary by a few per
+    // cent; denser cells get the rest of the headroom before the second partition level takes them)
     int cap = 2048;
-    while (cap < 16384 && avg * 8 > (int64_t)cap * 5) cap *= 2;
+    const int cap_max = key_bytes == 8 ? 8192 : 16384; // (16384 x 10 B does not fit the LDS)
+    while (cap < cap_max && avg * 8 > (int64_t)cap * 5) cap *= 2;
     if (f_cap) cap = f_cap;
-    if (avg * 8 > (int64_t)cap * 5 && !f_cap) return p; // one partition level is not enough: LSD path
-    if (key_bytes == 8 && cap > 8192) {
-        if (avg * 8 > (int64_t)8192 * 5) return p;
-        cap = 8192; // 16384 x 12 B does not fit the LDS
-    }
+    if (cap > cap_max) cap = cap_max;
     // partition tile: its records are staged in LDS (tile * leaf_bytes + 2 tables of 2^bits words <= 160 KiB)
     int tile = (n >= (int64_t(1) << 22) && leaf_bytes <= 32) ? 4096 : 2048;
     if (f_tile) tile = f_tile;
-    if (tile < (1 << bits)) tile = 1 << bits; // scratch sizing: radix * num_tiles <= n + radix
     while (tile > 1024 && (size_t)tile * leaf_bytes + ((size_t)8 << bits) + 128 > 160 * 1024) tile >>= 1;
-    if (tile < (1 << bits)) return p;
+    if (tile > cap / 2) tile = cap / 2 < 1024 ? 1024 : cap / 2; // a window of sub-cells (< tile + one sub-cell) should fit the LDS sort
     switch (tile) {
     case 1024: p.ptpb = 256, p.pipt = 4; break;
     case 2048: p.ptpb = 256, p.pipt = 8; break;
-    default: p.ptpb = 512, p.pipt = 8; break;
+    default: tile = 4096, p.ptpb = 512, p.pipt = 8; break;
     }
-    // finish workgroups are small (4 or 8 waves, many keys per thread): several buckets per CU at different phases
-    static const int f_ftpb = env_int("IBVH_MSD_FTPB", 0);
+    if ((size_t)tile * leaf_bytes + ((size_t)8 << bits) + 128 > 160 * 1024) return p;
+    // finish workgroups are small (4 or 8 waves, many keys per thread): several ranges per CU at different phases
     switch (cap) {
     case 2048: p.ftpb = 256; break;
     case 4096: p.ftpb = 256; break;
@@ -568,54 +788,76 @@ Plan make_plan(int64_t n, int key_bits, int key_bytes, int leaf_bytes, void *sor
     p.fipt = cap / p.ftpb;
     p.bits = bits;
     p.shift = key_bits - bits;
-    p.num_tiles = (int)ceil_div(n, (int64_t)p.ptpb * p.pipt);
-    p.tile_hist = (uint32_t *)sort_scratch;
-    const int64_t hist_bytes = align_up(((int64_t)1 << bits) * p.num_tiles * 4, 256);
-    p.tile_scan = (uint32_t *)((char *)sort_scratch + hist_bytes);
-    p.digit_total = (uint32_t *)((char *)sort_scratch + 2 * hist_bytes);
+    p.num_tiles = (int)ceil_div(n, (int64_t)tile);
+    p.max_tiles2 = p.num_tiles + (1 << bits);
+    carve_tables(&p.tb, (char *)sort_scratch, n, 1 << bits, p.num_tiles, p.max_tiles2);
     return p;
 }
 
-// scratch for tile histograms + digit totals (tile >= radix, so radix * num_tiles <= n + radix)
-size_t scratch_bytes(int64_t n) {
-    return 2 * (size_t)align_up((n + (1 << MSD_MAX_BITS)) * 4, 256) + ((size_t)4 << MSD_MAX_BITS) + 512;
+// scratch for the tables of the plan make_plan() chooses for this input (0 when the path does not apply)
+size_t scratch_bytes(int64_t n, int key_bits, int key_bytes, int leaf_bytes) {
+    const Plan p = make_plan(n, key_bits, key_bytes, leaf_bytes, nullptr);
+    if (!p.bits) return 0;
+    return carve_tables(nullptr, nullptr, n, 1 << p.bits, p.num_tiles, p.max_tiles2) + 4096;
 }
 
 template <class K, int PT, int PI>
-static int launch_partition(const Plan &p, const K *keys, int64_t n, const RecordArgs &ra, hipStream_t st) {
+static int launch_partitions(const Plan &p, const K *keys, int64_t n, const RecordArgs &ra, char *part2, int two_level, hipStream_t st) {
     const size_t smem = partition_smem<K, PT, PI>(p.bits, ra.lay.stride);
     if (smem > 160 * 1024) return IBVH_ERR_INVALID_ARG; // (make_plan sizes the tile for the record)
-    IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)partition_kernel<K, PT, PI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)partition_kernel<K, PT, PI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const uint32_t words = (uint32_t)ra.lay.stride / 8u;
-    IBVH_LAUNCH((partition_kernel<K, PT, PI>), dim3(p.num_tiles), dim3(PT), smem, st, keys, n, p.shift, p.bits, p.tile_scan,
-                p.digit_total, p.num_tiles, ra, (uint32_t)((((uint64_t)1 << 32) + words - 1) / words));
+    const uint32_t inv_words = (uint32_t)((((uint64_t)1 << 32) + words - 1) / words);
+    IBVH_LAUNCH((partition_kernel<K, PT, PI, false>), dim3(p.num_tiles), dim3(PT), smem, st, keys, n, p.shift, p.bits, p.tb,
+                p.num_tiles, ra, inv_words, p.bits);
+    if (!two_level) return IBVH_OK;
+    // level 2: only the cells the plan found oversized (none for a uniform cloud: every workgroup returns at once)
+    const int bits2 = p.shift < L2_BITS ? p.shift : L2_BITS, shift2 = p.shift - bits2;
+    const uint32_t tile = (uint32_t)PT * PI;
+    LeafLayout lay = ra.lay;
+    IBVH_LAUNCH((hist2_kernel), dim3(p.max_tiles2), dim3(256), 0, st, p.tb, (const char *)ra.dst, lay, shift2, (1u << bits2) - 1u, tile);
+    const int64_t max_over = (n / 2048 + 1) < (1 << p.bits) ? (n / 2048 + 1) : (1 << p.bits);
+    IBVH_LAUNCH((scan2_kernel), dim3((unsigned)max_over), dim3(1024), 0, st, p.tb);
+    RecordArgs r2 = ra;
+    r2.src = ra.dst; // the level-1 output: whole records, copied as they are
+    r2.dst = part2;
+    r2.src_stride = ra.lay.stride;
+    r2.src_wrapped = 1;
+    const size_t smem2 = partition_smem<K, PT, PI>(L2_BITS, ra.lay.stride);
+    IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)partition_kernel<K, PT, PI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
+    IBVH_LAUNCH((partition_kernel<K, PT, PI, true>), dim3(p.max_tiles2), dim3(PT), smem2, st, (const K *)nullptr, n, shift2, L2_BITS,
+                p.tb, p.max_tiles2, r2, inv_words, bits2);
     return IBVH_OK;
 }
 template <class K, int FT, int FI>
 static int launch_finish(const Plan &p, const FinishArgs &fa, hipStream_t st) {
     constexpr size_t smem = finish_smem<K, FT, FI>();
     IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)finish_kernel<K, FT, FI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    IBVH_LAUNCH((finish_kernel<K, FT, FI>), dim3(1u << p.bits), dim3(FT), smem, st, p.digit_total, p.shift, fa);
+    const int f2 = !fa.two_level ? 0 : (p.max_tiles2 < 1024 ? p.max_tiles2 : 1024); // workgroups that stride over the level-2 windows
+    IBVH_LAUNCH((finish_kernel<K, FT, FI>), dim3((1u << p.bits) + f2), dim3(FT), smem, st, p.tb, 1 << p.bits, fa);
     return IBVH_OK;
 }
 
-// keys: n Morton keys (uint32 / uint64) in source order, their top-digit tile histogram already in p.tile_hist.
-// ra: source -> partitioned records (ra.dst = scratch of n records); out: the sorted records.
-// (kalt, valt, kpri, vpri): n-entry scratch arrays for oversized buckets (kpri may alias `keys`: the keys are dead
-// once the partition has run).
-int sort_records(const Plan &p, int key_bytes, const void *keys, int64_t n, const RecordArgs &ra, char *out, void *kalt,
-                 uint32_t *valt, void *kpri, uint32_t *vpri, hipStream_t st) {
+// keys: n Morton keys (uint32 / uint64) in source order, their top-digit tile histogram already in p.tb.tile_hist.
+// ra: source -> level-1 partitioned records (ra.dst: n records of scratch); part2: n more records of scratch for the
+// level-2 partition; out: the sorted records.  (kalt, valt, kpri, vpri): n-entry scratch arrays of the slow path
+// (kpri may alias `keys`: the keys are dead once the partition has run).
+int sort_records(const Plan &p, int key_bytes, const void *keys, int64_t n, const RecordArgs &ra, char *part2, char *out, void *kalt,
+                 uint32_t *valt, void *kpri, uint32_t *vpri, int two_level, void *skew_flag, hipStream_t st) {
     {
         const int radix = 1 << p.bits, ndb = radix >> 6;
         int chunks = 512 / ndb < 1 ? 1 : 512 / ndb; // ~512 workgroups
         if (chunks > (p.num_tiles + 15) / 16) chunks = (p.num_tiles + 15) / 16;
         const int rows = (p.num_tiles + chunks - 1) / chunks;
         chunks = (p.num_tiles + rows - 1) / rows;
-        IBVH_LAUNCH((scan_tiles_kernel), dim3(ndb * chunks), dim3(SCAN_TPB), 0, st, p.tile_hist, p.tile_scan, p.num_tiles, radix, rows, p.digit_total);
+        IBVH_LAUNCH((scan_tiles_kernel), dim3(ndb * chunks), dim3(SCAN_TPB), 0, st, p.tb.tile_hist, p.tb.tile_scan, p.num_tiles, radix, rows,
+                    p.tb.cell_total);
+        IBVH_LAUNCH((plan_kernel), dim3(1), dim3(PLAN_TPB), 0, st, p.tb, radix, (uint32_t)(p.ftpb * p.fipt), (uint32_t)(p.ptpb * p.pipt),
+                    two_level, (int32_t *)skew_flag);
     }
     int rc = IBVH_ERR_INVALID_ARG;
 #define IBVH_PART(K, T, I) \
-    if (p.ptpb == T && p.pipt == I) rc = launch_partition<K, T, I>(p, (const K *)keys, n, ra, st);
+    if (p.ptpb == T && p.pipt == I) rc = launch_partitions<K, T, I>(p, (const K *)keys, n, ra, part2, two_level, st);
     if (key_bytes == 4) {
         IBVH_PART(uint32_t, 256, 4) IBVH_PART(uint32_t, 256, 8) IBVH_PART(uint32_t, 512, 8)
     } else {
@@ -625,10 +867,16 @@ int sort_records(const Plan &p, int key_bytes, const void *keys, int64_t n, cons
     if (rc) return rc;
     FinishArgs fa{};
     fa.part = ra.dst;
+    fa.part2 = part2;
     fa.out = out;
     fa.lay = ra.lay;
     fa.words = (uint32_t)ra.lay.stride / 8u;
     fa.inv_words = (uint32_t)((((uint64_t)1 << 32) + fa.words - 1) / fa.words);
+    fa.cap = (uint32_t)(p.ftpb * p.fipt);
+    fa.tile = (uint32_t)(p.ptpb * p.pipt);
+    fa.two_level = two_level;
+    fa.shift1 = p.shift;
+    fa.shift2 = p.shift - (p.shift < L2_BITS ? p.shift : L2_BITS);
     fa.kalt = kalt;
     fa.kpri = kpri;
     fa.valt = valt;

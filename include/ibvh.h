@@ -111,6 +111,17 @@ typedef struct ibvh_build_desc {
     int32_t compute_extrema; /* 1: derive mins/maxs from the centres (morton/default.jl:53)    */
     double mins[3];          /* used when compute_extrema == 0 (alg.mins / alg.maxs)           */
     double maxs[3];
+    /* Skewed inputs (clustered clouds, surfaces).  The sort first splits the leaves into the cells of a coarse Morton
+     * grid; a cell too crowded for one workgroup is split again by a second partition level.  For a uniform cloud that
+     * level finds nothing to do but still costs its launches (~4 % of a 1e6-leaf build), so it is the caller's choice:
+     *   two_level != 0 : run it (robust: what a cold build should pass);
+     *   two_level == 0 : crowded cells are sorted by one workgroup each — correct, slow when there are many.
+     * skew_flag (optional, may be NULL): 4 bytes the GPU can write — device memory or mapped pinned host memory.  Every
+     * build stores 1 there if it met a crowded cell, else 0, so a caller that rebuilds every time step can pass
+     * two_level = (the value the previous build left) without ever synchronising (build.jl:109-126 reuse pattern). */
+    int32_t two_level;
+    int32_t reserved_;
+    void *skew_flag;
 } ibvh_build_desc;
 
 /* ----------------------------------------------------------------------------------- */

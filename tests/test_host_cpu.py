@@ -94,7 +94,7 @@ def test_scratch_queries():
     t = abi.make_types()
     need = C.c_size_t()
     lib.call("ibvh_build_scratch_bytes", C.byref(t), 10**6, C.byref(need))
-    assert 10**6 * (4 + 4 + 4 + 4) <= need.value <= 10**6 * 64
+    assert 10**6 * (4 + 4 + 4 + 4) <= need.value <= 10**6 * 96  # keys + positions, twice; two record stagings; tables
     with pytest.raises(abi.DomainError):
         lib.call("ibvh_build_scratch_bytes", C.byref(t), 0, C.byref(need))
     lib.call("ibvh_lvt_scratch_bytes", C.byref(t), 10**6, 8, C.byref(need))

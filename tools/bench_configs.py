@@ -67,7 +67,48 @@ out["config2"] = {"leaves": n2, "build_cold_ms": round(ms_cold, 3), "build_cache
                   "bfs_contacts": t_bfs.num_contacts, "bfs_checks": t_bfs.num_checks,
                   "Mcontacts_per_s_lvt": round(t_lvt.num_contacts / ms_lvt / 1e3, 1),
                   "Mcontacts_per_s_bfs": round(t_bfs.num_contacts / ms_bfs2 / 1e3, 1)}
-del v2, s2, t_lvt, t_bfs
+# ---- skew and order: the same 1e6 leaves (a) drawn from 8 tight Gaussian clusters — a handful of Morton
+# cells hold everything, the build's second partition level takes them — and (b) uniform but handed over already in
+# Morton order (the time-stepping shape: leaves of the previous step fed back)
+def checked_build(vols, what):
+    b = ibvh.BVH(vols)
+    m = b.leaves.morton
+    assert bool((m[1:] >= m[:-1]).all()), what + ": Morton codes not ascending"
+    idx = b.leaves.index.cpu()
+    assert idx.sort().values.equal(torch.arange(1, len(idx) + 1, dtype=idx.dtype)), what + ": not a permutation"
+    return b
+
+
+g = torch.Generator(device="cuda").manual_seed(7)
+centres = torch.rand((8, 3), generator=g, device="cuda")
+which = torch.randint(0, 8, (n2,), generator=g, device="cuda")
+clustered = torch.empty((n2, 4), dtype=torch.float32, device="cuda")
+clustered[:, :3] = centres[which] + 0.004 * torch.randn((n2, 3), generator=g, device="cuda")
+clustered[:, 3] = 1e-4
+checked_build(clustered, "clustered")
+sc = {"bvh": None}
+
+
+def build_clustered():
+    sc["bvh"] = ibvh.BVH(clustered, cache=sc["bvh"])
+    return sc["bvh"]
+
+
+ms_clustered, _ = timed(build_clustered, 10)
+sorted_vols = checked_build(v2, "uniform").leaves.volume.contiguous()
+ss = {"bvh": None}
+
+
+def build_sorted():
+    ss["bvh"] = ibvh.BVH(sorted_vols, cache=ss["bvh"])
+    return ss["bvh"]
+
+
+ms_sorted, _ = timed(build_sorted, 10)
+out["config2_skew"] = {"leaves": n2, "build_uniform_ms": round(ms_warm, 3), "build_8_gaussian_clusters_ms": round(ms_clustered, 3),
+                       "clustered_over_uniform": round(ms_clustered / ms_warm, 2), "build_morton_sorted_input_ms": round(ms_sorted, 3),
+                       "kernels_clustered_ms": kernels(build_clustered)}
+del v2, s2, t_lvt, t_bfs, clustered, sorted_vols, sc, ss
 torch.cuda.empty_cache()
 # ---- config 3 -------------------------------------------------------------------------------
 from test_gpu_fullsize import torus_mesh
@@ -97,6 +138,7 @@ def rays():
 
 ms_rays, tr = timed(rays, 3)
 out["config3"] = {"triangles": int(tris.shape[0]), "volumes_ms": round(ms_vol, 3), "build_ms": round(ms_build, 3),
+                  "build_kernels_ms": kernels(build3),
                   "rays": nr, "traverse_rays_lvt_ms": round(ms_rays, 3), "hits": tr.num_contacts,
                   "Mrays_per_s": round(nr / ms_rays / 1e3, 2), "kernels_ms": kernels(rays)}
 state["t"] = None
