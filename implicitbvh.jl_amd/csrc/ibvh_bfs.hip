@@ -21,6 +21,10 @@ namespace bfs {
 
 constexpr int TPB = 256;
 
+// Workgroup barrier that orders LDS accesses only: __syncthreads() also drains every outstanding global store and
+// load (s_waitcnt vmcnt(0)), which would make a workgroup wait for its queue writes before it may read its next chunk.
+IBVH_D void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <class L, class N> struct TreeRef {
     const char *leaves;
     LeafLayout lay;
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(TPB) void level_kernel(const IndexPair<I> *__restri
         int wave_prefix = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
         int wave_sum = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
         if (lane == 0) wave_tot[w] = wave_sum;
-        __syncthreads();
+        lds_barrier();
         int block_prefix = 0, total = 0;
 #pragma unroll
         for (int j = 0; j < TPB / 64; ++j) {
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(TPB) void level_kernel(const IndexPair<I> *__restri
         for (int j = 0; j < MAXOUT; ++j)
             if (j < k) staged[at + j] = out[j];
         if (threadIdx.x == 0) s_base = total ? atomicAdd(&counters[2 + step], (unsigned long long)total) : 0ull;
-        __syncthreads();
+        lds_barrier();
         const unsigned long long base = s_base;
         if (total > 0) {
             if (base + (unsigned long long)total > (unsigned long long)capacity) {
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(TPB) void level_kernel(const IndexPair<I> *__restri
                 for (int p = threadIdx.x; p < total; p += TPB) dst[base + p] = staged[p];
             }
         }
-        __syncthreads(); // staged / wave_tot / s_base are reused by the next chunk
+        lds_barrier(); // staged / wave_tot / s_base are reused by the next chunk (LDS only: the stores above stay in flight)
     }
 }
 

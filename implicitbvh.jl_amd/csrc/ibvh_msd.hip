@@ -41,6 +41,7 @@ namespace ibvh {
 namespace msd {
 
 using rsort::block_exclusive_scan;
+using rsort::lds_barrier;
 using rsort::lds_exclusive_scan;
 using rsort::lds_radix_pass;
 using rsort::RecordArgs;
@@ -345,26 +346,53 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
     // this tile's row of the (scanned, tile-major) histogram and the digit starts: coalesced, in flight while the keys
     // are ranked
     constexpr int DPT = (1 << MSD_MAX_BITS) / TPB; // digits per thread, at most
-    uint32_t tile_off[DPT];
+    // (straight-line, unconditional loads with clamped indices: the compiler can then wait for exactly the values it
+    // needs — s_waitcnt vmcnt(N) — instead of draining everything before the first use)
+    uint32_t tile_off_a[DPT], tile_off_b[DPT];
 #pragma unroll
     for (int k = 0; k < DPT; ++k) {
         const int d = k * TPB + threadIdx.x;
-        tile_off[k] = d < radix ? scan_row[d] + digit_start[d] + dst_first : 0u;
+        const int dc = d < radix ? d : radix - 1;
+        tile_off_a[k] = scan_row[dc];
+        tile_off_b[k] = digit_start[dc];
     }
     for (int i = threadIdx.x; i < W * radix / 2; i += TPB) ((uint32_t *)whist)[i] = 0;
     K key[IPT];
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
         const int64_t i = wave_base + j * 64 + lane;
-        if constexpr (L2) key[j] = i < end ? (K)load_morton(rec.src + i * rec.src_stride, rec.lay) : (K) ~(K)0;
-        else key[j] = i < end ? keys[i] : (K) ~(K)0;
+        const int64_t ic = i < end ? i : end - 1;
+        if constexpr (L2) key[j] = (K)load_morton(rec.src + ic * rec.src_stride, rec.lay);
+        else key[j] = keys[ic];
     }
-    __syncthreads();
+    // 16-byte fresh volumes (BSphere{Float32}, the common case) are requested now and stay in flight while the keys are
+    // ranked (the barriers below do not wait for them); other layouts are fetched when they are staged
+    const uint32_t src_words = (uint32_t)(rec.src_stride / 8);
+    const uint32_t words = (uint32_t)rec.lay.stride / 8u;
+    const bool wrapped = rec.src_wrapped != 0;
+    const uint64_t *src = (const uint64_t *)rec.src;
+    const int code = (wrapped ? 100 : 0) + rec.vol_words * 10 + (int)words;
+    const bool preload = !L2 && (code == 23 || code == 24);
+    // (issued for EVERY layout — the first 16 bytes of a volume or record are always there — so that the code stays
+    // straight-line and the compiler can count the loads in flight exactly; only the 16-byte layouts use the values)
+    uint64_t pre[IPT][2];
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        int64_t i = wave_base + j * 64 + lane;
+        if (i >= end) i = end - 1;
+        const uint64_t *pv = src + (uint64_t)i * src_words;
+        pre[j][0] = pv[0];
+        pre[j][1] = pv[1];
+    }
+#pragma unroll
+    for (int j = 0; j < IPT; ++j)
+        if (wave_base + j * 64 + lane >= end) key[j] = (K) ~(K)0; // past the end: sentinels, ranked last
+    lds_barrier();
     IBVH_STAMP(0, 1);
     uint16_t rank[IPT];
     uint16_t *my_hist = whist + w * radix;
     wave_rank<K, IPT>(key, shift, mask, digit_bits, my_hist, lane, rank);
-    __syncthreads();
+    lds_barrier();
     IBVH_STAMP(0, 2);
     // per digit: exclusive prefix over the waves (in place), tile total
     for (int d = threadIdx.x; d < radix; d += TPB) {
@@ -377,14 +405,14 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
         }
         local_base[d] = run;
     }
-    __syncthreads();
+    lds_barrier();
     IBVH_STAMP(0, 3);
-    lds_exclusive_scan<TPB>(local_base, radix, wave_tot);
+    lds_exclusive_scan<TPB, true>(local_base, radix, wave_tot);
     IBVH_STAMP(0, 4);
 #pragma unroll
     for (int k = 0; k < DPT; ++k) {
         const int d = k * TPB + threadIdx.x;
-        if (d < radix) delta[d] = tile_off[k] - local_base[d]; // mod 2^32
+        if (d < radix) delta[d] = tile_off_a[k] + tile_off_b[k] + dst_first - local_base[d]; // mod 2^32
     }
     uint32_t pos[IPT];
 #pragma unroll
@@ -392,20 +420,28 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
         const uint32_t d = (uint32_t)(key[j] >> shift) & mask;
         pos[j] = local_base[d] + my_hist[d] + rank[j];
     }
-    __syncthreads(); // every wave is done with whist: its bytes become the stage
+    lds_barrier(); // every wave is done with whist: its bytes become the stage
     IBVH_STAMP(0, 5);
     // the records: sources are read in memory order (coalesced) and land at their sorted place in the stage
-    const uint32_t src_words = (uint32_t)(rec.src_stride / 8);
-    const uint32_t words = (uint32_t)rec.lay.stride / 8u;
-    const bool wrapped = rec.src_wrapped != 0;
-    const uint64_t *src = (const uint64_t *)rec.src;
     const TailLayout tl{rec.vol_words * 8, wrapped ? -64 : rec.lay.index_off, rec.lay.morton_off, rec.index_bytes, rec.lay.morton_bytes};
     static_assert(IPT % 4 == 0, "rows are moved 4 or 2 at a time");
 #define IBVH_MOVE(NW, OW, WR)                                                                                           \
     for (int j0 = 0; j0 < IPT; j0 += (NW <= 3 ? 4 : 2))                                                                 \
         stage_rows<NW, OW, WR, K, (NW <= 3 ? 4 : 2)>(src, src_words, stage, tl, wave_base + j0 * 64, end, key + j0, pos + j0);
     // (volume words, record words) of every layout layout_of() can produce; wrapped sources carry whole records
-    const int code = (wrapped ? 100 : 0) + rec.vol_words * 10 + (int)words;
+    if (preload) {
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const int64_t i = wave_base + j * 64 + lane;
+            if (i < end) {
+                uint64_t *q = stage + pos[j] * words;
+                q[0] = pre[j][0];
+                q[1] = pre[j][1];
+                q[2] = tail_word(tl, 2, (uint64_t)i + 1u, (uint64_t)key[j], 0);
+                if (words == 4) q[3] = tail_word(tl, 3, (uint64_t)i + 1u, (uint64_t)key[j], 0);
+            }
+        }
+    } else
     switch (code) {
     case 23: IBVH_MOVE(2, 3, false) break;  // BSphere{F32}, 24-byte record (Int32 / UInt16|UInt32)
     case 24: IBVH_MOVE(2, 4, false) break;  // BSphere{F32}, Int64 and/or UInt64
@@ -424,7 +460,7 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
     default: break; // (unreachable: the host refuses other layouts)
     }
 #undef IBVH_MOVE
-    __syncthreads();
+    lds_barrier();
     IBVH_STAMP(0, 6);
     // out: lane <-> 8-byte word of the tile's sorted records; a digit's run goes to consecutive addresses
     const int64_t left = end - tile_base;

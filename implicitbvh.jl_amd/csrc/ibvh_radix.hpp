@@ -14,7 +14,17 @@
 namespace ibvh {
 namespace rsort {
 
-template <int TPB> IBVH_D uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_tot /* TPB/64 */, uint32_t *total) {
+// Workgroup barrier that orders LDS accesses only.  __syncthreads() carries a workgroup-scope fence, for which the
+// compiler drains EVERY outstanding memory operation (s_waitcnt vmcnt(0)) — including global loads issued on purpose
+// long before their use.  Where only LDS contents are handed from wave to wave, this barrier waits for the LDS
+// operations alone and such loads stay in flight across it.
+IBVH_D void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <bool LDS_ONLY> IBVH_D void wg_barrier() {
+    if constexpr (LDS_ONLY) lds_barrier();
+    else __syncthreads();
+}
+
+template <int TPB, bool LDS_ONLY = false> IBVH_D uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_tot /* TPB/64 */, uint32_t *total) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t inc = v;
 #pragma unroll
@@ -23,7 +33,7 @@ template <int TPB> IBVH_D uint32_t block_exclusive_scan(uint32_t v, uint32_t *wa
         if (lane >= o) inc += t;
     }
     if (lane == 63) wave_tot[w] = inc;
-    __syncthreads();
+    wg_barrier<LDS_ONLY>();
     uint32_t base = 0, tot = 0;
 #pragma unroll
     for (int i = 0; i < TPB / 64; ++i) {
@@ -32,26 +42,26 @@ template <int TPB> IBVH_D uint32_t block_exclusive_scan(uint32_t v, uint32_t *wa
         tot += t;
     }
     if (total) *total = tot;
-    __syncthreads();
+    wg_barrier<LDS_ONLY>();
     return base + inc - v;
 }
 
 // in-place exclusive scan of an LDS array of `count` values by the whole workgroup; returns the total
-template <int TPB> IBVH_D uint32_t lds_exclusive_scan(uint32_t *arr, int count, uint32_t *wave_tot) {
+template <int TPB, bool LDS_ONLY = false> IBVH_D uint32_t lds_exclusive_scan(uint32_t *arr, int count, uint32_t *wave_tot) {
     const int per = (count + TPB - 1) / TPB;
     const int lo = threadIdx.x * per;
     uint32_t sum = 0;
     for (int k = 0; k < per; ++k)
         if (lo + k < count) sum += arr[lo + k];
     uint32_t total;
-    uint32_t run = block_exclusive_scan<TPB>(sum, wave_tot, &total);
+    uint32_t run = block_exclusive_scan<TPB, LDS_ONLY>(sum, wave_tot, &total);
     for (int k = 0; k < per; ++k)
         if (lo + k < count) {
             const uint32_t v = arr[lo + k];
             arr[lo + k] = run;
             run += v;
         }
-    __syncthreads();
+    wg_barrier<LDS_ONLY>();
     return total;
 }
 
