@@ -229,6 +229,22 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = leaves_total * args.steps / elapsed / 1e6
 
+    # The same K steps once more with the contact count READ on the host in every step (the reference blocks on it
+    # inside traverse, lvt/traverse_single.jl:60; SURVEY.md §8d times the step "incl. the count readback").  The
+    # headline loop above chains steps through cache= and reads the count once, at the end.
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        state = one_step(state)
+        _ = state[1].num_contacts
+    barrier()
+    elapsed_rb = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed_rb], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_rb = float(t.item())
+    ms_per_step_rb = elapsed_rb / args.steps * 1e3
+
     # ---- per-kernel timing pass (HIP events inside the library, on the launch stream) -------------
     prof_steps = max(3, min(10, args.steps))
     lib.call("ibvh_profile_enable", 1)
@@ -269,13 +285,29 @@ def main():
     # prescribes for gfx950 (calibrated here on the extrema kernel: 7.7 MiB reported for 16.0e6 bytes streamed),
     # WRITE_SIZE taken as is, KiB -> bytes
     if roofline is not None and n in (1_000_000, 10_000_000):
-        fname = "r01_pmc_fetch_write_n1e6.json" if n == 1_000_000 else "r01_pmc_fetch_write_n1e7.json"
+        fname = "r02_pmc_fetch_write_n1e6.json" if n == 1_000_000 else "r02_pmc_fetch_write_n1e7.json"
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", fname)))["kernels"]
             for name, v in pmc.items():
                 if pmc_key(name) == roofline["kernel"] and v["launches"] >= 5:
                     roofline["traffic"] = int((2 * v["FETCH_SIZE_KiB_avg"] + v["WRITE_SIZE_KiB_avg"]) * 1024)
                     roofline["traffic_source"] = f"profiles/{fname} (2*FETCH_SIZE + WRITE_SIZE: L2-miss bytes; Infinity-Cache hits included)"
+        except Exception:
+            pass
+        # issue roofline of the same kernel: wave-instructions per launch from the committed SQ counter passes
+        # (profiles/r02_sq_counters_n1e6.json, rocprofv3 --pmc SQ_INSTS_*) over the chip's issue capacity
+        # (256 CUs x 4 SIMDs x one instruction per cycle at 2.4 GHz), next to the HBM one: this kernel is issue bound
+        try:
+            if n == 1_000_000:
+                sq = json.load(open(os.path.join(ROOT, "profiles", "r02_sq_counters_n1e6.json")))["kernels"].get(roofline["kernel"])
+                if sq:
+                    instr = sum(sq.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM",
+                                                         "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"))
+                    peak = 256 * 4 * 2.4e9
+                    roofline["issue"] = {"wave_instructions_per_launch": int(instr), "achieved_Ginstr_per_s": round(instr / avg_s / 1e9, 1),
+                                         "peak_Ginstr_per_s": round(peak / 1e9, 1), "frac": round(instr / avg_s / peak, 4),
+                                         "valu_busy_frac": sq.get("valu_busy_frac"), "salu_busy_frac": sq.get("salu_busy_frac"),
+                                         "source": "profiles/r02_sq_counters_n1e6.json"}
         except Exception:
             pass
 
@@ -316,6 +348,40 @@ def main():
         del vols2, st2, b2
         torch.cuda.empty_cache()
 
+    # ---- IBVH_MESH=/path/to/mesh.obj: config 3 on the real mesh (build + self-traverse + 1e6 rays), reported beside the
+    # headline; without the variable nothing is run here (tools/bench_configs.py times the torus surrogate) ------------------
+    mesh = None
+    mesh_path = os.environ.get("IBVH_MESH", "")
+    if rank == 0 and world == 1 and mesh_path and os.path.exists(mesh_path):
+        tris = ibvh.load_obj_triangles(mesh_path)
+        mv = ibvh.bounding_volumes_from_triangles(tris)
+        mb = ibvh.BVH(mv)
+        mt = ibvh.traverse(mb)
+        lo, hi = mv[:, :3].min(0).values, mv[:, :3].max(0).values
+        g = torch.Generator(device="cuda").manual_seed(43)
+        pts = (lo + (hi - lo) * torch.rand((1_000_000, 3), generator=g, device="cuda")).t().contiguous()
+        dirs = torch.rand((1_000_000, 3), generator=g, device="cuda").t().contiguous()
+        mr = ibvh.traverse_rays(mb, pts, dirs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            mb = ibvh.BVH(mv, cache=mb)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            mt = ibvh.traverse(mb, cache=mt)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(3):
+            mr = ibvh.traverse_rays(mb, pts, dirs, cache=mr)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        mesh = {"path": mesh_path, "triangles": int(tris.shape[0]), "build_ms": round((t1 - t0) / 5 * 1e3, 4),
+                "self_traverse_ms": round((t2 - t1) / 5 * 1e3, 4), "self_contacts": mt.num_contacts,
+                "rays": 1_000_000, "traverse_rays_ms": round((t3 - t2) / 3 * 1e3, 4), "ray_hits": mr.num_contacts}
+        del tris, mv, mb, mt, mr, pts, dirs
+        torch.cuda.empty_cache()
+
     # ---- CPU baseline: the oracle's multi-threaded restatement, rank 0 only, bounded sample --------
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -324,30 +390,41 @@ def main():
         ncpu = os.cpu_count() or 1
         cpu_n = args.cpu_n or min(n, 2_000_000)
         host = orc.generate_spheres_f32(cpu_n, args.seed, r0=0.5 * (3 * 8 / (4 * math.pi * cpu_n)) ** (1 / 3))
-        # the host is shared and SMT-threaded: more threads are not always faster, so a few thread counts are tried and
-        # the best run is the baseline (its thread count is what `cores` reports)
+        # the baseline is the oracle's source built HERE with -O3 -march=native (strict IEEE flags kept,
+        # so its contact count must equal the GPU's); the portable -O2 build the parity tests use is the fallback
+        native = orc.load_native()
+        # one thread first (the reference's CPU path with num_threads = 1), then a few team sizes: the host is shared and
+        # SMT-threaded, more threads are not always faster; the best run is the baseline, its thread count is `cores`
+        _, cc1, tb1, tt1 = orc.bench_build_traverse_f32(host, 1, native)
         candidates = sorted({max(1, ncpu), max(1, ncpu // 2), max(1, ncpu // 4), min(32, ncpu)}, reverse=True)
         best = None
         t_budget = time.perf_counter()
         for threads in candidates:
             for _ in range(3):
-                _, cc, tb, tt = orc.bench_build_traverse_f32(host, threads)
+                _, cc, tb, tt = orc.bench_build_traverse_f32(host, threads, native)
                 if best is None or tb + tt < best[0] + best[1]:
                     best = (tb, tt, len(cc), threads)
-            if time.perf_counter() - t_budget > 25:
+            if time.perf_counter() - t_budget > 20:
                 break
         cores = best[3]
         cpu_baseline = {"value": round(cpu_n / (best[0] + best[1]) / 1e6, 4), "unit": "Mleaves/s", "cores": cores,
                         "kind": "port",
+                        "compiler_flags": "-O3 -march=native -ffp-contract=off (built on this host)" if native is not None
+                                          else "-O2 -ffp-contract=off (portable build: the native build failed here)",
                         "sample": f"{cpu_n} BSphere{{Float32}} leaves, same generator/law as the GPU workload, "
                                   f"build {best[0]*1e3:.1f} ms + LVT traverse {best[1]*1e3:.1f} ms, {best[2]} contacts, "
-                                  f"best run over thread counts {candidates} (<= 3 runs each), {cores} threads",
+                                  f"best run over thread counts {candidates} (<= 3 runs each; leaf ranges handed out "
+                                  f"dynamically in the traversal), {cores} threads",
                         "build_ms": round(best[0] * 1e3, 3), "traverse_ms": round(best[1] * 1e3, 3),
-                        "gpu_over_cpu": round(value / (cpu_n / (best[0] + best[1]) / 1e6), 1) if cpu_n == n else None}
+                        "one_thread": {"value": round(cpu_n / (tb1 + tt1) / 1e6, 4), "build_ms": round(tb1 * 1e3, 2),
+                                       "traverse_ms": round(tt1 * 1e3, 2), "contacts": len(cc1)},
+                        "contacts_match_gpu": (best[2] == contacts and len(cc1) == contacts) if cpu_n == n else None,
+                        "gpu_over_cpu": round(value / (cpu_n / (best[0] + best[1]) / 1e6), 1) if cpu_n == n else None,
+                        "gpu_over_cpu_one_thread": round(value / (cpu_n / (tb1 + tt1) / 1e6), 1) if cpu_n == n else None}
         if north_star is not None:
             n2 = north_star["leaves"]
             host2 = orc.generate_spheres_f32(n2, args.seed, r0=0.5 * (3 * 8 / (4 * math.pi * n2)) ** (1 / 3))
-            _, cc2, tb2, tt2 = orc.bench_build_traverse_f32(host2, cores)
+            _, cc2, tb2, tt2 = orc.bench_build_traverse_f32(host2, cores, native)
             north_star["cpu_baseline"] = {"value": round(n2 / (tb2 + tt2) / 1e6, 4), "unit": "Mleaves/s", "cores": cores,
                                           "kind": "port", "build_ms": round(tb2 * 1e3, 2), "traverse_ms": round(tt2 * 1e3, 2),
                                           "sample": f"{n2} leaves, one run"}
@@ -367,9 +444,11 @@ def main():
                                       if dist is not None else "(configs[1] law at another size)"),
                        "leaves_per_gpu": n, "leaves_total": leaves_total, "contacts_total": contacts_total,
                        "parallelism": "single GPU" if world == 1 else f"leaves sharded over {world} GPUs (RCCL build), per-GPU traversal"},
+            "ms_per_step_with_readback": round(ms_per_step_rb, 4),
+            "value_with_readback": round(leaves_total * args.steps / elapsed_rb / 1e6, 3),
             "mcontacts_per_s": round(contacts_total * args.steps / elapsed / 1e6, 3),
             "mcontacts_per_s_traverse_only": round(contacts / (t_trav * 1e-3) / 1e6, 3) if t_trav else None,
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "north_star_1e7": north_star, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "north_star_1e7": north_star, "mesh": mesh, "kernels": kernels,
             "profiled_ms_per_step": round(tp / prof_steps * 1e3, 4),
         }
         print(json.dumps(line))

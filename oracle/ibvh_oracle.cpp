@@ -1069,6 +1069,18 @@ template <class F> static void parallel_ranges(int64_t n, int threads, F &&f) {
 #pragma omp parallel for schedule(static, 1) num_threads(threads)
     for (int t = 0; t < threads; ++t) f(t, n * t / threads, n * (t + 1) / threads);
 }
+// The same, with the range cut into chunks that the threads take as they become free (the leaf-vs-tree walk of one
+// leaf costs anything from a few node tests to hundreds: equal contiguous shares leave threads idle at the end).
+// Results do not depend on who processes which chunk: every leaf writes its own count / its own output range.
+template <class F> static void parallel_chunks(int64_t n, int threads, int64_t chunk, F &&f) {
+    if (threads <= 1 || n < 2 * threads) {
+        f(0, int64_t(0), n);
+        return;
+    }
+    const int64_t nchunks = (n + chunk - 1) / chunk;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+    for (int64_t c = 0; c < nchunks; ++c) f(0, c * chunk, (c + 1) * chunk < n ? (c + 1) * chunk : n);
+}
 extern "C" {
 
 // SphereF32 leaves / BBoxF32 nodes / I32 / U32 — the bench types (benchmark/bvh_contact.jl:21-27)
@@ -1192,7 +1204,7 @@ int oracle_bench_build_traverse_f32(const void *volumes, int64_t n, int threads,
     I *c = (I *)counts;
     int64_t total = 0;
     if (tree.real_nodes > 1) {
-        parallel_ranges(n, threads, [&](int, int64_t lo, int64_t hi) {
+        parallel_chunks(n, threads, 2048, [&](int, int64_t lo, int64_t hi) {
             for (int64_t i = lo + 1; i <= hi; ++i) {
                 int64_t cnt = 0;
                 auto emit = [&](I, I) { ++cnt; };
@@ -1203,7 +1215,7 @@ int oracle_bench_build_traverse_f32(const void *volumes, int64_t n, int threads,
         if (int e = scan_counts(c, n, &total)) return e;
         if (total <= contacts_capacity) {
             IndexPair<I> *out = (IndexPair<I> *)contacts_out;
-            parallel_ranges(n, threads, [&](int, int64_t lo, int64_t hi) {
+            parallel_chunks(n, threads, 2048, [&](int, int64_t lo, int64_t hi) {
                 for (int64_t i = lo + 1; i <= hi; ++i) {
                     int64_t w = (i == 1) ? 0 : (int64_t)c[i - 2];
                     auto emit = [&](I a, I b) { out[w++] = {a, b}; };

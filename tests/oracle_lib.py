@@ -359,7 +359,22 @@ def generate_spheres_f32(n, seed, first_index=0, origin=(0, 0, 0), extent=(1, 1,
     return out
 
 
-def bench_build_traverse_f32(volumes, threads):
+def load_native():
+    """The -O3 -march=native build of the same source (oracle/Makefile target `native`), made on the machine that runs it:
+    bench.py's timed CPU baseline only.  Returns None if it cannot be built here."""
+    import subprocess
+    so = os.path.join(_ROOT, "oracle", "_native", "libibvh_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), "native"], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL, timeout=600)
+        nat = C.CDLL(so)
+        nat.oracle_bench_build_traverse_f32.restype = C.c_int
+        return nat
+    except Exception:
+        return None
+
+
+def bench_build_traverse_f32(volumes, threads, native=None):
     """Timed multi-threaded CPU restatement on BSphere{F32}/BBox{F32}/I32/U32."""
     types = abi.make_types()
     v = as_volumes(volumes, abi.BSPHERE, abi.F32)
@@ -372,7 +387,7 @@ def bench_build_traverse_f32(volumes, threads):
     cap = max(16 * n, 1024)
     contacts = np.zeros(cap, abi.pair_dtype(types))
     nc, tb, tt = C.c_int64(), C.c_double(), C.c_double()
-    st = lib.oracle_bench_build_traverse_f32(_p(v), C.c_int64(n), int(threads), _p(leaves), _p(nodes), _p(skips),
+    st = (native or lib).oracle_bench_build_traverse_f32(_p(v), C.c_int64(n), int(threads), _p(leaves), _p(nodes), _p(skips),
                                              _p(counts), _p(contacts), C.c_int64(cap), C.byref(nc), C.byref(tb),
                                              C.byref(tt))
     abi.check(st)

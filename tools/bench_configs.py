@@ -112,7 +112,15 @@ del v2, s2, t_lvt, t_bfs, clustered, sorted_vols, sc, ss
 torch.cuda.empty_cache()
 # ---- config 3 -------------------------------------------------------------------------------
 from test_gpu_fullsize import torus_mesh
-tris = torch.from_numpy(torus_mesh()).cuda()
+# IBVH_MESH=/path/to/xyzrgb_dragon.obj (benchmark/bvh_contact.jl:30-36): the real mesh when it is there,
+# the 7.2 M-triangle torus surrogate otherwise
+mesh_path = os.environ.get("IBVH_MESH", "")
+if mesh_path and os.path.exists(mesh_path):
+    tris = ibvh.load_obj_triangles(mesh_path)
+    out["config3_mesh"] = mesh_path
+else:
+    tris = torch.from_numpy(torus_mesh()).cuda()
+    out["config3_mesh"] = "torus surrogate (IBVH_MESH not set)"
 ms_vol, vols = timed(lambda: ibvh.bounding_volumes_from_triangles(tris))
 state = {"bvh": None, "t": None}
 
