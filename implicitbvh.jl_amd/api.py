@@ -362,10 +362,18 @@ class BVH:
             self.leaves.types = types  # node type is not part of the record layout
             vol_ptr = C.c_void_p(0)
         else:
-            self.leaves = BoundingVolumes(types, n, torch.empty(n * abi.leaf_dtype(types).itemsize, dtype=torch.uint8, device="cuda"))
+            # raw volumes: the wrapped, sorted leaves are this BVH's own array — the cached one when it has the right size
+            # and type (the reference allocates a new one every time, build.jl:345-349; with cache= a time step then
+            # allocates nothing at all: nodes, skips, leaves, extrema and scratch are all reused)
+            nbytes = n * abi.leaf_dtype(types).itemsize
+            reuse = (cache is not None and cache.leaves.buf.numel() == nbytes and cache.leaves.types.key() == types.key()
+                     and cache.leaves.buf.data_ptr() != bounding_volumes.data_ptr())
+            self.leaves = BoundingVolumes(types, n, cache.leaves.buf if reuse else torch.empty(nbytes, dtype=torch.uint8, device="cuda"))
             bounding_volumes = bounding_volumes.contiguous()
             vol_ptr = _ptr(bounding_volumes)
-        self.extrema = torch.empty(6, dtype=_torch_float(flt), device="cuda")
+        ext_dt = _torch_float(flt)
+        self.extrema = cache.extrema if (cache is not None and cache.extrema is not None and cache.extrema.dtype == ext_dt) \
+            else torch.empty(6, dtype=ext_dt, device="cuda")
         # skewed inputs: a cold build always runs the sort's second partition level; a build that reuses `cache=` runs it
         # only if the previous build of the chain met a crowded cell.  The GPU leaves that fact in a pinned host word
         # (mapped into the device's address space), which is read here WITHOUT synchronising: the latest value that has

@@ -241,6 +241,24 @@ template <class T> IBVH_HD bool isintersection(const BBox<T> &b, const T *p, con
     tmax = minimum2(tmax, maximum2(t1, t2));
     return (tmin <= tmax) && (tmax >= T(0));
 }
+// The same slab test with the three reciprocals 1/d[k] computed by the caller (they depend on the ray alone: a walk
+// that tests hundreds of boxes against one ray divides once) — the identical operations in the identical order.
+template <class T> IBVH_HD bool isintersection_inv(const BBox<T> &b, const T *p, const T *inv) {
+    T t1 = (b.lo[0] - p[0]) * inv[0];
+    T t2 = (b.up[0] - p[0]) * inv[0];
+    T tmin = minimum2(t1, t2);
+    T tmax = maximum2(t1, t2);
+    t1 = (b.lo[1] - p[1]) * inv[1];
+    t2 = (b.up[1] - p[1]) * inv[1];
+    tmin = maximum2(tmin, minimum2(t1, t2));
+    tmax = minimum2(tmax, maximum2(t1, t2));
+    t1 = (b.lo[2] - p[2]) * inv[2];
+    t2 = (b.up[2] - p[2]) * inv[2];
+    tmin = maximum2(tmin, minimum2(t1, t2));
+    tmax = minimum2(tmax, maximum2(t1, t2));
+    return (tmin <= tmax) && (tmax >= T(0));
+}
+template <class T> IBVH_HD bool isintersection_inv(const BSphere<T> &s, const T *p, const T *inv, const T *d) { return isintersection(s, p, d); }
 template <class T> IBVH_HD bool isintersection(const BSphere<T> &s, const T *p, const T *d) {
     T a = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
     T b = T(2) * ((p[0] - s.x[0]) * d[0] + (p[1] - s.x[1]) * d[1] + (p[2] - s.x[2]) * d[2]);

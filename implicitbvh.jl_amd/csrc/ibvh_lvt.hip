@@ -783,139 +783,247 @@ __global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, Pair
     }
 }
 
-// ---- (3a) rays: the walk of one lane -----
-// The per-lane depth-first walk of one ray (see lvt_rays_kernel); `emit(leaf index)` is called for every hit leaf, in
-// the reference's order.
-template <class L, class N, class I, class T, class Emit>
-IBVH_D void ray_dfs(const Args<L, N, I> &a, const T (&p)[3], const T (&d)[3], bool lane_on, Emit &&emit) {
-    const int levels = (int)a.tree.levels;
-    const uint32_t vl = (uint32_t)a.tree.virtual_leaves; // < 2^(levels-1) <= 2^31
-    const uint32_t leaf_first = 1u << (levels - 1);
-    const uint32_t n_leaves = (uint32_t)a.tree.real_leaves;
-    const int plevel = (int)a.start_level - 1;
-    const int64_t roots = level_num_real(a.tree.levels, a.tree.virtual_leaves, a.start_level);
-    const uint32_t pfirst = plevel >= 1 ? (1u << (plevel - 1)) : 0u;
-    const uint32_t pcount = (uint32_t)((roots + 1) / 2);
+// ---- (3) rays: per-lane walks, lanes refilled from the wave's block of rays -------------------------------
+// The rays of a wave are not spatially coherent, so every lane walks its own ray — leaner than the reference's loop
+// (raytrace/leaf_vs_tree/leaf_vs_tree.jl:187-225): a step tests BOTH children of the current node (adjacent in
+// memory: one 48-byte fetch instead of two dependent ones) and the pending right siblings are a 32-bit mask instead
+// of a 32-entry stack, possible because the tree is implicit.  Visit order is the reference's (left subtree, then the
+// pending sibling, deepest first), so the hits of a ray come out in the same order.
+//
+// What bounds it (config 3: 1e6 rays, 7.2 M-triangle surface; measured in round 2): a ray takes 207 steps on average
+// (2,621 at most), every step is a DEPENDENT fetch, and a wave's step costs what its lanes' different code paths cost
+// one after the other — node level from global memory, leaf level, hit bookkeeping.  So:
+//   * ONE fetch per step whatever the level: when a leaf record and a node have the same size (24 bytes for
+//     BSphere{F32} leaves / BBox{F32} nodes), the lane computes ONE address — its two child nodes or its two leaf
+//     records, 48 contiguous bytes either way — all lanes fetch together (three 16-byte requests each), and only the
+//     arithmetic afterwards differs; other type combinations keep two fetch paths;
+//   * the reciprocals 1/d are computed once per ray, not in every box test;
+//   * a wave owns a BLOCK of 64 .. 256 consecutive rays and deals them to its lanes as they become free (39 % of
+//     these rays hit nothing, the mean is 9.8 hits, the heaviest has 804: with one ray per lane for the life of a wave
+//     the lanes were busy 10 % of the time by hit count); idle lanes take the next rays of the block whenever a
+//     quarter of the wave is idle (ranked with v_mbcnt, no atomics).  The block size keeps ~3,000+ waves in the grid.
+// A ray is walked by one lane from start to end, so its hits keep their order; the per-ray counts and the scanned
+// output offsets make the result independent of which lane walked it.
+// Hit cache as for leaf queries: the wave fills the scratch bytes of its block (block * K pairs) densely with
+// (pair, ray-in-block | position in that ray's list << RAY_BITS) entries behind a 16-byte header {fill}; a wave walks
+// again in the writing pass only if ALL its rays together found more than fits.
+// (Tried and dropped in round 2: the top 10 levels of the tree in LDS — a third code path per step, no gain.)
+constexpr int RAY_BITS = 10, RAY_BLOCK_MAX = 1 << RAY_BITS;
 
-    for (uint32_t pi = 0; pi < pcount; ++pi) { // uniform: pseudo-parents of the start-level roots
-        uint32_t inode = pfirst + pi;
-        int level = plevel;
-        uint32_t pend = 0;
-        bool alive = lane_on;
-        while (alive) {
-            const int cl = level + 1;
-            const uint32_t c0 = 2u * inode, c1 = c0 + 1u;
-            const uint32_t first = 1u << (cl - 1);
-            const uint32_t nreal = first - (uint32_t)((uint64_t)vl >> (levels - cl));
-            const bool real0 = c0 != 0u, real1 = (c1 - first) < nreal;
-            if (cl == levels) {
-                const char *rec = a.leaves + ((int64_t)c0 - (int64_t)leaf_first) * a.lay.stride; // c0 may be the pseudo node 0
-                if (real0 && isintersection(load_vol<L>(rec), p, d)) emit(load_index<I>(rec, a.lay));
-                if (real1 && isintersection(load_vol<L>(rec + a.lay.stride), p, d)) emit(load_index<I>(rec + a.lay.stride, a.lay));
-            } else {
-                const uint64_t v = (uint64_t)vl >> (levels - cl + 1);
-                const uint32_t sk = (uint32_t)(2 * v) - (uint32_t)__popcll(v); // level_skips(cl)
-                const N *np = a.nodes + ((int64_t)c0 - (int64_t)sk - 1);
-                const bool h0 = real0 && isintersection(load_vol<N>(real0 ? np : np + 1), p, d);
-                const bool h1 = real1 && isintersection(load_vol<N>(real1 ? np + 1 : np), p, d);
-                if (h0) {
-                    if (h1) pend |= 1u << cl;
-                    inode = c0;
-                    level = cl;
-                    continue;
-                }
-                if (h1) {
-                    inode = c1;
-                    level = cl;
-                    continue;
-                }
-            }
-            if (pend == 0) {
-                alive = false;
-            } else {
-                const int pl = 31 - __builtin_clz(pend);
-                pend &= ~(1u << pl);
-                inode = (inode >> (level - pl)) | 1u;
-                level = pl;
-            }
-        }
-    }
-}
-
-// ---- (3) rays: per-lane walk ------------------------------------------------------------------------
-// The rays of a wave are not spatially coherent, so every lane walks on its own — but leaner than the
-// reference's loop (raytrace/leaf_vs_tree/leaf_vs_tree.jl:187-225): a step tests BOTH children of the
-// current node (adjacent in memory: one 48-byte fetch instead of two dependent ones) and the pending
-// right siblings are a 32-bit mask instead of a 32-entry stack, possible because the tree is implicit.
-// Visit order is the reference's (left subtree, then the pending sibling, deepest first), so the hits of a
-// ray come out in the same order.  Hit cache as for leaf queries (first K hits kept by the counting pass).
 template <class L, class N, class I, bool WRITE>
-__global__ __launch_bounds__(256) void lvt_rays_kernel(Args<L, N, I> a, PairCache<I> cache) {
+__global__ __launch_bounds__(64) void lvt_rays_kernel(Args<L, N, I> a, PairCache<I> cache, int ray_block) {
     using T = typename L::elt;
-    const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // (launched with one wave per workgroup, see launch())
-    const bool valid = item < a.n_items;
-    T p[3] = {0, 0, 0}, d[3] = {0, 0, 0};
-    if (valid) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            p[k] = a.points[3 * item + k];
-            d[k] = a.dirs[3 * item + k];
-        }
-    }
-    int64_t w = 0, cnt = 0;
-    bool lane_on = valid;
-    // Wave-dense hit cache, as in lvt_queue_kernel: the wave fills the scratch bytes of its 64 rays (64 * K pairs)
-    // densely with (pair, ray lane | position in that ray's list << 6) entries behind a 16-byte header {fill}.  The
-    // lanes walk independently, so a slot is claimed with one LDS atomic; a wave walks again in the writing pass only if
-    // ALL its rays together found more than fits (a per-ray limit of K made most waves of a mesh scene walk twice:
-    // config 3 spent 4.2 of 9.6 ms there).
     struct Entry {
         IndexPair<I> pair;
         I meta;
     };
-    __shared__ int s_fill[4];
-    __shared__ int64_t s_w[4][64];
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t first_item = item - lane;
-    const int64_t items_here = a.n_items - first_item < 64 ? a.n_items - first_item : 64;
+    __shared__ int s_fill;
+    const int lane = threadIdx.x;
+    const int64_t first_item = (int64_t)blockIdx.x * ray_block;
+    const int64_t left = a.n_items - first_item;
+    const int items_here = (int)(left < ray_block ? left : ray_block);
     char *region = cache.K > 0 && items_here > 0 ? (char *)(cache.slots + first_item * (int64_t)cache.K) : nullptr;
     const int entry_cap = region ? (int)(((int64_t)items_here * cache.K * (int64_t)sizeof(IndexPair<I>) - 16) / (int64_t)sizeof(Entry)) : 0;
     Entry *entries = (Entry *)(region + 16);
-    if (lane == 0) s_fill[wv] = 0;
+    if (lane == 0) s_fill = 0;
     __builtin_amdgcn_wave_barrier();
     if constexpr (WRITE) {
         if (a.guard_total != nullptr && load_total_uniform(a.guard_total) > a.guard_capacity) return;
-        w = (valid && item > 0) ? (int64_t)a.counts[item - 1] : 0;
         const int fill = region ? __builtin_amdgcn_readfirstlane(*(const int *)region) : -1;
-        if (fill >= 0) {
-            s_w[wv][lane] = w;
-            __builtin_amdgcn_wave_barrier();
+        if (fill >= 0) { // serve the whole block from its cache
             for (int t = lane; t < fill; t += 64) {
                 const Entry e = entries[t];
-                a.contacts[s_w[wv][(int)(e.meta & 63)] + (int64_t)(e.meta >> 6)] = e.pair;
+                const int64_t ray = first_item + (int64_t)(e.meta & (RAY_BLOCK_MAX - 1));
+                const int64_t w0 = ray > 0 ? (int64_t)a.counts[ray - 1] : 0;
+                a.contacts[w0 + (int64_t)(e.meta >> RAY_BITS)] = e.pair;
             }
             return;
         }
     }
+    // tree constants (wave-uniform)
+    const int levels = (int)a.tree.levels;
+    const uint32_t vl = (uint32_t)a.tree.virtual_leaves; // < 2^(levels-1) <= 2^31
+    const uint32_t leaf_first = 1u << (levels - 1);
+    const int plevel = (int)a.start_level - 1;
+    const int64_t roots = level_num_real(a.tree.levels, a.tree.virtual_leaves, a.start_level);
+    const uint32_t pfirst = plevel >= 1 ? (1u << (plevel - 1)) : 0u;
+    const uint32_t pcount = (uint32_t)((roots + 1) / 2); // pseudo-parents of the start-level roots
+    // one fetch path for nodes and leaves when both are 24-byte records whose volume comes first
+    constexpr bool SAME = sizeof(N) == 24 && sizeof(L) == 16;
+    const bool unified = SAME && a.lay.stride == 24;
+
+    // per-lane ray state
+    T p[3] = {0, 0, 0}, d[3] = {0, 0, 0}, inv[3] = {0, 0, 0}; // inv = 1 / d, once per ray (isintersection.jl:2-4)
+    int ray = -1;          // ray-in-block this lane walks (-1: idle)
+    uint32_t pi = 0;       // pseudo-parent being walked
+    uint32_t inode = 0, pend = 0;
+    int level = 0;
+    int64_t w = 0, cnt = 0;
+#ifdef IBVH_RAY_STEPS
+    int64_t steps = 0; // diagnostic build: the per-ray STEP count goes where the hit count belongs
+#endif
+    bool meta_bad = false; // a position that does not fit the entry's meta field: the block walks again when writing
+    int next = 0;          // wave-uniform: rays of the block handed out so far
+
+    auto node_hit = [&](const N &n) {
+        if constexpr (N::kind == IBVH_BBOX) return isintersection_inv(n, p, inv);
+        else return isintersection(n, p, d);
+    };
     auto emit = [&](I lidx) {
-        const IndexPair<I> c2{lidx, (I)(item + 1)}; // (leaf.index, iray), raytrace/lvt:200
+        const IndexPair<I> c2{lidx, (I)(first_item + ray + 1)}; // (leaf.index, iray), raytrace/lvt:200
         if constexpr (WRITE) {
             a.contacts[w++] = c2;
         } else {
             if (region) {
-                const int slot = atomicAdd(&s_fill[wv], 1);
-                if (slot < entry_cap) entries[slot] = Entry{c2, (I)((I)lane | ((I)cnt << 6))};
+                const int slot = atomicAdd(&s_fill, 1);
+                if (cnt >= ((int64_t)1 << (sizeof(I) * 8 - 1 - RAY_BITS))) meta_bad = true;
+                if (slot < entry_cap) entries[slot] = Entry{c2, (I)((I)ray | ((I)cnt << RAY_BITS))};
             }
             ++cnt;
         }
     };
 
-    ray_dfs(a, p, d, lane_on, emit);
+    for (;;) {
+        // ---- refill: idle lanes take the next rays of the block
+        const uint64_t idle = __builtin_amdgcn_ballot_w64(ray < 0);
+        if (idle != 0 && next < items_here) {
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            const int mine = next + rank;
+            if (ray < 0 && mine < items_here) {
+                ray = mine;
+                const int64_t item = first_item + mine;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    p[k] = a.points[3 * item + k];
+                    d[k] = a.dirs[3 * item + k];
+                    inv[k] = T(1) / d[k];
+                }
+                pi = 0;
+                inode = pfirst;
+                level = plevel;
+                pend = 0;
+                cnt = 0;
+                if constexpr (WRITE) w = item > 0 ? (int64_t)a.counts[item - 1] : 0;
+            }
+            const int taken = __popcll(idle);
+            next = next + taken < items_here ? next + taken : items_here;
+        }
+        if (__builtin_amdgcn_ballot_w64(ray >= 0) == 0) break;
+        // ---- walk: every busy lane advances its ray until a quarter of the wave has gone idle (or the block is used up
+        // and everybody is done)
+        for (;;) {
+            if (ray >= 0) {
+#ifdef IBVH_RAY_STEPS
+                ++steps;
+#endif
+                const int cl = level + 1;
+                const uint32_t c0 = 2u * inode, c1 = c0 + 1u;
+                const uint32_t first = 1u << (cl - 1);
+                const uint32_t nreal = first - (uint32_t)((uint64_t)vl >> (levels - cl));
+                const bool real0 = c0 != 0u, real1 = (c1 - first) < nreal; // (c0 == 0: the pseudo node above the root)
+                const bool at_leaves = cl == levels;
+                const uint64_t v = (uint64_t)vl >> (levels - cl + 1);
+                const uint32_t sk = (uint32_t)(2 * v) - (uint32_t)__popcll(v); // level_skips(cl)
+                bool h0 = false, h1 = false, descended = false;
+                I idx0 = 0, idx1 = 0;
+                if (unified) {
+                    if constexpr (SAME) {
+                        // the two children — nodes or leaf records — are 48 contiguous bytes; a missing one re-reads its sibling
+                        const char *base = at_leaves ? a.leaves + ((int64_t)c0 - (int64_t)leaf_first) * 24
+                                                     : (const char *)(a.nodes + ((int64_t)c0 - (int64_t)sk - 1));
+                        struct Raw {
+                            uint32_t w[12];
+                        } raw;
+                        const char *lo = real0 ? base : base + 24;
+                        if (real0 && real1) {
+                            __builtin_memcpy(&raw, __builtin_assume_aligned(base, 8), 48);
+                        } else {
+                            __builtin_memcpy(&raw, __builtin_assume_aligned(lo, 8), 24);
+                            __builtin_memcpy(&raw.w[6], &raw.w[0], 24);
+                        }
+                        if (at_leaves) {
+                            L la, lb;
+                            __builtin_memcpy(&la, &raw.w[0], 16);
+                            __builtin_memcpy(&lb, &raw.w[6], 16);
+                            h0 = real0 && isintersection(la, p, d);
+                            h1 = real1 && isintersection(lb, p, d);
+                            // .index sits right behind the 16-byte volume (4 or 8 bytes)
+                            I ia, ib;
+                            __builtin_memcpy(&ia, (const char *)&raw.w[0] + a.lay.index_off, sizeof(I) <= 8 ? sizeof(I) : 8);
+                            __builtin_memcpy(&ib, (const char *)&raw.w[6] + a.lay.index_off, sizeof(I) <= 8 ? sizeof(I) : 8);
+                            idx0 = ia;
+                            idx1 = ib;
+                        } else {
+                            N na, nb;
+                            __builtin_memcpy(&na, &raw.w[0], 24);
+                            __builtin_memcpy(&nb, &raw.w[6], 24);
+                            h0 = real0 && node_hit(na);
+                            h1 = real1 && node_hit(nb);
+                        }
+                    }
+                } else if (at_leaves) {
+                    const char *rec = a.leaves + ((int64_t)c0 - (int64_t)leaf_first) * a.lay.stride;
+                    h0 = real0 && isintersection(load_vol<L>(real0 ? rec : rec + a.lay.stride), p, d);
+                    h1 = real1 && isintersection(load_vol<L>(real1 ? rec + a.lay.stride : rec), p, d);
+                    if (h0) idx0 = load_index<I>(rec, a.lay);
+                    if (h1) idx1 = load_index<I>(rec + a.lay.stride, a.lay);
+                } else {
+                    const N *np = a.nodes + ((int64_t)c0 - (int64_t)sk - 1);
+                    struct Two {
+                        N a, b;
+                    };
+                    Two ch;
+                    if (real0 && real1) {
+                        __builtin_memcpy(&ch, __builtin_assume_aligned(np, 8), sizeof(Two));
+                    } else {
+                        ch.a = load_vol<N>(real0 ? np : np + 1);
+                        ch.b = ch.a;
+                    }
+                    h0 = real0 && node_hit(ch.a);
+                    h1 = real1 && node_hit(ch.b);
+                }
+                if (at_leaves) {
+                    if (h0) emit(idx0);
+                    if (h1) emit(idx1);
+                } else if (h0) {
+                    if (h1) pend |= 1u << cl;
+                    inode = c0;
+                    level = cl;
+                    descended = true;
+                } else if (h1) {
+                    inode = c1;
+                    level = cl;
+                    descended = true;
+                }
+                if (!descended) {
+                    if (pend != 0) { // back to the deepest pending right sibling
+                        const int pl = 31 - __builtin_clz(pend);
+                        pend &= ~(1u << pl);
+                        inode = (inode >> (level - pl)) | 1u;
+                        level = pl;
+                    } else if (++pi < pcount) { // next root pair of the start level
+                        inode = pfirst + pi;
+                        level = plevel;
+                    } else { // ray finished
+#ifdef IBVH_RAY_STEPS
+                        if constexpr (!WRITE) a.counts[first_item + ray] = (I)steps;
+                        steps = 0;
+#else
+                        if constexpr (!WRITE) a.counts[first_item + ray] = (I)cnt;
+#endif
+                        ray = -1;
+                    }
+                }
+            }
+            const uint64_t idle_now = __builtin_amdgcn_ballot_w64(ray < 0);
+            if (idle_now == ~(uint64_t)0) break;
+            if (next < items_here && __popcll(idle_now) >= 16) break;
+        }
+    }
     if constexpr (!WRITE) {
-        if (valid) a.counts[item] = (I)cnt;
         __builtin_amdgcn_wave_barrier();
-        const bool meta_ok = __ballot(cnt >= ((int64_t)1 << (sizeof(I) * 8 - 7))) == 0;
-        if (region && lane == 0) *(int *)region = (s_fill[wv] <= entry_cap && meta_ok) ? s_fill[wv] : -1;
+        const bool ok = __builtin_amdgcn_ballot_w64(meta_bad) == 0;
+        if (region && lane == 0) *(int *)region = (s_fill <= entry_cap && ok) ? s_fill : -1;
     }
 }
 
@@ -1040,9 +1148,18 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
         // walks on one lane), but rays grazing the surface outgrow any LDS slice that still allows a decent occupancy
         // and at 1e6 rays it was 2x slower than this walk, so it was dropped.)
         // one wave per workgroup: a wave's time is its heaviest ray, and a finished wave should hand its slot back at once
-        const unsigned rblocks = (unsigned)ceil_div(a.n_items, 64);
-        if (write) IBVH_LAUNCH((lvt_rays_kernel<L, N, I, true>), dim3(rblocks), dim3(64), 0, st, a, cache);
-        else IBVH_LAUNCH((lvt_rays_kernel<L, N, I, false>), dim3(rblocks), dim3(64), 0, st, a, cache);
+        // rays per wave: the largest block of 64 / 128 / 256 that still leaves ~3,000 waves in the grid (measured on config
+        // 3, 1e6 rays: 5.41 / 5.09 / 4.25 ms with 64 / 128 / 256, 5.25 with 512; 1e5 rays: 2.35 / 3.18 ms with 64 / 256)
+        int ray_block = 64;
+        while (ray_block < 256 && a.n_items / (2 * ray_block) >= 3000) ray_block *= 2;
+        static const int forced_block = [] {
+            const char *e = getenv("IBVH_RAY_BLOCK"); // tuning knob: rays per wave (a power of two, 64 .. 1024)
+            return e ? atoi(e) : 0;
+        }();
+        if (forced_block >= 64 && forced_block <= RAY_BLOCK_MAX && (forced_block & (forced_block - 1)) == 0) ray_block = forced_block;
+        const unsigned rblocks = (unsigned)ceil_div(a.n_items, (int64_t)ray_block);
+        if (write) IBVH_LAUNCH((lvt_rays_kernel<L, N, I, true>), dim3(rblocks), dim3(64), 0, st, a, cache, ray_block);
+        else IBVH_LAUNCH((lvt_rays_kernel<L, N, I, false>), dim3(rblocks), dim3(64), 0, st, a, cache, ray_block);
     } else {
         // BBox nodes with at least one node level below the start level: frontier descent + brute force;
         // everything else (BSphere nodes, start_level == levels): the exact joint walk
