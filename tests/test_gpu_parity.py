@@ -233,6 +233,43 @@ def test_build_clustered_cloud_bit_exact():
         assert_bvh_equal(o, g)
 
 
+@pytest.mark.parametrize("shape", ["uniform", "clustered", "duplicates", "presorted", "reversed"])
+def test_build_every_sort_route_with_and_without_the_second_partition_level(shape):
+    """The MSD build (n >= 4096): one partition level, two levels, and the tiled slow finish of cells that stay
+    crowded, each reached with `two_level` 1 (cold build) and 0 (a cached build whose predecessor saw no skew);
+    the skew word tells the next build of the chain which one to run."""
+    rng = np.random.default_rng(len(shape) * 1000 + ord(shape[0]))
+    n = 250_000
+    if shape == "clustered":
+        centres = rng.random((3, 3)) * 50
+        c = centres[rng.choice(3, n, p=[0.7, 0.2, 0.1])] + rng.normal(0, 1e-3, (n, 3))
+    elif shape == "duplicates":
+        c = np.repeat(rng.random((37, 3)), n // 37 + 1, axis=0)[:n]
+        rng.shuffle(c)
+    else:
+        c = rng.random((n, 3))
+    vols = np.concatenate([c, 1e-4 + 1e-4 * rng.random((n, 1))], axis=1).astype(np.float32)
+    if shape in ("presorted", "reversed"):
+        order = orc.build(vols, abi.make_types()).leaves["index"].astype(np.int64) - 1
+        vols = vols[order if shape == "presorted" else order[::-1]]
+    expect_skew = shape in ("clustered", "duplicates")
+    for combo, mt in [((abi.BSPHERE, abi.F32, abi.BBOX, abi.F32), abi.U32),
+                      ((abi.BSPHERE, abi.F64, abi.BBOX, abi.F64), abi.U64)]:
+        types = abi.make_types(*combo, abi.I32, mt)
+        o, g = build_both(vols, types)                 # cold: two_level = 1
+        assert_bvh_equal(o, g)
+        torch.cuda.synchronize()
+        assert bool(int(g._skew[0])) == expect_skew
+        g._skew[0] = 0                                 # pretend the previous step saw no crowded cell
+        node_type = TOKENS[types.node_kind](torch.float32 if types.node_float == abi.F32 else torch.float64)
+        g2 = ibvh.BVH(cuda(vols.astype(NP_F[types.leaf_float])), node_type, options=make_options(types), cache=g)
+        assert_bvh_equal(o, g2)                        # two_level = 0: crowded cells take the tiled finish
+        torch.cuda.synchronize()
+        assert bool(int(g2._skew[0])) == expect_skew   # ... and the word asks for two levels next time
+        g3 = ibvh.BVH(cuda(vols.astype(NP_F[types.leaf_float])), node_type, options=make_options(types), cache=g2)
+        assert_bvh_equal(o, g3)
+
+
 def test_extrema_and_keys_entry_points():
     rng = np.random.default_rng(12)
     for kind, flt in ((abi.BSPHERE, abi.F32), (abi.BBOX, abi.F64)):
@@ -560,6 +597,40 @@ def test_lvt_pair_identical_order():
                 assert (contacts_np(got) == exp).all(), (n1, n2, sl1, sl2)
         brute = sorted(map(tuple, orc.brute_force_pair(abi.BSPHERE, abi.F32, a, b).tolist()))
         assert sorted(map(tuple, contacts_np(ibvh.traverse(g1, g2)).tolist())) == brute
+
+
+@pytest.mark.parametrize("slots", [8, 0])
+@pytest.mark.parametrize("idx", [abi.I32, abi.I64], ids=["i32", "i64"])
+def test_lvt_pair_clouds_that_miss_or_barely_touch_each_others_root_box(slots, idx, monkeypatch):
+    """The pair walk lets a wave leave before the descent when none of its queries touches the other tree's root
+    box; with a partially built tree (built_level > 1) there is no root box and the exit must be skipped.  Disjoint,
+    corner-touching and ragged (n % 64 != 0) clouds, contact cache on and off, both argument orders, the enqueue
+    path — lists identical to the oracle's, order included."""
+    from implicitbvh_amd import api
+    monkeypatch.setattr(api, "LVT_CACHE_SLOTS", slots)
+    rng = np.random.default_rng(31 + slots)
+    types = abi.make_types(abi.BSPHERE, abi.F32, abi.BBOX, abi.F32, idx, abi.U32)
+    n1, n2 = 1000 + 37, 700 + 5
+    a = random_volumes(rng, n1, abi.BSPHERE, abi.F32, scale=4.0, size=0.2)
+    far = a[:n2].copy()
+    far[:, :3] += 100.0                                   # disjoint: every wave leaves at once
+    corner = random_volumes(rng, n2, abi.BSPHERE, abi.F32, scale=4.0, size=0.2)
+    corner[:, :3] += 3.9                                  # only the (4,4,4) corner region of `a` is in reach
+    touch = corner.copy()
+    touch[:, :3] += 0.45                                  # root boxes overlap by a sliver, almost no contacts
+    for b in (far, corner, touch):
+        for bl in (1, 3):
+            (o1, g1), (o2, g2) = build_both(a, types, built_level=bl), build_both(b, types, built_level=bl)
+            sl1, sl2 = max(bl, o1.tree.levels // 2), max(bl, o2.tree.levels // 2)
+            e12 = oracle_pairs(orc.traverse_pair_lvt(o1, o2, sl1, sl2)[0])
+            e21 = oracle_pairs(orc.traverse_pair_lvt(o2, o1, sl2, sl1)[0])
+            t12 = ibvh.traverse(g1, g2, start_level1=sl1, start_level2=sl2)
+            assert (contacts_np(t12) == e12).all() and len(e12) == t12.num_contacts
+            t21 = ibvh.traverse(g2, g1, start_level1=sl2, start_level2=sl1, cache=t12)   # enqueue path, swapped
+            assert (contacts_np(t21) == e21).all() and len(e21) == t21.num_contacts
+            assert sorted(map(tuple, e12.tolist())) == sorted((y, x) for x, y in e21.tolist())
+    assert len(oracle_pairs(orc.traverse_pair_lvt(*[build_both(v, types)[0] for v in (a, far)])[0])) == 0
+    assert len(oracle_pairs(orc.traverse_pair_lvt(*[build_both(v, types)[0] for v in (a, corner)])[0])) > 0
 
 
 def test_lvt_rays_identical_order_incl_zero_direction_components():
