@@ -615,9 +615,9 @@ def test_lvt_pair_clouds_that_miss_or_barely_touch_each_others_root_box(slots, i
     far = a[:n2].copy()
     far[:, :3] += 100.0                                   # disjoint: every wave leaves at once
     corner = random_volumes(rng, n2, abi.BSPHERE, abi.F32, scale=4.0, size=0.2)
-    corner[:, :3] += 3.9                                  # only the (4,4,4) corner region of `a` is in reach
+    corner[:, :3] += 3.0                                  # only the corner region [3,4]^3 of `a` is in reach
     touch = corner.copy()
-    touch[:, :3] += 0.45                                  # root boxes overlap by a sliver, almost no contacts
+    touch[:, :3] += 0.95                                  # root boxes overlap by a sliver: no contacts at all
     for b in (far, corner, touch):
         for bl in (1, 3):
             (o1, g1), (o2, g2) = build_both(a, types, built_level=bl), build_both(b, types, built_level=bl)
