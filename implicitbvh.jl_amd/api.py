@@ -374,12 +374,13 @@ class BVH:
         ext_dt = _torch_float(flt)
         self.extrema = cache.extrema if (cache is not None and cache.extrema is not None and cache.extrema.dtype == ext_dt) \
             else torch.empty(6, dtype=ext_dt, device="cuda")
-        # skewed inputs: a cold build always runs the sort's second partition level; a build that reuses `cache=` runs it
-        # only if the previous build of the chain met a crowded cell.  The GPU leaves that fact in a pinned host word
-        # (mapped into the device's address space), which is read here WITHOUT synchronising: the latest value that has
-        # arrived is good enough for a hint (include/ibvh.h, ibvh_build_desc.two_level / skew_flag).
+        # skewed inputs: a cold build launches COLD_SORT_LEVELS extra partition levels of the sort; a build that reuses
+        # `cache=` launches as many as the previous build of the chain would have used, plus a spare one (none at all
+        # after a uniform cloud).  The GPU leaves that number in a pinned host word (mapped into the device's address
+        # space), which is read here WITHOUT synchronising: the latest value that has arrived is good enough for a
+        # hint (include/ibvh.h, ibvh_build_desc.sort_levels / skew_flag).
         self._skew = cache._skew if cache is not None and getattr(cache, "_skew", None) is not None else \
-            torch.ones(1, dtype=torch.int32).pin_memory()
+            torch.full((1,), COLD_SORT_LEVELS, dtype=torch.int32).pin_memory()
         d = abi.BuildDesc()
         d.types = types
         d.n = n
@@ -390,7 +391,8 @@ class BVH:
         if not alg.compute_extrema:
             d.mins[:] = [float(v) for v in alg.mins]
             d.maxs[:] = [float(v) for v in alg.maxs]
-        d.two_level = 1 if (cache is None or int(self._skew[0]) != 0) else 0
+        used = int(self._skew[0])
+        d.sort_levels = COLD_SORT_LEVELS if cache is None else (min(used + 1, abi.MAX_SORT_LEVELS) if used > 0 else 0)
         d.skew_flag = self._skew.data_ptr()
         lib.call("ibvh_build", C.byref(d), vol_ptr, _ptr(self.leaves.buf), _ptr(self.nodes), _ptr(self.skips),
                  _ptr(self.extrema), _ptr(self._scratch), self._scratch.numel(), _stream())
@@ -524,6 +526,7 @@ def _cache_tensor(cache_t, need_rows, cols, dtype, what):
     return cache_t
 
 
+COLD_SORT_LEVELS = 2  # extra partition levels a build without cache= launches (include/ibvh.h, sort_levels)
 LVT_CACHE_SLOTS = 8  # contacts per work item kept from the counting pass (include/ibvh.h)
 RAY_CACHE_SLOTS = 32  # hits per ray kept from the counting pass
 

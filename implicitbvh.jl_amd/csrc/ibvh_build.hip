@@ -572,7 +572,7 @@ ibvh_status ibvh_build(const ibvh_build_desc *desc, const void *volumes, void *l
             rsort::RecordArgs ra{src, sc.records, src_stride, wrapped ? 1 : 0, (int32_t)(lay.volume_bytes / 8),
                                  ty.index_type == IBVH_I32 ? 4 : 8, dlay};
             if (int e = msd::sort_records(mp, key_bytes, sc.keys, n, ra, sc.records2, (char *)leaves, sc.keys_alt, (uint32_t *)sc.vals_alt, sc.keys,
-                                          (uint32_t *)sc.vals, desc->two_level != 0, desc->skew_flag, st))
+                                          (uint32_t *)sc.vals, desc->sort_levels, desc->skew_flag, st))
                 return e;
             return aggregate<L, N>((const char *)leaves, lay.leaf_bytes, tree, desc->built_level, (N *)nodes, st);
         }

@@ -15,12 +15,16 @@
 // against 4 + 4*16 + 44 (+ 48 of sector over-fetch) before.
 //
 // Skew: a cell that holds more records than a finish workgroup sorts in LDS (clustered clouds, surfaces: a mesh
-// fills a fraction of the grid's cells) is split again, by its next 8 key bits, by a SECOND partition level that
-// touches only such cells: plan (which cells, which tiles) -> hist2 -> scan2 -> partition2, tiles of ALL oversized
-// cells side by side in one grid, so a single huge cell is still shared by many workgroups.  The same finish
-// kernel then sorts windows of consecutive sub-cells.  For a uniform cloud the three level-2 launches find nothing
-// to do and return at once.  A sub-cell that is still too large (> 2^19 duplicates of one key prefix) is sorted by
-// one workgroup with a tiled LSD through scratch arrays: slower, never wrong.
+// fills a fraction of the grid's cells, duplicates) becomes a SEGMENT of the next partition level, which touches only
+// such segments: range (which key bits vary inside each segment) -> hist -> scan -> partition on the top 8 VARYING
+// bits, the tiles of all segments side by side in one grid, so a single huge cell is still shared by many workgroups.
+// Sub-cells that are still crowded become the segments of the level after (up to MAX_LEVELS extra levels, ping-pong
+// between the two record buffers); a segment with at most 8 varying bits left is partitioned straight into the
+// output, sorted (a cell of identical keys: one tiled copy).  The finish kernel sorts windows of consecutive
+// sub-cells of every level.  Levels are launched up to a depth the caller chooses (`levels`); for a uniform cloud
+// their launches find nothing to do and return at once.  What is still crowded at the last launched level is sorted
+// by one workgroup with a tiled LSD through scratch arrays: slower, never wrong; `needed` tells the caller how many
+// levels the input would have used.
 //
 // Stability: partitions rank in memory order and the LDS passes are stable, so equal keys keep input order (the
 // oracle's definition of the unpinned AK.sort! tie order).
@@ -125,16 +129,17 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_tiles_kernel(const uint32_t *__
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// plan (one workgroup): cell starts (every later kernel reads them instead of re-deriving them), the oversized cells
-// (more than `cap` records), their level-2 tiles (`tile` records each) and the tile -> cell map.
+// plan (one workgroup): cell starts (every later kernel reads them instead of re-deriving them); the crowded cells
+// (more than `cap` records) become the segments of the first extra level, with their tiles (`tile` records each)
 // ------------------------------------------------------------------------------------------------------------
 constexpr int PLAN_TPB = 1024;
-__global__ __launch_bounds__(PLAN_TPB) void plan_kernel(Tables tb, int radix, uint32_t cap, uint32_t tile, int two_level,
-                                                        int32_t *__restrict__ skew_flag) {
+IBVH_D uint32_t segment_tiles(uint32_t count, uint32_t tile);
+__global__ __launch_bounds__(PLAN_TPB) void plan_kernel(Tables tb, int radix, uint32_t cap, uint32_t tile, int levels) {
     constexpr int PER = (1 << MSD_MAX_BITS) / PLAN_TPB; // cells per thread, at most
     __shared__ uint32_t wave_tot[PLAN_TPB / 64];
-    __shared__ uint32_t s_tbase[(1 << MSD_MAX_BITS) + 1]; // over_tile_base, for the tile -> cell search
+    __shared__ uint32_t s_tbase[(1 << MSD_MAX_BITS) + 1]; // first tile of every segment, for the tile -> segment search
     __shared__ uint32_t s_nover, s_ntiles;
+    const Level L = tb.lvl[0];
     const int lo = threadIdx.x * PER;
     uint32_t tot[PER], sum = 0, nov = 0, nt = 0;
 #pragma unroll
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(PLAN_TPB) void plan_kernel(Tables tb, int radix, ui
         sum += tot[k];
         if (tot[k] > cap) {
             nov += 1;
-            nt += (tot[k] + tile - 1) / tile;
+            nt += segment_tiles(tot[k], tile);
         }
     }
     uint32_t total_n = 0, total_over = 0, total_tiles = 0;
@@ -156,24 +161,30 @@ __global__ __launch_bounds__(PLAN_TPB) void plan_kernel(Tables tb, int radix, ui
         const int d = lo + k;
         if (d < radix) {
             tb.cell_start[d] = run;
-            run += tot[k];
             if (tot[k] > cap) {
-                tb.over_cell[kk] = (uint32_t)d;
-                tb.over_tile_base[kk] = tt;
+                if (levels > 0) {
+                    L.seg_start[kk] = run;
+                    L.seg_count[kk] = tot[k];
+                    L.seg_tile[kk] = tt;
+                    L.seg_and[kk] = ~(uint64_t)0;
+                    L.seg_or[kk] = 0;
+                }
                 s_tbase[kk] = tt;
                 kk += 1;
-                tt += (tot[k] + tile - 1) / tile;
+                tt += segment_tiles(tot[k], tile);
             }
+            run += tot[k];
         }
     }
     if (threadIdx.x == 0) {
         tb.cell_start[radix] = total_n;
-        tb.over_tile_base[total_over] = total_tiles;
         s_tbase[total_over] = total_tiles;
-        if (skew_flag) *skew_flag = total_over > 0 ? 1 : 0; // the caller's hint for its next build
-        if (!two_level) total_over = total_tiles = 0;        // the finish kernel sorts crowded cells by itself
-        tb.hdr[0] = total_over;
-        tb.hdr[1] = total_tiles;
+        *tb.needed = total_over > 0 ? 1u : 0u;
+        if (levels <= 0) total_over = total_tiles = 0; // the finish kernel sorts crowded cells by itself
+#pragma unroll
+        for (int l = 0; l < MAX_LEVELS; ++l) tb.lvl[l].hdr[0] = tb.lvl[l].hdr[1] = 0;
+        L.hdr[0] = total_over;
+        L.hdr[1] = total_tiles;
         s_nover = total_over;
         s_ntiles = total_tiles;
     }
@@ -186,59 +197,209 @@ __global__ __launch_bounds__(PLAN_TPB) void plan_kernel(Tables tb, int radix, ui
             if (s_tbase[mid] <= t) a = mid;
             else b = mid;
         }
-        tb.tile_cell[t] = a;
+        L.tile_seg[t] = a;
     }
 }
 
-// level-2 histogram: tile t of an oversized cell counts the next L2 digit of its records' keys
-__global__ __launch_bounds__(256) void hist2_kernel(Tables tb, const char *__restrict__ part, LeafLayout lay, int shift2,
-                                                    uint32_t mask2, uint32_t tile) {
-    __shared__ uint32_t h[1 << L2_BITS];
-    const uint32_t t = blockIdx.x;
-    if (t >= tb.hdr[1]) return;
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t k = tb.tile_cell[t], d = tb.over_cell[k];
-    const uint32_t first = tb.cell_start[d] + (t - tb.over_tile_base[k]) * tile, end = tb.cell_start[d + 1];
-    const uint32_t cnt = end - first < tile ? end - first : tile;
-    for (uint32_t i = threadIdx.x; i < cnt; i += 256)
-        atomicAdd(&h[(uint32_t)(load_morton(part + (int64_t)(first + i) * lay.stride, lay) >> shift2) & mask2], 1u);
-    __syncthreads();
-    tb.tile_hist2[(int64_t)t * (1 << L2_BITS) + threadIdx.x] = h[threadIdx.x];
+// ------------------------------------------------------------------------------------------------------------
+// extra levels.  The digit of a segment: the top L2_BITS of the bits that vary among its keys (and ^ or).  With at
+// most L2_BITS varying bits the digit is all of them and the partition leaves the segment sorted (terminal).
+// ------------------------------------------------------------------------------------------------------------
+struct Digit {
+    int shift, bits;
+    uint32_t mask;
+    bool terminal;
+};
+IBVH_D Digit level_digit(uint64_t a, uint64_t o) {
+    const uint64_t x = a ^ o;
+    const int hi = x ? 64 - __builtin_clzll(x) : 0;
+    int bits = hi < L2_BITS ? hi : L2_BITS;
+    if (bits < 1) bits = 1;
+    const int shift = hi > bits ? hi - bits : 0;
+    return Digit{shift, bits, (1u << bits) - 1u, shift == 0};
+}
+IBVH_D uint64_t common_prefix(uint64_t a, uint64_t o) { // the bits above the varying ones (equal in every key)
+    const uint64_t x = a ^ o;
+    const int hi = x ? 64 - __builtin_clzll(x) : 0;
+    return hi >= 64 ? 0 : (a >> hi) << hi;
 }
 
-// level-2 scan: workgroup k = one oversized cell: per sub-digit, the exclusive prefix over the cell's tiles; the
-// sub-cell totals and their exclusive prefix (sub-cell starts inside the cell)
-__global__ __launch_bounds__(1024) void scan2_kernel(Tables tb) {
+struct TileRange {
+    uint32_t seg, first, cnt;
+};
+// A segment's tiles are `reps` partition tiles long (reps = 1 up to MAX_ROWS * tile records): no segment has more than
+// MAX_ROWS of them, which bounds the column scan one workgroup does per segment
+constexpr uint32_t MAX_ROWS = 256;
+IBVH_D uint32_t segment_reps(uint32_t count, uint32_t tile) {
+    const uint32_t r = (count + MAX_ROWS * tile - 1) / (MAX_ROWS * tile);
+    return r ? r : 1u;
+}
+IBVH_D uint32_t segment_tiles(uint32_t count, uint32_t tile) {
+    const uint32_t macro = segment_reps(count, tile) * tile;
+    return (count + macro - 1) / macro;
+}
+IBVH_D TileRange level_tile(const Level &L, uint32_t t, uint32_t tile) {
+    const uint32_t s = L.tile_seg[t], count = L.seg_count[s];
+    const uint32_t macro = segment_reps(count, tile) * tile;
+    const uint32_t first = L.seg_start[s] + (t - L.seg_tile[s]) * macro, end = L.seg_start[s] + count;
+    return TileRange{s, first, end - first < macro ? end - first : macro};
+}
+
+// which key bits vary inside every segment of level li
+__global__ __launch_bounds__(256) void range_kernel(Tables tb, int li, const char *__restrict__ src, LeafLayout lay, uint32_t tile) {
+    __shared__ uint64_t s_and[4], s_or[4];
+    const Level L = tb.lvl[li];
+    const uint32_t ntiles = L.hdr[1];
+    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const TileRange r = level_tile(L, t, tile);
+        uint64_t a = ~(uint64_t)0, o = 0;
+        for (uint32_t i0 = threadIdx.x; i0 < r.cnt; i0 += 256 * 8) { // (8 independent loads in flight)
+            uint64_t k[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t i = i0 + u * 256;
+                k[u] = load_morton(src + (int64_t)(r.first + (i < r.cnt ? i : i0)) * lay.stride, lay);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a &= k[u];
+                o |= k[u];
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            a &= __shfl_xor(a, m, 64);
+            o |= __shfl_xor(o, m, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            s_and[threadIdx.x >> 6] = a;
+            s_or[threadIdx.x >> 6] = o;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            a = (s_and[0] & s_and[1]) & (s_and[2] & s_and[3]);
+            o = (s_or[0] | s_or[1]) | (s_or[2] | s_or[3]);
+            // AND only loses bits and OR only gains them: a (possibly stale) value this tile cannot change means the
+            // current one cannot be changed either — thousands of tiles of one huge segment then skip the atomic
+            const uint64_t ca = __builtin_nontemporal_load(&L.seg_and[r.seg]), co = __builtin_nontemporal_load(&L.seg_or[r.seg]);
+            if ((ca & a) != ca) atomicAnd((unsigned long long *)&L.seg_and[r.seg], (unsigned long long)a);
+            if ((co | o) != co) atomicOr((unsigned long long *)&L.seg_or[r.seg], (unsigned long long)o);
+        }
+        __syncthreads();
+    }
+}
+
+// per tile of a segment: counts of the segment's digit
+__global__ __launch_bounds__(256) void hist_level_kernel(Tables tb, int li, const char *__restrict__ src, LeafLayout lay, uint32_t tile) {
+    __shared__ uint32_t h[1 << L2_BITS];
+    const Level L = tb.lvl[li];
+    const uint32_t ntiles = L.hdr[1];
+    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        h[threadIdx.x] = 0;
+        __syncthreads();
+        const TileRange r = level_tile(L, t, tile);
+        const Digit dg = level_digit(L.seg_and[r.seg], L.seg_or[r.seg]);
+        for (uint32_t i0 = threadIdx.x; i0 < r.cnt; i0 += 256 * 8) {
+            uint64_t k[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t i = i0 + u * 256;
+                k[u] = load_morton(src + (int64_t)(r.first + (i < r.cnt ? i : i0)) * lay.stride, lay);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u * 256 < r.cnt) atomicAdd(&h[(uint32_t)(k[u] >> dg.shift) & dg.mask], 1u);
+        }
+        __syncthreads();
+        tb.tile_hist2[(int64_t)t * (1 << L2_BITS) + threadIdx.x] = h[threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// one workgroup per segment: per sub-cell, the exclusive prefix over the segment's tiles; the sub-cell starts inside
+// the segment; sub-cells that are still crowded become segments of the next level (or raise `needed`)
+__global__ __launch_bounds__(1024) void scan_level_kernel(Tables tb, int li, int levels, uint32_t cap, uint32_t tile) {
     constexpr int C = 1 << L2_BITS, G = 1024 / C; // G row groups x C columns
     __shared__ uint32_t part[G][C];
     __shared__ uint32_t wave_tot[16];
-    const uint32_t k = blockIdx.x;
-    if (k >= tb.hdr[0]) return;
+    __shared__ uint32_t s_base[2];
+    const Level L = tb.lvl[li];
+    const uint32_t nseg = L.hdr[0];
     const int col = threadIdx.x % C, rg = threadIdx.x / C;
-    const uint32_t t0 = tb.over_tile_base[k], t1 = tb.over_tile_base[k + 1];
-    const uint32_t share = (t1 - t0 + G - 1) / G;
-    const uint32_t a = t0 + rg * share < t1 ? t0 + rg * share : t1, b = a + share < t1 ? a + share : t1;
-    uint32_t mine = 0;
-    for (uint32_t r = a; r < b; ++r) mine += tb.tile_hist2[(int64_t)r * C + col];
-    part[rg][col] = mine;
-    __syncthreads();
-    uint32_t run = 0, total = 0;
+    for (uint32_t k = blockIdx.x; k < nseg; k += gridDim.x) {
+        const uint32_t count = L.seg_count[k];
+        const uint32_t t0 = L.seg_tile[k], t1 = t0 + segment_tiles(count, tile);
+        const uint32_t share = (t1 - t0 + G - 1) / G;
+        const uint32_t a = t0 + rg * share < t1 ? t0 + rg * share : t1, b = a + share < t1 ? a + share : t1;
+        uint32_t mine = 0;
+        {
+            uint32_t r = a;
+            for (; r + 8 <= b; r += 8) { // (8 independent loads in flight)
+                uint32_t v[8];
 #pragma unroll
-    for (int i = 0; i < G; ++i) {
-        const uint32_t v = part[i][col];
-        if (i < rg) run += v;
-        total += v;
-    }
-    for (uint32_t r = a; r < b; ++r) {
-        const uint32_t v = tb.tile_hist2[(int64_t)r * C + col];
-        tb.tile_scan2[(int64_t)r * C + col] = run;
-        run += v;
-    }
-    const uint32_t ex = block_exclusive_scan<1024>(rg == 0 ? total : 0u, wave_tot, nullptr); // (threads 0..C-1 carry the totals)
-    if (rg == 0) {
-        tb.sub_total[(int64_t)k * C + col] = total;
-        tb.sub_start[(int64_t)k * C + col] = ex;
+                for (int u = 0; u < 8; ++u) v[u] = tb.tile_hist2[(int64_t)(r + u) * C + col];
+                mine += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
+            for (; r < b; ++r) mine += tb.tile_hist2[(int64_t)r * C + col];
+        }
+        part[rg][col] = mine;
+        __syncthreads();
+        uint32_t run = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const uint32_t v = part[i][col];
+            if (i < rg) run += v;
+            total += v;
+        }
+        {
+            uint32_t r = a;
+            for (; r + 8 <= b; r += 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = tb.tile_hist2[(int64_t)(r + u) * C + col];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    tb.tile_scan2[(int64_t)(r + u) * C + col] = run;
+                    run += v[u];
+                }
+            }
+            for (; r < b; ++r) {
+                const uint32_t v = tb.tile_hist2[(int64_t)r * C + col];
+                tb.tile_scan2[(int64_t)r * C + col] = run;
+                run += v;
+            }
+        }
+        const uint32_t ex = block_exclusive_scan<1024>(rg == 0 ? total : 0u, wave_tot, nullptr); // (threads 0..C-1 carry the totals)
+        if (rg == 0) L.sub_start[(int64_t)k * (C + 1) + col] = ex;
+        if (threadIdx.x == 0) L.sub_start[(int64_t)k * (C + 1) + C] = count;
+        // still crowded?
+        const Digit dg = level_digit(L.seg_and[k], L.seg_or[k]);
+        const bool crowded = rg == 0 && total > cap && !dg.terminal;
+        const uint32_t my_tiles = crowded ? segment_tiles(total, tile) : 0u;
+        uint32_t n_crowded = 0, n_tiles = 0;
+        const uint32_t ci = block_exclusive_scan<1024>(crowded ? 1u : 0u, wave_tot, &n_crowded);
+        const uint32_t ti = block_exclusive_scan<1024>(my_tiles, wave_tot, &n_tiles);
+        if (n_crowded) { // (workgroup-uniform)
+            if (li + 1 < levels) {
+                const Level N = tb.lvl[li + 1];
+                if (threadIdx.x == 0) {
+                    s_base[0] = atomicAdd(&N.hdr[0], n_crowded);
+                    s_base[1] = atomicAdd(&N.hdr[1], n_tiles);
+                }
+                __syncthreads();
+                if (crowded) {
+                    const uint32_t s = s_base[0] + ci, tb0 = s_base[1] + ti;
+                    N.seg_start[s] = L.seg_start[k] + ex;
+                    N.seg_count[s] = total;
+                    N.seg_tile[s] = tb0;
+                    N.seg_and[s] = ~(uint64_t)0;
+                    N.seg_or[s] = 0;
+                    for (uint32_t t = 0; t < my_tiles; ++t) N.tile_seg[tb0 + t] = s;
+                }
+            }
+            if (threadIdx.x == 0) atomicMax(tb.needed, (uint32_t)(li + 2 < MAX_LEVELS ? li + 2 : MAX_LEVELS));
+        }
+        __syncthreads();
     }
 }
 
@@ -246,8 +407,9 @@ __global__ __launch_bounds__(1024) void scan2_kernel(Tables tb) {
 // partition: a tile ranks its keys by a digit and writes every leaf's finished record to its cell's range in dst.
 // Level 1 (L2 = false): tile t = TILE consecutive SOURCE leaves; digit = top `bits` bits; records assembled from the
 //   source volumes (or copied from wrapped source records).
-// Level 2 (L2 = true):  tile t = TILE consecutive records of an oversized cell in the level-1 output; digit = the
-//   next L2_BITS bits; records copied as they are.
+// Extra levels (L2 = true): tile t = TILE consecutive records of a crowded segment in the output of the level
+//   before; digit = the segment's own (level_digit); records copied as they are, into the other record buffer — or
+//   into `out` when the segment is terminal (sorted by this very partition).
 // ------------------------------------------------------------------------------------------------------------
 // The record of source leaf i is assembled word by word (8-byte words; every layout is a multiple of 8 with the
 // volume first): volume words are copied, the words behind the volume carry .index and .morton.
@@ -306,12 +468,14 @@ constexpr int partition_min_waves(int tpb, int ipt) { return tpb * ipt <= 2048 ?
 
 template <class K, int TPB, int IPT, bool L2>
 __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_kernel(const K *__restrict__ keys, int64_t n, int shift, int bits,
-                                                        Tables tb, int num_tiles, RecordArgs rec, uint32_t inv_words, int digit_bits) {
+                                                        Tables tb, int num_tiles, RecordArgs rec, uint32_t inv_words, int digit_bits,
+                                                        int li, char *out) {
     constexpr int W = TPB / 64;
     constexpr int TILE = TPB * IPT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int radix = 1 << bits;                             // table size (level 2: always 2^L2_BITS columns)
-    const uint32_t mask = ((uint32_t)1 << digit_bits) - 1u; // the digit itself may be narrower (few key bits left)
+    uint32_t mask = ((uint32_t)1 << digit_bits) - 1u;      // the digit itself may be narrower (few key bits left)
+    uint64_t *__restrict__ dst = (uint64_t *)rec.dst;
     // layout: local_base[radix] | delta[radix] | wave_tot[32] | { whist[W * radix] (u16), later stage[TILE records] }
     uint32_t *local_base = (uint32_t *)smem;         // radix: tile-local start of digit d
     uint32_t *delta = local_base + radix;            // radix: (global position) - (tile-local sorted position) of digit d
@@ -321,18 +485,24 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int64_t tile_base, end;         // the tile's records are [tile_base, min(tile_base + TILE, end))
+    int reps = 1;                   // extra levels: partition tiles this workgroup does one after the other
     const uint32_t *scan_row;       // this tile's row of the scanned histogram
     const uint32_t *digit_start;    // where each digit's range starts in dst (relative to dst_first)
     uint32_t dst_first = 0;
     if constexpr (L2) {
+        const Level L = tb.lvl[li];
         const uint32_t t = blockIdx.x;
-        if (t >= tb.hdr[1]) return;
-        const uint32_t k = tb.tile_cell[t], d = tb.over_cell[k];
-        dst_first = tb.cell_start[d];
-        tile_base = (int64_t)dst_first + (int64_t)(t - tb.over_tile_base[k]) * TILE;
-        end = (int64_t)tb.cell_start[d + 1];
+        if (t >= L.hdr[1]) return;
+        const uint32_t k = L.tile_seg[t];
+        dst_first = L.seg_start[k];
+        reps = (int)segment_reps(L.seg_count[k], TILE);
+        tile_base = (int64_t)dst_first + (int64_t)(t - L.seg_tile[k]) * reps * TILE;
+        end = (int64_t)dst_first + L.seg_count[k];
         scan_row = tb.tile_scan2 + (int64_t)t * radix;
-        digit_start = tb.sub_start + (int64_t)k * radix;
+        digit_start = L.sub_start + (int64_t)k * (radix + 1);
+        const Digit dg = level_digit(L.seg_and[k], L.seg_or[k]);
+        shift = dg.shift, mask = dg.mask, digit_bits = dg.bits;
+        if (dg.terminal) dst = (uint64_t *)out;
     } else {
         const int tile = xcd_remap(blockIdx.x, num_tiles);
         tile_base = (int64_t)tile * TILE;
@@ -340,7 +510,6 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
         scan_row = tb.tile_scan + (int64_t)tile * radix;
         digit_start = tb.cell_start;
     }
-    const int64_t wave_base = tile_base + (int64_t)w * (64 * IPT);
 
     IBVH_STAMP(0, 0);
     // this tile's row of the (scanned, tile-major) histogram and the digit starts: coalesced, in flight while the keys
@@ -356,6 +525,9 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
         tile_off_a[k] = scan_row[dc];
         tile_off_b[k] = digit_start[dc];
     }
+    for (int rp = 0; rp < (L2 ? reps : 1); ++rp, tile_base += TILE) {
+    if (L2 && tile_base >= end) break;
+    const int64_t wave_base = tile_base + (int64_t)w * (64 * IPT);
     for (int i = threadIdx.x; i < W * radix / 2; i += TPB) ((uint32_t *)whist)[i] = 0;
     K key[IPT];
 #pragma unroll
@@ -395,15 +567,22 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
     lds_barrier();
     IBVH_STAMP(0, 2);
     // per digit: exclusive prefix over the waves (in place), tile total
-    for (int d = threadIdx.x; d < radix; d += TPB) {
-        uint32_t run = 0;
+    uint32_t tile_cnt[DPT];
 #pragma unroll
-        for (int i = 0; i < W; ++i) {
-            const uint32_t c = whist[i * radix + d];
-            whist[i * radix + d] = (uint16_t)run;
-            run += c;
+    for (int k = 0; k < DPT; ++k) {
+        const int d = k * TPB + threadIdx.x;
+        tile_cnt[k] = 0;
+        if (d < radix) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const uint32_t c = whist[i * radix + d];
+                whist[i * radix + d] = (uint16_t)run;
+                run += c;
+            }
+            local_base[d] = run;
+            tile_cnt[k] = run;
         }
-        local_base[d] = run;
     }
     lds_barrier();
     IBVH_STAMP(0, 3);
@@ -466,7 +645,6 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
     const int64_t left = end - tile_base;
     const uint32_t valid = left < (int64_t)TILE ? (uint32_t)left : (uint32_t)TILE;
     const uint32_t total = valid * words;
-    uint64_t *__restrict__ dst = (uint64_t *)rec.dst;
     const char *stage_bytes = (const char *)stage;
     constexpr int U = 4; // LDS reads of U words are issued before the first global store
     for (uint32_t g0 = threadIdx.x; g0 < total; g0 += TPB * U) {
@@ -489,6 +667,12 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
         }
     }
     IBVH_STAMP(0, 7);
+    if constexpr (L2) { // the next tile of this workgroup starts where this one's digits ended
+#pragma unroll
+        for (int k = 0; k < DPT; ++k) tile_off_a[k] += tile_cnt[k];
+        lds_barrier();
+    }
+    } // rp
 }
 template <class K, int TPB, int IPT> inline size_t partition_smem(int bits, int stride) {
     const size_t hist = (size_t)(TPB / 64) * ((size_t)2 << bits), st = (size_t)TPB * IPT * (size_t)stride;
@@ -500,16 +684,16 @@ template <class K, int TPB, int IPT> inline size_t partition_smem(int bits, int 
 // sub-cells of an oversized cell — on the key bits that still vary inside it, and write the records to `out`
 // ------------------------------------------------------------------------------------------------------------
 struct FinishArgs {
-    const char *part;   // level-1 partition output
-    const char *part2;  // level-2 partition output (oversized cells only)
+    const char *buf[2]; // the two record buffers: level 1 writes buf[0]; extra level li reads buf[li & 1], writes buf[(li + 1) & 1]
     char *out;          // sorted records
     LeafLayout lay;
     uint32_t words;     // lay.stride / 8
     uint32_t inv_words; // ceil(2^32 / words): g / words == __umulhi(g, inv_words) for g < 2^29
-    uint32_t cap;       // cells above this size went through level 2
-    uint32_t tile;      // level-2 tile = window of sub-cells one workgroup finishes
-    int two_level;      // 0: no second level ran; crowded cells take the slow path of their own workgroup
-    int shift1, shift2; // key >> shift1 = cell, (key >> shift2) & 255 = sub-cell
+    uint32_t cap;       // cells / sub-cells above this size are segments of the next level
+    uint32_t tile;      // tile of the extra levels = window of sub-cells one workgroup finishes
+    int levels;         // extra levels that ran; what is still crowded after them takes the slow path
+    int shift1;         // key >> shift1 = cell
+    int32_t *skew_flag; // caller's hint word (may be null): receives `needed`
     // slow path only: (key, position) arrays of n entries each
     void *kalt, *kpri;
     uint32_t *valt, *vpri;
@@ -690,54 +874,84 @@ IBVH_D void finish_range(const FinishArgs &fa, const FinishLds<K, TPB, IPT> &l, 
 }
 
 IBVH_D int bit_length(uint32_t v) { return v == 0 ? 0 : 32 - __builtin_clz(v); }
+// workgroup-uniform values loaded through vector loads: moved to scalar registers (they are live across the sort)
+IBVH_D uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+IBVH_D uint64_t uni(uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); }
 
-// grid = R + F2 workgroups: workgroup b < R finishes cell b (unless it went through level 2); the others stride over
-// the level-2 tiles: tile t of oversized cell k finishes the window of sub-cells that START inside records
-// [t * tile, (t + 1) * tile) of the cell (consecutive sub-cells: one LDS sort with the sub-cell number as the top bits)
+// grid = R + F2 workgroups: workgroup b < R finishes cell b (unless it became a segment); the others stride over the
+// tiles of every extra level: tile t of segment k finishes the window of sub-cells that START inside records
+// [t * tile, (t + 1) * tile) of the segment (consecutive sub-cells: one LDS sort with the sub-cell number as the top
+// bits); a window that does not fit is finished sub-cell by sub-cell, skipping those the next level took
 template <class K, int TPB, int IPT>
 __global__ __launch_bounds__(TPB) void finish_kernel(Tables tb, int radix, FinishArgs fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
     const FinishLds<K, TPB, IPT> l(bsm);
     IBVH_STAMP(1, 0);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && fa.skew_flag) *fa.skew_flag = (int32_t)*tb.needed;
     if ((int)blockIdx.x < radix) {
         const uint32_t d = blockIdx.x;
-        const uint32_t start = tb.cell_start[d], m = tb.cell_start[d + 1] - start;
-        if (m == 0 || (m > fa.cap && fa.two_level)) return; // (with two levels, crowded cells are finished window by window below)
-        finish_range<K, TPB, IPT>(fa, l, fa.part, (int64_t)start, (int64_t)m, (K)((K)d << fa.shift1), fa.shift1);
+        const uint32_t start = uni(tb.cell_start[d]), m = uni(tb.cell_start[d + 1]) - start;
+        if (m == 0 || (m > fa.cap && fa.levels > 0)) return; // (crowded cells are finished window by window below)
+        finish_range<K, TPB, IPT>(fa, l, fa.buf[0], (int64_t)start, (int64_t)m, (K)((K)d << fa.shift1), fa.shift1);
         return;
     }
     constexpr int C = 1 << L2_BITS;
-    const uint32_t ntiles = tb.hdr[1];
-    for (uint32_t t = blockIdx.x - radix; t < ntiles; t += gridDim.x - radix) {
-        const uint32_t k = tb.tile_cell[t], d = tb.over_cell[k];
-        const uint32_t *ss = tb.sub_start + (int64_t)k * C;
-        const uint32_t cell_total = tb.cell_start[d + 1] - tb.cell_start[d];
-        const uint32_t lo = (t - tb.over_tile_base[k]) * fa.tile, hi = lo + fa.tile;
-        // e0 = first sub-cell starting at or after lo, e1 = first one starting at or after hi (binary searches; the
-        // whole workgroup walks the same path)
-        uint32_t e0 = 0, e1 = 0;
-        {
-            uint32_t a = 0, b = C; // first e with ss[e] >= lo
-            while (a < b) {
-                const uint32_t mid = (a + b) >> 1;
-                if (ss[mid] < lo) a = mid + 1;
-                else b = mid;
+    for (int li = 0; li < fa.levels; ++li) {
+        const Level L = tb.lvl[li];
+        const uint32_t ntiles = uni(L.hdr[1]);
+        const char *buf = fa.buf[(li + 1) & 1];
+        const bool handed_down = li + 1 < fa.levels; // crowded sub-cells are segments of the next level
+        for (uint32_t t = blockIdx.x - radix; t < ntiles; t += gridDim.x - radix) {
+            const uint32_t k = uni(L.tile_seg[t]);
+            const uint64_t ka = uni(L.seg_and[k]), ko = uni(L.seg_or[k]);
+            const Digit dg = level_digit(ka, ko);
+            if (dg.terminal) continue; // the partition wrote the segment to `out`, sorted
+            const uint32_t *ssp = L.sub_start + (int64_t)k * (C + 1);
+            auto ss = [&](uint32_t i) { return uni(ssp[i]); };
+            const uint32_t count = uni(L.seg_count[k]), reps = segment_reps(count, fa.tile);
+            const uint32_t t_in_seg = t - uni(L.seg_tile[k]);
+            for (uint32_t sub = 0; sub < reps; ++sub) {
+            const uint32_t lo = (t_in_seg * reps + sub) * fa.tile, hi = lo + fa.tile;
+            if (lo >= count) break;
+            // e0 = first sub-cell starting at or after lo, e1 = first one starting at or after hi (binary searches; the
+            // whole workgroup walks the same path)
+            uint32_t e0 = 0, e1 = 0;
+            {
+                uint32_t a = 0, b = C; // first e with ss[e] >= lo
+                while (a < b) {
+                    const uint32_t mid = (a + b) >> 1;
+                    if (ss(mid) < lo) a = mid + 1;
+                    else b = mid;
+                }
+                e0 = a;
+                a = e0, b = C;
+                while (a < b) {
+                    const uint32_t mid = (a + b) >> 1;
+                    if (ss(mid) < hi) a = mid + 1;
+                    else b = mid;
+                }
+                e1 = a;
             }
-            e0 = a;
-            a = e0, b = C;
-            while (a < b) {
-                const uint32_t mid = (a + b) >> 1;
-                if (ss[mid] < hi) a = mid + 1;
-                else b = mid;
+            if (e0 == e1) continue; // no sub-cell starts in this window (a large one covers it)
+            if (ss(e1) == ss(e0)) continue; // empty sub-cells only
+            const int64_t seg0 = (int64_t)uni(L.seg_start[k]);
+            const K prefix = (K)common_prefix(ka, ko);
+            // runs of consecutive sub-cells that fit one LDS sort (normally the whole window), one sort each; a single
+            // crowded sub-cell is a segment of the next level — or, after the last level, takes the slow path
+            for (uint32_t e = e0; e < e1;) {
+                const uint32_t s0 = ss(e);
+                uint32_t f = e + 1;
+                const bool crowded = ss(f) - s0 > fa.cap;
+                if (!crowded)
+                    while (f < e1 && ss(f + 1) - s0 <= fa.cap) ++f;
+                const uint32_t m = ss(f) - s0;
+                if (m != 0 && !(crowded && handed_down))
+                    finish_range<K, TPB, IPT>(fa, l, buf, seg0 + s0, (int64_t)m, (K)(prefix + ((K)e << dg.shift)),
+                                              dg.shift + bit_length(f - e - 1));
+                e = f;
             }
-            e1 = a;
+            } // sub
         }
-        if (e0 == e1) continue; // no sub-cell starts in this window (a large one covers it)
-        const uint32_t rs = ss[e0], re = e1 < C ? ss[e1] : cell_total;
-        if (re == rs) continue; // empty sub-cells only
-        const K key_base = (K)(((K)d << fa.shift1) + ((K)e0 << fa.shift2));
-        const int nbits = fa.shift2 + bit_length(e1 - e0 - 1);
-        finish_range<K, TPB, IPT>(fa, l, fa.part2, (int64_t)tb.cell_start[d] + rs, (int64_t)(re - rs), key_base, nbits);
     }
 }
 template <class K, int TPB, int IPT> constexpr size_t finish_smem() {
@@ -752,7 +966,7 @@ static int env_int(const char *name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-static size_t carve_tables(Tables *tb, char *base, int64_t n, int radix, int num_tiles, int max_tiles2) {
+static size_t carve_tables(Tables *tb, char *base, int radix, int num_tiles, int max_seg, int max_tiles2) {
     size_t off = 0;
     auto take = [&](size_t bytes) {
         uint32_t *p = base ? (uint32_t *)(base + off) : nullptr;
@@ -764,16 +978,20 @@ static size_t carve_tables(Tables *tb, char *base, int64_t n, int radix, int num
     t.tile_scan = take((size_t)radix * num_tiles * 4);
     t.cell_total = take((size_t)radix * 4);
     t.cell_start = take((size_t)(radix + 1) * 4);
-    t.hdr = take(64);
-    t.over_cell = take((size_t)radix * 4);
-    t.over_tile_base = take((size_t)(radix + 1) * 4);
-    t.tile_cell = take((size_t)max_tiles2 * 4);
+    t.needed = take(64);
     t.tile_hist2 = take((size_t)max_tiles2 * 4 << L2_BITS);
     t.tile_scan2 = take((size_t)max_tiles2 * 4 << L2_BITS);
-    // at most n / cap + 1 cells can be oversized; cap >= 2048
-    const size_t max_over = (size_t)(n / 2048 + 1 < radix ? n / 2048 + 1 : radix);
-    t.sub_total = take(max_over * 4 << L2_BITS);
-    t.sub_start = take(max_over * 4 << L2_BITS);
+    for (int l = 0; l < MAX_LEVELS; ++l) {
+        Level &L = t.lvl[l];
+        L.hdr = take(64);
+        L.seg_start = take((size_t)max_seg * 4);
+        L.seg_count = take((size_t)max_seg * 4);
+        L.seg_tile = take((size_t)max_seg * 4);
+        L.seg_and = (uint64_t *)take((size_t)max_seg * 8);
+        L.seg_or = (uint64_t *)take((size_t)max_seg * 8);
+        L.sub_start = take((size_t)max_seg * 4 * ((1 << L2_BITS) + 1));
+        L.tile_seg = take((size_t)max_tiles2 * 4);
+    }
     if (tb) *tb = t;
     return off;
 }
@@ -825,8 +1043,10 @@ Plan make_plan(int64_t n, int key_bits, int key_bytes, int leaf_bytes, void *sor
     p.bits = bits;
     p.shift = key_bits - bits;
     p.num_tiles = (int)ceil_div(n, (int64_t)tile);
-    p.max_tiles2 = p.num_tiles + (1 << bits);
-    carve_tables(&p.tb, (char *)sort_scratch, n, 1 << bits, p.num_tiles, p.max_tiles2);
+    // segments of an extra level hold more than cap records each; a segment's last tile may be partial
+    p.max_seg = (int)(n / cap + 1);
+    p.max_tiles2 = p.num_tiles + p.max_seg;
+    carve_tables(&p.tb, (char *)sort_scratch, 1 << bits, p.num_tiles, p.max_seg, p.max_tiles2);
     return p;
 }
 
@@ -834,42 +1054,48 @@ Plan make_plan(int64_t n, int key_bits, int key_bytes, int leaf_bytes, void *sor
 size_t scratch_bytes(int64_t n, int key_bits, int key_bytes, int leaf_bytes) {
     const Plan p = make_plan(n, key_bits, key_bytes, leaf_bytes, nullptr);
     if (!p.bits) return 0;
-    return carve_tables(nullptr, nullptr, n, 1 << p.bits, p.num_tiles, p.max_tiles2) + 4096;
+    return carve_tables(nullptr, nullptr, 1 << p.bits, p.num_tiles, p.max_seg, p.max_tiles2) + 4096;
 }
 
 template <class K, int PT, int PI>
-static int launch_partitions(const Plan &p, const K *keys, int64_t n, const RecordArgs &ra, char *part2, int two_level, hipStream_t st) {
+static int launch_partitions(const Plan &p, const K *keys, int64_t n, const RecordArgs &ra, char *part2, char *out, int levels, hipStream_t st) {
     const size_t smem = partition_smem<K, PT, PI>(p.bits, ra.lay.stride);
     if (smem > 160 * 1024) return IBVH_ERR_INVALID_ARG; // (make_plan sizes the tile for the record)
     IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)partition_kernel<K, PT, PI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const uint32_t words = (uint32_t)ra.lay.stride / 8u;
     const uint32_t inv_words = (uint32_t)((((uint64_t)1 << 32) + words - 1) / words);
     IBVH_LAUNCH((partition_kernel<K, PT, PI, false>), dim3(p.num_tiles), dim3(PT), smem, st, keys, n, p.shift, p.bits, p.tb,
-                p.num_tiles, ra, inv_words, p.bits);
-    if (!two_level) return IBVH_OK;
-    // level 2: only the cells the plan found oversized (none for a uniform cloud: every workgroup returns at once)
-    const int bits2 = p.shift < L2_BITS ? p.shift : L2_BITS, shift2 = p.shift - bits2;
-    const uint32_t tile = (uint32_t)PT * PI;
-    LeafLayout lay = ra.lay;
-    IBVH_LAUNCH((hist2_kernel), dim3(p.max_tiles2), dim3(256), 0, st, p.tb, (const char *)ra.dst, lay, shift2, (1u << bits2) - 1u, tile);
-    const int64_t max_over = (n / 2048 + 1) < (1 << p.bits) ? (n / 2048 + 1) : (1 << p.bits);
-    IBVH_LAUNCH((scan2_kernel), dim3((unsigned)max_over), dim3(1024), 0, st, p.tb);
-    RecordArgs r2 = ra;
-    r2.src = ra.dst; // the level-1 output: whole records, copied as they are
-    r2.dst = part2;
-    r2.src_stride = ra.lay.stride;
-    r2.src_wrapped = 1;
+                p.num_tiles, ra, inv_words, p.bits, 0, out);
+    if (levels <= 0) return IBVH_OK;
+    // extra levels: only the segments the level before found crowded (none for a uniform cloud: every workgroup
+    // returns at once)
+    const uint32_t tile = (uint32_t)PT * PI, cap = (uint32_t)(p.ftpb * p.fipt);
+    const LeafLayout lay = ra.lay;
     const size_t smem2 = partition_smem<K, PT, PI>(L2_BITS, ra.lay.stride);
     IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)partition_kernel<K, PT, PI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
-    IBVH_LAUNCH((partition_kernel<K, PT, PI, true>), dim3(p.max_tiles2), dim3(PT), smem2, st, (const K *)nullptr, n, shift2, L2_BITS,
-                p.tb, p.max_tiles2, r2, inv_words, bits2);
+    char *buf[2] = {(char *)ra.dst, part2};
+    const unsigned stride_grid = (unsigned)(p.max_tiles2 < 2048 ? p.max_tiles2 : 2048);
+    const unsigned seg_grid = (unsigned)(p.max_seg < 1024 ? p.max_seg : 1024);
+    for (int li = 0; li < levels; ++li) {
+        const char *src = buf[li & 1];
+        IBVH_LAUNCH((range_kernel), dim3(stride_grid), dim3(256), 0, st, p.tb, li, src, lay, tile);
+        IBVH_LAUNCH((hist_level_kernel), dim3(stride_grid), dim3(256), 0, st, p.tb, li, src, lay, tile);
+        IBVH_LAUNCH((scan_level_kernel), dim3(seg_grid), dim3(1024), 0, st, p.tb, li, levels, cap, tile);
+        RecordArgs r2 = ra;
+        r2.src = src; // whole records, copied as they are
+        r2.dst = buf[(li + 1) & 1];
+        r2.src_stride = ra.lay.stride;
+        r2.src_wrapped = 1;
+        IBVH_LAUNCH((partition_kernel<K, PT, PI, true>), dim3(p.max_tiles2), dim3(PT), smem2, st, (const K *)nullptr, n, 0, L2_BITS, p.tb,
+                    p.max_tiles2, r2, inv_words, L2_BITS, li, out);
+    }
     return IBVH_OK;
 }
 template <class K, int FT, int FI>
 static int launch_finish(const Plan &p, const FinishArgs &fa, hipStream_t st) {
     constexpr size_t smem = finish_smem<K, FT, FI>();
     IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)finish_kernel<K, FT, FI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    const int f2 = !fa.two_level ? 0 : (p.max_tiles2 < 1024 ? p.max_tiles2 : 1024); // workgroups that stride over the level-2 windows
+    const int f2 = fa.levels <= 0 ? 0 : (p.max_tiles2 < 1024 ? p.max_tiles2 : 1024); // workgroups that stride over the extra levels' windows
     IBVH_LAUNCH((finish_kernel<K, FT, FI>), dim3((1u << p.bits) + f2), dim3(FT), smem, st, p.tb, 1 << p.bits, fa);
     return IBVH_OK;
 }
@@ -879,7 +1105,8 @@ static int launch_finish(const Plan &p, const FinishArgs &fa, hipStream_t st) {
 // level-2 partition; out: the sorted records.  (kalt, valt, kpri, vpri): n-entry scratch arrays of the slow path
 // (kpri may alias `keys`: the keys are dead once the partition has run).
 int sort_records(const Plan &p, int key_bytes, const void *keys, int64_t n, const RecordArgs &ra, char *part2, char *out, void *kalt,
-                 uint32_t *valt, void *kpri, uint32_t *vpri, int two_level, void *skew_flag, hipStream_t st) {
+                 uint32_t *valt, void *kpri, uint32_t *vpri, int levels, void *skew_flag, hipStream_t st) {
+    if (levels < 0 || levels > MAX_LEVELS) levels = MAX_LEVELS;
     {
         const int radix = 1 << p.bits, ndb = radix >> 6;
         int chunks = 512 / ndb < 1 ? 1 : 512 / ndb; // ~512 workgroups
@@ -889,11 +1116,11 @@ int sort_records(const Plan &p, int key_bytes, const void *keys, int64_t n, cons
         IBVH_LAUNCH((scan_tiles_kernel), dim3(ndb * chunks), dim3(SCAN_TPB), 0, st, p.tb.tile_hist, p.tb.tile_scan, p.num_tiles, radix, rows,
                     p.tb.cell_total);
         IBVH_LAUNCH((plan_kernel), dim3(1), dim3(PLAN_TPB), 0, st, p.tb, radix, (uint32_t)(p.ftpb * p.fipt), (uint32_t)(p.ptpb * p.pipt),
-                    two_level, (int32_t *)skew_flag);
+                    levels);
     }
     int rc = IBVH_ERR_INVALID_ARG;
 #define IBVH_PART(K, T, I) \
-    if (p.ptpb == T && p.pipt == I) rc = launch_partitions<K, T, I>(p, (const K *)keys, n, ra, part2, two_level, st);
+    if (p.ptpb == T && p.pipt == I) rc = launch_partitions<K, T, I>(p, (const K *)keys, n, ra, part2, out, levels, st);
     if (key_bytes == 4) {
         IBVH_PART(uint32_t, 256, 4) IBVH_PART(uint32_t, 256, 8) IBVH_PART(uint32_t, 512, 8)
     } else {
@@ -902,17 +1129,17 @@ int sort_records(const Plan &p, int key_bytes, const void *keys, int64_t n, cons
 #undef IBVH_PART
     if (rc) return rc;
     FinishArgs fa{};
-    fa.part = ra.dst;
-    fa.part2 = part2;
+    fa.buf[0] = ra.dst;
+    fa.buf[1] = part2;
     fa.out = out;
     fa.lay = ra.lay;
     fa.words = (uint32_t)ra.lay.stride / 8u;
     fa.inv_words = (uint32_t)((((uint64_t)1 << 32) + fa.words - 1) / fa.words);
     fa.cap = (uint32_t)(p.ftpb * p.fipt);
     fa.tile = (uint32_t)(p.ptpb * p.pipt);
-    fa.two_level = two_level;
+    fa.levels = levels;
     fa.shift1 = p.shift;
-    fa.shift2 = p.shift - (p.shift < L2_BITS ? p.shift : L2_BITS);
+    fa.skew_flag = (int32_t *)skew_flag;
     fa.kalt = kalt;
     fa.kpri = kpri;
     fa.valt = valt;

@@ -7,21 +7,32 @@
 namespace ibvh {
 namespace msd {
 
-// Device-side tables shared by the kernels below (all in the sort scratch; sizes: R = 2^bits cells, T2 = the most
-// level-2 tiles an input of n records can have = n / tile + R).
+constexpr int MAX_LEVELS = 4; // partition levels beyond the first (levels 2 .. 5)
+
+// One extra partition level: the SEGMENTS (contiguous record ranges with a common key prefix) the level before found
+// crowded, each split into 256 sub-cells by the top 8 of the key bits that actually vary inside it.
+struct Level {
+    uint32_t *hdr;       // [0] segments, [1] tiles
+    uint32_t *seg_start; // [S]       first record (absolute)
+    uint32_t *seg_count; // [S]
+    uint32_t *seg_tile;  // [S]       first tile of the segment
+    uint64_t *seg_and;   // [S]       AND of the segment's keys
+    uint64_t *seg_or;    // [S]       OR of the segment's keys: bits of (and ^ or) are the ones that vary
+    uint32_t *sub_start; // [S][257]  exclusive prefix of the sub-cell sizes inside the segment; [256] = seg_count
+    uint32_t *tile_seg;  // [T2]      tile -> segment
+};
+
+// Device-side tables shared by the kernels below (all in the sort scratch; sizes: R = 2^bits cells, S = the most
+// crowded segments a level can have = n / cap + 1, T2 = the most tiles a level can have = num_tiles + S).
 struct Tables {
-    uint32_t *tile_hist;      // [num_tiles][R]   counts            (histogram kernel)
-    uint32_t *tile_scan;      // [num_tiles][R]   exclusive prefix over the tiles (scan)
-    uint32_t *cell_total;     // [R]
-    uint32_t *cell_start;     // [R + 1]          exclusive prefix of cell_total (plan)
-    uint32_t *hdr;            // [0] oversized cells, [1] level-2 tiles
-    uint32_t *over_cell;      // [R]              k -> cell
-    uint32_t *over_tile_base; // [R + 1]          k -> first level-2 tile of oversized cell k
-    uint32_t *tile_cell;      // [T2]             level-2 tile -> k
-    uint32_t *tile_hist2;     // [T2][256]
-    uint32_t *tile_scan2;     // [T2][256]
-    uint32_t *sub_total;      // [R][256]         (indexed by k)
-    uint32_t *sub_start;      // [R][256]         exclusive prefix of sub_total within the cell
+    uint32_t *tile_hist;  // [num_tiles][R]   counts            (histogram kernel)
+    uint32_t *tile_scan;  // [num_tiles][R]   exclusive prefix over the tiles (scan)
+    uint32_t *cell_total; // [R]
+    uint32_t *cell_start; // [R + 1]          exclusive prefix of cell_total (plan)
+    uint32_t *needed;     // [1]              extra levels this input would have used (the caller's hint)
+    uint32_t *tile_hist2; // [T2][256]        per-tile sub-cell counts of the level being run (shared by the levels)
+    uint32_t *tile_scan2; // [T2][256]
+    Level lvl[MAX_LEVELS];
 };
 
 struct Plan {
@@ -30,14 +41,15 @@ struct Plan {
     int ptpb, pipt;      // partition (and histogram) tile geometry
     int num_tiles;
     int ftpb, fipt;      // finish workgroup: threads, keys per thread (capacity = ftpb * fipt)
-    int max_tiles2;      // most level-2 tiles this input can have
+    int max_seg;         // S
+    int max_tiles2;      // T2
     Tables tb;
 };
 
 Plan make_plan(int64_t n, int key_bits, int key_bytes, int leaf_bytes, void *sort_scratch);
 size_t scratch_bytes(int64_t n, int key_bits, int key_bytes, int leaf_bytes);
 int sort_records(const Plan &p, int key_bytes, const void *keys, int64_t n, const rsort::RecordArgs &ra, char *part2, char *out,
-                 void *kalt, uint32_t *valt, void *kpri, uint32_t *vpri, int two_level, void *skew_flag, hipStream_t st);
+                 void *kalt, uint32_t *valt, void *kpri, uint32_t *vpri, int levels, void *skew_flag, hipStream_t st);
 
 } // namespace msd
 } // namespace ibvh

@@ -49,7 +49,7 @@ end
 struct IbvhBuildDesc
     types::IbvhTypes; n::Int64; built_level::Int64; already_wrapped::Int32; compute_extrema::Int32
     mins::NTuple{3, Float64}; maxs::NTuple{3, Float64}
-    two_level::Int32; reserved_::Int32; skew_flag::Ptr{Cvoid}
+    sort_levels::Int32; reserved_::Int32; skew_flag::Ptr{Cvoid}
 end
 mutable struct IbvhBfsResult
     num_contacts::Int64; num_checks::Int64; contacts_in::Int64; required_capacity::Int64
@@ -245,10 +245,11 @@ function ImplicitBVH.BVH(
     alg = options.morton
     desc = IbvhBuildDesc(types, numbv, Int64(built_ilevel), wrapped ? 1 : 0, alg.compute_extrema ? 1 : 0,
                          Float64.(alg.mins), Float64.(alg.maxs),   # NB alg.mins/maxs, not options.mins (default.jl:55-56)
-                         # two_level = 1: always run the second partition level (robust against clustered clouds; ~4 % of
-                         # a uniform 1e6-leaf build).  A shim that rebuilds every time step can hand the library a mapped
-                         # pinned host word as skew_flag and pass the value the previous build left there (include/ibvh.h).
-                         Int32(1), Int32(0), Ptr{Cvoid}(C_NULL))
+                         # sort_levels = 2: always launch two extra partition levels (robust against clustered clouds; a
+                         # few per cent of a uniform 1e6-leaf build).  A shim that rebuilds every time step can hand the
+                         # library a mapped pinned host word as skew_flag and pass the value the previous build left there,
+                         # plus one (include/ibvh.h).
+                         Int32(2), Int32(0), Ptr{Cvoid}(C_NULL))
     check(c_build(desc, wrapped ? C_NULL : devptr(bounding_volumes), devptr(leaves), devptr(nodes), devptr(skips),
                   C_NULL, devptr(scratch), need[], stream_ptr()), "ibvh_build")
     BVH(I(built_ilevel), tree, skips, nodes, leaves)

@@ -100,6 +100,8 @@ typedef struct ibvh_bvh {
     const void *skips;  /* levels x I, see ibvh_compute_skips                     */
 } ibvh_bvh;
 
+#define IBVH_MAX_SORT_LEVELS 4
+
 /* Inputs of one BVH construction: BVH(bounding_volumes, node_type; built_level, options)
  * (build.jl:198-271) with options.morton = DefaultMortonAlgorithm (morton/default.jl:21-40). */
 typedef struct ibvh_build_desc {
@@ -111,15 +113,18 @@ typedef struct ibvh_build_desc {
     int32_t compute_extrema; /* 1: derive mins/maxs from the centres (morton/default.jl:53)    */
     double mins[3];          /* used when compute_extrema == 0 (alg.mins / alg.maxs)           */
     double maxs[3];
-    /* Skewed inputs (clustered clouds, surfaces).  The sort first splits the leaves into the cells of a coarse Morton
-     * grid; a cell too crowded for one workgroup is split again by a second partition level.  For a uniform cloud that
-     * level finds nothing to do but still costs its launches (~4 % of a 1e6-leaf build), so it is the caller's choice:
-     *   two_level != 0 : run it (robust: what a cold build should pass);
-     *   two_level == 0 : crowded cells are sorted by one workgroup each — correct, slow when there are many.
+    /* Skewed inputs (clustered clouds, surfaces, duplicates).  The sort first splits the leaves into the cells of a
+     * coarse Morton grid; a cell too crowded for one workgroup is split again, by the key bits that vary inside it, by
+     * up to IBVH_MAX_SORT_LEVELS further partition levels.  For a uniform cloud those levels find nothing to do but
+     * still cost their launches (4 per level, ~2 us each), so their number is the caller's choice:
+     *   sort_levels = k (0 .. IBVH_MAX_SORT_LEVELS; negative or larger = all): launch k extra levels.  Whatever is
+     *   still crowded after them is sorted by one workgroup per piece — always correct, slow when pieces are large.
      * skew_flag (optional, may be NULL): 4 bytes the GPU can write — device memory or mapped pinned host memory.  Every
-     * build stores 1 there if it met a crowded cell, else 0, so a caller that rebuilds every time step can pass
-     * two_level = (the value the previous build left) without ever synchronising (build.jl:109-126 reuse pattern). */
-    int32_t two_level;
+     * build stores there how many extra levels its input would have used (0 for a uniform cloud; at most one more than
+     * it was given), so a caller that rebuilds every time step can pass sort_levels = (the value the previous build
+     * left, plus one spare level when it is not 0) without ever synchronising (build.jl:109-126 reuse pattern); a cold
+     * build should pass 2 or more. */
+    int32_t sort_levels;
     int32_t reserved_;
     void *skew_flag;
 } ibvh_build_desc;

@@ -233,16 +233,24 @@ def test_build_clustered_cloud_bit_exact():
         assert_bvh_equal(o, g)
 
 
-@pytest.mark.parametrize("shape", ["uniform", "clustered", "duplicates", "presorted", "reversed"])
-def test_build_every_sort_route_with_and_without_the_second_partition_level(shape):
-    """The MSD build (n >= 4096): one partition level, two levels, and the tiled slow finish of cells that stay
-    crowded, each reached with `two_level` 1 (cold build) and 0 (a cached build whose predecessor saw no skew);
-    the skew word tells the next build of the chain which one to run."""
+@pytest.mark.parametrize("shape", ["uniform", "clustered", "gaussian", "nested", "duplicates", "presorted", "reversed"])
+def test_build_every_sort_route_at_every_partition_depth(shape):
+    """The MSD build (n >= 4096): one partition level, up to four more for crowded cells (each on the key bits that
+    vary inside the cell, straight into the output when at most 8 are left), and the tiled slow finish of whatever
+    is still crowded after the last level that was launched — reached with every `sort_levels` from 0 to the maximum;
+    the skew word tells the next build of the chain how many levels to launch."""
     rng = np.random.default_rng(len(shape) * 1000 + ord(shape[0]))
     n = 250_000
-    if shape == "clustered":
+    if shape == "clustered":      # a few very tight clusters: most leaves share a handful of Morton codes
         centres = rng.random((3, 3)) * 50
         c = centres[rng.choice(3, n, p=[0.7, 0.2, 0.1])] + rng.normal(0, 1e-3, (n, 3))
+    elif shape == "gaussian":     # clusters a few dozen grid cells wide: crowded cells AND crowded sub-cells
+        centres = rng.random((8, 3))
+        c = centres[rng.integers(0, 8, n)] + rng.normal(0, 0.004, (n, 3))
+    elif shape == "nested":       # clusters inside clusters, down to exact duplicates
+        sigma = rng.choice([0.05, 2e-3, 1e-4, 0.0], n, p=[0.2, 0.3, 0.3, 0.2])[:, None]
+        c = np.array([[0.3, 0.6, 0.2]]) + sigma * rng.normal(0, 1, (n, 3))
+        c[:100] = rng.random((100, 3))  # (a sparse background fixes the extent)
     elif shape == "duplicates":
         c = np.repeat(rng.random((37, 3)), n // 37 + 1, axis=0)[:n]
         rng.shuffle(c)
@@ -252,22 +260,25 @@ def test_build_every_sort_route_with_and_without_the_second_partition_level(shap
     if shape in ("presorted", "reversed"):
         order = orc.build(vols, abi.make_types()).leaves["index"].astype(np.int64) - 1
         vols = vols[order if shape == "presorted" else order[::-1]]
-    expect_skew = shape in ("clustered", "duplicates")
+    expect_skew = shape in ("clustered", "gaussian", "nested", "duplicates")
     for combo, mt in [((abi.BSPHERE, abi.F32, abi.BBOX, abi.F32), abi.U32),
                       ((abi.BSPHERE, abi.F64, abi.BBOX, abi.F64), abi.U64)]:
         types = abi.make_types(*combo, abi.I32, mt)
-        o, g = build_both(vols, types)                 # cold: two_level = 1
+        o, g = build_both(vols, types)                 # cold: COLD_SORT_LEVELS extra levels launched
         assert_bvh_equal(o, g)
         torch.cuda.synchronize()
         assert bool(int(g._skew[0])) == expect_skew
-        g._skew[0] = 0                                 # pretend the previous step saw no crowded cell
         node_type = TOKENS[types.node_kind](torch.float32 if types.node_float == abi.F32 else torch.float64)
-        g2 = ibvh.BVH(cuda(vols.astype(NP_F[types.leaf_float])), node_type, options=make_options(types), cache=g)
-        assert_bvh_equal(o, g2)                        # two_level = 0: crowded cells take the tiled finish
-        torch.cuda.synchronize()
-        assert bool(int(g2._skew[0])) == expect_skew   # ... and the word asks for two levels next time
-        g3 = ibvh.BVH(cuda(vols.astype(NP_F[types.leaf_float])), node_type, options=make_options(types), cache=g2)
-        assert_bvh_equal(o, g3)
+        dev = cuda(vols.astype(NP_F[types.leaf_float]))
+        for pretend in (0, 1, 2, 3):                   # what "the previous build" left: launches 0, 2, 3, 4 extra levels
+            g._skew[0] = pretend
+            g = ibvh.BVH(dev, node_type, options=make_options(types), cache=g)
+            assert_bvh_equal(o, g)
+            torch.cuda.synchronize()
+            used = int(g._skew[0])
+            assert (used > 0) == expect_skew and used <= abi.MAX_SORT_LEVELS
+            if pretend == 0 and expect_skew:
+                assert used == 1                       # no extra level ran: all it can know is that one is needed
 
 
 def test_extrema_and_keys_entry_points():

@@ -20,6 +20,8 @@ elif case == "onecluster":
 elif case == "dups":
     base = torch.rand((1000, 4), generator=g, device="cuda")
     v = base[torch.randint(0, 1000, (n,), generator=g, device="cuda")].contiguous()
+elif case == "uniform":
+    v = ibvh.generate_spheres(n, 42, r0=0.5 * (3 * 8 / (4 * math.pi * n)) ** (1 / 3))
 elif case == "mesh":
     from test_gpu_fullsize import torus_mesh
     tris = torch.from_numpy(torus_mesh()).cuda()
@@ -43,7 +45,15 @@ import time
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(5): b = ibvh.BVH(v, cache=b)
 torch.cuda.synchronize()
-print("ok", case, n, "build %.3f ms" % ((time.perf_counter() - t0) / 5 * 1e3))
+print("ok", case, n, "build %.3f ms" % ((time.perf_counter() - t0) / 5 * 1e3), "levels used", int(b._skew[0]))
+from implicitbvh_amd import lib
+sys.path.insert(0, {ROOT!r})
+from bench import collect_profile
+lib.call("ibvh_profile_enable", 1)
+b = ibvh.BVH(v, cache=b); torch.cuda.synchronize()
+p = collect_profile(lib)
+lib.call("ibvh_profile_enable", 0)
+print("   ", {{k: (round(x[0] * 1e3, 1), x[1]) for k, x in p.items()}}, "sum %.1f us" % sum(x[0] * 1e3 for x in p.values()))
 '''
 for spec in sys.argv[1:]:
     case, n = spec.split(":")
