@@ -16,8 +16,9 @@
 //
 // Skew: a cell that holds more records than a finish workgroup sorts in LDS (clustered clouds, surfaces: a mesh
 // fills a fraction of the grid's cells, duplicates) becomes a SEGMENT of the next partition level, which touches only
-// such segments: range (which key bits vary inside each segment) -> hist -> scan -> partition on the top 8 VARYING
-// bits, the tiles of all segments side by side in one grid, so a single huge cell is still shared by many workgroups.
+// such segments: range (which key bits vary inside each segment; first extra level only, the others take "everything
+// below the parent's digit") -> hist -> scan -> partition on the top 8 VARYING bits (range and hist read a COMPACT copy of the keys that the partition before wrote next to its records — 4 or 8
+// bytes a record instead of a strided walk over whole records), the tiles of all segments side by side in one grid, so a single huge cell is still shared by many workgroups.
 // Sub-cells that are still crowded become the segments of the level after (up to MAX_LEVELS extra levels, ping-pong
 // between the two record buffers); a segment with at most 8 varying bits left is partitioned straight into the
 // output, sorted (a cell of identical keys: one tiled copy).  The finish kernel sorts windows of consecutive
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_tiles_kernel(const uint32_t *__
 // ------------------------------------------------------------------------------------------------------------
 constexpr int PLAN_TPB = 1024;
 IBVH_D uint32_t segment_tiles(uint32_t count, uint32_t tile);
-__global__ __launch_bounds__(PLAN_TPB) void plan_kernel(Tables tb, int radix, uint32_t cap, uint32_t tile, int levels) {
+__global__ __launch_bounds__(PLAN_TPB) void plan_kernel(Tables tb, int radix, uint32_t cap, uint32_t tile, int levels, int shift1) {
     constexpr int PER = (1 << MSD_MAX_BITS) / PLAN_TPB; // cells per thread, at most
     __shared__ uint32_t wave_tot[PLAN_TPB / 64];
     __shared__ uint32_t s_tbase[(1 << MSD_MAX_BITS) + 1]; // first tile of every segment, for the tile -> segment search
@@ -166,8 +167,9 @@ __global__ __launch_bounds__(PLAN_TPB) void plan_kernel(Tables tb, int radix, ui
                     L.seg_start[kk] = run;
                     L.seg_count[kk] = tot[k];
                     L.seg_tile[kk] = tt;
-                    L.seg_and[kk] = ~(uint64_t)0;
-                    L.seg_or[kk] = 0;
+                    // (bounds; range_kernel + hist_level_kernel replace them by what the keys really span)
+                    L.seg_and[kk] = (uint64_t)d << shift1;
+                    L.seg_or[kk] = ((uint64_t)d << shift1) | (((uint64_t)1 << shift1) - 1);
                 }
                 s_tbase[kk] = tt;
                 kk += 1;
@@ -246,7 +248,8 @@ IBVH_D TileRange level_tile(const Level &L, uint32_t t, uint32_t tile) {
 }
 
 // which key bits vary inside every segment of level li
-__global__ __launch_bounds__(256) void range_kernel(Tables tb, int li, const char *__restrict__ src, LeafLayout lay, uint32_t tile) {
+template <class K>
+__global__ __launch_bounds__(256) void range_kernel(Tables tb, int li, const K *__restrict__ keys, uint32_t tile) {
     __shared__ uint64_t s_and[4], s_or[4];
     const Level L = tb.lvl[li];
     const uint32_t ntiles = L.hdr[1];
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(256) void range_kernel(Tables tb, int li, const cha
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const uint32_t i = i0 + u * 256;
-                k[u] = load_morton(src + (int64_t)(r.first + (i < r.cnt ? i : i0)) * lay.stride, lay);
+                k[u] = (uint64_t)keys[r.first + (i < r.cnt ? i : i0)];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -276,35 +279,60 @@ __global__ __launch_bounds__(256) void range_kernel(Tables tb, int li, const cha
             s_or[threadIdx.x >> 6] = o;
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            a = (s_and[0] & s_and[1]) & (s_and[2] & s_and[3]);
-            o = (s_or[0] | s_or[1]) | (s_or[2] | s_or[3]);
-            // AND only loses bits and OR only gains them: a (possibly stale) value this tile cannot change means the
-            // current one cannot be changed either — thousands of tiles of one huge segment then skip the atomic
-            const uint64_t ca = __builtin_nontemporal_load(&L.seg_and[r.seg]), co = __builtin_nontemporal_load(&L.seg_or[r.seg]);
-            if ((ca & a) != ca) atomicAnd((unsigned long long *)&L.seg_and[r.seg], (unsigned long long)a);
-            if ((co | o) != co) atomicOr((unsigned long long *)&L.seg_or[r.seg], (unsigned long long)o);
+        if (threadIdx.x == 0) { // per tile, no atomics: the histogram kernel merges a segment's (<= MAX_ROWS) tiles
+            tb.tile_and[t] = (s_and[0] & s_and[1]) & (s_and[2] & s_and[3]);
+            tb.tile_or[t] = (s_or[0] | s_or[1]) | (s_or[2] | s_or[3]);
         }
         __syncthreads();
     }
 }
 
 // per tile of a segment: counts of the segment's digit
-__global__ __launch_bounds__(256) void hist_level_kernel(Tables tb, int li, const char *__restrict__ src, LeafLayout lay, uint32_t tile) {
+template <class K>
+__global__ __launch_bounds__(256) void hist_level_kernel(Tables tb, int li, const K *__restrict__ keys, uint32_t tile, int measured) {
     __shared__ uint32_t h[1 << L2_BITS];
+    __shared__ uint64_t s_and[4], s_or[4];
     const Level L = tb.lvl[li];
     const uint32_t ntiles = L.hdr[1];
     for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         h[threadIdx.x] = 0;
-        __syncthreads();
         const TileRange r = level_tile(L, t, tile);
-        const Digit dg = level_digit(L.seg_and[r.seg], L.seg_or[r.seg]);
+        uint64_t sa, so;
+        if (measured) { // merge what range_kernel found in the segment's tiles; its first tile records the result
+            const uint32_t t0 = L.seg_tile[r.seg], nt = segment_tiles(L.seg_count[r.seg], tile);
+            uint64_t a = ~(uint64_t)0, o = 0;
+            for (uint32_t i = threadIdx.x; i < nt; i += 256) {
+                a &= tb.tile_and[t0 + i];
+                o |= tb.tile_or[t0 + i];
+            }
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                a &= __shfl_xor(a, m, 64);
+                o |= __shfl_xor(o, m, 64);
+            }
+            if ((threadIdx.x & 63) == 0) {
+                s_and[threadIdx.x >> 6] = a;
+                s_or[threadIdx.x >> 6] = o;
+            }
+            __syncthreads();
+            sa = (s_and[0] & s_and[1]) & (s_and[2] & s_and[3]);
+            so = (s_or[0] | s_or[1]) | (s_or[2] | s_or[3]);
+            if (t == t0 && threadIdx.x == 0) {
+                L.seg_and[r.seg] = sa;
+                L.seg_or[r.seg] = so;
+            }
+        } else {
+            sa = L.seg_and[r.seg];
+            so = L.seg_or[r.seg];
+        }
+        __syncthreads();
+        const Digit dg = level_digit(sa, so);
         for (uint32_t i0 = threadIdx.x; i0 < r.cnt; i0 += 256 * 8) {
             uint64_t k[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const uint32_t i = i0 + u * 256;
-                k[u] = load_morton(src + (int64_t)(r.first + (i < r.cnt ? i : i0)) * lay.stride, lay);
+                k[u] = (uint64_t)keys[r.first + (i < r.cnt ? i : i0)];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
@@ -392,8 +420,11 @@ __global__ __launch_bounds__(1024) void scan_level_kernel(Tables tb, int li, int
                     N.seg_start[s] = L.seg_start[k] + ex;
                     N.seg_count[s] = total;
                     N.seg_tile[s] = tb0;
-                    N.seg_and[s] = ~(uint64_t)0;
-                    N.seg_or[s] = 0;
+                    // which bits vary inside it: at most those below this level's digit (only the first extra level
+                    // measures its segments — range_kernel; a pass over the keys per level costs more than it saves)
+                    const uint64_t fixed = common_prefix(L.seg_and[k], L.seg_or[k]) | ((uint64_t)col << dg.shift);
+                    N.seg_and[s] = fixed;
+                    N.seg_or[s] = fixed | (((uint64_t)1 << dg.shift) - 1);
                     for (uint32_t t = 0; t < my_tiles; ++t) N.tile_seg[tb0 + t] = s;
                 }
             }
@@ -469,7 +500,7 @@ constexpr int partition_min_waves(int tpb, int ipt) { return tpb * ipt <= 2048 ?
 template <class K, int TPB, int IPT, bool L2>
 __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_kernel(const K *__restrict__ keys, int64_t n, int shift, int bits,
                                                         Tables tb, int num_tiles, RecordArgs rec, uint32_t inv_words, int digit_bits,
-                                                        int li, char *out) {
+                                                        int li, char *out, K *__restrict__ side_out) {
     constexpr int W = TPB / 64;
     constexpr int TILE = TPB * IPT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -534,8 +565,7 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
     for (int j = 0; j < IPT; ++j) {
         const int64_t i = wave_base + j * 64 + lane;
         const int64_t ic = i < end ? i : end - 1;
-        if constexpr (L2) key[j] = (K)load_morton(rec.src + ic * rec.src_stride, rec.lay);
-        else key[j] = keys[ic];
+        key[j] = keys[ic]; // (extra levels: the compact keys the partition before wrote; same index space as the records)
     }
     // 16-byte fresh volumes (BSphere{Float32}, the common case) are requested now and stay in flight while the keys are
     // ranked (the barriers below do not wait for them); other layouts are fetched when they are staged
@@ -667,6 +697,17 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
         }
     }
     IBVH_STAMP(0, 7);
+    // a compact copy of the keys, in the records' new order, for the range and histogram kernels of the next level —
+    // only when that level has segments at all (one scalar load; a uniform cloud never pays this)
+    {
+        const int nli = L2 ? li + 1 : 0;
+        if (side_out != nullptr && nli < MAX_LEVELS && tb.lvl[nli < MAX_LEVELS ? nli : 0].hdr[0] != 0) {
+            for (uint32_t r = threadIdx.x; r < valid; r += TPB) {
+                const K kk = (K)load_morton(stage_bytes + r * (uint32_t)rec.lay.stride, rec.lay);
+                side_out[r + delta[(uint32_t)(kk >> shift) & mask]] = kk;
+            }
+        }
+    }
     if constexpr (L2) { // the next tile of this workgroup starts where this one's digits ended
 #pragma unroll
         for (int k = 0; k < DPT; ++k) tile_off_a[k] += tile_cnt[k];
@@ -942,8 +983,19 @@ __global__ __launch_bounds__(TPB) void finish_kernel(Tables tb, int radix, Finis
                 const uint32_t s0 = ss(e);
                 uint32_t f = e + 1;
                 const bool crowded = ss(f) - s0 > fa.cap;
-                if (!crowded)
-                    while (f < e1 && ss(f + 1) - s0 <= fa.cap) ++f;
+                if (!crowded) { // the largest f <= e1 with ss(f) - s0 <= cap (ss ascends: binary search, usually f = e1 at once)
+                    if (ss(e1) - s0 <= fa.cap) {
+                        f = e1;
+                    } else {
+                        uint32_t lo_f = f, hi_f = e1; // ss(lo_f) fits, ss(hi_f) does not
+                        while (hi_f - lo_f > 1) {
+                            const uint32_t mid = (lo_f + hi_f) >> 1;
+                            if (ss(mid) - s0 <= fa.cap) lo_f = mid;
+                            else hi_f = mid;
+                        }
+                        f = lo_f;
+                    }
+                }
                 const uint32_t m = ss(f) - s0;
                 if (m != 0 && !(crowded && handed_down))
                     finish_range<K, TPB, IPT>(fa, l, buf, seg0 + s0, (int64_t)m, (K)(prefix + ((K)e << dg.shift)),
@@ -981,6 +1033,8 @@ static size_t carve_tables(Tables *tb, char *base, int radix, int num_tiles, int
     t.needed = take(64);
     t.tile_hist2 = take((size_t)max_tiles2 * 4 << L2_BITS);
     t.tile_scan2 = take((size_t)max_tiles2 * 4 << L2_BITS);
+    t.tile_and = (uint64_t *)take((size_t)max_tiles2 * 8);
+    t.tile_or = (uint64_t *)take((size_t)max_tiles2 * 8);
     for (int l = 0; l < MAX_LEVELS; ++l) {
         Level &L = t.lvl[l];
         L.hdr = take(64);
@@ -1058,14 +1112,15 @@ size_t scratch_bytes(int64_t n, int key_bits, int key_bytes, int leaf_bytes) {
 }
 
 template <class K, int PT, int PI>
-static int launch_partitions(const Plan &p, const K *keys, int64_t n, const RecordArgs &ra, char *part2, char *out, int levels, hipStream_t st) {
+static int launch_partitions(const Plan &p, const K *keys, int64_t n, const RecordArgs &ra, char *part2, char *out, K *side0, K *side1, int levels,
+                             hipStream_t st) {
     const size_t smem = partition_smem<K, PT, PI>(p.bits, ra.lay.stride);
     if (smem > 160 * 1024) return IBVH_ERR_INVALID_ARG; // (make_plan sizes the tile for the record)
     IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)partition_kernel<K, PT, PI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const uint32_t words = (uint32_t)ra.lay.stride / 8u;
     const uint32_t inv_words = (uint32_t)((((uint64_t)1 << 32) + words - 1) / words);
     IBVH_LAUNCH((partition_kernel<K, PT, PI, false>), dim3(p.num_tiles), dim3(PT), smem, st, keys, n, p.shift, p.bits, p.tb,
-                p.num_tiles, ra, inv_words, p.bits, 0, out);
+                p.num_tiles, ra, inv_words, p.bits, 0, out, levels > 0 ? side0 : (K *)nullptr);
     if (levels <= 0) return IBVH_OK;
     // extra levels: only the segments the level before found crowded (none for a uniform cloud: every workgroup
     // returns at once)
@@ -1074,20 +1129,23 @@ static int launch_partitions(const Plan &p, const K *keys, int64_t n, const Reco
     const size_t smem2 = partition_smem<K, PT, PI>(L2_BITS, ra.lay.stride);
     IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)partition_kernel<K, PT, PI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
     char *buf[2] = {(char *)ra.dst, part2};
+    K *side[2] = {side0, side1}; // compact keys of the records in buf[0] / buf[1]
     const unsigned stride_grid = (unsigned)(p.max_tiles2 < 2048 ? p.max_tiles2 : 2048);
     const unsigned seg_grid = (unsigned)(p.max_seg < 1024 ? p.max_seg : 1024);
     for (int li = 0; li < levels; ++li) {
         const char *src = buf[li & 1];
-        IBVH_LAUNCH((range_kernel), dim3(stride_grid), dim3(256), 0, st, p.tb, li, src, lay, tile);
-        IBVH_LAUNCH((hist_level_kernel), dim3(stride_grid), dim3(256), 0, st, p.tb, li, src, lay, tile);
+        static const int measure = env_int("IBVH_MSD_RANGE", 1); // tuning knob: 0 = first extra level on the next 8 bits, unmeasured
+        const bool measured = li == 0 && measure != 0;
+        if (measured) IBVH_LAUNCH((range_kernel<K>), dim3(stride_grid), dim3(256), 0, st, p.tb, li, (const K *)side[li & 1], tile);
+        IBVH_LAUNCH((hist_level_kernel<K>), dim3(stride_grid), dim3(256), 0, st, p.tb, li, (const K *)side[li & 1], tile, measured ? 1 : 0);
         IBVH_LAUNCH((scan_level_kernel), dim3(seg_grid), dim3(1024), 0, st, p.tb, li, levels, cap, tile);
         RecordArgs r2 = ra;
         r2.src = src; // whole records, copied as they are
         r2.dst = buf[(li + 1) & 1];
         r2.src_stride = ra.lay.stride;
         r2.src_wrapped = 1;
-        IBVH_LAUNCH((partition_kernel<K, PT, PI, true>), dim3(p.max_tiles2), dim3(PT), smem2, st, (const K *)nullptr, n, 0, L2_BITS, p.tb,
-                    p.max_tiles2, r2, inv_words, L2_BITS, li, out);
+        IBVH_LAUNCH((partition_kernel<K, PT, PI, true>), dim3(p.max_tiles2), dim3(PT), smem2, st, (const K *)side[li & 1], n, 0, L2_BITS, p.tb,
+                    p.max_tiles2, r2, inv_words, L2_BITS, li, out, li + 1 < levels ? side[(li + 1) & 1] : (K *)nullptr);
     }
     return IBVH_OK;
 }
@@ -1116,11 +1174,11 @@ int sort_records(const Plan &p, int key_bytes, const void *keys, int64_t n, cons
         IBVH_LAUNCH((scan_tiles_kernel), dim3(ndb * chunks), dim3(SCAN_TPB), 0, st, p.tb.tile_hist, p.tb.tile_scan, p.num_tiles, radix, rows,
                     p.tb.cell_total);
         IBVH_LAUNCH((plan_kernel), dim3(1), dim3(PLAN_TPB), 0, st, p.tb, radix, (uint32_t)(p.ftpb * p.fipt), (uint32_t)(p.ptpb * p.pipt),
-                    levels);
+                    levels, p.shift);
     }
     int rc = IBVH_ERR_INVALID_ARG;
 #define IBVH_PART(K, T, I) \
-    if (p.ptpb == T && p.pipt == I) rc = launch_partitions<K, T, I>(p, (const K *)keys, n, ra, part2, out, levels, st);
+    if (p.ptpb == T && p.pipt == I) rc = launch_partitions<K, T, I>(p, (const K *)keys, n, ra, part2, out, (K *)kalt, (K *)kpri, levels, st);
     if (key_bytes == 4) {
         IBVH_PART(uint32_t, 256, 4) IBVH_PART(uint32_t, 256, 8) IBVH_PART(uint32_t, 512, 8)
     } else {

@@ -32,6 +32,8 @@ struct Tables {
     uint32_t *needed;     // [1]              extra levels this input would have used (the caller's hint)
     uint32_t *tile_hist2; // [T2][256]        per-tile sub-cell counts of the level being run (shared by the levels)
     uint32_t *tile_scan2; // [T2][256]
+    uint64_t *tile_and;   // [T2]             AND / OR of the keys of every tile of the first extra level (range_kernel)
+    uint64_t *tile_or;    // [T2]
     Level lvl[MAX_LEVELS];
 };
 
