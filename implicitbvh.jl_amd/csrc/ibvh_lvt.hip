@@ -373,17 +373,21 @@ IBVH_D uint64_t test_and_append_f32(uint64_t init, float slo0, float slo1, float
 }
 
 constexpr int QUEUE_CAP = 512; // candidate pairs per wave (LDS); drained whenever fewer than 64 slots are free
+#ifndef IBVH_QUEUE_WAVES
+#define IBVH_QUEUE_WAVES 1
+#endif
+constexpr int QUEUE_WAVES = IBVH_QUEUE_WAVES; // waves per workgroup (they share nothing: a workgroup is only a unit of dispatch)
 
 // WIDE: 64-bit queue entries for trees of 29 .. 31 levels (leaf-parent indices beyond 2^26), see launch().
 template <class L, class N, class I, int MODE, bool WRITE, bool NARROW, bool WIDE>
-__global__ __launch_bounds__(256, 6) void lvt_queue_kernel(Args<L, N, I> a, PairCache<I> cache, int cut_level) {
+__global__ __launch_bounds__(64 * QUEUE_WAVES, 8) void lvt_queue_kernel(Args<L, N, I> a, PairCache<I> cache, int cut_level) {
     using TN = typename N::elt;
     using Q = Query<L, N, I, MODE, WRITE, NARROW>;
     using Cnt = typename Q::Cnt;
-    __shared__ uint32_t s_frontier[4][2][FRONTIER_CAP];
+    __shared__ uint32_t s_frontier[QUEUE_WAVES][2][FRONTIER_CAP];
     using QE = typename std::conditional<WIDE, uint64_t, uint32_t>::type; // queue entry: query lane | leaf-parent index << 6
-    __shared__ QE s_queue[4][QUEUE_CAP];
-    __shared__ Cnt s_cnt[4][64];
+    __shared__ QE s_queue[QUEUE_WAVES][QUEUE_CAP];
+    __shared__ Cnt s_cnt[QUEUE_WAVES][64];
     Q q(a, cache);
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // (uniform: LDS bases stay scalar)
     // Wave-dense contact cache.  The wave owns the scratch bytes its 64 items own in the slot-major layout of the
@@ -1178,6 +1182,8 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
                     // header comment), so the descent always starts where one 64-lane step covers all roots (level 7,
                     // or the highest built level below it) whatever level the caller named.
                     Args<L, N, I> aq = a;
+                    aq.xcd_tiles = a.xcd_tiles > 1 ? a.xcd_tiles * 4 / QUEUE_WAVES : a.xcd_tiles; // (runs are counted in 256-item units)
+                    const unsigned qblocks = (unsigned)ceil_div(a.n_items, (int64_t)64 * QUEUE_WAVES);
                     int64_t top = a.built_level > 7 ? a.built_level : 7; // level 7: 64 nodes, one 64-lane step
                     if (top > a.tree.levels - 1) top = a.tree.levels - 1;
                     aq.start_level = top; // also when the caller named a HIGHER level: levels 1..6 hold < 64 nodes each
@@ -1185,7 +1191,7 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
                     const int cut = (int)(c > aq.start_level ? c : aq.start_level);
                     const int variant = (write ? 1 : 0) | (aq.narrow != IBVH_NARROW_NONE ? 2 : 0) | (wide ? 4 : 0);
 #define IBVH_QUEUE_LAUNCH(W_, N_, D_)                                                                                 \
-    IBVH_LAUNCH((lvt_queue_kernel<L, N, I, MODE, W_, N_, D_>), dim3(blocks), dim3(256), 0, st, aq, cache, cut)
+    IBVH_LAUNCH((lvt_queue_kernel<L, N, I, MODE, W_, N_, D_>), dim3(qblocks), dim3(64 * QUEUE_WAVES), 0, st, aq, cache, cut)
                     switch (variant) {
                     case 0: IBVH_QUEUE_LAUNCH(false, false, false); break;
                     case 1: IBVH_QUEUE_LAUNCH(true, false, false); break;

@@ -109,15 +109,11 @@ def test_config4_pair_two_5e6_clouds_full_size():
     assert np.array_equal(np.unique(cb[:, 0] * (n + 1) + cb[:, 1]), np.unique(c[:, 0] * (n + 1) + c[:, 1]))
 
 
-def test_north_star_ten_million_properties():
-    """The north-star size (1e7 leaves, one GPU) through size-independent properties: sortedness, permutation,
-    stability, records follow their index, every node is the exact merge of its children (spot-checked per level),
-    every reported pair touches and is reported once, per-leaf counts agree with the list, BFS finds the same SET of
-    contacts, and a second traversal into the cached buffers is identical."""
-    n = 10_000_000
-    r0 = 0.5 * (3 * 8 / (4 * np.pi * n)) ** (1 / 3)
-    vols = ibvh.generate_spheres(n, 42, r0=r0)
-    g = ibvh.BVH(vols)
+def check_build_properties(vols, g):
+    """Size-independent checks of a BVH of BSphere{Float32} leaves: codes ascending, .index a permutation, ties in
+    input order, records follow their index, the codes are the oracle's for the build's extrema (on a sample), every
+    level's nodes spot-checked as the exact merge of their children.  Returns (host volumes, leaves)."""
+    n = len(g.leaves)
     leaves = g.leaves.to_numpy()
     m = leaves["morton"].astype(np.int64)
     assert (np.diff(m) >= 0).all()
@@ -129,10 +125,13 @@ def test_north_star_ten_million_properties():
     assert (idx[1:][ties] > idx[:-1][ties]).all()                # stable
     host = vols.cpu().numpy()
     assert leaves["volume"].tobytes() == host[idx - 1].tobytes()  # records follow their index
+    rng = np.random.default_rng(3)
+    sample = rng.integers(0, n, 100_000)
+    keys = orc.morton_keys(abi.make_types(), np.ascontiguousarray(host[idx[sample] - 1]), False, g.extrema.cpu().numpy())
+    assert np.array_equal(np.asarray(keys).astype(np.int64), m[sample])  # the codes themselves
     # nodes: level l node i == merge(children); checked exactly on random samples of every level
     tree = orc.tree_shape(n)
     nodes = g.nodes.cpu().numpy()                                # (real_nodes - real_leaves, 6) float32 boxes
-    rng = np.random.default_rng(3)
     lv = leaves["volume"]
     leaf_lo = lv["x"] - lv["r"][:, None]
     leaf_up = lv["x"] + lv["r"][:, None]
@@ -151,6 +150,19 @@ def test_north_star_ten_million_properties():
             lo = np.minimum(nodes[l, :3], nodes[r, :3])
             up = np.maximum(nodes[l, 3:], nodes[r, 3:])
         assert np.array_equal(nodes[first + pick, :3], lo) and np.array_equal(nodes[first + pick, 3:], up), level
+    return host, leaves
+
+
+def test_north_star_ten_million_properties():
+    """The north-star size (1e7 leaves, one GPU) through size-independent properties: sortedness, permutation,
+    stability, records follow their index, every node is the exact merge of its children (spot-checked per level),
+    every reported pair touches and is reported once, per-leaf counts agree with the list, BFS finds the same SET of
+    contacts, and a second traversal into the cached buffers is identical."""
+    n = 10_000_000
+    r0 = 0.5 * (3 * 8 / (4 * np.pi * n)) ** (1 / 3)
+    vols = ibvh.generate_spheres(n, 42, r0=r0)
+    g = ibvh.BVH(vols)
+    host, leaves = check_build_properties(vols, g)
     t = ibvh.traverse(g)
     c = contacts_np(t)
     assert len(c) > n and (c[:, 0] < c[:, 1]).all()
@@ -170,3 +182,31 @@ def test_north_star_ten_million_properties():
     assert len(cb) == len(c)
     assert np.array_equal(np.sort(cb[:, 0] * (n + 1) + cb[:, 1]), np.sort(key))
 
+
+
+@pytest.mark.parametrize("shape", ["clusters", "one_cluster", "few_centres"])
+def test_skewed_ten_million_leaf_builds_properties(shape):
+    """1e7 leaves that crowd a few cells of the sort's Morton grid — segments of millions of records, workgroups that
+    do several partition tiles in a row, terminal segments, every extra partition level — checked through
+    size-independent properties (check_build_properties); the rebuild with cache= gives the same bytes."""
+    n = 10_000_000
+    g = torch.Generator(device="cuda").manual_seed(5)
+    v = torch.empty((n, 4), device="cuda")
+    if shape == "clusters":
+        c = torch.rand((8, 3), generator=g, device="cuda")
+        v[:, :3] = c[torch.randint(0, 8, (n,), generator=g, device="cuda")] + 0.004 * torch.randn((n, 3), generator=g, device="cuda")
+        v[:, 3] = 1e-4
+    elif shape == "one_cluster":
+        v[:, :3] = 0.5 + 0.001 * torch.randn((n, 3), generator=g, device="cuda")
+        v[:, 3] = 1e-4
+        v[0, :3] = 100.0  # a far outlier collapses the grid: all other leaves share a handful of codes
+    else:
+        base = torch.rand((1000, 4), generator=g, device="cuda")
+        v = base[torch.randint(0, 1000, (n,), generator=g, device="cuda")].contiguous()
+    b = ibvh.BVH(v)
+    torch.cuda.synchronize()
+    assert int(b._skew[0]) >= 1
+    _, leaves = check_build_properties(v, b)
+    b2 = ibvh.BVH(v, cache=b)  # (reuses the buffers; launches as many levels as the first build reported, plus one)
+    torch.cuda.synchronize()
+    assert b2.leaves.to_numpy().tobytes() == leaves.tobytes()
