@@ -64,14 +64,50 @@ IBVH_D bool narrow_eval(int narrow, uint64_t ma, int64_t ia, uint64_t mb, int64_
 }
 
 // ------------------------------------------------------------------------------------------
-// policies: expand(src pair) -> up to MAXOUT dst pairs
+// policies.  The reference's kernels CHECK a pair of the level's queue and, if it passes, append its child pairs for
+// the next level to check (bfs/traverse_single_gpu.jl:30-120): every generated pair is written to the queue, read
+// back one launch later and costs two unrelated volume fetches there.  Here a step is shifted by half a level: the
+// queues hold pairs that have already PASSED their check; a step enumerates the children of such a pair (no memory
+// access) and checks them at once — the four children of (a, b) need the volumes 2a, 2a+1, 2b, 2b+1: two adjacent
+// pairs, fetched once — and only the passing ones reach the queue (about a third).  The same pairs are checked as in
+// the reference, one launch earlier: num_checks (every generated pair, bfs/traverse_single.jl:25,48) and the
+// contact set are unchanged; queue traffic and volume fetches drop by 3 - 4 x.
+// A policy = check(pair, result) (does the pair pass at its level? `result`: what goes into the queue — the pair
+// itself, or the contact at leaf level) + children(pair, out) (the next level's pairs of a passing pair).
 // ------------------------------------------------------------------------------------------
-// _traverse_nodes_gpu! — bfs/traverse_single_gpu.jl:30-120 (same rules as traverse_single_cpu.jl:64-133)
-template <class L, class N, class I> struct SelfNodes {
+template <class I> struct Identity { // the initial queue: "children" of nothing, still to be checked
+    static constexpr int MAXOUT = 1;
+    IBVH_D int children(IndexPair<I> s, IndexPair<I> *out) const {
+        out[0] = s;
+        return 1;
+    }
+};
+
+// _traverse_nodes_gpu! — bfs/traverse_single_gpu.jl:30-120 (same rules as traverse_single_cpu.jl:64-133) — and
+// _traverse_leaves_gpu! — :153-211
+template <class L, class N, class I> struct SelfStep {
     static constexpr int MAXOUT = 4;
     TreeRef<L, N> t;
-    int self_checks;
-    IBVH_D int expand(IndexPair<I> s, IndexPair<I> *out) const {
+    int leaf;        // entries are leaf pairs
+    int self_checks; // (nodes) :44
+    int narrow;      // (leaves)
+    IBVH_D bool check(IndexPair<I> s, IndexPair<I> &res) const {
+        if (leaf) {
+            const char *r1 = t.leaf_rec(s.a), *r2 = t.leaf_rec(s.b);
+            if (!iscontact(load_vol<L>(r1), load_vol<L>(r2))) return false;
+            I i1 = load_index<I>(r1, t.lay), i2 = load_index<I>(r2, t.lay);
+            if (narrow != IBVH_NARROW_NONE) {
+                uint64_t m1 = narrow == IBVH_NARROW_MORTON_LT ? load_morton(r1, t.lay) : 0;
+                uint64_t m2 = narrow == IBVH_NARROW_MORTON_LT ? load_morton(r2, t.lay) : 0;
+                if (!narrow_eval(narrow, m1, i1, m2, i2)) return false;
+            }
+            res = i1 > i2 ? IndexPair<I>{i2, i1} : IndexPair<I>{i1, i2};
+            return true;
+        }
+        res = s;
+        return s.a == s.b || iscontact(t.node(s.a), t.node(s.b)); // (a node against itself is not tested, :52-70)
+    }
+    IBVH_D int children(IndexPair<I> s, IndexPair<I> *out) const {
         const I a = s.a, b = s.b;
         if (a == b) {
             if (t.right_child_virtual(a)) {
@@ -88,7 +124,6 @@ template <class L, class N, class I> struct SelfNodes {
             out[0] = {I(2 * a), I(2 * a + 1)};
             return 1;
         }
-        if (!iscontact(t.node(a), t.node(b))) return 0;
         // node a is left of node b, so its children are real (traverse_single_cpu.jl:103-105)
         out[0] = {I(2 * a), I(2 * b)};
         if (t.right_child_virtual(b)) {
@@ -102,127 +137,111 @@ template <class L, class N, class I> struct SelfNodes {
     }
 };
 
-// _traverse_leaves_gpu! — bfs/traverse_single_gpu.jl:153-211
-template <class L, class N, class I> struct SelfLeaves {
-    static constexpr int MAXOUT = 1;
-    TreeRef<L, N> t;
-    int narrow;
-    IBVH_D int expand(IndexPair<I> s, IndexPair<I> *out) const {
-        const char *r1 = t.leaf_rec(s.a), *r2 = t.leaf_rec(s.b);
-        if (!iscontact(load_vol<L>(r1), load_vol<L>(r2))) return 0;
-        I i1 = load_index<I>(r1, t.lay), i2 = load_index<I>(r2, t.lay);
-        if (narrow != IBVH_NARROW_NONE) {
-            uint64_t m1 = narrow == IBVH_NARROW_MORTON_LT ? load_morton(r1, t.lay) : 0;
-            uint64_t m2 = narrow == IBVH_NARROW_MORTON_LT ? load_morton(r2, t.lay) : 0;
-            if (!narrow_eval(narrow, m1, i1, m2, i2)) return 0;
-        }
-        out[0] = i1 > i2 ? IndexPair<I>{i2, i1} : IndexPair<I>{i1, i2};
-        return 1;
-    }
-};
-
 // The six pair kernels of bfs/traverse_pair_gpu.jl:34-609 in one policy: which side is at leaf level
-// (LEAF1/LEAF2) and which side descends (D1/D2).
-template <class L, class N, class I, bool LEAF1, bool LEAF2, bool D1, bool D2> struct PairStep {
-    static constexpr int MAXOUT = (D1 && D2) ? 4 : ((D1 || D2) ? 2 : 1);
+// (leaf1 / leaf2) and which side descends (d1 / d2).
+template <class L, class N, class I> struct PairStep {
+    static constexpr int MAXOUT = 4;
     TreeRef<L, N> t1, t2;
     int narrow;
-    IBVH_D int expand(IndexPair<I> s, IndexPair<I> *out) const {
+    int leaf1, leaf2, d1, d2;
+    IBVH_D bool check(IndexPair<I> s, IndexPair<I> &res) const {
         const I a = s.a, b = s.b;
-        bool hit;
-        if constexpr (LEAF1 && LEAF2) {
+        res = s;
+        if (leaf1 && leaf2) {
             // _traverse_leaves_pair_gpu! (:556-609): (leaf1.index, leaf2.index), not re-ordered
             const char *r1 = t1.leaf_rec(a), *r2 = t2.leaf_rec(b);
-            if (!iscontact(load_vol<L>(r1), load_vol<L>(r2))) return 0;
+            if (!iscontact(load_vol<L>(r1), load_vol<L>(r2))) return false;
             I i1 = load_index<I>(r1, t1.lay), i2 = load_index<I>(r2, t2.lay);
             if (narrow != IBVH_NARROW_NONE) {
                 uint64_t m1 = narrow == IBVH_NARROW_MORTON_LT ? load_morton(r1, t1.lay) : 0;
                 uint64_t m2 = narrow == IBVH_NARROW_MORTON_LT ? load_morton(r2, t2.lay) : 0;
-                if (!narrow_eval(narrow, m1, i1, m2, i2)) return 0;
+                if (!narrow_eval(narrow, m1, i1, m2, i2)) return false;
             }
-            out[0] = {i1, i2};
-            return 1;
-        } else if constexpr (LEAF1) {
-            hit = iscontact(load_vol<L>(t1.leaf_rec(a)), t2.node(b)); // iscontact(leaf1.volume, node2), :461-527
-        } else if constexpr (LEAF2) {
-            hit = iscontact(t1.node(a), load_vol<L>(t2.leaf_rec(b))); // :360-426
-        } else {
-            hit = iscontact(t1.node(a), t2.node(b));
+            res = {i1, i2};
+            return true;
         }
-        if constexpr (!(LEAF1 && LEAF2)) {
-            if (!hit) return 0;
-            if constexpr (D1 && D2) { // _traverse_nodes_pair_gpu! (:34-119)
-                const bool v1 = t1.right_child_virtual(a), v2 = t2.right_child_virtual(b);
-                out[0] = {I(2 * a), I(2 * b)};
-                if (v1) {
-                    if (v2) return 1;
-                    out[1] = {I(2 * a), I(2 * b + 1)};
-                    return 2;
-                }
-                if (v2) {
-                    out[1] = {I(2 * a + 1), I(2 * b)};
-                    return 2;
-                }
+        if (leaf1) return iscontact(load_vol<L>(t1.leaf_rec(a)), t2.node(b)); // iscontact(leaf1.volume, node2), :461-527
+        if (leaf2) return iscontact(t1.node(a), load_vol<L>(t2.leaf_rec(b))); // :360-426
+        return iscontact(t1.node(a), t2.node(b));
+    }
+    IBVH_D int children(IndexPair<I> s, IndexPair<I> *out) const {
+        const I a = s.a, b = s.b;
+        if (d1 && d2) { // _traverse_nodes_pair_gpu! (:34-119)
+            const bool v1 = t1.right_child_virtual(a), v2 = t2.right_child_virtual(b);
+            out[0] = {I(2 * a), I(2 * b)};
+            if (v1) {
+                if (v2) return 1;
                 out[1] = {I(2 * a), I(2 * b + 1)};
-                out[2] = {I(2 * a + 1), I(2 * b)};
-                out[3] = {I(2 * a + 1), I(2 * b + 1)};
-                return 4;
-            } else if constexpr (D1) { // _left_ kernels (:155-222, :360-426)
-                out[0] = {I(2 * a), b};
-                if (t1.right_child_virtual(a)) return 1;
-                out[1] = {I(2 * a + 1), b};
-                return 2;
-            } else { // _right_ kernels (:258-325, :461-527)
-                out[0] = {a, I(2 * b)};
-                if (t2.right_child_virtual(b)) return 1;
-                out[1] = {a, I(2 * b + 1)};
                 return 2;
             }
+            if (v2) {
+                out[1] = {I(2 * a + 1), I(2 * b)};
+                return 2;
+            }
+            out[1] = {I(2 * a), I(2 * b + 1)};
+            out[2] = {I(2 * a + 1), I(2 * b)};
+            out[3] = {I(2 * a + 1), I(2 * b + 1)};
+            return 4;
         }
-        return 0;
+        if (d1) { // _left_ kernels (:155-222, :360-426)
+            out[0] = {I(2 * a), b};
+            if (t1.right_child_virtual(a)) return 1;
+            out[1] = {I(2 * a + 1), b};
+            return 2;
+        }
+        // _right_ kernels (:258-325, :461-527)
+        out[0] = {a, I(2 * b)};
+        if (t2.right_child_virtual(b)) return 1;
+        out[1] = {a, I(2 * b + 1)};
+        return 2;
     }
 };
 
 // _traverse_rays_nodes_gpu! / _traverse_rays_leaves_gpu! — raytrace/breadth_first/raytrace_gpu.jl:26-179
-template <class L, class N, class I, bool LEAF> struct RayStep {
-    static constexpr int MAXOUT = LEAF ? 1 : 2;
+template <class L, class N, class I> struct RayStep {
+    static constexpr int MAXOUT = 2;
     using T = typename L::elt;
     TreeRef<L, N> t;
     const T *points, *dirs;
-    IBVH_D int expand(IndexPair<I> s, IndexPair<I> *out) const {
+    int leaf;
+    IBVH_D bool check(IndexPair<I> s, IndexPair<I> &res) const {
         const I a = s.a, iray = s.b;
         const T p[3] = {points[3 * ((int64_t)iray - 1)], points[3 * ((int64_t)iray - 1) + 1], points[3 * ((int64_t)iray - 1) + 2]};
         const T d[3] = {dirs[3 * ((int64_t)iray - 1)], dirs[3 * ((int64_t)iray - 1) + 1], dirs[3 * ((int64_t)iray - 1) + 2]};
-        if constexpr (LEAF) {
+        res = s;
+        if (leaf) {
             const char *r = t.leaf_rec(a);
-            if (!isintersection(load_vol<L>(r), p, d)) return 0;
-            out[0] = {load_index<I>(r, t.lay), iray};
-            return 1;
-        } else {
-            if (!isintersection(t.node(a), p, d)) return 0;
-            out[0] = {I(2 * a), iray};
-            if (t.right_child_virtual(a)) return 1;
-            out[1] = {I(2 * a + 1), iray};
-            return 2;
+            if (!isintersection(load_vol<L>(r), p, d)) return false;
+            res = {load_index<I>(r, t.lay), iray};
+            return true;
         }
+        return isintersection(t.node(a), p, d);
+    }
+    IBVH_D int children(IndexPair<I> s, IndexPair<I> *out) const {
+        out[0] = {I(2 * s.a), s.b};
+        if (t.right_child_virtual(s.a)) return 1;
+        out[1] = {I(2 * s.a + 1), s.b};
+        return 2;
     }
 };
 
 // ------------------------------------------------------------------------------------------
-// the level kernel: expand + wave64 ballot compaction + one global atomic per workgroup
+// the level kernel: children of the source pairs, checked at once; wave64 ballot compaction of the passing ones +
+// one global atomic per workgroup
 // ------------------------------------------------------------------------------------------
-// counters[0]      overflow flag: 0, or 1 + the index of the first step whose destination queue was too small
-// counters[1 + s]  entries in the SOURCE queue of step s (counters[1] = the initial queue; step s produces
-//                  counters[2 + s], counting on past `capacity` so that the exact need is known)
+// counters[0]          overflow flag: 0, or 1 + the index of the first step whose destination queue was too small
+// counters[1 + s]      entries in the SOURCE queue of step s (counters[1] = the initial queue; step s produces
+//                      counters[2 + s], counting on past `capacity` so that the exact need is known)
+// counters[chk + s]    pairs step s generated and checked (num_checks is their sum)
 // No host read between the levels: a step takes its source count from the device word the previous step
 // accumulated, so the grid is a fixed number of workgroups that stride over the source queue; once a step has
 // overflowed, the later steps (already enqueued) return at once and the caller resumes from that step with larger
 // queues (the source queue of the overflowed step is intact).
-template <class I, class Policy>
+template <class I, class PolA, class PolB>
 __global__ __launch_bounds__(TPB) void level_kernel(const IndexPair<I> *__restrict__ src, IndexPair<I> *__restrict__ dst,
-                                                    int64_t capacity, unsigned long long *__restrict__ counters, int step,
-                                                    Policy pol) {
-    constexpr int MAXOUT = Policy::MAXOUT;
+                                                    int64_t capacity, unsigned long long *__restrict__ counters, int step, int chk,
+                                                    PolA pa, PolB pb) {
+    constexpr int MAXOUT = PolA::MAXOUT;
     __shared__ IndexPair<I> staged[MAXOUT * TPB];
     __shared__ int wave_tot[TPB / 64];
     __shared__ unsigned long long s_base;
@@ -231,11 +250,18 @@ __global__ __launch_bounds__(TPB) void level_kernel(const IndexPair<I> *__restri
     const int64_t num_src = (int64_t)counters[1 + step];
     if (num_src > capacity) return;   // (defensive: the flag covers this)
     const uint64_t lt = ((uint64_t)1 << lane) - 1;
+    unsigned long long generated = 0;
     for (int64_t chunk = blockIdx.x; chunk * TPB < num_src; chunk += gridDim.x) {
         const int64_t i = chunk * TPB + threadIdx.x;
-        IndexPair<I> out[MAXOUT];
-        int k = 0;
-        if (i < num_src) k = pol.expand(src[i], out);
+        IndexPair<I> kids[MAXOUT], out[MAXOUT];
+        int nk = 0, k = 0;
+        if (i < num_src) nk = pa.children(src[i], kids);
+        generated += (unsigned long long)nk;
+#pragma unroll
+        for (int j = 0; j < MAXOUT; ++j) {
+            IndexPair<I> r;
+            if (j < nk && pb.check(kids[j], r)) out[k++] = r;
+        }
 
         // exclusive offset inside the wave from ballots over the bit planes of k (k <= 4)
         uint64_t b0 = __ballot(k & 1), b1 = __ballot(k & 2), b2 = __ballot(k & 4);
@@ -266,6 +292,10 @@ __global__ __launch_bounds__(TPB) void level_kernel(const IndexPair<I> *__restri
         }
         lds_barrier(); // staged / wave_tot / s_base are reused by the next chunk (LDS only: the stores above stay in flight)
     }
+    // pairs checked by this workgroup
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) generated += __shfl_xor(generated, o, 64);
+    if (lane == 0 && generated != 0ull) atomicAdd(&counters[chk + step], generated);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -310,6 +340,7 @@ struct Run {
     unsigned long long *counters;
     int64_t capacity;
     int64_t total_levels;
+    int chk = 0;           // index of the first per-step check counter
     int step = 0;          // index of the next step
     int first = 0;         // steps below `first` were completed by an earlier call (resume): they are not launched
     bool swapped = false;  // false: step `step` reads q[0]
@@ -327,10 +358,10 @@ inline int level_grid() {
     return g;
 }
 
-template <class I, class Policy> int step(Run &r, const Policy &pol) {
+template <class I, class PolA, class PolB> int step(Run &r, const PolA &pa, const PolB &pb) {
     if (r.step >= r.first) {
-        IBVH_LAUNCH((level_kernel<I, Policy>), dim3(level_grid()), dim3(TPB), 0, r.st, (const IndexPair<I> *)r.src(),
-                    (IndexPair<I> *)r.dst(), r.capacity, r.counters, r.step, pol);
+        IBVH_LAUNCH((level_kernel<I, PolA, PolB>), dim3(level_grid()), dim3(TPB), 0, r.st, (const IndexPair<I> *)r.src(),
+                    (IndexPair<I> *)r.dst(), r.capacity, r.counters, r.step, r.chk, pa, pb);
         IBVH_LAUNCH_CHECK();
     }
     r.step += 1;
@@ -338,7 +369,8 @@ template <class I, class Policy> int step(Run &r, const Policy &pol) {
     return IBVH_OK;
 }
 
-inline size_t counters_bytes(int64_t total_levels) { return (size_t)(total_levels + 8) * 8; }
+// flag + per-step queue counts, then per-step check counts
+inline size_t counters_bytes(int64_t total_levels) { return (size_t)(total_levels + 8) * 8 * 2; }
 
 // fresh run: counters zeroed, counters[1] = initial queue size.  Resume (res->resume_step > 0): the queue the
 // overflowed step reads — res->contacts_in says which buffer — still holds res->resume_num entries; the flag and
@@ -351,12 +383,16 @@ inline int begin(Run &r, void *bvtt1, void *bvtt2, int64_t capacity, void *count
     r.total_levels = total_levels;
     r.q[0] = bvtt1;
     r.q[1] = bvtt2;
+    r.chk = (int)(total_levels + 8);
     if (res->resume_step > 0) {
         if (res->resume_step > total_levels + 4) return IBVH_ERR_INVALID_ARG;
         r.first = (int)res->resume_step;
+        const size_t half = (size_t)(total_levels + 8) * 8;
         const size_t keep = (size_t)(2 + r.first) * 8; // flag + counts of the sources of steps 0 .. first
         IBVH_HIP_CHECK(hipMemsetAsync(counters, 0, 8, st));
-        IBVH_HIP_CHECK(hipMemsetAsync((char *)counters + keep, 0, counters_bytes(total_levels) - keep, st));
+        IBVH_HIP_CHECK(hipMemsetAsync((char *)counters + keep, 0, half - keep, st));
+        // the checks of steps 0 .. first - 1 stay; step `first` runs again from the start
+        IBVH_HIP_CHECK(hipMemsetAsync((char *)counters + half + (size_t)r.first * 8, 0, half - (size_t)r.first * 8, st));
         return IBVH_OK;
     }
     IBVH_HIP_CHECK(hipMemsetAsync(counters, 0, counters_bytes(total_levels), st));
@@ -367,10 +403,10 @@ inline int begin(Run &r, void *bvtt1, void *bvtt2, int64_t capacity, void *count
 
 // the one blocking read: flag + all counts
 inline int finish(const Run &r, ibvh_bfs_result *res) {
-    unsigned long long host[80];
+    unsigned long long host[160];
     const int nsteps = r.step;
-    if (nsteps + 2 > 80) return IBVH_ERR_INVALID_ARG;
-    IBVH_HIP_CHECK(hipMemcpyAsync(host, r.counters, (size_t)(nsteps + 2) * 8, hipMemcpyDeviceToHost, r.st));
+    if (nsteps + 2 > 80 || r.chk + nsteps > 160) return IBVH_ERR_INVALID_ARG;
+    IBVH_HIP_CHECK(hipMemcpyAsync(host, r.counters, (size_t)(r.chk + nsteps) * 8, hipMemcpyDeviceToHost, r.st));
     IBVH_HIP_CHECK(hipStreamSynchronize(r.st));
     const unsigned long long flag = host[0];
     if (flag != 0ull) {
@@ -385,10 +421,11 @@ inline int finish(const Run &r, ibvh_bfs_result *res) {
         res->resume_num = (int64_t)host[1 + s];
         return IBVH_ERR_CAPACITY;
     }
-    // num_checks (bfs/traverse_single.jl:25,48, traverse_pair.jl:146-150): every entry of every SOURCE queue is one
-    // check — the initial queue plus each node-level result; the result of the last (leaf) step is the contact list
+    // num_checks (bfs/traverse_single.jl:25,48, traverse_pair.jl:146-150): every entry of every queue of the reference
+    // is one check — the initial queue plus each node-level result, i.e. every pair a step here generated and checked;
+    // what passes the last (leaf) step is the contact list
     int64_t checks = 0;
-    for (int s = 0; s < nsteps; ++s) checks += (int64_t)host[1 + s];
+    for (int s = 0; s < nsteps; ++s) checks += (int64_t)host[r.chk + s];
     res->num_contacts = (int64_t)host[1 + nsteps];
     res->num_checks = checks;
     res->contacts_in = r.swapped ? 2 : 1;
@@ -432,12 +469,12 @@ int run_self(const ibvh_bvh &b, int64_t start_level, int narrow, void *bvtt1, vo
     if (r.first == 0 && total0 > 0)
         IBVH_LAUNCH((fill_self_kernel<I>), dim3((unsigned)ceil_div(total0, TPB)), dim3(TPB), 0, st, (IndexPair<I> *)bvtt1,
                            n0, int64_t(1) << (start_level - 1), start_level != levels ? 1 : 0, total0);
-    for (int64_t level = start_level; level < levels; ++level) {
-        SelfNodes<L, N, I> pol{make_ref<L, N>(b, dl, level), level < levels - 1 ? 1 : 0}; // self_checks (:44)
-        if (int e = step<I>(r, pol)) return e;
-    }
-    SelfLeaves<L, N, I> leaves{make_ref<L, N>(b, dl, levels), narrow};
-    if (int e = step<I>(r, leaves)) return e;
+    auto at = [&](int64_t level) {
+        return SelfStep<L, N, I>{make_ref<L, N>(b, dl, level), level == levels ? 1 : 0, level < levels - 1 ? 1 : 0 /* self_checks (:44) */, narrow};
+    };
+    if (int e = step<I>(r, Identity<I>{}, at(start_level))) return e; // the initial queue is checked ...
+    for (int64_t level = start_level; level < levels; ++level)       // ... then children of what passed, level by level
+        if (int e = step<I>(r, at(level), at(level + 1))) return e;
     return finish(r, res);
 }
 
@@ -456,42 +493,47 @@ int run_pair(const ibvh_bvh &b1, const ibvh_bvh &b2, int64_t sl1, int64_t sl2, i
     if (r.first == 0)
         IBVH_LAUNCH((fill_product_kernel<I>), dim3((unsigned)ceil_div(total0, TPB)), dim3(TPB), 0, st, (IndexPair<I> *)bvtt1,
                            nr1, nr2, int64_t(1) << (sl1 - 1), int64_t(1) << (sl2 - 1));
+    // the six-phase descent of bfs/traverse_pair.jl:50-143 as a list of (levels, which side is a leaf, which descends)
+    PairStep<L, N, I> seq[132];
+    int ns = 0;
     int64_t l1 = sl1, l2 = sl2;
-    int rc = IBVH_OK;
-    auto do_step = [&](auto pol) {
-        pol.t1 = make_ref<L, N>(b1, dl, l1);
-        pol.t2 = make_ref<L, N>(b2, dl, l2);
-        pol.narrow = narrow;
-        rc = step<I>(r, pol);
-        return rc == IBVH_OK;
+    auto add = [&](bool leaf1, bool leaf2, bool d1, bool d2) {
+        PairStep<L, N, I> p;
+        p.t1 = make_ref<L, N>(b1, dl, l1);
+        p.t2 = make_ref<L, N>(b2, dl, l2);
+        p.narrow = narrow;
+        p.leaf1 = leaf1, p.leaf2 = leaf2, p.d1 = d1, p.d2 = d2;
+        seq[ns++] = p;
     };
-    // the six-phase descent of bfs/traverse_pair.jl:50-143
     while (l1 < L1 - 1 && l2 < L2 - 1) {
-        if (!do_step(PairStep<L, N, I, false, false, true, true>{})) return rc;
+        add(false, false, true, true);
         ++l1, ++l2;
     }
     while (l1 < L1 - 1 && l2 == L2 - 1) {
-        if (!do_step(PairStep<L, N, I, false, false, true, false>{})) return rc;
+        add(false, false, true, false);
         ++l1;
     }
     while (l2 < L2 - 1 && l1 == L1 - 1) {
-        if (!do_step(PairStep<L, N, I, false, false, false, true>{})) return rc;
+        add(false, false, false, true);
         ++l2;
     }
     while (l2 == L2 && l1 < L1) {
-        if (!do_step(PairStep<L, N, I, false, true, true, false>{})) return rc;
+        add(false, true, true, false);
         ++l1;
     }
     while (l1 == L1 && l2 < L2) {
-        if (!do_step(PairStep<L, N, I, true, false, false, true>{})) return rc;
+        add(true, false, false, true);
         ++l2;
     }
     if (l1 == L1 - 1 && l2 == L2 - 1) {
-        if (!do_step(PairStep<L, N, I, false, false, true, true>{})) return rc;
+        add(false, false, true, true);
         ++l1, ++l2;
     }
-    // leaf-leaf: its result is the contact list (num_checks is not incremented after it, bfs/traverse_pair.jl:146-150)
-    if (!do_step(PairStep<L, N, I, true, true, false, false>{})) return rc;
+    // leaf-leaf: what passes is the contact list (num_checks is not incremented after it, bfs/traverse_pair.jl:146-150)
+    add(true, true, false, false);
+    if (int e = step<I>(r, Identity<I>{}, seq[0])) return e;
+    for (int i = 0; i + 1 < ns; ++i)
+        if (int e = step<I>(r, seq[i], seq[i + 1])) return e;
     return finish(r, res);
 }
 
@@ -511,12 +553,12 @@ int run_rays(const ibvh_bvh &b, const void *points, const void *dirs, int64_t nu
     if (r.first == 0)
         IBVH_LAUNCH((fill_product_kernel<I>), dim3((unsigned)ceil_div(total0, TPB)), dim3(TPB), 0, st, (IndexPair<I> *)bvtt1, nr,
                            num_rays, int64_t(1) << (start_level - 1), int64_t(1));
-    for (int64_t level = start_level; level < levels; ++level) {
-        RayStep<L, N, I, false> pol{make_ref<L, N>(b, dl, level), (const T *)points, (const T *)dirs};
-        if (int e = step<I>(r, pol)) return e;
-    }
-    RayStep<L, N, I, true> leaves{make_ref<L, N>(b, dl, levels), (const T *)points, (const T *)dirs};
-    if (int e = step<I>(r, leaves)) return e;
+    auto at = [&](int64_t level) {
+        return RayStep<L, N, I>{make_ref<L, N>(b, dl, level), (const T *)points, (const T *)dirs, level == levels ? 1 : 0};
+    };
+    if (int e = step<I>(r, Identity<I>{}, at(start_level))) return e;
+    for (int64_t level = start_level; level < levels; ++level)
+        if (int e = step<I>(r, at(level), at(level + 1))) return e;
     return finish(r, res);
 }
 

@@ -305,7 +305,9 @@ ibvh_status ibvh_bfs_counters_bytes(int64_t total_levels, size_t *bytes_out);
 
 /* traverse(bvh, BFSTraversal()) — bfs/traverse_single.jl:1-61.  bvtt1/bvtt2: two queues of
  * `capacity` IndexPair{I} each (cache1/cache2).  counters: DEVICE scratch of
- * ibvh_bfs_counters_bytes() bytes (overflow flag + one count per level).  All levels are enqueued back to back — a
+ * ibvh_bfs_counters_bytes() bytes (overflow flag + a queue count and a check count per level).  A queue holds pairs
+ * that have already passed their check: a step enumerates their children and checks them at once (the same checks as the
+ * reference's, one launch earlier; num_checks is unchanged).  All levels are enqueued back to back — a
  * level takes its queue length from the device word the previous level accumulated — and the stream is synchronised
  * ONCE, at the end (the reference reads one count per level, bfs/traverse_single_gpu.jl:24).  On IBVH_ERR_CAPACITY
  * grow both queues to result->required_capacity and call again with the same `result` (see ibvh_bfs_result: the
