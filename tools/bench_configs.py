@@ -62,8 +62,18 @@ def bfs2():
 ms_warm, _ = timed(build2, 10)
 ms_lvt, t_lvt = timed(lvt2, 10)
 ms_bfs2, t_bfs = timed(bfs2, 5)
+# the same traversal without cache=: queues allocated at 4x the initial pair count, grown and RESUMED where they overflow
+torch.cuda.synchronize()
+_t0 = time.perf_counter()
+for _ in range(3):
+    _c = ibvh.traverse(s2["bvh"], ibvh.BFSTraversal())
+    _c.num_contacts
+torch.cuda.synchronize()
+ms_bfs_cold = (time.perf_counter() - _t0) / 3 * 1e3
+del _c
 out["config2"] = {"leaves": n2, "build_cold_ms": round(ms_cold, 3), "build_cache_ms": round(ms_warm, 3),
-                  "traverse_lvt_ms": round(ms_lvt, 3), "traverse_bfs_ms": round(ms_bfs2, 3), "contacts": t_lvt.num_contacts,
+                  "traverse_lvt_ms": round(ms_lvt, 3), "traverse_bfs_ms": round(ms_bfs2, 3), "traverse_bfs_no_cache_ms": round(ms_bfs_cold, 3),
+                  "contacts": t_lvt.num_contacts,
                   "bfs_contacts": t_bfs.num_contacts, "bfs_checks": t_bfs.num_checks,
                   "Mcontacts_per_s_lvt": round(t_lvt.num_contacts / ms_lvt / 1e3, 1),
                   "Mcontacts_per_s_bfs": round(t_bfs.num_contacts / ms_bfs2 / 1e3, 1)}
