@@ -695,7 +695,7 @@ def _traverse_lvt_pair(bvh1, bvh2, sl1, sl2, narrow, cache):
 
 
 BFS_INITIAL_FACTOR = 4  # queues start at 4x the initial pair count (bfs/traverse_single.jl:73)
-BFS_GROWTH = 2          # and at least double when a level does not fit
+BFS_GROWTH = 4          # and grow at least 4x when a level does not fit (deeper levels need more still: 2x cost twice the resumes)
 
 
 def _bfs_run(entry, types, initial_capacity, cache, levels_hint, *args):

@@ -410,7 +410,7 @@ function bfs_run(::Type{I}, like, initial_pairs, total_levels, cache, run, what)
         if st == IBVH_ERR_CAPACITY                          # the reference's resize! (bfs/traverse_single.jl:40)
             # resize! keeps the contents: the queue res.contacts_in still holds the res.resume_num pairs of the level
             # that overflowed, and the next call (same `res`, same counters) resumes there instead of starting over
-            newcap = max(res.required_capacity, 2 * min(length(bvtt1), length(bvtt2)))
+            newcap = max(res.required_capacity, 4 * min(length(bvtt1), length(bvtt2)))   # (deeper levels need more still)
             resize!(bvtt1, newcap); resize!(bvtt2, newcap)
             continue
         end
