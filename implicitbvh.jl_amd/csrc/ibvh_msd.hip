@@ -504,7 +504,7 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
     constexpr int W = TPB / 64;
     constexpr int TILE = TPB * IPT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int radix = 1 << bits;                             // table size (level 2: always 2^L2_BITS columns)
+    const int radix = 1 << bits;                             // table size (extra levels: always 2^L2_BITS columns)
     uint32_t mask = ((uint32_t)1 << digit_bits) - 1u;      // the digit itself may be narrower (few key bits left)
     uint64_t *__restrict__ dst = (uint64_t *)rec.dst;
     // layout: local_base[radix] | delta[radix] | wave_tot[32] | { whist[W * radix] (u16), later stage[TILE records] }
@@ -1159,9 +1159,10 @@ static int launch_finish(const Plan &p, const FinishArgs &fa, hipStream_t st) {
 }
 
 // keys: n Morton keys (uint32 / uint64) in source order, their top-digit tile histogram already in p.tb.tile_hist.
-// ra: source -> level-1 partitioned records (ra.dst: n records of scratch); part2: n more records of scratch for the
-// level-2 partition; out: the sorted records.  (kalt, valt, kpri, vpri): n-entry scratch arrays of the slow path
-// (kpri may alias `keys`: the keys are dead once the partition has run).
+// ra: source -> level-1 partitioned records (ra.dst: n records of scratch); part2: n more records of scratch (the
+// extra levels ping-pong between the two); out: the sorted records.  (kalt, valt, kpri, vpri): n-entry scratch arrays:
+// kalt / kpri carry the compact key copies of the extra levels, then all four serve the slow path (kpri may alias
+// `keys`: the source keys are dead once the first partition has run).  levels: extra partition levels to launch.
 int sort_records(const Plan &p, int key_bytes, const void *keys, int64_t n, const RecordArgs &ra, char *part2, char *out, void *kalt,
                  uint32_t *valt, void *kpri, uint32_t *vpri, int levels, void *skew_flag, hipStream_t st) {
     if (levels < 0 || levels > MAX_LEVELS) levels = MAX_LEVELS;
