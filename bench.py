@@ -141,8 +141,10 @@ def self_launch(n_ranks):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # (defaults: long enough for the GPU's clocks to settle — a 6 ms burst of 20 steps measures 4 % slower than the
+    # steady state — and still a fraction of a second)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--n", type=int, default=0,
                     help="leaves per GPU (default: 1e6 at one GPU = BASELINE.json configs[1]; 12.5e6 at N > 1 = configs[4], "
                          "1e8 leaves over 8 GPUs)")
