@@ -210,3 +210,15 @@ def test_skewed_ten_million_leaf_builds_properties(shape):
     b2 = ibvh.BVH(v, cache=b)  # (reuses the buffers; launches as many levels as the first build reported, plus one)
     torch.cuda.synchronize()
     assert b2.leaves.to_numpy().tobytes() == leaves.tobytes()
+
+
+@pytest.mark.parametrize("n", [12_500_000, 13_500_000])
+def test_build_properties_where_the_sort_changes_geometry(n):
+    """config 5's per-GPU size (the 8,192-record finish workgroup at 75 % average fill) and the first size sorted with
+    4,096 cells: the same size-independent checks as at the north-star size."""
+    r0 = 0.5 * (3 * 8 / (4 * np.pi * n)) ** (1 / 3)
+    vols = ibvh.generate_spheres(n, 7, r0=r0)
+    g = ibvh.BVH(vols)
+    torch.cuda.synchronize()
+    assert int(g._skew[0]) == 0  # a uniform cloud crowds no cell of either geometry
+    check_build_properties(vols, g)
