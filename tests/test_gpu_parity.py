@@ -281,6 +281,20 @@ def test_build_every_sort_route_at_every_partition_depth(shape):
                 assert used == 1                       # no extra level ran: all it can know is that one is needed
 
 
+@pytest.mark.parametrize("levels", [-1, 99])
+def test_build_accepts_any_sort_levels_value(levels, monkeypatch):
+    """ibvh_build_desc.sort_levels outside 0 .. IBVH_MAX_SORT_LEVELS means "all of them" (include/ibvh.h)."""
+    from implicitbvh_amd import api
+    monkeypatch.setattr(api, "COLD_SORT_LEVELS", levels)
+    rng = np.random.default_rng(5)
+    c = rng.random((3, 3))[rng.integers(0, 3, 60_000)] + rng.normal(0, 1e-3, (60_000, 3))
+    vols = np.concatenate([c, 1e-4 * np.ones((60_000, 1))], axis=1).astype(np.float32)
+    o, g = build_both(vols, abi.make_types())
+    assert_bvh_equal(o, g)
+    torch.cuda.synchronize()
+    assert 1 <= int(g._skew[0]) <= abi.MAX_SORT_LEVELS
+
+
 def test_extrema_and_keys_entry_points():
     rng = np.random.default_rng(12)
     for kind, flt in ((abi.BSPHERE, abi.F32), (abi.BBOX, abi.F64)):
