@@ -8,12 +8,15 @@ import ctypes as C
 
 import numpy as np
 
+ABI_VERSION = 3  # IBVH_ABI_VERSION of the include/ibvh.h this mirror was written against
+
 # enums ---------------------------------------------------------------------------------------
 BSPHERE, BBOX = 0, 1
 F32, F64 = 0, 1
 I32, I64 = 0, 1
 U16, U32, U64 = 0, 1, 2
-NARROW_NONE, NARROW_MORTON_LT, NARROW_INDEX_LT = 0, 1, 2
+NARROW_NONE, NARROW_MORTON_LT, NARROW_INDEX_LT, NARROW_RAY_ORIGIN_OUTSIDE = 0, 1, 2, 3
+NARROW_MASK, OUTPUT_POSITIONS = 0xff, 0x100  # IBVH_NARROW_MASK, IBVH_OUTPUT_POSITIONS
 
 OK, ERR_INVALID_ARG, ERR_DOMAIN, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_OVERFLOW, ERR_HIP, ERR_SCRATCH = range(8)
 

@@ -29,11 +29,12 @@ __all__ = [
     "load_obj_triangles", "BSphere", "BBox", "BoundingVolumes", "BVHOptions", "DefaultMortonAlgorithm", "ImplicitTree", "BVH",
     "BVHTraversal", "LVTTraversal", "BFSTraversal", "traverse", "traverse_rays", "default_start_level",
     "memory_index", "level_indices", "isvirtual", "bounding_volumes_from_triangles", "generate_spheres",
-    "NARROW_MORTON_LT", "NARROW_INDEX_LT",
+    "NARROW_MORTON_LT", "NARROW_INDEX_LT", "NARROW_RAY_ORIGIN_OUTSIDE", "LeafBatch", "lvt_work_counters",
 ]
 
 NARROW_MORTON_LT = abi.NARROW_MORTON_LT
 NARROW_INDEX_LT = abi.NARROW_INDEX_LT
+NARROW_RAY_ORIGIN_OUTSIDE = abi.NARROW_RAY_ORIGIN_OUTSIDE
 
 
 def _torch():
@@ -267,6 +268,14 @@ class BoundingVolumes:
         m = self.to_numpy()["morton"].astype(np.int64)
         return torch.from_numpy(m)
 
+    @property
+    def morton_device(self):
+        """Morton codes as an int64 DEVICE tensor (a strided view widened on the fly; same value convention as .morton)."""
+        torch = _torch()
+        mb = {abi.U16: (torch.int16, 0xffff), abi.U32: (torch.int32, 0xffffffff), abi.U64: (torch.int64, None)}[self.types.morton_type]
+        m = self._strided(mb[0], self.layout.morton_off, 1)[:, 0].to(torch.int64)
+        return m if mb[1] is None else m & mb[1]
+
     def to_numpy(self):
         """Host copy as a numpy structured array (volume, index, morton)."""
         dt = abi.leaf_dtype(self.types)
@@ -280,6 +289,78 @@ def _volume_kind(volumes):
     if not volumes.is_cuda:
         raise ValueError("bounding volumes must live on the GPU (device='cuda')")
     return (abi.BSPHERE if volumes.shape[1] == 4 else abi.BBOX), _float_code(volumes.dtype)
+
+
+# ---------------------------------------------------------------------------------------------
+# words the GPU writes for the host (traversal totals, skew hints)
+# ---------------------------------------------------------------------------------------------
+class _HostWords:
+    """ONE block of mapped pinned host memory for the whole process, allocated once and never freed, handed out word by
+    word, round robin.  The GPU writes into it (the total of an enqueued traversal: `total_host` of include/ibvh.h; the
+    skew hint of a build: `skew_flag`) and the host reads it WITHOUT a stream synchronisation or a device-to-host copy.
+    Because the block is never returned to torch's caching host allocator, a kernel still in flight when its BVH /
+    traversal object dies can only ever write into memory this module owns.  A word is recycled after SLOTS later
+    requests; a reader holding an older generation of the slot is told so instead of being given another call's value."""
+    SLOTS = 8192       # totals: [0, SLOTS)
+    HINT_SLOTS = 1024  # skew hints: [SLOTS, SLOTS + HINT_SLOTS) — a ring of their own, so that a build still in flight
+    #                    can at worst overwrite another chain's HINT (speed only), never a traversal's total
+    PENDING = -(1 << 62)  # what the host stores before the launch; the GPU overwrites it
+
+    def __init__(self):
+        torch = _torch()
+        self.tensor = torch.zeros(self.SLOTS + self.HINT_SLOTS, dtype=torch.int64).pin_memory()
+        self.words = self.tensor.numpy()  # the same memory
+        self.base = self.tensor.data_ptr()
+        self.generation = [0] * (self.SLOTS + self.HINT_SLOTS)
+        self.next = 0
+        self.next_hint = 0
+        import threading
+        self.lock = threading.Lock()
+
+    def take(self, initial, hint=False):
+        with self.lock:
+            if hint:
+                slot = self.SLOTS + self.next_hint
+                self.next_hint = (self.next_hint + 1) % self.HINT_SLOTS
+            else:
+                slot = self.next
+                self.next = (self.next + 1) % self.SLOTS
+            self.generation[slot] += 1
+            gen = self.generation[slot]
+        self.words[slot] = initial
+        return slot, gen
+
+    def ptr(self, slot):
+        return self.base + 8 * slot
+
+
+class _HintWord:
+    """A build chain's skew hint: one word of the _HostWords hint ring; word[0] reads / writes the value."""
+
+    def __init__(self, initial):
+        self.slot, self.gen = _host_words().take(initial, hint=True)
+
+    def valid(self):
+        return _host_words().generation[self.slot] == self.gen
+
+    def ptr(self):
+        return _host_words().ptr(self.slot)
+
+    def __getitem__(self, i):
+        return int(_host_words().words[self.slot]) & 0xffffffff  # (the GPU writes the low 4 bytes)
+
+    def __setitem__(self, i, v):
+        _host_words().words[self.slot] = int(v)
+
+
+_host_words_singleton = None
+
+
+def _host_words():
+    global _host_words_singleton
+    if _host_words_singleton is None:
+        _host_words_singleton = _HostWords()
+    return _host_words_singleton
 
 
 # ---------------------------------------------------------------------------------------------
@@ -379,8 +460,10 @@ class BVH:
         # after a uniform cloud).  The GPU leaves that number in a pinned host word (mapped into the device's address
         # space), which is read here WITHOUT synchronising: the latest value that has arrived is good enough for a
         # hint (include/ibvh.h, ibvh_build_desc.sort_levels / skew_flag).
-        self._skew = cache._skew if cache is not None and getattr(cache, "_skew", None) is not None else \
-            torch.full((1,), COLD_SORT_LEVELS, dtype=torch.int32).pin_memory()
+        if cache is not None and getattr(cache, "_skew", None) is not None and cache._skew.valid():
+            self._skew = cache._skew  # the chain's hint word
+        else:
+            self._skew = _HintWord(COLD_SORT_LEVELS)
         d = abi.BuildDesc()
         d.types = types
         d.n = n
@@ -391,9 +474,12 @@ class BVH:
         if not alg.compute_extrema:
             d.mins[:] = [float(v) for v in alg.mins]
             d.maxs[:] = [float(v) for v in alg.maxs]
-        used = int(self._skew[0])
-        d.sort_levels = COLD_SORT_LEVELS if cache is None else (min(used + 1, abi.MAX_SORT_LEVELS) if used > 0 else 0)
-        d.skew_flag = self._skew.data_ptr()
+        used = self._skew[0]
+        # at least ONE extra level also after a uniform cloud: if the next input is clustered (or the cache is reused for
+        # another scene) that level splits every crowded cell 256 ways before anything reaches the one-workgroup slow
+        # path — a handful of near-empty launches per step against a ~100x latency spike on the step where the input changes
+        d.sort_levels = COLD_SORT_LEVELS if cache is None else min(used + 1, abi.MAX_SORT_LEVELS)
+        d.skew_flag = self._skew.ptr()
         lib.call("ibvh_build", C.byref(d), vol_ptr, _ptr(self.leaves.buf), _ptr(self.nodes), _ptr(self.skips),
                  _ptr(self.extrema), _ptr(self._scratch), self._scratch.numel(), _stream())
 
@@ -503,14 +589,64 @@ class BVHTraversal:
         return self._cache1
 
 
-def _narrow_code(narrow):
+class LeafBatch:
+    """What a `narrow` callable sees for one side of m candidate pairs, as tensors on the GPU: .volume (m, 4|6),
+    .index (m,), .morton (m,) int64 — the fields of the reference's BoundingVolume (bounding_volumes.jl:55-59), batched."""
+
+    def __init__(self, bvh, positions):
+        rows = positions.long() - 1
+        self.volume = bvh.leaves.volume[rows]
+        self.index = bvh.leaves.index[rows]
+        self.morton = bvh.leaves.morton_device[rows]
+
+    def __len__(self):
+        return int(self.index.shape[0])
+
+
+def _narrow_code(narrow, rays=False):
+    """-> (code for the C ABI, callable or None).  The reference takes any closure (traverse.jl:213, raytrace.jl:76) and
+    only ever evaluates it as `iscontact(...) && narrow(...)` at leaf level, i.e. as a post-filter.  Menu entries run on
+    the device; any other callable — VECTORISED: narrow(a: LeafBatch, b: LeafBatch) -> bool tensor, for rays
+    narrow(bv: LeafBatch, points (m, 3), directions (m, 3)) — is applied by this mirror to the candidate list the device
+    returns as leaf positions (IBVH_OUTPUT_POSITIONS, include/ibvh.h)."""
     if narrow is None:
-        return abi.NARROW_NONE
-    if narrow in (abi.NARROW_MORTON_LT, abi.NARROW_INDEX_LT, abi.NARROW_NONE):
-        return int(narrow)
-    raise NotImplementedError(
-        "arbitrary `narrow` closures cannot cross the C ABI; use NARROW_MORTON_LT / NARROW_INDEX_LT, or filter "
-        "traversal.contacts afterwards (narrow is only ever evaluated as iscontact(...) && narrow(...))")
+        return abi.NARROW_NONE, None
+    menu = (abi.NARROW_NONE, abi.NARROW_RAY_ORIGIN_OUTSIDE) if rays else (abi.NARROW_NONE, abi.NARROW_MORTON_LT, abi.NARROW_INDEX_LT)
+    if isinstance(narrow, (int, np.integer)) and not isinstance(narrow, bool):
+        if int(narrow) in menu:
+            return int(narrow), None
+        raise ValueError(f"narrow = {narrow} is not on the {'ray' if rays else 'pair'} menu of include/ibvh.h")
+    if callable(narrow):
+        return abi.OUTPUT_POSITIONS, narrow
+    raise TypeError("narrow must be None, a menu constant (NARROW_*) or a vectorised callable")
+
+
+def _post_filter(trav, narrow, bvh1, bvh2=None, rays=None):
+    """Apply a callable `narrow` to a traversal whose contact list holds leaf POSITIONS; returns the traversal with the
+    surviving contacts as user indices, order preserved (so LVT results keep the reference's order)."""
+    torch = _torch()
+    pos = trav.contacts
+    if pos.shape[0] == 0:
+        keep = torch.zeros(0, dtype=torch.bool, device=pos.device)
+    if rays is not None:
+        p, d = rays  # (N, 3) row-major
+        a = LeafBatch(bvh1, pos[:, 0])
+        r = pos[:, 1].long() - 1
+        keep = narrow(a, p[r], d[r]) if pos.shape[0] else keep
+        out = torch.stack([a.index, pos[:, 1]], dim=1)
+    else:
+        a = LeafBatch(bvh1, pos[:, 0])
+        b = LeafBatch(bvh2 if bvh2 is not None else bvh1, pos[:, 1])
+        keep = narrow(a, b) if pos.shape[0] else keep
+        if bvh2 is None:  # (min, max) of the user indices, traverse_single.jl:176-180
+            out = torch.stack([torch.minimum(a.index, b.index), torch.maximum(a.index, b.index)], dim=1)
+        else:
+            out = torch.stack([a.index, b.index], dim=1)
+    keep = torch.as_tensor(keep, device=pos.device).to(torch.bool).reshape(-1)
+    if keep.shape[0] != pos.shape[0]:
+        raise ValueError("narrow must return one bool per candidate pair")
+    contacts = out[keep].to(pos.dtype).contiguous()
+    return BVHTraversal(trav.start_level1, trav.start_level2, trav.num_checks, int(contacts.shape[0]), contacts, trav.cache2)
 
 
 def _cache_tensor(cache_t, need_rows, cols, dtype, what):
@@ -571,15 +707,20 @@ class _LvtScratch:
         return self.buf.numel()
 
     def next_total(self):
-        """(device pointer of this call's total word, handle to read it later)"""
+        """(device pointer of this call's total word, pinned host pointer of its mirror, handle to read it later)"""
         slot = self.calls % self.SLOTS
         self.calls += 1
-        return C.c_void_p(self.totals.data_ptr() + 8 * slot), _PendingTotal(self, slot, self.calls)
+        hw = _host_words()
+        hslot, hgen = hw.take(_HostWords.PENDING)
+        return C.c_void_p(self.totals.data_ptr() + 8 * slot), C.c_void_p(hw.ptr(hslot)), _PendingTotal(self, slot, self.calls, hslot, hgen)
 
 
 class _PendingTotal:
-    def __init__(self, owner, slot, calls):
+    SPIN = 2_000_000  # polls of the pinned word before falling back to the event + device read (seconds of spinning)
+
+    def __init__(self, owner, slot, calls, hslot, hgen):
         self.owner, self.slot, self.calls = owner, slot, calls
+        self.hslot, self.hgen = hslot, hgen
         self.event = None
 
     def launched(self):
@@ -592,6 +733,16 @@ class _PendingTotal:
         if self.owner.calls - self.calls >= self.owner.SLOTS:
             raise RuntimeError("this traversal's contact count was never read and its slot in the totals ring has been "
                                f"recycled by {self.owner.SLOTS} later traversals on the same cache")
+        # The scan kernel stores the total into the pinned word as well (total_host): poll it — no stream
+        # synchronisation, no device-to-host copy (the reference's blocking `@allowscalar` read costs both,
+        # lvt/traverse_single.jl:60).
+        hw = _host_words()
+        if hw.generation[self.hslot] == self.hgen:
+            words, k = hw.words, self.hslot
+            for _ in range(self.SPIN):
+                v = int(words[k])
+                if v != _HostWords.PENDING:
+                    return v
         if self.event is not None:
             self.event.synchronize()
         return int(self.owner.totals[self.slot].item())
@@ -637,9 +788,9 @@ def _traverse_lvt_single(bvh, start_level, narrow, cache):
     s = bvh.struct()
     spec = _speculative_buffer(cache, idt)
     if spec is not None:
-        tdev, pending = scratch.next_total()
+        tdev, thost, pending = scratch.next_total()
         lib.call("ibvh_traverse_lvt_enqueue", C.byref(s), start_level, narrow, _ptr(counts), _ptr(spec), spec.shape[0],
-                 tdev, sp, sn, _stream())
+                 tdev, thost, sp, sn, _stream())
         pending.launched()
 
         def finish(total):
@@ -673,9 +824,9 @@ def _traverse_lvt_pair(bvh1, bvh2, sl1, sl2, narrow, cache):
     s1, s2 = bvh1.struct(), bvh2.struct()
     spec = _speculative_buffer(cache, idt)
     if spec is not None:
-        tdev, pending = scratch.next_total()
+        tdev, thost, pending = scratch.next_total()
         lib.call("ibvh_traverse_pair_lvt_enqueue", C.byref(s1), C.byref(s2), sl1, sl2, narrow, _ptr(counts), _ptr(spec),
-                 spec.shape[0], tdev, sp, sn, _stream())
+                 spec.shape[0], tdev, thost, sp, sn, _stream())
         pending.launched()
 
         def finish(total):
@@ -776,17 +927,21 @@ def traverse(bvh, *args, start_level=None, start_level1=None, start_level2=None,
         else:
             raise ValueError(f"Traversal algorithm not implemented: {a}")  # traverse.jl:217
     alg = alg or LVTTraversal()
-    code = _narrow_code(narrow)
+    code, fn = _narrow_code(narrow)
     if bvh2 is None:
         sl = default_start_level(bvh, alg) if start_level is None else int(start_level)
         if isinstance(alg, LVTTraversal):
-            return _traverse_lvt_single(bvh, sl, code, cache)
-        return _traverse_bfs_single(bvh, sl, code, cache)
+            t = _traverse_lvt_single(bvh, sl, code, cache)
+        else:
+            t = _traverse_bfs_single(bvh, sl, code, cache)
+        return _post_filter(t, fn, bvh) if fn else t
     sl1 = default_start_level(bvh, alg) if start_level1 is None else int(start_level1)
     sl2 = default_start_level(bvh2, alg) if start_level2 is None else int(start_level2)
     if isinstance(alg, LVTTraversal):
-        return _traverse_lvt_pair(bvh, bvh2, sl1, sl2, code, cache)
-    return _traverse_bfs_pair(bvh, bvh2, sl1, sl2, code, cache)
+        t = _traverse_lvt_pair(bvh, bvh2, sl1, sl2, code, cache)
+    else:
+        t = _traverse_bfs_pair(bvh, bvh2, sl1, sl2, code, cache)
+    return _post_filter(t, fn, bvh, bvh2) if fn else t
 
 
 def traverse_rays(bvh, points, directions, alg=None, start_level=1, narrow=None, cache=None, options=None):
@@ -795,8 +950,7 @@ def traverse_rays(bvh, points, directions, alg=None, start_level=1, narrow=None,
     contacts are (leaf.index, iray).  Rays are converted to the leaf float type (raytrace/lvt:116-125)."""
     torch = _require_gpu()
     alg = alg or LVTTraversal()
-    if narrow is not None:
-        raise NotImplementedError("ray `narrow` closures cannot cross the C ABI; filter traversal.contacts instead")
+    code, fn = _narrow_code(narrow, rays=True)
     if not (points.dim() == 2 and directions.dim() == 2 and points.shape[0] == 3 and directions.shape[0] == 3):
         raise ValueError("size(points, 1) == size(directions, 1) == 3 must hold")
     if points.shape[1] != directions.shape[1]:
@@ -821,31 +975,61 @@ def traverse_rays(bvh, points, directions, alg=None, start_level=1, narrow=None,
         sp, sn = _ptr(scratch), scratch.numel()
         spec = _speculative_buffer(cache, idt)
         if spec is not None:
-            tdev, pending = scratch.next_total()
-            lib.call("ibvh_traverse_rays_lvt_enqueue", C.byref(s), _ptr(p), _ptr(d), nr, start_level, _ptr(counts), _ptr(spec),
-                     spec.shape[0], tdev, sp, sn, _stream())
+            tdev, thost, pending = scratch.next_total()
+            lib.call("ibvh_traverse_rays_lvt_enqueue", C.byref(s), _ptr(p), _ptr(d), nr, start_level, code, _ptr(counts), _ptr(spec),
+                     spec.shape[0], tdev, thost, sp, sn, _stream())
             pending.launched()
 
             def finish(total):
                 contacts = torch.empty((total, 2), dtype=idt, device="cuda")
-                lib.call("ibvh_traverse_rays_lvt_write", C.byref(s), _ptr(p), _ptr(d), nr, start_level, _ptr(counts),
+                lib.call("ibvh_traverse_rays_lvt_write", C.byref(s), _ptr(p), _ptr(d), nr, start_level, code, _ptr(counts),
                          _ptr(contacts), sp, sn, _stream())
                 return contacts
-            return BVHTraversal(start_level, 0, 0, None, spec, counts, scratch,
-                                _pending=(pending, spec.shape[0], finish))
+            t = BVHTraversal(start_level, 0, 0, None, spec, counts, scratch, _pending=(pending, spec.shape[0], finish))
+            return _post_filter(t, fn, bvh, rays=(p, d)) if fn else t
         total = C.c_int64()
-        lib.call("ibvh_traverse_rays_lvt_count", C.byref(s), _ptr(p), _ptr(d), nr, start_level, _ptr(counts),
+        lib.call("ibvh_traverse_rays_lvt_count", C.byref(s), _ptr(p), _ptr(d), nr, start_level, code, _ptr(counts),
                  C.byref(total), sp, sn, _stream())
         contacts = _cache_tensor(cache.cache1 if cache else None, total.value, 2, idt, "cache1")
         if total.value:
-            lib.call("ibvh_traverse_rays_lvt_write", C.byref(s), _ptr(p), _ptr(d), nr, start_level, _ptr(counts),
+            lib.call("ibvh_traverse_rays_lvt_write", C.byref(s), _ptr(p), _ptr(d), nr, start_level, code, _ptr(counts),
                      _ptr(contacts), sp, sn, _stream())
-        return BVHTraversal(start_level, 0, 0, total.value, contacts, counts, scratch)
+        t = BVHTraversal(start_level, 0, 0, total.value, contacts, counts, scratch)
+        return _post_filter(t, fn, bvh, rays=(p, d)) if fn else t
     cap = C.c_int64()
     lib.call("ibvh_bfs_rays_initial_capacity", C.byref(s), nr, start_level, C.byref(cap))
     res, q1, q2 = _bfs_run("ibvh_traverse_rays_bfs", bvh.types, cap.value, cache, bvh.tree.levels, C.byref(s), _ptr(p),
-                           _ptr(d), nr, start_level)
-    return BVHTraversal(start_level, 0, res.num_checks, res.num_contacts, q1, q2)
+                           _ptr(d), nr, start_level, code)
+    t = BVHTraversal(start_level, 0, res.num_checks, res.num_contacts, q1, q2)
+    return _post_filter(t, fn, bvh, rays=(p, d)) if fn else t
+
+
+def lvt_work_counters(bvh, bvh2=None, points=None, directions=None):
+    """Measurement helper (ibvh_lvt_work_counters, include/ibvh.h): the work of ONE counting pass of the leaf-vs-tree walk
+    the ordinary call would take — traverse(bvh), traverse(bvh, bvh2) or traverse_rays(bvh, points, directions) — as a dict
+    {node_tests, leaf_tests, node_fetches, leaf_fetches, touched_bytes}.  Bench types only (the reference
+    counts such work for BFS only, BVHTraversal.num_checks)."""
+    torch = _require_gpu()
+    idt = _torch_index(bvh.types.index_type)
+    work = torch.zeros(4, dtype=torch.int64, device="cuda")
+    s = bvh.struct()
+    if points is not None:
+        ft = _torch_float(bvh.types.leaf_float)
+        p = points.to(device="cuda", dtype=ft).t().contiguous()
+        d = directions.to(device="cuda", dtype=ft).t().contiguous()
+        counts = torch.empty(p.shape[0], dtype=idt, device="cuda")
+        lib.call("ibvh_lvt_work_counters", C.byref(s), None, _ptr(p), _ptr(d), p.shape[0], _ptr(counts), _ptr(work), _stream())
+    elif bvh2 is not None:
+        s2 = bvh2.struct()
+        counts = torch.empty(max(len(bvh.leaves), len(bvh2.leaves)), dtype=idt, device="cuda")
+        lib.call("ibvh_lvt_work_counters", C.byref(s), C.byref(s2), None, None, 0, _ptr(counts), _ptr(work), _stream())
+    else:
+        counts = torch.empty(len(bvh.leaves), dtype=idt, device="cuda")
+        lib.call("ibvh_lvt_work_counters", C.byref(s), None, None, None, 0, _ptr(counts), _ptr(work), _stream())
+    w = [int(x) for x in work.cpu().tolist()]
+    lay = bvh.leaves.layout
+    return {"node_tests": w[0], "leaf_tests": w[1], "node_fetches": w[2], "leaf_fetches": w[3],
+            "touched_bytes": w[2] * int(lay.node_bytes) + w[3] * int(lay.leaf_bytes), "contacts_counted": int(counts.sum().item())}
 
 
 # ---------------------------------------------------------------------------------------------

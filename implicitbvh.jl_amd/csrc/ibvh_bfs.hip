@@ -57,6 +57,18 @@ template <class L, class N> TreeRef<L, N> make_ref(const ibvh_bvh &b, const Leaf
     return r;
 }
 
+// `narrow` arguments carry the menu code and the IBVH_OUTPUT_POSITIONS flag (include/ibvh.h)
+inline bool narrow_arg_ok(int32_t narrow, bool rays) {
+    if (narrow & ~(IBVH_NARROW_MASK | IBVH_OUTPUT_POSITIONS)) return false;
+    const int code = narrow & IBVH_NARROW_MASK;
+    return rays ? (code == IBVH_NARROW_NONE || code == IBVH_NARROW_RAY_ORIGIN_OUTSIDE)
+                : (code == IBVH_NARROW_NONE || code == IBVH_NARROW_MORTON_LT || code == IBVH_NARROW_INDEX_LT);
+}
+template <class T> IBVH_D bool origin_outside(const BSphere<T> &s, const T *p) { return dist3sq(p, s.x) > s.r * s.r; }
+template <class T> IBVH_D bool origin_outside(const BBox<T> &b, const T *p) {
+    return (p[0] < b.lo[0]) | (p[0] > b.up[0]) | (p[1] < b.lo[1]) | (p[1] > b.up[1]) | (p[2] < b.lo[2]) | (p[2] > b.up[2]);
+}
+
 IBVH_D bool narrow_eval(int narrow, uint64_t ma, int64_t ia, uint64_t mb, int64_t ib) {
     if (narrow == IBVH_NARROW_MORTON_LT) return ma < mb;
     if (narrow == IBVH_NARROW_INDEX_LT) return ia < ib;
@@ -90,7 +102,8 @@ template <class L, class N, class I> struct SelfStep {
     TreeRef<L, N> t;
     int leaf;        // entries are leaf pairs
     int self_checks; // (nodes) :44
-    int narrow;      // (leaves)
+    int narrow;      // (leaves) menu code
+    int positions;   // (leaves) IBVH_OUTPUT_POSITIONS: 1-based leaf positions instead of user indices, left leaf first
     IBVH_D bool check(IndexPair<I> s, IndexPair<I> &res) const {
         if (leaf) {
             const char *r1 = t.leaf_rec(s.a), *r2 = t.leaf_rec(s.b);
@@ -101,7 +114,8 @@ template <class L, class N, class I> struct SelfStep {
                 uint64_t m2 = narrow == IBVH_NARROW_MORTON_LT ? load_morton(r2, t.lay) : 0;
                 if (!narrow_eval(narrow, m1, i1, m2, i2)) return false;
             }
-            res = i1 > i2 ? IndexPair<I>{i2, i1} : IndexPair<I>{i1, i2};
+            if (positions) res = {I(s.a - t.leaf_first + 1), I(s.b - t.leaf_first + 1)}; // (a is left of b)
+            else res = i1 > i2 ? IndexPair<I>{i2, i1} : IndexPair<I>{i1, i2};
             return true;
         }
         res = s;
@@ -142,7 +156,7 @@ template <class L, class N, class I> struct SelfStep {
 template <class L, class N, class I> struct PairStep {
     static constexpr int MAXOUT = 4;
     TreeRef<L, N> t1, t2;
-    int narrow;
+    int narrow, positions;
     int leaf1, leaf2, d1, d2;
     IBVH_D bool check(IndexPair<I> s, IndexPair<I> &res) const {
         const I a = s.a, b = s.b;
@@ -157,7 +171,7 @@ template <class L, class N, class I> struct PairStep {
                 uint64_t m2 = narrow == IBVH_NARROW_MORTON_LT ? load_morton(r2, t2.lay) : 0;
                 if (!narrow_eval(narrow, m1, i1, m2, i2)) return false;
             }
-            res = {i1, i2};
+            res = positions ? IndexPair<I>{I(a - t1.leaf_first + 1), I(b - t2.leaf_first + 1)} : IndexPair<I>{i1, i2};
             return true;
         }
         if (leaf1) return iscontact(load_vol<L>(t1.leaf_rec(a)), t2.node(b)); // iscontact(leaf1.volume, node2), :461-527
@@ -204,6 +218,7 @@ template <class L, class N, class I> struct RayStep {
     TreeRef<L, N> t;
     const T *points, *dirs;
     int leaf;
+    int narrow, positions;
     IBVH_D bool check(IndexPair<I> s, IndexPair<I> &res) const {
         const I a = s.a, iray = s.b;
         const T p[3] = {points[3 * ((int64_t)iray - 1)], points[3 * ((int64_t)iray - 1) + 1], points[3 * ((int64_t)iray - 1) + 2]};
@@ -211,8 +226,10 @@ template <class L, class N, class I> struct RayStep {
         res = s;
         if (leaf) {
             const char *r = t.leaf_rec(a);
-            if (!isintersection(load_vol<L>(r), p, d)) return false;
-            res = {load_index<I>(r, t.lay), iray};
+            const L leaf_vol = load_vol<L>(r);
+            if (!isintersection(leaf_vol, p, d)) return false;
+            if (narrow == IBVH_NARROW_RAY_ORIGIN_OUTSIDE && !origin_outside(leaf_vol, p)) return false; // raytrace_gpu.jl:159
+            res = {positions ? I(a - t.leaf_first + 1) : load_index<I>(r, t.lay), iray};
             return true;
         }
         return isintersection(t.node(a), p, d);
@@ -246,7 +263,11 @@ __global__ __launch_bounds__(TPB) void level_kernel(const IndexPair<I> *__restri
     __shared__ int wave_tot[TPB / 64];
     __shared__ unsigned long long s_base;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (counters[0] != 0ull) return; // an earlier step overflowed: its destination (our source) is incomplete
+    // an EARLIER step overflowed: its destination (our source) is incomplete.  The step that overflows itself keeps going
+    // in every workgroup — also those that start, or reach their next chunk, after a sibling raised the flag — so that
+    // counters[2 + step] ends as the exact number of pairs the step produces (required_capacity).
+    const unsigned long long flag = counters[0];
+    if (flag != 0ull && flag - 1ull < (unsigned long long)step) return;
     const int64_t num_src = (int64_t)counters[1 + step];
     if (num_src > capacity) return;   // (defensive: the flag covers this)
     const uint64_t lt = ((uint64_t)1 << lane) - 1;
@@ -470,7 +491,8 @@ int run_self(const ibvh_bvh &b, int64_t start_level, int narrow, void *bvtt1, vo
         IBVH_LAUNCH((fill_self_kernel<I>), dim3((unsigned)ceil_div(total0, TPB)), dim3(TPB), 0, st, (IndexPair<I> *)bvtt1,
                            n0, int64_t(1) << (start_level - 1), start_level != levels ? 1 : 0, total0);
     auto at = [&](int64_t level) {
-        return SelfStep<L, N, I>{make_ref<L, N>(b, dl, level), level == levels ? 1 : 0, level < levels - 1 ? 1 : 0 /* self_checks (:44) */, narrow};
+        return SelfStep<L, N, I>{make_ref<L, N>(b, dl, level), level == levels ? 1 : 0, level < levels - 1 ? 1 : 0 /* self_checks (:44) */,
+                                 narrow & IBVH_NARROW_MASK, (narrow & IBVH_OUTPUT_POSITIONS) ? 1 : 0};
     };
     if (int e = step<I>(r, Identity<I>{}, at(start_level))) return e; // the initial queue is checked ...
     for (int64_t level = start_level; level < levels; ++level)       // ... then children of what passed, level by level
@@ -501,7 +523,8 @@ int run_pair(const ibvh_bvh &b1, const ibvh_bvh &b2, int64_t sl1, int64_t sl2, i
         PairStep<L, N, I> p;
         p.t1 = make_ref<L, N>(b1, dl, l1);
         p.t2 = make_ref<L, N>(b2, dl, l2);
-        p.narrow = narrow;
+        p.narrow = narrow & IBVH_NARROW_MASK;
+        p.positions = (narrow & IBVH_OUTPUT_POSITIONS) ? 1 : 0;
         p.leaf1 = leaf1, p.leaf2 = leaf2, p.d1 = d1, p.d2 = d2;
         seq[ns++] = p;
     };
@@ -538,8 +561,8 @@ int run_pair(const ibvh_bvh &b1, const ibvh_bvh &b2, int64_t sl1, int64_t sl2, i
 }
 
 template <class L, class N, class I>
-int run_rays(const ibvh_bvh &b, const void *points, const void *dirs, int64_t num_rays, int64_t start_level, void *bvtt1,
-             void *bvtt2, int64_t capacity, void *counters, ibvh_bfs_result *res, hipStream_t st) {
+int run_rays(const ibvh_bvh &b, const void *points, const void *dirs, int64_t num_rays, int64_t start_level, int narrow,
+             void *bvtt1, void *bvtt2, int64_t capacity, void *counters, ibvh_bfs_result *res, hipStream_t st) {
     using T = typename L::elt;
     ibvh_layout lay;
     LeafLayout dl;
@@ -554,7 +577,8 @@ int run_rays(const ibvh_bvh &b, const void *points, const void *dirs, int64_t nu
         IBVH_LAUNCH((fill_product_kernel<I>), dim3((unsigned)ceil_div(total0, TPB)), dim3(TPB), 0, st, (IndexPair<I> *)bvtt1, nr,
                            num_rays, int64_t(1) << (start_level - 1), int64_t(1));
     auto at = [&](int64_t level) {
-        return RayStep<L, N, I>{make_ref<L, N>(b, dl, level), (const T *)points, (const T *)dirs, level == levels ? 1 : 0};
+        return RayStep<L, N, I>{make_ref<L, N>(b, dl, level), (const T *)points, (const T *)dirs, level == levels ? 1 : 0,
+                                narrow & IBVH_NARROW_MASK, (narrow & IBVH_OUTPUT_POSITIONS) ? 1 : 0};
     };
     if (int e = step<I>(r, Identity<I>{}, at(start_level))) return e;
     for (int64_t level = start_level; level < levels; ++level)
@@ -618,6 +642,7 @@ ibvh_status ibvh_traverse_bfs(const ibvh_bvh *bvh, int64_t start_level, int32_t 
     *result = {0, 0, 1, 0, in.resume_step, in.resume_num};
     if (in.resume_step < 0 || in.resume_num < 0) return IBVH_ERR_INVALID_ARG;
     if (int e = check_levels(*bvh, start_level)) return (ibvh_status)e;
+    if (!narrow_arg_ok(narrow, false)) return IBVH_ERR_INVALID_ARG;
     if (bvh->tree.real_nodes <= 1) return IBVH_OK; // bfs/traverse_single.jl:17-21
     if (!bvtt1 || !bvtt2 || !counters || capacity < 1) return IBVH_ERR_INVALID_ARG;
     if (bvh->types.index_type == IBVH_I32 && bvh->tree.levels > 31) return IBVH_ERR_OVERFLOW;
@@ -637,6 +662,7 @@ ibvh_status ibvh_traverse_pair_bfs(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, i
     if (int e = check_levels(*bvh1, sl1)) return (ibvh_status)e;
     if (int e = check_levels(*bvh2, sl2)) return (ibvh_status)e;
     if (!same_types(bvh1->types, bvh2->types)) return IBVH_ERR_UNSUPPORTED;
+    if (!narrow_arg_ok(narrow, false)) return IBVH_ERR_INVALID_ARG;
     if (!bvtt1 || !bvtt2 || !counters || capacity < 1) return IBVH_ERR_INVALID_ARG;
     if (bvh1->types.index_type == IBVH_I32 && (bvh1->tree.levels > 31 || bvh2->tree.levels > 31)) return IBVH_ERR_OVERFLOW;
     return (ibvh_status)dispatch(bvh1->types, [&](auto lt, auto nt, auto it) -> int {
@@ -646,9 +672,9 @@ ibvh_status ibvh_traverse_pair_bfs(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, i
 }
 
 ibvh_status ibvh_traverse_rays_bfs(const ibvh_bvh *bvh, const void *points, const void *dirs, int64_t num_rays,
-                                   int64_t start_level, void *bvtt1, void *bvtt2, int64_t capacity, void *counters,
-                                   ibvh_bfs_result *result, void *stream) {
-    if (!bvh || !result || num_rays < 0) return IBVH_ERR_INVALID_ARG;
+                                   int64_t start_level, int32_t narrow, void *bvtt1, void *bvtt2, int64_t capacity,
+                                   void *counters, ibvh_bfs_result *result, void *stream) {
+    if (!bvh || !result || num_rays < 0 || !narrow_arg_ok(narrow, true)) return IBVH_ERR_INVALID_ARG;
     const ibvh_bfs_result in = *result;
     *result = {0, 0, 1, 0, in.resume_step, in.resume_num};
     if (in.resume_step < 0 || in.resume_num < 0) return IBVH_ERR_INVALID_ARG;
@@ -663,7 +689,7 @@ ibvh_status ibvh_traverse_rays_bfs(const ibvh_bvh *bvh, const void *points, cons
         using I = typename decltype(it)::type;
         if constexpr (!std::is_same<typename L::elt, typename N::elt>::value) return (int)IBVH_ERR_UNSUPPORTED;
         else
-            return run_rays<L, N, I>(*bvh, points, dirs, num_rays, start_level, bvtt1, bvtt2, capacity, counters, result,
+            return run_rays<L, N, I>(*bvh, points, dirs, num_rays, start_level, narrow, bvtt1, bvtt2, capacity, counters, result,
                                      (hipStream_t)stream);
     });
 }

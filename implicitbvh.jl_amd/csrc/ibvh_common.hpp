@@ -455,11 +455,15 @@ inline bool layout_of(const ibvh_types &t, ibvh_layout &out, LeafLayout *dev = n
     return true;
 }
 
+// IBVH_ONLY_BENCH_TYPES (development builds only, never the shipped library): instantiate nothing but Float32
+// volumes and Int32 indices, so that one kernel can be recompiled in seconds while it is being tuned.
 template <class F> int dispatch_volume(int kind, int flt, F &&f) {
     if (kind == IBVH_BSPHERE && flt == IBVH_F32) return f(Tag<BSphere<float>>{});
-    if (kind == IBVH_BSPHERE && flt == IBVH_F64) return f(Tag<BSphere<double>>{});
     if (kind == IBVH_BBOX && flt == IBVH_F32) return f(Tag<BBox<float>>{});
+#ifndef IBVH_ONLY_BENCH_TYPES
+    if (kind == IBVH_BSPHERE && flt == IBVH_F64) return f(Tag<BSphere<double>>{});
     if (kind == IBVH_BBOX && flt == IBVH_F64) return f(Tag<BBox<double>>{});
+#endif
     return IBVH_ERR_UNSUPPORTED;
 }
 template <class F> int dispatch_leaf_node(const ibvh_types &t, F &&f) {
@@ -477,7 +481,9 @@ template <class F> int dispatch_leaf_node(const ibvh_types &t, F &&f) {
 }
 template <class F> int dispatch_index(int index_type, F &&f) {
     if (index_type == IBVH_I32) return f(Tag<int32_t>{});
+#ifndef IBVH_ONLY_BENCH_TYPES
     if (index_type == IBVH_I64) return f(Tag<int64_t>{});
+#endif
     return IBVH_ERR_UNSUPPORTED;
 }
 
@@ -493,6 +499,24 @@ template <class F> int dispatch_index(int index_type, F &&f) {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 IBVH_HD int64_t ceil_div_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Development knobs (ibvh_set_tuning in include/ibvh.h): one process-wide table, written only through that entry
+// point and read by the launch code.  The defaults are the shipped geometry; the library itself never reads the
+// environment.
+struct Tuning {
+    int ray_block = 0;      // rays per wave of lvt_rays_kernel (0 = chosen from the batch size; a power of two, 64 .. 1024)
+    int lvt_wide = 0;       // 1 = 64-bit queue entries for every tree (otherwise only for 29 .. 31 levels)
+    int lvt_xcd = 64;       // LVT item placement: 0 = round robin, 1 = one range per XCD, n = runs of n workgroups
+    int sort_tile = 0;      // LSD path: keys per tile (0 = by size; 2048, 4096, 8192, 16384)
+    int sort_lsd = 0;       // 1 = ibvh_sort_pairs always takes the plain LSD passes
+    int sort_msd_avg = 1536; // ibvh_sort_pairs: largest average bucket before another partition bit is taken
+    int bucket_tpb = 0;     // ibvh_sort_pairs: threads of a bucket workgroup (0 = by capacity)
+    int msd = 1;            // 0 = the build never takes the MSD partition path
+    int msd_bits = 0, msd_cap = 0, msd_tile = 0, msd_ftpb = 0; // forced partition geometry (0 = chosen from n)
+    int msd_avg = 1024;     // largest average cell before another first-level bit is taken
+    int msd_range = 1;      // 0 = first extra level on the next 8 bits, unmeasured
+};
+extern Tuning g_tuning;
 
 // Optional per-launch timing (ibvh_profile_* in include/ibvh.h): when enabled every kernel launch is
 // bracketed by a pair of HIP events recorded on the launch stream.  Off by default: one predictable

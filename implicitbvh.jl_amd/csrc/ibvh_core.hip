@@ -54,7 +54,21 @@ static void reset() {
 } // namespace prof
 } // namespace ibvh
 
+namespace ibvh {
+Tuning g_tuning;
+}
 namespace {
+struct Knob {
+    const char *name;
+    int Tuning::*field;
+};
+const Knob kKnobs[] = {
+    {"ray_block", &Tuning::ray_block},   {"lvt_wide", &Tuning::lvt_wide},     {"lvt_xcd", &Tuning::lvt_xcd},
+    {"sort_tile", &Tuning::sort_tile},   {"sort_lsd", &Tuning::sort_lsd},     {"sort_msd_avg", &Tuning::sort_msd_avg},
+    {"bucket_tpb", &Tuning::bucket_tpb}, {"msd", &Tuning::msd},               {"msd_bits", &Tuning::msd_bits},
+    {"msd_cap", &Tuning::msd_cap},       {"msd_tile", &Tuning::msd_tile},     {"msd_ftpb", &Tuning::msd_ftpb},
+    {"msd_avg", &Tuning::msd_avg},       {"msd_range", &Tuning::msd_range},
+};
 inline int64_t ilog2_down(int64_t n) { return 63 - __builtin_clzll((unsigned long long)n); }
 } // namespace
 
@@ -146,7 +160,27 @@ ibvh_status ibvh_profile_get(int64_t i, const char **name_out, float *ms_out) {
     return IBVH_OK;
 }
 
-const char *ibvh_version(void) { return "libibvh 0.1.0 (gfx950)"; }
+ibvh_status ibvh_set_tuning(const char *name, int32_t value) {
+    if (!name) return IBVH_ERR_INVALID_ARG;
+    for (const Knob &k : kKnobs)
+        if (std::string(name) == k.name) {
+            g_tuning.*(k.field) = value;
+            return IBVH_OK;
+        }
+    return IBVH_ERR_INVALID_ARG;
+}
+ibvh_status ibvh_get_tuning(const char *name, int32_t *value_out) {
+    if (!name || !value_out) return IBVH_ERR_INVALID_ARG;
+    for (const Knob &k : kKnobs)
+        if (std::string(name) == k.name) {
+            *value_out = g_tuning.*(k.field);
+            return IBVH_OK;
+        }
+    return IBVH_ERR_INVALID_ARG;
+}
+
+const char *ibvh_version(void) { return "libibvh 0.3.0 (gfx950)"; }
+int32_t ibvh_abi_version(void) { return IBVH_ABI_VERSION; }
 
 const char *ibvh_status_string(int32_t status) {
     switch (status) {

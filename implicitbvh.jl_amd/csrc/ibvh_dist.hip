@@ -21,8 +21,16 @@ constexpr int MAX_SPLITTERS = 255;
 struct Splitters {
     uint64_t v[MAX_SPLITTERS];
 };
+// counts (optional, zeroed by the caller): leaves per destination rank, accumulated through an LDS histogram (one global
+// atomic per workgroup and non-empty destination)
 template <class K>
-__global__ __launch_bounds__(256) void dest_kernel(const K *__restrict__ keys, int64_t n, Splitters sp, int nsplit, uint32_t *__restrict__ dest) {
+__global__ __launch_bounds__(256) void dest_kernel(const K *__restrict__ keys, int64_t n, Splitters sp, int nsplit, uint32_t *__restrict__ dest,
+                                                   unsigned long long *__restrict__ counts) {
+    __shared__ uint32_t s_cnt[MAX_SPLITTERS + 1];
+    if (counts) {
+        for (int i = threadIdx.x; i <= nsplit; i += 256) s_cnt[i] = 0;
+        __syncthreads();
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const uint64_t k = (uint64_t)keys[i];
         int lo = 0, hi = nsplit; // first splitter > k
@@ -32,6 +40,12 @@ __global__ __launch_bounds__(256) void dest_kernel(const K *__restrict__ keys, i
             else hi = mid;
         }
         dest[i] = (uint32_t)lo;
+        if (counts) atomicAdd(&s_cnt[lo], 1u);
+    }
+    if (counts) {
+        __syncthreads();
+        for (int i = threadIdx.x; i <= nsplit; i += 256)
+            if (s_cnt[i]) atomicAdd(&counts[i], (unsigned long long)s_cnt[i]);
     }
 }
 
@@ -160,9 +174,10 @@ ibvh_status ibvh_dist_partition_scratch_bytes(int64_t n, size_t *bytes_out) {
     return IBVH_OK;
 }
 ibvh_status ibvh_dist_partition(int32_t key_bytes, const void *keys, int64_t n, const uint64_t *splitters, int32_t nranks,
-                                void *perm_out, void *scratch, size_t scratch_bytes, void *stream) {
+                                void *perm_out, void *counts_out, void *scratch, size_t scratch_bytes, void *stream) {
     if (n < 0 || nranks < 1 || (key_bytes != 4 && key_bytes != 8)) return IBVH_ERR_INVALID_ARG;
     if (nranks - 1 > distk::MAX_SPLITTERS) return IBVH_ERR_UNSUPPORTED;
+    if (counts_out && hipMemsetAsync(counts_out, 0, (size_t)nranks * 8, (hipStream_t)stream) != hipSuccess) return IBVH_ERR_HIP;
     if (n == 0) return IBVH_OK;
     if (!keys || !perm_out || !scratch || (nranks > 1 && !splitters)) return IBVH_ERR_INVALID_ARG;
     size_t need;
@@ -175,8 +190,9 @@ ibvh_status ibvh_dist_partition(int32_t key_bytes, const void *keys, int64_t n, 
     distk::Splitters sp;
     for (int i = 0; i < nranks - 1; ++i) sp.v[i] = splitters[i];
     const int blocks = (int)(ceil_div(n, 256) < 4096 ? ceil_div(n, 256) : 4096);
-    if (key_bytes == 8) IBVH_LAUNCH((distk::dest_kernel<uint64_t>), dim3(blocks), dim3(256), 0, st, (const uint64_t *)keys, n, sp, nranks - 1, dest);
-    else IBVH_LAUNCH((distk::dest_kernel<uint32_t>), dim3(blocks), dim3(256), 0, st, (const uint32_t *)keys, n, sp, nranks - 1, dest);
+    unsigned long long *cnt = (unsigned long long *)counts_out;
+    if (key_bytes == 8) IBVH_LAUNCH((distk::dest_kernel<uint64_t>), dim3(blocks), dim3(256), 0, st, (const uint64_t *)keys, n, sp, nranks - 1, dest, cnt);
+    else IBVH_LAUNCH((distk::dest_kernel<uint32_t>), dim3(blocks), dim3(256), 0, st, (const uint32_t *)keys, n, sp, nranks - 1, dest, cnt);
     int bits = 1;
     while ((1 << bits) < nranks) ++bits; // <= 8: exactly one LSD pass, whose output lands in the alternate buffers
     int32_t in_alt = 0;
@@ -205,13 +221,13 @@ ibvh_status ibvh_key_histogram(int32_t key_bytes, const void *keys, int64_t n, i
     unsigned blocks = (unsigned)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
     if (key_bytes == 4) {
         if (hipFuncSetAttribute((const void *)distk::key_hist_kernel<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess)
+                                160 * 1024) != hipSuccess) // (always the same value: concurrent callers cannot interleave badly)
             return IBVH_ERR_HIP;
         IBVH_LAUNCH((distk::key_hist_kernel<uint32_t>), dim3(blocks), dim3(distk::HIST_TPB), smem, st, (const uint32_t *)keys, n,
                     shift, bits, prefix_shift, pre, nprefix, (uint32_t *)out);
     } else {
         if (hipFuncSetAttribute((const void *)distk::key_hist_kernel<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess)
+                                160 * 1024) != hipSuccess) // (always the same value: concurrent callers cannot interleave badly)
             return IBVH_ERR_HIP;
         IBVH_LAUNCH((distk::key_hist_kernel<uint64_t>), dim3(blocks), dim3(distk::HIST_TPB), smem, st, (const uint64_t *)keys, n,
                     shift, bits, prefix_shift, pre, nprefix, (uint32_t *)out);

@@ -10,7 +10,6 @@
 // lvt_rays_kernel (per-lane walk with a bitmask stack).  The reference's 32-entry per-thread index stack
 // (traverse_single.jl:188-203) is never needed: the tree is implicit, so "the pending right siblings of
 // the current path" is one 32-bit mask.
-#include <cstdlib>
 #include <type_traits>
 
 #include "ibvh_common.hpp"
@@ -34,7 +33,8 @@ template <class L, class N, class I> struct Args {
     TreeDev tree;
     int64_t start_level;
     int64_t built_level;       // nodes above it do not exist
-    int32_t narrow;
+    int32_t narrow;    // menu code (IBVH_NARROW_MASK already applied)
+    int32_t positions; // IBVH_OUTPUT_POSITIONS: contacts hold 1-based leaf positions instead of user indices
     int32_t flip;
     int32_t xcd_tiles; // work items handed out so that each XCD walks one contiguous range (speed only)
     // outputs
@@ -44,6 +44,28 @@ template <class L, class N, class I> struct Args {
     // *guard_total <= guard_capacity (guard_total == nullptr: unguarded)
     const int64_t *guard_total;
     int64_t guard_capacity;
+    // ibvh_lvt_work_counters only (COUNT instantiations): [0] node tests, [1] leaf tests, [2] node records fetched,
+    // [3] leaf records fetched, summed over the launch
+    unsigned long long *work;
+};
+
+// per-lane work counters of the COUNT instantiations (nothing at all otherwise)
+template <bool COUNT> struct Work {
+    uint32_t v[4] = {0, 0, 0, 0};
+    IBVH_D void add(int k, uint32_t n) {
+        if constexpr (COUNT) v[k] += n;
+    }
+    IBVH_D void flush(unsigned long long *out) {
+        if constexpr (COUNT) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                unsigned long long t = v[k];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+                if ((threadIdx.x & 63) == 0 && t != 0) atomicAdd(out + k, t);
+            }
+        }
+    }
 };
 
 IBVH_D int64_t load_total_uniform(const int64_t *p) {
@@ -54,6 +76,15 @@ IBVH_D bool narrow_eval(int narrow, uint64_t ma, int64_t ia, uint64_t mb, int64_
     if (narrow == IBVH_NARROW_MORTON_LT) return ma < mb;
     if (narrow == IBVH_NARROW_INDEX_LT) return ia < ib;
     return true;
+}
+
+// IBVH_NARROW_RAY_ORIGIN_OUTSIDE: (bv, p, d) -> p lies outside bv.volume (strictly outside the sphere: distance > r;
+// outside the box: beyond a face on some axis), evaluated only for leaves the ray already hits
+template <class T> IBVH_D bool origin_outside(const BSphere<T> &s, const T *p) {
+    return dist3sq(p, s.x) > s.r * s.r;
+}
+template <class T> IBVH_D bool origin_outside(const BBox<T> &b, const T *p) {
+    return (p[0] < b.lo[0]) | (p[0] > b.up[0]) | (p[1] < b.lo[1]) | (p[1] > b.up[1]) | (p[2] < b.lo[2]) | (p[2] > b.up[2]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -164,9 +195,12 @@ template <class L, class N, class I, int MODE, bool WRITE, bool NARROW> struct Q
         return (MODE == MODE_PAIR && a.flip) ? narrow_eval(a.narrow, lm, lidx, q_morton, q_index)
                                              : narrow_eval(a.narrow, q_morton, q_index, lm, lidx);
     }
-    IBVH_D void emit(I lidx) {
+    IBVH_D void emit(I lidx, int64_t lpos) { // lpos: 0-based position of the leaf in the walked tree's leaves
         IndexPair<I> c2;
-        if constexpr (MODE == MODE_SELF) c2 = q_index > lidx ? IndexPair<I>{lidx, q_index} : IndexPair<I>{q_index, lidx};
+        if (a.positions) { // (query, partner) / (bvh1, bvh2) positions, 1-based (include/ibvh.h, IBVH_OUTPUT_POSITIONS)
+            const I qp = (I)(item + 1), lp = (I)(lpos + 1);
+            c2 = (MODE == MODE_PAIR && a.flip) ? IndexPair<I>{lp, qp} : IndexPair<I>{qp, lp};
+        } else if constexpr (MODE == MODE_SELF) c2 = q_index > lidx ? IndexPair<I>{lidx, q_index} : IndexPair<I>{q_index, lidx};
         else c2 = a.flip ? IndexPair<I>{lidx, q_index} : IndexPair<I>{q_index, lidx};
         if constexpr (WRITE) {
             a.contacts[(int64_t)w] = c2;
@@ -201,7 +235,7 @@ IBVH_D void joint_walk(Query<L, N, I, MODE, WRITE, NARROW> &q, const Args<L, N, 
             const uint64_t lm = a.narrow == IBVH_NARROW_MORTON_LT ? load_morton_uniform(rec, a.lay) : 0;
             hit = hit && q.narrow_ok(lm, lidx);
         }
-        if (hit) q.emit(lidx);
+        if (hit) q.emit(lidx, (int64_t)(c - leaf_first));
     };
 
     // pseudo-parents: the nodes one level above the start level are entered unconditionally, which
@@ -379,9 +413,10 @@ constexpr int QUEUE_CAP = 512; // candidate pairs per wave (LDS); drained whenev
 constexpr int QUEUE_WAVES = IBVH_QUEUE_WAVES; // waves per workgroup (they share nothing: a workgroup is only a unit of dispatch)
 
 // WIDE: 64-bit queue entries for trees of 29 .. 31 levels (leaf-parent indices beyond 2^26), see launch().
-template <class L, class N, class I, int MODE, bool WRITE, bool NARROW, bool WIDE>
+template <class L, class N, class I, int MODE, bool WRITE, bool NARROW, bool WIDE, bool COUNT = false>
 __global__ __launch_bounds__(64 * QUEUE_WAVES, 8) void lvt_queue_kernel(Args<L, N, I> a, PairCache<I> cache, int cut_level) {
     using TN = typename N::elt;
+    Work<COUNT> work; // (COUNT: one lane-level box / sphere test = one count; lane 0 carries the wave-uniform parts)
     using Q = Query<L, N, I, MODE, WRITE, NARROW>;
     using Cnt = typename Q::Cnt;
     __shared__ uint32_t s_frontier[QUEUE_WAVES][2][FRONTIER_CAP];
@@ -430,7 +465,10 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, 8) void lvt_queue_kernel(Args<L, 
     if constexpr (MODE == MODE_PAIR) {
         if (a.built_level <= 1 && a.tree.levels >= 2) {
             const N root = load_vol_uniform<N>(a.nodes);
+            work.add(0, q.lane_on);
+            work.add(2, lane == 0);
             if (__builtin_amdgcn_ballot_w64(q.lane_on & iscontact(q.q_node, root)) == 0) {
+                work.flush(a.work);
                 if constexpr (!WRITE) {
                     if (q.valid) a.counts[q.item] = (I)0;
                     if (region && lane == 0) *(int *)region = 0;
@@ -558,6 +596,8 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, 8) void lvt_queue_kernel(Args<L, 
         const I qidx = __shfl(q.q_index, qi, 64);
         const uint32_t item_q = wave_item0 + (uint32_t)qi;
         bool hit_a = v & iscontact(ql, leaf_a), hit_b = has_b & iscontact(ql, leaf_b);
+        work.add(1, (uint32_t)v + (uint32_t)has_b);
+        work.add(3, (uint32_t)v + (uint32_t)has_b);
         if constexpr (MODE == MODE_SELF) { // only partners to the right of the query
             hit_a = hit_a & (pos > item_q);
             hit_b = hit_b & (pos + 1u > item_q);
@@ -585,9 +625,12 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, 8) void lvt_queue_kernel(Args<L, 
         __builtin_amdgcn_wave_barrier();
         // WRITE: straight to the output; counting pass: appended to the wave's dense cache (slot = running fill +
         // number of hitting lanes below this one, a-hits of the step before its b-hits)
-        auto put = [&](Cnt at, I lidx, int slot) {
+        auto put = [&](Cnt at, I lidx, int slot, uint32_t lpos) {
             IndexPair<I> c2;
-            if constexpr (MODE == MODE_SELF) c2 = qidx > lidx ? IndexPair<I>{lidx, qidx} : IndexPair<I>{qidx, lidx};
+            if (a.positions) { // 1-based positions, query / bvh1 first (include/ibvh.h, IBVH_OUTPUT_POSITIONS)
+                const I qp = (I)(item_q + 1u), lp = (I)(lpos + 1u);
+                c2 = (MODE == MODE_PAIR && a.flip) ? IndexPair<I>{lp, qp} : IndexPair<I>{qp, lp};
+            } else if constexpr (MODE == MODE_SELF) c2 = qidx > lidx ? IndexPair<I>{lidx, qidx} : IndexPair<I>{qidx, lidx};
             else c2 = a.flip ? IndexPair<I>{lidx, qidx} : IndexPair<I>{qidx, lidx};
             if constexpr (WRITE) {
                 a.contacts[(int64_t)at] = c2;
@@ -598,8 +641,8 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, 8) void lvt_queue_kernel(Args<L, 
         const Cnt at = base + (Cnt)rank;
         const int n_a = __popcll(m_a);
         auto below = [](uint64_t m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
-        if (hit_a) put(at, idx_a, wfill + below(m_a));
-        if (hit_b) put(at + (hit_a ? 1 : 0), idx_b, wfill + n_a + below(m_b));
+        if (hit_a) put(at, idx_a, wfill + below(m_a), pos);
+        if (hit_b) put(at + (hit_a ? 1 : 0), idx_b, wfill + n_a + below(m_b), pos + 1u);
         if constexpr (!WRITE) wfill = __builtin_amdgcn_readfirstlane(wfill + n_a + __popcll(m_b));
     };
     // drain the full 64-pair steps (all == false) or everything (all == true); a remainder moves to the front
@@ -623,6 +666,7 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, 8) void lvt_queue_kernel(Args<L, 
     // b: candidates of the subtree rooted at node c (level cut_level) whose box is `cbox`
     auto brute = [&](uint32_t c, const N &cbox) {
         bool on = q.lane_on & iscontact(q.q_node, cbox);
+        work.add(0, q.lane_on);
         if constexpr (MODE == MODE_SELF) on = on & !((c + 1u) <= (self_next >> (levels - cut_level)));
         const uint64_t on_mask = __builtin_amdgcn_ballot_w64(on);
         if (on_mask == 0) return;
@@ -637,6 +681,8 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, 8) void lvt_queue_kernel(Args<L, 
             mybox.up[k] = -float_max<TN>();
         }
         if (lane < np) mybox = load_vol<N>(lp_nodes + (first32 + (uint32_t)lane));
+        work.add(2, lane < np);
+        work.add(0, lane < np ? 2u : 0u); // against the wave's two boxes
         const uint32_t right_leaf = 2u * (first32 + (uint32_t)lane) + 1u; // of this lane's parent
         bool box_on = touches_wave(mybox);
         if constexpr (MODE == MODE_SELF) box_on = box_on & (right_leaf > wave_item0);
@@ -657,6 +703,8 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, 8) void lvt_queue_kernel(Args<L, 
                     // (the parent box comes straight from memory with scalar loads — it is L2-hot, lane u just loaded it —
                     // instead of six v_readlane out of `mybox`: 3 % fewer VALU cycles, measured)
                     const N p = load_vol_uniform<N>(lp_nodes + (first32 + (uint32_t)u));
+                    work.add(0, (uint32_t)(on_mask >> lane) & 1u);
+                    work.add(2, lane == 0);
                     const uint32_t thr = MODE == MODE_SELF ? 2u * (first32 + (uint32_t)u) + 1u : 0xffffffffu; // > my_item
                     const uint64_t hm = test_and_append_f32<true>(on_mask, p.lo[0], p.lo[1], p.lo[2], p.up[0], p.up[1], p.up[2],
                                                                   q.q_node.lo[0], q.q_node.lo[1], q.q_node.lo[2], q.q_node.up[0],
@@ -669,6 +717,7 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, 8) void lvt_queue_kernel(Args<L, 
                     if (qn > QUEUE_CAP - 64) drain(false);
                     const int u = __builtin_ctzll(todo);
                     const N qb = broadcast_from_lane(q.q_node, u);
+                    work.add(0, (uint32_t)(box_mask >> lane) & 1u);
                     const uint32_t thr = MODE == MODE_SELF ? wave_item0 + (uint32_t)u : 0u; // < right_leaf
                     const uint64_t hm = test_and_append_f32<false>(box_mask, qb.lo[0], qb.lo[1], qb.lo[2], qb.up[0], qb.up[1], qb.up[2],
                                                                    mybox.lo[0], mybox.lo[1], mybox.lo[2], mybox.up[0], mybox.up[1],
@@ -683,6 +732,7 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, 8) void lvt_queue_kernel(Args<L, 
                 const int u = __builtin_ctzll(todo);
                 bool h;
                 QE e;
+                work.add(0, (uint32_t)((by_box ? on_mask : box_mask) >> lane) & 1u);
                 if (by_box) {
                     const N pbox = broadcast_from_lane(mybox, u);
                     h = on & iscontact(q.q_node, pbox);
@@ -724,6 +774,8 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, 8) void lvt_queue_kernel(Args<L, 
                 const uint32_t idx = have ? cur[base + lane] : 0u;
                 N box;
                 bool hit = false;
+                work.add(2, have);
+                work.add(0, have ? 2u : 0u);
                 if (have) {
                     box = load_vol<N>(lvl_nodes + (idx - lvl_first));
                     hit = touches_wave(box);
@@ -773,11 +825,13 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, 8) void lvt_queue_kernel(Args<L, 
         if constexpr (WRITE) q.w = (q.valid && q.item > 0) ? (Cnt)a.counts[q.item - 1] : 0;
         joint_walk(q, a);
         q.finish();
+        work.flush(a.work); // (the exact walk's own tests are not counted: frontier overflow only happens on heavily overlapping input)
         if constexpr (!WRITE)
             if (region && lane == 0) *(int *)region = -1;
         return;
     }
     drain(true);
+    work.flush(a.work);
     if constexpr (!WRITE) {
         if (q.valid) a.counts[q.item] = (I)cnts[lane];
         // positions within a query's list must fit the entry's meta field: 2^25 contacts of one leaf never happen
@@ -814,9 +868,10 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, 8) void lvt_queue_kernel(Args<L, 
 // (Tried and dropped in round 2: the top 10 levels of the tree in LDS — a third code path per step, no gain.)
 constexpr int RAY_BITS = 10, RAY_BLOCK_MAX = 1 << RAY_BITS;
 
-template <class L, class N, class I, bool WRITE>
+template <class L, class N, class I, bool WRITE, bool COUNT = false>
 __global__ __launch_bounds__(64) void lvt_rays_kernel(Args<L, N, I> a, PairCache<I> cache, int ray_block) {
     using T = typename L::elt;
+    Work<COUNT> work;
     struct Entry {
         IndexPair<I> pair;
         I meta;
@@ -873,8 +928,9 @@ __global__ __launch_bounds__(64) void lvt_rays_kernel(Args<L, N, I> a, PairCache
         if constexpr (N::kind == IBVH_BBOX) return isintersection_inv(n, p, inv);
         else return isintersection(n, p, d);
     };
-    auto emit = [&](I lidx) {
-        const IndexPair<I> c2{lidx, (I)(first_item + ray + 1)}; // (leaf.index, iray), raytrace/lvt:200
+    auto emit = [&](I lidx, uint32_t lpos) {
+        // (leaf.index, iray), raytrace/lvt:200 — or the leaf's 1-based position (IBVH_OUTPUT_POSITIONS)
+        const IndexPair<I> c2{a.positions ? (I)(lpos + 1u) : lidx, (I)(first_item + ray + 1)};
         if constexpr (WRITE) {
             a.contacts[w++] = c2;
         } else {
@@ -926,6 +982,8 @@ __global__ __launch_bounds__(64) void lvt_rays_kernel(Args<L, N, I> a, PairCache
                 const uint32_t nreal = first - (uint32_t)((uint64_t)vl >> (levels - cl));
                 const bool real0 = c0 != 0u, real1 = (c1 - first) < nreal; // (c0 == 0: the pseudo node above the root)
                 const bool at_leaves = cl == levels;
+                work.add(at_leaves ? 1 : 0, (uint32_t)real0 + (uint32_t)real1);
+                work.add(at_leaves ? 3 : 2, (uint32_t)real0 + (uint32_t)real1);
                 const uint64_t v = (uint64_t)vl >> (levels - cl + 1);
                 const uint32_t sk = (uint32_t)(2 * v) - (uint32_t)__popcll(v); // level_skips(cl)
                 bool h0 = false, h1 = false, descended = false;
@@ -951,6 +1009,10 @@ __global__ __launch_bounds__(64) void lvt_rays_kernel(Args<L, N, I> a, PairCache
                             __builtin_memcpy(&lb, &raw.w[6], 16);
                             h0 = real0 && isintersection(la, p, d);
                             h1 = real1 && isintersection(lb, p, d);
+                            if (a.narrow == IBVH_NARROW_RAY_ORIGIN_OUTSIDE) { // raytrace/lvt:194: isintersection(...) && narrow(leaf, p, d)
+                                h0 = h0 && origin_outside(la, p);
+                                h1 = h1 && origin_outside(lb, p);
+                            }
                             // .index sits right behind the 16-byte volume (4 or 8 bytes)
                             I ia, ib;
                             __builtin_memcpy(&ia, (const char *)&raw.w[0] + a.lay.index_off, sizeof(I) <= 8 ? sizeof(I) : 8);
@@ -967,8 +1029,13 @@ __global__ __launch_bounds__(64) void lvt_rays_kernel(Args<L, N, I> a, PairCache
                     }
                 } else if (at_leaves) {
                     const char *rec = a.leaves + ((int64_t)c0 - (int64_t)leaf_first) * a.lay.stride;
-                    h0 = real0 && isintersection(load_vol<L>(real0 ? rec : rec + a.lay.stride), p, d);
-                    h1 = real1 && isintersection(load_vol<L>(real1 ? rec + a.lay.stride : rec), p, d);
+                    const L la = load_vol<L>(real0 ? rec : rec + a.lay.stride), lb = load_vol<L>(real1 ? rec + a.lay.stride : rec);
+                    h0 = real0 && isintersection(la, p, d);
+                    h1 = real1 && isintersection(lb, p, d);
+                    if (a.narrow == IBVH_NARROW_RAY_ORIGIN_OUTSIDE) {
+                        h0 = h0 && origin_outside(la, p);
+                        h1 = h1 && origin_outside(lb, p);
+                    }
                     if (h0) idx0 = load_index<I>(rec, a.lay);
                     if (h1) idx1 = load_index<I>(rec + a.lay.stride, a.lay);
                 } else {
@@ -987,8 +1054,8 @@ __global__ __launch_bounds__(64) void lvt_rays_kernel(Args<L, N, I> a, PairCache
                     h1 = real1 && node_hit(ch.b);
                 }
                 if (at_leaves) {
-                    if (h0) emit(idx0);
-                    if (h1) emit(idx1);
+                    if (h0) emit(idx0, c0 - leaf_first);
+                    if (h1) emit(idx1, c1 - leaf_first);
                 } else if (h0) {
                     if (h1) pend |= 1u << cl;
                     inode = c0;
@@ -1024,6 +1091,7 @@ __global__ __launch_bounds__(64) void lvt_rays_kernel(Args<L, N, I> a, PairCache
             if (next < items_here && __popcll(idle_now) >= 16) break;
         }
     }
+    work.flush(a.work);
     if constexpr (!WRITE) {
         __builtin_amdgcn_wave_barrier();
         const bool ok = __builtin_amdgcn_ballot_w64(meta_bad) == 0;
@@ -1061,7 +1129,8 @@ template <class I> __global__ __launch_bounds__(SCAN_TPB) void scan_reduce_kerne
 // Every workgroup derives its own tile offset from the raw tile sums (a redundant reduction of <= a few thousand
 // values) instead of waiting for a single-workgroup scan launch in between; the last tile also publishes the total.
 template <class I>
-__global__ __launch_bounds__(SCAN_TPB) void scan_apply_kernel(I *c, int64_t n, const int64_t *partials, int64_t *totals) {
+__global__ __launch_bounds__(SCAN_TPB) void scan_apply_kernel(I *c, int64_t n, const int64_t *partials, int64_t *totals,
+                                                              int64_t *total_host) {
     __shared__ int64_t s_w[SCAN_TPB / 64], s_p[SCAN_TPB / 64];
     int64_t before = 0;
     for (int64_t j = threadIdx.x; j < (int64_t)blockIdx.x; j += SCAN_TPB) before += partials[j];
@@ -1123,7 +1192,11 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_apply_kernel(I *c, int64_t n, c
             if (i < n) c[i] = (I)run;
         }
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_TPB - 1) totals[0] = run; // inclusive value of the last item
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_TPB - 1) {
+        totals[0] = run; // inclusive value of the last item
+        // the host's copy (mapped pinned memory, polled by the caller instead of a stream sync + D2H copy)
+        if (total_host) __hip_atomic_store(total_host, run, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // scratch layout of the *_count / *_write calls:
@@ -1142,12 +1215,14 @@ inline int cache_slots_for(size_t scratch_bytes, int64_t n_items, int64_t pair_b
 }
 
 // inclusive scan in place + (total_out != nullptr) blocking read of the total (the reference's @allowscalar, :60)
-template <class I> int scan_counts(I *counts, int64_t n, int64_t *total_out, void *scratch, hipStream_t st, int64_t *total_dev = nullptr) {
+template <class I>
+int scan_counts(I *counts, int64_t n, int64_t *total_out, void *scratch, hipStream_t st, int64_t *total_dev = nullptr,
+                int64_t *total_host = nullptr) {
     int64_t nparts = ceil_div(n, SCAN_TILE);
     int64_t *totals = total_dev ? total_dev : (int64_t *)scratch; // where the device-side total goes
     int64_t *partials = (int64_t *)scratch + 8;
     IBVH_LAUNCH((scan_reduce_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, partials);
-    IBVH_LAUNCH((scan_apply_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, partials, totals);
+    IBVH_LAUNCH((scan_apply_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, partials, totals, total_host);
     IBVH_LAUNCH_CHECK();
     if (!total_out) return IBVH_OK; // *_enqueue: the total stays in the scratch header, nobody waits
     int64_t total = 0;
@@ -1169,9 +1244,15 @@ inline bool same_types(const ibvh_types &x, const ibvh_types &y) {
            x.node_float == y.node_float && x.index_type == y.index_type && x.morton_type == y.morton_type;
 }
 
+// the instantiations ibvh_lvt_work_counters may ask for: the bench types only
+template <class L, class N, class I> constexpr bool kWorkTypes =
+    std::is_same<L, BSphere<float>>::value && std::is_same<N, BBox<float>>::value && std::is_same<I, int32_t>::value;
+
 template <class L, class N, class I, int MODE>
 int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStream_t st) {
     if (a.n_items == 0) return IBVH_OK;
+    const bool count_work = a.work != nullptr; // (the counting pass of the COUNT instantiation; nothing else is launched)
+    if (count_work && (!kWorkTypes<L, N, I> || write)) return IBVH_ERR_UNSUPPORTED;
     unsigned blocks = (unsigned)ceil_div(a.n_items, 256);
     if constexpr (MODE == MODE_RAYS) {
         // rays of one wave are not spatially coherent: each lane walks on its own
@@ -1184,12 +1265,16 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
         // 3, 1e6 rays: 5.41 / 5.09 / 4.25 ms with 64 / 128 / 256, 5.25 with 512; 1e5 rays: 2.35 / 3.18 ms with 64 / 256)
         int ray_block = 64;
         while (ray_block < 256 && a.n_items / (2 * ray_block) >= 3000) ray_block *= 2;
-        static const int forced_block = [] {
-            const char *e = getenv("IBVH_RAY_BLOCK"); // tuning knob: rays per wave (a power of two, 64 .. 1024)
-            return e ? atoi(e) : 0;
-        }();
+        const int forced_block = g_tuning.ray_block;
         if (forced_block >= 64 && forced_block <= RAY_BLOCK_MAX && (forced_block & (forced_block - 1)) == 0) ray_block = forced_block;
         const unsigned rblocks = (unsigned)ceil_div(a.n_items, (int64_t)ray_block);
+        if constexpr (kWorkTypes<L, N, I>) {
+            if (count_work) {
+                IBVH_LAUNCH((lvt_rays_kernel<L, N, I, false, true>), dim3(rblocks), dim3(64), 0, st, a, cache, ray_block);
+                IBVH_LAUNCH_CHECK();
+                return IBVH_OK;
+            }
+        }
         if (write) IBVH_LAUNCH((lvt_rays_kernel<L, N, I, true>), dim3(rblocks), dim3(64), 0, st, a, cache, ray_block);
         else IBVH_LAUNCH((lvt_rays_kernel<L, N, I, false>), dim3(rblocks), dim3(64), 0, st, a, cache, ray_block);
     } else {
@@ -1197,10 +1282,7 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
         // everything else (BSphere nodes, start_level == levels): the exact joint walk
         if constexpr (N::kind == IBVH_BBOX) {
             if (a.start_level < a.tree.levels) {
-                static const bool force_wide = [] {
-                    const char *e = getenv("IBVH_LVT_WIDE"); // test knob: 64-bit queue entries for every tree
-                    return e && atoi(e) != 0;
-                }();
+                const bool force_wide = g_tuning.lvt_wide != 0; // test knob: 64-bit queue entries for every tree
                 // queue entries pack (leaf-parent index << 6 | lane): 32 bits up to 28 levels (134 M leaves), 64 bits up to
                 // 31 levels (wave-uniform arithmetic is 32-bit: positions + 2^(levels-1) must stay below 2^32); deeper
                 // trees take the exact walk
@@ -1217,6 +1299,15 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
                     aq.start_level = top; // also when the caller named a HIGHER level: levels 1..6 hold < 64 nodes each
                     const int64_t c = aq.tree.levels - BRUTE_DEPTH;
                     const int cut = (int)(c > aq.start_level ? c : aq.start_level);
+                    if constexpr (kWorkTypes<L, N, I>) {
+                        if (count_work) {
+                            if (wide || aq.narrow != IBVH_NARROW_NONE) return IBVH_ERR_UNSUPPORTED;
+                            IBVH_LAUNCH((lvt_queue_kernel<L, N, I, MODE, false, false, false, true>), dim3(qblocks), dim3(64 * QUEUE_WAVES), 0, st,
+                                        aq, cache, cut);
+                            IBVH_LAUNCH_CHECK();
+                            return IBVH_OK;
+                        }
+                    }
                     const int variant = (write ? 1 : 0) | (aq.narrow != IBVH_NARROW_NONE ? 2 : 0) | (wide ? 4 : 0);
 #define IBVH_QUEUE_LAUNCH(W_, N_, D_)                                                                                 \
     IBVH_LAUNCH((lvt_queue_kernel<L, N, I, MODE, W_, N_, D_>), dim3(qblocks), dim3(64 * QUEUE_WAVES), 0, st, aq, cache, cut)
@@ -1236,6 +1327,7 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
                 }
             }
         }
+        if (count_work) return IBVH_ERR_UNSUPPORTED; // (BSphere nodes / start at the leaf level: the exact walk has no counters)
         // (the exact walk keeps the run-time narrow switch: NARROW = true covers both)
         if (write) IBVH_LAUNCH((lvt_joint_kernel<L, N, I, MODE, true, true>), dim3(blocks), dim3(256), 0, st, a, cache);
         else IBVH_LAUNCH((lvt_joint_kernel<L, N, I, MODE, false, true>), dim3(blocks), dim3(256), 0, st, a, cache);
@@ -1248,16 +1340,23 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
 template <int MODE>
 int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const void *dirs, int64_t n_items,
         int64_t start_level, int32_t narrow, int32_t flip, void *counts, int64_t *total_out, void *contacts, void *scratch,
-        size_t scratch_bytes, hipStream_t st, bool enqueue = false, int64_t capacity = 0, int64_t *total_dev = nullptr) {
+        size_t scratch_bytes, hipStream_t st, bool enqueue = false, int64_t capacity = 0, int64_t *total_dev = nullptr,
+        int64_t *total_host = nullptr, unsigned long long *work = nullptr) {
     // three shapes: count (contacts == nullptr), write (contacts, !enqueue), enqueue = count + scan + guarded write
     const bool write = contacts != nullptr && !enqueue;
+    const int32_t positions = (narrow & IBVH_OUTPUT_POSITIONS) ? 1 : 0;
+    if (narrow & ~(IBVH_NARROW_MASK | IBVH_OUTPUT_POSITIONS)) return IBVH_ERR_INVALID_ARG;
+    narrow &= IBVH_NARROW_MASK;
+    if (MODE == MODE_RAYS ? (narrow != IBVH_NARROW_NONE && narrow != IBVH_NARROW_RAY_ORIGIN_OUTSIDE)
+                          : (narrow != IBVH_NARROW_NONE && narrow != IBVH_NARROW_MORTON_LT && narrow != IBVH_NARROW_INDEX_LT))
+        return IBVH_ERR_INVALID_ARG;
     ibvh_layout lay;
     LeafLayout wl, dl;
     if (!layout_of(walk->types, lay, &wl)) return IBVH_ERR_UNSUPPORTED;
     dl = wl;
     if (drv && !layout_of(drv->types, lay, &dl)) return IBVH_ERR_UNSUPPORTED;
-    if (!scratch || scratch_bytes < scan_scratch_bytes(n_items)) return IBVH_ERR_SCRATCH;
-    const int K = cache_slots_for(scratch_bytes, n_items, lay.pair_bytes);
+    if (!work && (!scratch || scratch_bytes < scan_scratch_bytes(n_items))) return IBVH_ERR_SCRATCH;
+    const int K = work ? 0 : cache_slots_for(scratch_bytes, n_items, lay.pair_bytes);
     return dispatch_leaf_node(walk->types, [&](auto lt, auto nt) -> int {
         using L = typename decltype(lt)::type;
         using N = typename decltype(nt)::type;
@@ -1279,20 +1378,20 @@ int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const voi
                 a.start_level = start_level;
                 a.built_level = walk->built_level;
                 a.narrow = narrow;
+                a.positions = positions;
                 a.flip = flip;
-                static const int xcd_env = [] {
-                    const char *e = getenv("IBVH_LVT_XCD"); // tuning knob: 0 = round robin, 1 = one range per XCD, n = runs of n
-                    return e ? atoi(e) : 64;
-                }();
+                const int xcd_env = g_tuning.lvt_xcd;
                 a.xcd_tiles = MODE != MODE_RAYS ? xcd_env : 0; // 0: round robin, 1: one contiguous range per XCD, n > 1: runs of n
                 a.counts = (I *)counts;
                 a.contacts = (IndexPair<I> *)contacts;
                 a.guard_total = nullptr;
                 a.guard_capacity = 0;
+                a.work = work;
                 PairCache<I> cache{K ? (IndexPair<I> *)((char *)scratch + scan_scratch_bytes(n_items)) : nullptr, K};
                 if (int e = launch<L, N, I, MODE>(a, cache, write, st)) return e;
-                if (write) return (int)IBVH_OK;
-                if (int e = scan_counts<I>((I *)counts, n_items, enqueue ? nullptr : total_out, scratch, st, enqueue ? total_dev : nullptr)) return e;
+                if (write || work) return (int)IBVH_OK;
+                if (int e = scan_counts<I>((I *)counts, n_items, enqueue ? nullptr : total_out, scratch, st, enqueue ? total_dev : nullptr,
+                                           enqueue ? total_host : nullptr)) return e;
                 if (enqueue && capacity > 0) {
                     a.guard_total = total_dev ? (const int64_t *)total_dev : (const int64_t *)scratch; // the total contacts
                     a.guard_capacity = sizeof(I) == 4 && capacity > (int64_t)INT32_MAX ? (int64_t)INT32_MAX : capacity;
@@ -1351,18 +1450,20 @@ ibvh_status ibvh_traverse_lvt_write(const ibvh_bvh *bvh, int64_t start_level, in
 // fits `capacity` pairs.  The total stays in the scratch header: read it with ibvh_lvt_total whenever convenient;
 // if it exceeds `capacity`, call ibvh_traverse_lvt_write with a larger buffer (counts and scratch are ready for it).
 ibvh_status ibvh_traverse_lvt_enqueue(const ibvh_bvh *bvh, int64_t start_level, int32_t narrow, void *counts, void *contacts,
-                                      int64_t capacity, void *total_dev, void *scratch, size_t scratch_bytes, void *stream) {
+                                      int64_t capacity, void *total_dev, void *total_host, void *scratch, size_t scratch_bytes,
+                                      void *stream) {
     if (!bvh || capacity < 0) return IBVH_ERR_INVALID_ARG;
     if (int e = check_levels(*bvh, start_level)) return (ibvh_status)e;
     if (!scratch || scratch_bytes < scan_scratch_bytes(bvh->tree.real_leaves)) return IBVH_ERR_SCRATCH;
     if (bvh->tree.real_nodes <= 1) { // traverse_single.jl:17-21: no contacts
         if (hipMemsetAsync(total_dev ? total_dev : scratch, 0, 8, (hipStream_t)stream) != hipSuccess) return IBVH_ERR_HIP;
+        if (total_host) *(volatile int64_t *)total_host = 0; // (host memory: nothing was launched that could write it later)
         return IBVH_OK;
     }
     if (!counts || (capacity > 0 && !contacts)) return IBVH_ERR_INVALID_ARG;
     return (ibvh_status)run<MODE_SELF>(bvh, bvh, nullptr, nullptr, bvh->tree.real_leaves, start_level, narrow, 0, counts,
                                        nullptr, contacts, scratch, scratch_bytes, (hipStream_t)stream, true, capacity,
-                                       (int64_t *)total_dev);
+                                       (int64_t *)total_dev, (int64_t *)total_host);
 }
 // blocking read of the total contact count a *_count / *_enqueue call left in the scratch header
 ibvh_status ibvh_lvt_total(const void *scratch, int64_t *total_out, void *stream) {
@@ -1372,10 +1473,36 @@ ibvh_status ibvh_lvt_total(const void *scratch, int64_t *total_out, void *stream
     return IBVH_OK;
 }
 
+// Work of ONE counting pass (see include/ibvh.h)
+ibvh_status ibvh_lvt_work_counters(const ibvh_bvh *bvh, const ibvh_bvh *bvh2, const void *points, const void *directions,
+                                   int64_t num_rays, void *counts, void *work_out, void *stream) {
+    if (!bvh || !counts || !work_out) return IBVH_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(work_out, 0, 4 * sizeof(unsigned long long), st) != hipSuccess) return IBVH_ERR_HIP;
+    const int64_t sl = bvh->built_level > 1 ? bvh->built_level : 1;
+    if (points) {
+        if (!directions || num_rays <= 0) return IBVH_ERR_INVALID_ARG;
+        return (ibvh_status)run<MODE_RAYS>(nullptr, bvh, points, directions, num_rays, sl, 0, 0, counts, nullptr, nullptr, nullptr,
+                                           0, st, false, 0, nullptr, nullptr, (unsigned long long *)work_out);
+    }
+    if (bvh2) {
+        if (!same_types(bvh->types, bvh2->types)) return IBVH_ERR_UNSUPPORTED;
+        const bool flip = !(bvh->tree.real_leaves >= bvh2->tree.real_leaves); // the BVH with more leaves drives (:15-36)
+        const ibvh_bvh *drv = flip ? bvh2 : bvh, *oth = flip ? bvh : bvh2;
+        const int64_t slo = oth->built_level > 1 ? oth->built_level : 1;
+        return (ibvh_status)run<MODE_PAIR>(drv, oth, nullptr, nullptr, drv->tree.real_leaves, slo, 0, flip ? 1 : 0, counts, nullptr,
+                                           nullptr, nullptr, 0, st, false, 0, nullptr, nullptr, (unsigned long long *)work_out);
+    }
+    if (bvh->tree.real_nodes <= 1) return IBVH_OK;
+    return (ibvh_status)run<MODE_SELF>(bvh, bvh, nullptr, nullptr, bvh->tree.real_leaves, sl, 0, 0, counts, nullptr, nullptr, nullptr, 0,
+                                       st, false, 0, nullptr, nullptr, (unsigned long long *)work_out);
+}
+
 // traverse(bvh1, bvh2, LVTTraversal()) — lvt/traverse_pair.jl:1-116
 static ibvh_status pair_common(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, int64_t sl1, int64_t sl2, int32_t narrow,
                                void *counts, int64_t *total_out, void *contacts, void *scratch, size_t scratch_bytes,
-                               void *stream, bool enqueue = false, int64_t capacity = 0, void *total_dev = nullptr) {
+                               void *stream, bool enqueue = false, int64_t capacity = 0, void *total_dev = nullptr,
+                               void *total_host = nullptr) {
     if (!bvh1 || !bvh2) return IBVH_ERR_INVALID_ARG;
     if (int e = check_levels(*bvh1, sl1)) return (ibvh_status)e;
     if (int e = check_levels(*bvh2, sl2)) return (ibvh_status)e;
@@ -1386,7 +1513,7 @@ static ibvh_status pair_common(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, int64
     const ibvh_bvh *drv = flip ? bvh2 : bvh1, *oth = flip ? bvh1 : bvh2;
     return (ibvh_status)run<MODE_PAIR>(drv, oth, nullptr, nullptr, drv->tree.real_leaves, flip ? sl1 : sl2, narrow,
                                        flip ? 1 : 0, counts, total_out, contacts, scratch, scratch_bytes,
-                                       (hipStream_t)stream, enqueue, capacity, (int64_t *)total_dev);
+                                       (hipStream_t)stream, enqueue, capacity, (int64_t *)total_dev, (int64_t *)total_host);
 }
 ibvh_status ibvh_traverse_pair_lvt_count(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, int64_t sl1, int64_t sl2,
                                          int32_t narrow, void *counts, int64_t *total_out, void *scratch,
@@ -1405,49 +1532,52 @@ ibvh_status ibvh_traverse_pair_lvt_write(const ibvh_bvh *bvh1, const ibvh_bvh *b
 
 ibvh_status ibvh_traverse_pair_lvt_enqueue(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, int64_t sl1, int64_t sl2,
                                            int32_t narrow, void *counts, void *contacts, int64_t capacity, void *total_dev,
-                                           void *scratch, size_t scratch_bytes, void *stream) {
+                                           void *total_host, void *scratch, size_t scratch_bytes, void *stream) {
     if (!scratch || capacity < 0 || (capacity > 0 && !contacts)) return IBVH_ERR_INVALID_ARG;
     return pair_common(bvh1, bvh2, sl1, sl2, narrow, counts, nullptr, contacts, scratch, scratch_bytes, stream, true, capacity,
-                       total_dev);
+                       total_dev, total_host);
 }
 
 // traverse_rays(bvh, points, directions, LVTTraversal()) — raytrace/leaf_vs_tree/leaf_vs_tree.jl:1-90
 static ibvh_status rays_common(const ibvh_bvh *bvh, const void *points, const void *dirs, int64_t num_rays, int64_t sl,
-                               void *counts, int64_t *total_out, void *contacts, void *scratch, size_t scratch_bytes,
-                               void *stream, bool enqueue = false, int64_t capacity = 0, void *total_dev = nullptr) {
+                               int32_t narrow, void *counts, int64_t *total_out, void *contacts, void *scratch, size_t scratch_bytes,
+                               void *stream, bool enqueue = false, int64_t capacity = 0, void *total_dev = nullptr,
+                               void *total_host = nullptr) {
     if (!bvh || num_rays < 0) return IBVH_ERR_INVALID_ARG;
     if (int e = check_levels(*bvh, sl)) return (ibvh_status)e;
     if (bvh->types.leaf_float != bvh->types.node_float) return IBVH_ERR_UNSUPPORTED;
     if (num_rays == 0) { // :22-26
         if (enqueue && (total_dev || scratch) && hipMemsetAsync(total_dev ? total_dev : scratch, 0, 8, (hipStream_t)stream) != hipSuccess)
             return IBVH_ERR_HIP;
+        if (enqueue && total_host) *(volatile int64_t *)total_host = 0;
         return IBVH_OK;
     }
     if (!points || !dirs || !counts) return IBVH_ERR_INVALID_ARG;
-    return (ibvh_status)run<MODE_RAYS>(nullptr, bvh, points, dirs, num_rays, sl, 0, 0, counts, total_out, contacts,
-                                       scratch, scratch_bytes, (hipStream_t)stream, enqueue, capacity, (int64_t *)total_dev);
+    return (ibvh_status)run<MODE_RAYS>(nullptr, bvh, points, dirs, num_rays, sl, narrow, 0, counts, total_out, contacts,
+                                       scratch, scratch_bytes, (hipStream_t)stream, enqueue, capacity, (int64_t *)total_dev,
+                                       (int64_t *)total_host);
 }
 ibvh_status ibvh_traverse_rays_lvt_count(const ibvh_bvh *bvh, const void *points, const void *dirs, int64_t num_rays,
-                                         int64_t sl, void *counts, int64_t *total_out, void *scratch,
+                                         int64_t sl, int32_t narrow, void *counts, int64_t *total_out, void *scratch,
                                          size_t scratch_bytes, void *stream) {
     if (!total_out) return IBVH_ERR_INVALID_ARG;
     *total_out = 0;
     if (num_rays > 0 && !scratch) return IBVH_ERR_INVALID_ARG;
-    return rays_common(bvh, points, dirs, num_rays, sl, counts, total_out, nullptr, scratch, scratch_bytes, stream);
+    return rays_common(bvh, points, dirs, num_rays, sl, narrow, counts, total_out, nullptr, scratch, scratch_bytes, stream);
 }
 ibvh_status ibvh_traverse_rays_lvt_write(const ibvh_bvh *bvh, const void *points, const void *dirs, int64_t num_rays,
-                                         int64_t sl, const void *counts, void *contacts, void *scratch,
+                                         int64_t sl, int32_t narrow, const void *counts, void *contacts, void *scratch,
                                          size_t scratch_bytes, void *stream) {
     if (num_rays > 0 && !contacts) return IBVH_ERR_INVALID_ARG;
     int64_t dummy;
-    return rays_common(bvh, points, dirs, num_rays, sl, (void *)counts, &dummy, contacts, scratch, scratch_bytes, stream);
+    return rays_common(bvh, points, dirs, num_rays, sl, narrow, (void *)counts, &dummy, contacts, scratch, scratch_bytes, stream);
 }
 ibvh_status ibvh_traverse_rays_lvt_enqueue(const ibvh_bvh *bvh, const void *points, const void *dirs, int64_t num_rays,
-                                           int64_t sl, void *counts, void *contacts, int64_t capacity, void *total_dev,
-                                           void *scratch, size_t scratch_bytes, void *stream) {
+                                           int64_t sl, int32_t narrow, void *counts, void *contacts, int64_t capacity,
+                                           void *total_dev, void *total_host, void *scratch, size_t scratch_bytes, void *stream) {
     if (!scratch || capacity < 0 || (capacity > 0 && !contacts)) return IBVH_ERR_INVALID_ARG;
-    return rays_common(bvh, points, dirs, num_rays, sl, counts, nullptr, contacts, scratch, scratch_bytes, stream, true, capacity,
-                       total_dev);
+    return rays_common(bvh, points, dirs, num_rays, sl, narrow, counts, nullptr, contacts, scratch, scratch_bytes, stream, true, capacity,
+                       total_dev, total_host);
 }
 
 } // extern "C"

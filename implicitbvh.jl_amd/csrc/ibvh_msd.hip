@@ -1013,11 +1013,6 @@ template <class K, int TPB, int IPT> constexpr size_t finish_smem() {
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
-static int env_int(const char *name, int dflt) {
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
 static size_t carve_tables(Tables *tb, char *base, int radix, int num_tiles, int max_seg, int max_tiles2) {
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -1051,13 +1046,9 @@ static size_t carve_tables(Tables *tb, char *base, int radix, int num_tiles, int
 }
 
 Plan make_plan(int64_t n, int key_bits, int key_bytes, int leaf_bytes, void *sort_scratch) {
-    // tuning knobs (measurement only): IBVH_MSD=0 disables the path, IBVH_MSD_BITS / _CAP / _TILE force a geometry
-    static const int enabled = env_int("IBVH_MSD", 1);
-    static const int f_bits = env_int("IBVH_MSD_BITS", 0);
-    static const int f_cap = env_int("IBVH_MSD_CAP", 0);
-    static const int f_tile = env_int("IBVH_MSD_TILE", 0);
-    static const int f_avg = env_int("IBVH_MSD_AVG", 1024);
-    static const int f_ftpb = env_int("IBVH_MSD_FTPB", 0);
+    // development knobs (ibvh_set_tuning): msd = 0 disables the path, msd_bits / _cap / _tile / _ftpb force a geometry
+    const int enabled = g_tuning.msd, f_bits = g_tuning.msd_bits, f_cap = g_tuning.msd_cap, f_tile = g_tuning.msd_tile,
+              f_avg = g_tuning.msd_avg, f_ftpb = g_tuning.msd_ftpb;
     Plan p{};
     if (!enabled || n < 4096 || key_bits <= 8 || n >= ((int64_t)1 << 32) - 65536) return p;
     int bits = 6; // (>= 6: the scan kernel works on blocks of 64 digits)
@@ -1117,12 +1108,17 @@ size_t scratch_bytes(int64_t n, int key_bits, int key_bytes, int leaf_bytes) {
     return carve_tables(nullptr, nullptr, 1 << p.bits, p.num_tiles, p.max_seg, p.max_tiles2) + 4096;
 }
 
+constexpr int kMaxLds = 160 * 1024; // LDS of a gfx950 CU
+
 template <class K, int PT, int PI>
 static int launch_partitions(const Plan &p, const K *keys, int64_t n, const RecordArgs &ra, char *part2, char *out, K *side0, K *side1, int levels,
                              hipStream_t st) {
     const size_t smem = partition_smem<K, PT, PI>(p.bits, ra.lay.stride);
     if (smem > 160 * 1024) return IBVH_ERR_INVALID_ARG; // (make_plan sizes the tile for the record)
-    IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)partition_kernel<K, PT, PI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    // The attribute is per function and per device, and calls may come from several host threads with different geometries:
+    // always the SAME value (the whole LDS), so that the order of concurrent calls cannot matter; a launch still only
+    // allocates what it asks for.
+    IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)partition_kernel<K, PT, PI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
     const uint32_t words = (uint32_t)ra.lay.stride / 8u;
     const uint32_t inv_words = (uint32_t)((((uint64_t)1 << 32) + words - 1) / words);
     IBVH_LAUNCH((partition_kernel<K, PT, PI, false>), dim3(p.num_tiles), dim3(PT), smem, st, keys, n, p.shift, p.bits, p.tb,
@@ -1133,14 +1129,14 @@ static int launch_partitions(const Plan &p, const K *keys, int64_t n, const Reco
     const uint32_t tile = (uint32_t)PT * PI, cap = (uint32_t)(p.ftpb * p.fipt);
     const LeafLayout lay = ra.lay;
     const size_t smem2 = partition_smem<K, PT, PI>(L2_BITS, ra.lay.stride);
-    IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)partition_kernel<K, PT, PI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
+    IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)partition_kernel<K, PT, PI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
     char *buf[2] = {(char *)ra.dst, part2};
     K *side[2] = {side0, side1}; // compact keys of the records in buf[0] / buf[1]
     const unsigned stride_grid = (unsigned)(p.max_tiles2 < 2048 ? p.max_tiles2 : 2048);
     const unsigned seg_grid = (unsigned)(p.max_seg < 1024 ? p.max_seg : 1024);
     for (int li = 0; li < levels; ++li) {
         const char *src = buf[li & 1];
-        static const int measure = env_int("IBVH_MSD_RANGE", 1); // tuning knob: 0 = first extra level on the next 8 bits, unmeasured
+        const int measure = g_tuning.msd_range; // 0 = first extra level on the next 8 bits, unmeasured
         const bool measured = li == 0 && measure != 0;
         if (measured) IBVH_LAUNCH((range_kernel<K>), dim3(stride_grid), dim3(256), 0, st, p.tb, li, (const K *)side[li & 1], tile);
         IBVH_LAUNCH((hist_level_kernel<K>), dim3(stride_grid), dim3(256), 0, st, p.tb, li, (const K *)side[li & 1], tile, measured ? 1 : 0);
@@ -1158,7 +1154,7 @@ static int launch_partitions(const Plan &p, const K *keys, int64_t n, const Reco
 template <class K, int FT, int FI>
 static int launch_finish(const Plan &p, const FinishArgs &fa, hipStream_t st) {
     constexpr size_t smem = finish_smem<K, FT, FI>();
-    IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)finish_kernel<K, FT, FI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)finish_kernel<K, FT, FI>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
     const int f2 = fa.levels <= 0 ? 0 : (p.max_tiles2 < 1024 ? p.max_tiles2 : 1024); // workgroups that stride over the extra levels' windows
     IBVH_LAUNCH((finish_kernel<K, FT, FI>), dim3((1u << p.bits) + f2), dim3(FT), smem, st, p.tb, 1 << p.bits, fa);
     return IBVH_OK;

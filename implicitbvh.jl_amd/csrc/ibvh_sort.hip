@@ -511,10 +511,7 @@ struct FirstPassPlan {
 // Small inputs get small tiles so the grid still covers the 256 CUs; large inputs get 8192-element
 // tiles so that one digit's run in a tile is >= 128 B on average.
 inline Geometry choose_geometry(int64_t n) {
-    static const int forced = [] {
-        const char *e = getenv("IBVH_SORT_TILE"); // tuning knob: 2048, 4096, 8192 or 16384 keys per tile
-        return e ? atoi(e) : 0;
-    }();
+    const int forced = g_tuning.sort_tile; // 2048, 4096, 8192 or 16384 keys per tile
     switch (forced) {
     case 2048: return Geometry{256, 8};
     case 4096: return Geometry{256, 16};
@@ -531,15 +528,9 @@ struct MsdPlan {
     int btpb;     // threads of the bucket workgroup (capacity / btpb keys per thread)
 };
 inline MsdPlan choose_msd(int64_t n, int key_bits, int key_bytes) {
-    static const int mode = [] {
-        const char *e = getenv("IBVH_SORT_MODE"); // tuning knob: "lsd" forces the plain LSD passes
-        return (e && e[0] == 'l') ? 1 : 0;
-    }();
+    const int mode = g_tuning.sort_lsd ? 1 : 0;
     if (mode == 1 || n < 2048 || key_bits <= 8) return {0, 0, 0};
-    static const int msd_avg_max = [] {
-        const char *e = getenv("IBVH_MSD_AVG"); // tuning knob: largest average bucket before another partition bit is taken
-        return e ? atoi(e) : 1536;
-    }();
+    const int msd_avg_max = g_tuning.sort_msd_avg;
     int bits = 1;
     while (bits < MSD_MAX_BITS && bits < key_bits && (n >> bits) > msd_avg_max) ++bits;
     const int64_t avg = n >> bits;
@@ -550,10 +541,7 @@ inline MsdPlan choose_msd(int64_t n, int key_bits, int key_bytes) {
     int cap = 2048;
     while (cap < cap_max && avg * 4 > cap * 3) cap *= 2; // average bucket <= 3/4 of the capacity
     if (avg * 4 > (int64_t)cap * 3) return {0, 0, 0};   // too many keys for one partition level: LSD
-    static const int forced_tpb = [] {
-        const char *e = getenv("IBVH_BUCKET_TPB"); // tuning knob: 256 / 512 / 1024 threads per bucket workgroup
-        return e ? atoi(e) : 0;
-    }();
+    const int forced_tpb = g_tuning.bucket_tpb;
     int btpb = cap == 2048 ? 256 : (cap == 4096 ? 512 : 1024);
     if (forced_tpb == 256 || forced_tpb == 512 || forced_tpb == 1024) btpb = forced_tpb;
     if (cap / btpb < 8) btpb = cap / 8;

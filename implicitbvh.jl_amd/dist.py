@@ -131,39 +131,27 @@ class HipEngine:
         return out if raw else out.to(torch.int64)
 
     def partition(self, keys, splitters, nranks, known_counts=None):
-        """Stable partition of the local leaves by destination rank: (perm, counts per rank).  `known_counts`:
-        the per-destination counts when the caller already derived them (saves a bincount + host sync)."""
+        """Stable partition of the local leaves by destination rank: (perm, counts per rank), always inside the library
+        (ibvh_dist_partition: destination kernel + ONE stable radix pass).  `known_counts`: this rank's row of the send
+        matrix when the caller already derived it from the all-gathered histograms; otherwise the destination kernel
+        counts as well and the row is read back (one small device -> host copy)."""
         torch = self.torch
         n = keys.numel()
         if nranks == 1:
             return None, [n]
+        if nranks > 256:
+            raise ValueError("the distributed build supports at most 256 ranks (ibvh_dist_partition)")
         if n == 0:
             return torch.empty(0, dtype=torch.int32, device=self.device), [0] * nranks
-        if known_counts is not None and nranks <= 256:
-            # fused path: destination kernel + one stable radix pass inside the library (ibvh_dist_partition)
-            perm = torch.empty(n, dtype=torch.int32, device=self.device)
-            need = C.c_size_t()
-            lib.call("ibvh_dist_partition_scratch_bytes", n, C.byref(need))
-            scratch = torch.empty(need.value, dtype=torch.uint8, device=self.device)
-            arr = (C.c_uint64 * max(len(splitters), 1))(*[int(sp) for sp in splitters])
-            lib.call("ibvh_dist_partition", keys.element_size(), api._ptr(keys), n, arr, nranks, api._ptr(perm), api._ptr(scratch),
-                     need.value, api._stream())
-            return perm, list(known_counts)
-        if splitters:
-            dest = torch.bucketize(keys, torch.tensor(splitters, dtype=keys.dtype, device=self.device), right=True).to(torch.int32)
-        else:
-            dest = torch.zeros(n, dtype=torch.int32, device=self.device)
-        counts = known_counts if known_counts is not None else torch.bincount(dest, minlength=nranks).cpu().tolist()
-        vals = torch.arange(n, dtype=torch.int32, device=self.device)
-        d2, v2 = torch.empty_like(dest), torch.empty_like(vals)
+        perm = torch.empty(n, dtype=torch.int32, device=self.device)
+        counts = None if known_counts is not None else torch.empty(nranks, dtype=torch.int64, device=self.device)
         need = C.c_size_t()
-        lib.call("ibvh_sort_scratch_bytes", 4, n, C.byref(need))
+        lib.call("ibvh_dist_partition_scratch_bytes", n, C.byref(need))
         scratch = torch.empty(need.value, dtype=torch.uint8, device=self.device)
-        in_alt = C.c_int32()
-        bits = max(1, int(nranks - 1).bit_length())
-        lib.call("ibvh_sort_pairs", 4, bits, n, api._ptr(dest), api._ptr(vals), api._ptr(d2), api._ptr(v2), C.byref(in_alt),
-                 api._ptr(scratch), need.value, api._stream())
-        return (v2 if in_alt.value else vals), counts
+        arr = (C.c_uint64 * max(len(splitters), 1))(*[int(sp) for sp in splitters])
+        lib.call("ibvh_dist_partition", keys.element_size(), api._ptr(keys), n, arr, nranks, api._ptr(perm),
+                 api._ptr(counts) if counts is not None else None, api._ptr(scratch), need.value, api._stream())
+        return perm, (list(known_counts) if known_counts is not None else counts.cpu().tolist())
 
     def pack(self, types, vols, keys, perm, index_base):
         torch = self.torch
@@ -186,6 +174,11 @@ class HipEngine:
 
     def to_host(self, t):
         return t.cpu().numpy()
+
+    def event_pair(self):
+        """two HIP events for timing a span of the current stream (the all-to-all: torch's RCCL backend makes its own
+        stream wait for the current one and the current one wait for the collective)"""
+        return self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
 
     # ---- cross-shard completion ------------------------------------------------------------------
     def root_box(self, bvh):
@@ -307,6 +300,7 @@ class DistributedBuilder:
         self.engine = engine or HipEngine()
         self.tolerance = tolerance  # allowed imbalance per splitter, as a fraction of N/P (0 = exact)
         self.last = {}
+        self.time_exchange = False  # exchange_stats(): bracket the all-to-all with HIP events
 
     def build(self, volumes, node_type=None, cache=None, options=None):
         eng, comm = self.engine, self.comm
@@ -383,10 +377,15 @@ class DistributedBuilder:
             recv_counts = eng.to_host(rc).tolist()
         else:
             recv_counts = list(send_counts)
+        events = eng.event_pair() if self.time_exchange and hasattr(eng, "event_pair") else None
+        if events:
+            events[0].record()
         if comm.size > 1:
             recv = comm.all_to_all(records, [c * rec_bytes for c in send_counts], [c * rec_bytes for c in recv_counts])
         else:
             recv = records
+        if events:
+            events[1].record()
         n_recv = int(sum(recv_counts))
         # A rank left without leaves (all its keys' neighbours are duplicates of one splitter key, or the cloud is
         # heavily clustered) cannot build a tree.  EVERY rank must learn that and raise together: a rank that
@@ -402,12 +401,34 @@ class DistributedBuilder:
         if min_recv < 1:
             raise abi.DomainError("a rank received no leaves (degenerate key distribution): every rank stops here")
         self.last = {"splitters": splitters, "send_counts": send_counts, "recv_counts": recv_counts, "base": base,
-                     "n_global": n_global, "extrema": ext_host}
+                     "n_global": n_global, "extrema": ext_host, "record_bytes": rec_bytes, "exchange_events": events}
         # 4. local build over the received slice
         bvh = eng.build_local(types, recv, n_recv, ext_host, node_type, options, cache)
         self.last["types"] = types
         self.last["n_slice"] = n_recv
         return bvh
+
+    def exchange_stats(self, volumes, node_type=None, options=None, repeats=3):
+        """What this rank's share of the distributed sort exchange costs: `repeats` builds with the all-to-all bracketed
+        by HIP events.  Returns {"rank", "exchange_ms" (mean), "bytes_sent", "bytes_received" (both WITHOUT the part
+        that stays on this GPU), "peers"}: with 7 xGMI links of ~153 GB/s per GPU the exchange is per-link bound, so
+        bytes_sent / peers / exchange_ms against 153 GB/s is the figure to watch on a real node."""
+        self.time_exchange = True
+        try:
+            ms, cache = [], None
+            for _ in range(max(1, repeats)):
+                cache = self.build(volumes, node_type, cache=cache, options=options)
+                ev = self.last.get("exchange_events")
+                if ev:
+                    ev[1].synchronize()
+                    ms.append(ev[0].elapsed_time(ev[1]))
+        finally:
+            self.time_exchange = False
+        me, rb = self.comm.rank, self.last["record_bytes"]
+        sent = sum(c for r, c in enumerate(self.last["send_counts"]) if r != me) * rb
+        received = sum(c for r, c in enumerate(self.last["recv_counts"]) if r != me) * rb
+        return {"rank": me, "exchange_ms": round(sum(ms) / len(ms), 4) if ms else None, "bytes_sent": int(sent),
+                "bytes_received": int(received), "peers": self.comm.size - 1}
 
     def cross_contacts(self, bvh):
         """Cross-shard contact completion: contacts between leaves of DIFFERENT slices.

@@ -35,6 +35,15 @@ using AMDGPU: ROCArray, ROCVector, ROCMatrix
 
 const libibvh = get(ENV, "LIBIBVH", "libibvh.so")
 
+# The header this file was written against (include/ibvh.h, IBVH_ABI_VERSION).  A library with another struct layout or
+# argument list would make the GPU write through garbage pointers, so a mismatch is refused when the extension loads.
+const IBVH_ABI_VERSION = Int32(3)
+function __init__()
+    got = ccall((:ibvh_abi_version, libibvh), Int32, ())
+    got == IBVH_ABI_VERSION ||
+        error("libibvh ABI version $got, ImplicitBVHlibibvhExt was written against $IBVH_ABI_VERSION: rebuild / update one of them")
+end
+
 # ---- POD descriptors (must match include/ibvh.h) ------------------------------------------------------
 struct IbvhTypes
     leaf_kind::Int32; leaf_float::Int32; node_kind::Int32; node_float::Int32; index_type::Int32; morton_type::Int32
@@ -101,6 +110,18 @@ struct IndexLess end
 (::IndexLess)(a, b) = a.index < b.index
 # the device-side menu, or `nothing`: the caller then hands the whole call to the reference's generic method
 narrow_code(f) = f === DEFAULT_NARROW ? Int32(0) : f isa MortonLess ? Int32(1) : f isa IndexLess ? Int32(2) : nothing
+"`narrow=OriginOutside()` for traverse_rays: (bv, p, d) -> the ray's origin lies outside bv.volume, evaluated on the device
+(IBVH_NARROW_RAY_ORIGIN_OUTSIDE): drops the leaves a ray starts in."
+struct OriginOutside end
+(::OriginOutside)(bv::BoundingVolume{<:BSphere}, p, d) =
+    (p[1] - bv.volume.x[1])^2 + (p[2] - bv.volume.x[2])^2 + (p[3] - bv.volume.x[3])^2 > bv.volume.r * bv.volume.r
+(::OriginOutside)(bv::BoundingVolume{<:BBox}, p, d) = any(p .< bv.volume.lo) || any(p .> bv.volume.up)
+ray_narrow_code(f) = f === DEFAULT_RAY_NARROW ? Int32(0) : f isa OriginOutside ? Int32(3) : nothing
+# Any other PURE predicate can also be served without the generic path: OR IBVH_OUTPUT_POSITIONS (0x100) into the code
+# and the contact list holds leaf positions ((query, partner) / (bvh1, bvh2) / (leaf, iray), include/ibvh.h) on which the
+# caller evaluates the predicate itself — `narrow` is only ever used as `iscontact(...) && narrow(...)` at leaf level.
+# The methods below keep handing unknown closures to the reference's own generic method instead: a closure is not
+# known to be pure.
 
 # ---- scratch: one growing ROCVector{UInt8} per (task, purpose) instead of an allocation per call -------------
 function scratch!(purpose::Symbol, nbytes::Integer)
@@ -119,6 +140,34 @@ function next_total_word()
     slot = calls[] % 64
     calls[] += 1
     Ptr{Cvoid}(UInt(pointer(words)) + 8 * slot)
+end
+
+# The host-side mirror of a total (include/ibvh.h, `total_host`): words of ONE block of mapped pinned host memory,
+# allocated once per process and never freed (a kernel still in flight can only ever write into memory this module owns).
+# The scan kernel stores the total there with a system-scope release; the host polls the word instead of synchronising
+# the stream and copying 8 bytes back (the reference's blocking `@allowscalar`, lvt/traverse_single.jl:60).
+const HOST_WORDS = 4096
+const HOST_PENDING = typemin(Int64) >> 1
+const host_block = Ref{Ptr{Int64}}(C_NULL)
+const host_next = Threads.Atomic{Int}(0)
+function next_host_word()
+    if host_block[] == C_NULL
+        p = Ref{Ptr{Cvoid}}(C_NULL)
+        AMDGPU.HIP.hipHostMalloc(p, 8 * HOST_WORDS, 0) |> AMDGPU.HIP.check   # hipHostMallocDefault: mapped, coherent
+        host_block[] = Ptr{Int64}(p[])
+    end
+    w = host_block[] + 8 * (Threads.atomic_add!(host_next, 1) % HOST_WORDS)
+    unsafe_store!(w, HOST_PENDING)
+    w
+end
+function poll_total(w::Ptr{Int64}, tdev, stream)
+    for _ in 1:50_000_000
+        v = unsafe_load(w)          # (a volatile read of pinned memory: the GPU's store becomes visible here)
+        v != HOST_PENDING && return v
+    end
+    total = Ref{Int64}(0)           # never arrived (should not happen): the blocking device read
+    check(c_lvt_total(tdev, total, stream), "ibvh_lvt_total")
+    total[]
 end
 
 # ---- one ccall per C entry point (include/ibvh.h) ---------------------------------------------------------
@@ -146,10 +195,10 @@ c_traverse_lvt_write(bvh, sl, narrow, counts, contacts, scratch, sb, stream) =
     ccall((:ibvh_traverse_lvt_write, libibvh), Cint,
           (Ref{IbvhBvh}, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
           bvh, sl, narrow, counts, contacts, scratch, sb, stream)
-c_traverse_lvt_enqueue(bvh, sl, narrow, counts, contacts, capacity, total_dev, scratch, sb, stream) =
+c_traverse_lvt_enqueue(bvh, sl, narrow, counts, contacts, capacity, total_dev, total_host, scratch, sb, stream) =
     ccall((:ibvh_traverse_lvt_enqueue, libibvh), Cint,
-          (Ref{IbvhBvh}, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
-          bvh, sl, narrow, counts, contacts, capacity, total_dev, scratch, sb, stream)
+          (Ref{IbvhBvh}, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+          bvh, sl, narrow, counts, contacts, capacity, total_dev, total_host, scratch, sb, stream)
 c_traverse_pair_lvt_count(bvh1, bvh2, sl1, sl2, narrow, counts, total, scratch, sb, stream) =
     ccall((:ibvh_traverse_pair_lvt_count, libibvh), Cint,
           (Ref{IbvhBvh}, Ref{IbvhBvh}, Int64, Int64, Int32, Ptr{Cvoid}, Ref{Int64}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
@@ -158,22 +207,22 @@ c_traverse_pair_lvt_write(bvh1, bvh2, sl1, sl2, narrow, counts, contacts, scratc
     ccall((:ibvh_traverse_pair_lvt_write, libibvh), Cint,
           (Ref{IbvhBvh}, Ref{IbvhBvh}, Int64, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
           bvh1, bvh2, sl1, sl2, narrow, counts, contacts, scratch, sb, stream)
-c_traverse_pair_lvt_enqueue(bvh1, bvh2, sl1, sl2, narrow, counts, contacts, capacity, total_dev, scratch, sb, stream) =
+c_traverse_pair_lvt_enqueue(bvh1, bvh2, sl1, sl2, narrow, counts, contacts, capacity, total_dev, total_host, scratch, sb, stream) =
     ccall((:ibvh_traverse_pair_lvt_enqueue, libibvh), Cint,
-          (Ref{IbvhBvh}, Ref{IbvhBvh}, Int64, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
-          bvh1, bvh2, sl1, sl2, narrow, counts, contacts, capacity, total_dev, scratch, sb, stream)
-c_traverse_rays_lvt_count(bvh, points, dirs, num_rays, sl, counts, total, scratch, sb, stream) =
+          (Ref{IbvhBvh}, Ref{IbvhBvh}, Int64, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+          bvh1, bvh2, sl1, sl2, narrow, counts, contacts, capacity, total_dev, total_host, scratch, sb, stream)
+c_traverse_rays_lvt_count(bvh, points, dirs, num_rays, sl, narrow, counts, total, scratch, sb, stream) =
     ccall((:ibvh_traverse_rays_lvt_count, libibvh), Cint,
-          (Ref{IbvhBvh}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ref{Int64}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
-          bvh, points, dirs, num_rays, sl, counts, total, scratch, sb, stream)
-c_traverse_rays_lvt_write(bvh, points, dirs, num_rays, sl, counts, contacts, scratch, sb, stream) =
+          (Ref{IbvhBvh}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int32, Ptr{Cvoid}, Ref{Int64}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+          bvh, points, dirs, num_rays, sl, narrow, counts, total, scratch, sb, stream)
+c_traverse_rays_lvt_write(bvh, points, dirs, num_rays, sl, narrow, counts, contacts, scratch, sb, stream) =
     ccall((:ibvh_traverse_rays_lvt_write, libibvh), Cint,
-          (Ref{IbvhBvh}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
-          bvh, points, dirs, num_rays, sl, counts, contacts, scratch, sb, stream)
-c_traverse_rays_lvt_enqueue(bvh, points, dirs, num_rays, sl, counts, contacts, capacity, total_dev, scratch, sb, stream) =
+          (Ref{IbvhBvh}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+          bvh, points, dirs, num_rays, sl, narrow, counts, contacts, scratch, sb, stream)
+c_traverse_rays_lvt_enqueue(bvh, points, dirs, num_rays, sl, narrow, counts, contacts, capacity, total_dev, total_host, scratch, sb, stream) =
     ccall((:ibvh_traverse_rays_lvt_enqueue, libibvh), Cint,
-          (Ref{IbvhBvh}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
-          bvh, points, dirs, num_rays, sl, counts, contacts, capacity, total_dev, scratch, sb, stream)
+          (Ref{IbvhBvh}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+          bvh, points, dirs, num_rays, sl, narrow, counts, contacts, capacity, total_dev, total_host, scratch, sb, stream)
 c_bfs_initial_capacity(bvh, sl, out) =
     ccall((:ibvh_bfs_initial_capacity, libibvh), Cint,
           (Ref{IbvhBvh}, Int64, Ref{Int64}),
@@ -198,10 +247,10 @@ c_traverse_pair_bfs(bvh1, bvh2, sl1, sl2, narrow, bvtt1, bvtt2, capacity, counte
     ccall((:ibvh_traverse_pair_bfs, libibvh), Cint,
           (Ref{IbvhBvh}, Ref{IbvhBvh}, Int64, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ref{IbvhBfsResult}, Ptr{Cvoid}),
           bvh1, bvh2, sl1, sl2, narrow, bvtt1, bvtt2, capacity, counters, result, stream)
-c_traverse_rays_bfs(bvh, points, dirs, num_rays, sl, bvtt1, bvtt2, capacity, counters, result, stream) =
+c_traverse_rays_bfs(bvh, points, dirs, num_rays, sl, narrow, bvtt1, bvtt2, capacity, counters, result, stream) =
     ccall((:ibvh_traverse_rays_bfs, libibvh), Cint,
-          (Ref{IbvhBvh}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ref{IbvhBfsResult}, Ptr{Cvoid}),
-          bvh, points, dirs, num_rays, sl, bvtt1, bvtt2, capacity, counters, result, stream)
+          (Ref{IbvhBvh}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ref{IbvhBfsResult}, Ptr{Cvoid}),
+          bvh, points, dirs, num_rays, sl, narrow, bvtt1, bvtt2, capacity, counters, result, stream)
 
 # ---- BVH(...) — build.jl:198-271 ------------------------------------------------------------------------
 function ImplicitBVH.BVH(
@@ -282,8 +331,10 @@ function lvt_two_pass(::Type{I}, like, n_items, types, slots, cache, count, writ
         # work is queued — and the ordinary _write runs only if the cached buffer turned out too small.
         eltype(cache.cache1) === IndexPair{I} || throw(ArgumentError("eltype(cache.cache1) === IndexPair{I} must hold"))
         tdev = next_total_word()
-        check(enqueue(counts, cache.cache1, length(cache.cache1), tdev, scratch, need[]), "ibvh_traverse_*_lvt_enqueue")
-        check(c_lvt_total(tdev, total, stream_ptr()), "ibvh_lvt_total")
+        thost = next_host_word()
+        check(enqueue(counts, cache.cache1, length(cache.cache1), tdev, Ptr{Cvoid}(thost), scratch, need[]), "ibvh_traverse_*_lvt_enqueue")
+        total[] = poll_total(thost, tdev, stream_ptr())
+        I === Int32 && total[] > typemax(Int32) && throw(OverflowError("more than typemax(Int32) contacts"))
         if total[] > length(cache.cache1)
             resize!(cache.cache1, total[])
             check(write(counts, cache.cache1, scratch, need[]), "ibvh_traverse_*_lvt_write")
@@ -319,7 +370,7 @@ function ImplicitBVH.traverse(
     total, contacts, counts = lvt_two_pass(I, bvh.nodes, length(bvh.leaves), d.types, LVT_CACHE_SLOTS, cache,
         (cn, tot, sc, sb) -> c_traverse_lvt_count(d, start_level, code, devptr(cn), tot, devptr(sc), sb, s),
         (cn, ct, sc, sb) -> c_traverse_lvt_write(d, start_level, code, devptr(cn), devptr(ct), devptr(sc), sb, s),
-        (cn, ct, cap, td, sc, sb) -> c_traverse_lvt_enqueue(d, start_level, code, devptr(cn), devptr(ct), cap, td, devptr(sc), sb, s))
+        (cn, ct, cap, td, th, sc, sb) -> c_traverse_lvt_enqueue(d, start_level, code, devptr(cn), devptr(ct), cap, td, th, devptr(sc), sb, s))
     BVHTraversal(Int(start_level), 0, total, contacts, counts)
 end
 
@@ -349,7 +400,7 @@ function ImplicitBVH.traverse(
     total, contacts, counts = lvt_two_pass(I, bvh1.nodes, n_items, d1.types, LVT_CACHE_SLOTS, cache,
         (cn, tot, sc, sb) -> c_traverse_pair_lvt_count(d1, d2, start_level1, start_level2, code, devptr(cn), tot, devptr(sc), sb, s),
         (cn, ct, sc, sb) -> c_traverse_pair_lvt_write(d1, d2, start_level1, start_level2, code, devptr(cn), devptr(ct), devptr(sc), sb, s),
-        (cn, ct, cap, td, sc, sb) -> c_traverse_pair_lvt_enqueue(d1, d2, start_level1, start_level2, code, devptr(cn), devptr(ct), cap, td, devptr(sc), sb, s))
+        (cn, ct, cap, td, th, sc, sb) -> c_traverse_pair_lvt_enqueue(d1, d2, start_level1, start_level2, code, devptr(cn), devptr(ct), cap, td, th, devptr(sc), sb, s))
     BVHTraversal(Int(start_level1), Int(start_level2), 0, total, contacts, counts)
 end
 
@@ -375,7 +426,8 @@ function ImplicitBVH.traverse_rays(
     options=BVHOptions(),
 ) where {I}
     d = bvh_desc(bvh)
-    if narrow !== DEFAULT_RAY_NARROW || d.types.leaf_float != d.types.node_float   # (isintersection needs one T)
+    code = ray_narrow_code(narrow)
+    if isnothing(code) || d.types.leaf_float != d.types.node_float   # (isintersection needs one T)
         return invoke(ImplicitBVH.traverse_rays, Tuple{BVH, AbstractMatrix, AbstractMatrix, LVTTraversal},
                       bvh, points, directions, alg; start_level=start_level, narrow=narrow, cache=cache, options=options)
     end
@@ -388,9 +440,9 @@ function ImplicitBVH.traverse_rays(
     end
     s = stream_ptr()
     total, contacts, counts = lvt_two_pass(I, bvh.nodes, nr, d.types, RAY_CACHE_SLOTS, cache,
-        (cn, tot, sc, sb) -> c_traverse_rays_lvt_count(d, devptr(p), devptr(dr), nr, start_level, devptr(cn), tot, devptr(sc), sb, s),
-        (cn, ct, sc, sb) -> c_traverse_rays_lvt_write(d, devptr(p), devptr(dr), nr, start_level, devptr(cn), devptr(ct), devptr(sc), sb, s),
-        (cn, ct, cap, td, sc, sb) -> c_traverse_rays_lvt_enqueue(d, devptr(p), devptr(dr), nr, start_level, devptr(cn), devptr(ct), cap, td, devptr(sc), sb, s))
+        (cn, tot, sc, sb) -> c_traverse_rays_lvt_count(d, devptr(p), devptr(dr), nr, start_level, code, devptr(cn), tot, devptr(sc), sb, s),
+        (cn, ct, sc, sb) -> c_traverse_rays_lvt_write(d, devptr(p), devptr(dr), nr, start_level, code, devptr(cn), devptr(ct), devptr(sc), sb, s),
+        (cn, ct, cap, td, th, sc, sb) -> c_traverse_rays_lvt_enqueue(d, devptr(p), devptr(dr), nr, start_level, code, devptr(cn), devptr(ct), cap, td, th, devptr(sc), sb, s))
     BVHTraversal(Int(start_level), 0, total, contacts, counts)
 end
 
@@ -487,7 +539,8 @@ function ImplicitBVH.traverse_rays(
     options=BVHOptions(),
 ) where {I}
     d = bvh_desc(bvh)
-    if narrow !== DEFAULT_RAY_NARROW || d.types.leaf_float != d.types.node_float
+    code = ray_narrow_code(narrow)
+    if isnothing(code) || d.types.leaf_float != d.types.node_float
         return invoke(ImplicitBVH.traverse_rays, Tuple{BVH, AbstractMatrix, AbstractMatrix, BFSTraversal},
                       bvh, points, directions, alg; start_level=start_level, narrow=narrow, cache=cache, options=options)
     end
@@ -502,7 +555,7 @@ function ImplicitBVH.traverse_rays(
     cap = Ref{Int64}(0)
     check(c_bfs_rays_initial_capacity(d, nr, start_level, cap), "ibvh_bfs_rays_initial_capacity")
     checks, total, contacts, other = bfs_run(I, bvh.nodes, cap[], bvh.tree.levels, cache,
-        (q1, q2, c, ctr, res) -> c_traverse_rays_bfs(d, devptr(p), devptr(dr), nr, start_level, devptr(q1), devptr(q2), c, devptr(ctr), res, s),
+        (q1, q2, c, ctr, res) -> c_traverse_rays_bfs(d, devptr(p), devptr(dr), nr, start_level, code, devptr(q1), devptr(q2), c, devptr(ctr), res, s),
         "ibvh_traverse_rays_bfs")
     BVHTraversal(start_level, checks, total, contacts, other)
 end

@@ -37,11 +37,11 @@ SIGNATURES = {
     "ibvh_traverse_lvt_write": [_P(abi.Bvh), _i64, _i32, _vp, _vp, _vp, _sz, _vp],
     "ibvh_traverse_pair_lvt_count": [_P(abi.Bvh), _P(abi.Bvh), _i64, _i64, _i32, _vp, _P(_i64), _vp, _sz, _vp],
     "ibvh_traverse_pair_lvt_write": [_P(abi.Bvh), _P(abi.Bvh), _i64, _i64, _i32, _vp, _vp, _vp, _sz, _vp],
-    "ibvh_traverse_rays_lvt_count": [_P(abi.Bvh), _vp, _vp, _i64, _i64, _vp, _P(_i64), _vp, _sz, _vp],
-    "ibvh_traverse_rays_lvt_write": [_P(abi.Bvh), _vp, _vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp],
-    "ibvh_traverse_lvt_enqueue": [_P(abi.Bvh), _i64, _i32, _vp, _vp, _i64, _vp, _vp, _sz, _vp],
-    "ibvh_traverse_pair_lvt_enqueue": [_P(abi.Bvh), _P(abi.Bvh), _i64, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _sz, _vp],
-    "ibvh_traverse_rays_lvt_enqueue": [_P(abi.Bvh), _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _sz, _vp],
+    "ibvh_traverse_rays_lvt_count": [_P(abi.Bvh), _vp, _vp, _i64, _i64, _i32, _vp, _P(_i64), _vp, _sz, _vp],
+    "ibvh_traverse_rays_lvt_write": [_P(abi.Bvh), _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _sz, _vp],
+    "ibvh_traverse_lvt_enqueue": [_P(abi.Bvh), _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp],
+    "ibvh_traverse_pair_lvt_enqueue": [_P(abi.Bvh), _P(abi.Bvh), _i64, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp],
+    "ibvh_traverse_rays_lvt_enqueue": [_P(abi.Bvh), _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp],
     "ibvh_lvt_total": [_vp, _P(_i64), _vp],
     "ibvh_bfs_initial_capacity": [_P(abi.Bvh), _i64, _P(_i64)],
     "ibvh_bfs_pair_initial_capacity": [_P(abi.Bvh), _P(abi.Bvh), _i64, _i64, _P(_i64)],
@@ -50,12 +50,12 @@ SIGNATURES = {
     "ibvh_traverse_bfs": [_P(abi.Bvh), _i64, _i32, _vp, _vp, _i64, _vp, _P(abi.BfsResult), _vp],
     "ibvh_traverse_pair_bfs": [_P(abi.Bvh), _P(abi.Bvh), _i64, _i64, _i32, _vp, _vp, _i64, _vp,
                                _P(abi.BfsResult), _vp],
-    "ibvh_traverse_rays_bfs": [_P(abi.Bvh), _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _P(abi.BfsResult), _vp],
+    "ibvh_traverse_rays_bfs": [_P(abi.Bvh), _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _P(abi.BfsResult), _vp],
     "ibvh_expand_extrema": [_i32, _vp, _vp],
     "ibvh_dist_pack_extrema": [_i32, _vp, _i32, _i32, _i32, _i64, _vp, _vp],
     "ibvh_dist_unpack_extrema": [_i32, _vp, _vp, _vp],
     "ibvh_dist_partition_scratch_bytes": [_i64, _P(_sz)],
-    "ibvh_dist_partition": [_i32, _vp, _i64, _P(C.c_uint64), _i32, _vp, _vp, _sz, _vp],
+    "ibvh_dist_partition": [_i32, _vp, _i64, _P(C.c_uint64), _i32, _vp, _vp, _vp, _sz, _vp],
     "ibvh_key_histogram": [_i32, _vp, _i64, _i32, _i32, _i32, _P(C.c_uint64), _i32, _vp, _vp],
     "ibvh_pack_records": [_P(abi.Types), _vp, _vp, _vp, _i64, _i64, _vp, _vp],
     "ibvh_volumes_from_triangles": [_i32, _i32, _vp, _i64, _vp, _vp],
@@ -63,10 +63,14 @@ SIGNATURES = {
     "ibvh_profile_enable": [_i32],
     "ibvh_profile_count": [_P(_i64)],
     "ibvh_profile_get": [_i64, _P(C.c_char_p), _P(C.c_float)],
+    "ibvh_lvt_work_counters": [_P(abi.Bvh), _P(abi.Bvh), _vp, _vp, _i64, _vp, _vp, _vp],
+    "ibvh_set_tuning": [C.c_char_p, _i32],
+    "ibvh_get_tuning": [C.c_char_p, _P(_i32)],
+    "ibvh_abi_version": [],
     "ibvh_version": [],
     "ibvh_status_string": [_i32],
 }
-_RESTYPES = {"ibvh_version": C.c_char_p, "ibvh_status_string": C.c_char_p}
+_RESTYPES = {"ibvh_version": C.c_char_p, "ibvh_status_string": C.c_char_p, "ibvh_abi_version": C.c_int32}
 
 _lib = None
 
@@ -85,8 +89,22 @@ def load():
         fn = getattr(lib, name)  # AttributeError here = header / library mismatch
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
+    got = lib.ibvh_abi_version()
+    if got != abi.ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {got}, this binding was written against {abi.ABI_VERSION} "
+                          "(include/ibvh.h IBVH_ABI_VERSION): rebuild the library")
+    # Development knobs (measurement scripts only): IBVH_TUNING="name=value,name=value" is applied once, here, through
+    # ibvh_set_tuning — the library itself never reads the environment.
+    for item in filter(None, os.environ.get("IBVH_TUNING", "").split(",")):
+        name, _, value = item.partition("=")
+        abi.check(lib.ibvh_set_tuning(name.strip().encode(), int(value)), f"IBVH_TUNING {item!r}")
     _lib = lib
     return lib
+
+
+def set_tuning(name, value):
+    """ibvh_set_tuning: a process-wide development knob (include/ibvh.h)."""
+    call("ibvh_set_tuning", name.encode(), int(value))
 
 
 def call(name, *args):

@@ -2,8 +2,10 @@
  * ibvh.h — C ABI of libibvh, the MI355X (gfx950) implicit-BVH engine.
  *
  * This is the drop-in boundary for ImplicitBVH.jl's hot path (Morton encode ->
- * stable LSB radix sort -> bottom-up ImplicitTree merge -> LVT / BFS traversal
- * of one BVH, two BVHs, or rays).  The reference has no FFI: its back-end seam is
+ * stable radix sort by Morton code (an MSD partition of whole records + an in-LDS
+ * LSD finish; plain LSD passes for tiny inputs: the result is the stable order
+ * either way) -> bottom-up ImplicitTree merge -> LVT / BFS traversal of one BVH,
+ * two BVHs, or rays).  The reference has no FFI: its back-end seam is
  * Julia method dispatch on the array type (src/build.jl:198, src/traverse/
  * leaf_vs_tree/traverse_single.jl:1, src/raytrace/raytrace.jl:71).  A package
  * extension for AMDGPU.jl's ROCArray `ccall`s the entry points below (see
@@ -31,6 +33,14 @@
 extern "C" {
 #endif
 
+/* Bumped whenever a struct layout or an entry point's argument list changes.  A binding checks
+ * ibvh_abi_version() == IBVH_ABI_VERSION (the header it was written against) right after loading the
+ * library and refuses a mismatch: a stale caller would otherwise hand the GPU garbage pointers.
+ *   1: round 1   2: ibvh_build_desc.sort_levels / skew_flag, ibvh_bfs_result.resume_*, *_enqueue(total_dev)
+ *   3: *_enqueue(total_host), ibvh_set_tuning, ibvh_lvt_work_counters, ray `narrow`, contact positions */
+#define IBVH_ABI_VERSION 3
+int32_t ibvh_abi_version(void);
+
 /* ----------------------------------------------------------------------------------- */
 /* status codes -> exceptions the Julia shim raises                                      */
 /* ----------------------------------------------------------------------------------- */
@@ -57,9 +67,22 @@ enum { IBVH_U16 = 0, IBVH_U32 = 1, IBVH_U64 = 2 }; /* Morton types (morton/defau
  * evaluated as `iscontact(...) && narrow(a, b)` at leaf level
  * (lvt/traverse_single.jl:170); closures cannot cross a C ABI, so a fixed menu is offered. */
 enum {
-    IBVH_NARROW_NONE = 0,      /* (a, b) -> true  (the reference default)                 */
-    IBVH_NARROW_MORTON_LT = 1, /* (a, b) -> a.morton < b.morton (runtests.jl:1239)        */
-    IBVH_NARROW_INDEX_LT = 2   /* (a, b) -> a.index < b.index                             */
+    IBVH_NARROW_NONE = 0,      /* (a, b) -> true / (bv, p, d) -> true  (the reference defaults)        */
+    IBVH_NARROW_MORTON_LT = 1, /* self / pair: (a, b) -> a.morton < b.morton (runtests.jl:1239)        */
+    IBVH_NARROW_INDEX_LT = 2,  /* self / pair: (a, b) -> a.index < b.index                             */
+    IBVH_NARROW_RAY_ORIGIN_OUTSIDE = 3, /* rays (raytrace/raytrace.jl:76): (bv, p, d) -> p lies outside
+                                  bv.volume — drops the leaves a ray STARTS in (rays cast from a surface) */
+    IBVH_NARROW_MASK = 0xff,
+    /* Any other pure `narrow`: OR this flag into the `narrow` argument of a traversal (of its _count AND its _write /
+     * _enqueue call) and the contact list holds leaf POSITIONS instead of user indices, in the same order:
+     *   one BVH   (position of the query leaf, position of its partner) in bvh.leaves, 1-based, query first
+     *             (the reference evaluates narrow(query, partner); the query is the leaf with the smaller position)
+     *   two BVHs  (position in bvh1.leaves, position in bvh2.leaves)
+     *   rays      (position of the leaf in bvh.leaves, iray)
+     * so the caller can evaluate the predicate on the records itself and keep what passes: `narrow` is only ever
+     * evaluated as `iscontact(...) && narrow(...)` at leaf level (lvt/traverse_single.jl:170,
+     * bfs/traverse_single_gpu.jl:187, raytrace/leaf_vs_tree/leaf_vs_tree.jl:194), i.e. a post-filter. */
+    IBVH_OUTPUT_POSITIONS = 0x100
 };
 
 typedef struct ibvh_types {
@@ -188,7 +211,8 @@ ibvh_status ibvh_extrema(const ibvh_types *types, const void *records, int32_t w
 ibvh_status ibvh_morton_keys(const ibvh_types *types, const void *records, int32_t wrapped,
                              int64_t n, const void *extrema, void *keys_out, void *stream);
 
-/* Stable LSB radix sort of (key, value=uint32) pairs; key_bits = significant low bits.
+/* Stable radix sort of (key, value=uint32) pairs (LSD passes, or one MSD partition + in-LDS bucket sort, chosen
+ * from n: same result); key_bits = significant low bits.
  * keys/vals are sorted into keys_out/vals_out (may alias the alt buffers as documented in
  * DESIGN.md); key_bytes is 4 or 8. */
 ibvh_status ibvh_sort_pairs(int32_t key_bytes, int32_t key_bits, int64_t n, void *keys, void *vals,
@@ -242,33 +266,39 @@ ibvh_status ibvh_traverse_pair_lvt_write(const ibvh_bvh *bvh1, const ibvh_bvh *b
  * float type; contacts are (leaf.index, iray). */
 ibvh_status ibvh_traverse_rays_lvt_count(const ibvh_bvh *bvh, const void *points,
                                          const void *directions, int64_t num_rays,
-                                         int64_t start_level, void *counts, int64_t *total_out,
-                                         void *scratch, size_t scratch_bytes, void *stream);
+                                         int64_t start_level, int32_t narrow, void *counts,
+                                         int64_t *total_out, void *scratch, size_t scratch_bytes,
+                                         void *stream);
 ibvh_status ibvh_traverse_rays_lvt_write(const ibvh_bvh *bvh, const void *points,
                                          const void *directions, int64_t num_rays,
-                                         int64_t start_level, const void *counts, void *contacts,
-                                         void *scratch, size_t scratch_bytes, void *stream);
+                                         int64_t start_level, int32_t narrow, const void *counts,
+                                         void *contacts, void *scratch, size_t scratch_bytes,
+                                         void *stream);
 
 /* _enqueue : _count + _write without the host read in between, for callers that already own a contact
  *   buffer (the reference's `cache=` reuse, traverse.jl:54-107): pass 1, the scan and pass 2 are enqueued
  *   back to back and NOTHING synchronises the stream; pass 2 does nothing unless the total fits
  *   `capacity` pairs.  The total is written to `total_dev`, a DEVICE pointer to one int64 owned by the caller
- *   (NULL: the first 8 bytes of `scratch`): fetch it with ibvh_lvt_total() when it is needed; if it exceeds
+ *   (NULL: the first 8 bytes of `scratch`), and — when `total_host` is not NULL — also to that int64 in MAPPED
+ *   PINNED HOST memory (hipHostMalloc; the store is a system-scope release, so a host that set the word to a
+ *   sentinel before the call can poll it instead of synchronising the stream: the reference's blocking
+ *   `@allowscalar` read, lvt/traverse_single.jl:60, without the copy and the stream sync).  Otherwise
+ *   fetch it with ibvh_lvt_total() when it is needed; if it exceeds
  *   `capacity`, grow the buffer and call the matching _write (counts and scratch are ready for it).  A caller that
  *   chains traversals through one scratch buffer and reads the totals late gives every call its own `total_dev`
  *   word: the scratch (header included) is rewritten by the next call.  Replaces the same reference lines as
  *   _count/_write; only the place of the blocking read (`@allowscalar`, lvt/traverse_single.jl:60) moves. */
 ibvh_status ibvh_traverse_lvt_enqueue(const ibvh_bvh *bvh, int64_t start_level, int32_t narrow,
                                       void *counts, void *contacts, int64_t capacity, void *total_dev,
-                                      void *scratch, size_t scratch_bytes, void *stream);
+                                      void *total_host, void *scratch, size_t scratch_bytes, void *stream);
 ibvh_status ibvh_traverse_pair_lvt_enqueue(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2,
                                            int64_t start_level1, int64_t start_level2, int32_t narrow,
                                            void *counts, void *contacts, int64_t capacity, void *total_dev,
-                                           void *scratch, size_t scratch_bytes, void *stream);
+                                           void *total_host, void *scratch, size_t scratch_bytes, void *stream);
 ibvh_status ibvh_traverse_rays_lvt_enqueue(const ibvh_bvh *bvh, const void *points,
                                            const void *directions, int64_t num_rays,
-                                           int64_t start_level, void *counts, void *contacts,
-                                           int64_t capacity, void *total_dev, void *scratch,
+                                           int64_t start_level, int32_t narrow, void *counts, void *contacts,
+                                           int64_t capacity, void *total_dev, void *total_host, void *scratch,
                                            size_t scratch_bytes, void *stream);
 /* blocking read of the total a _count / _enqueue call left behind: pass the call's `total_dev`, or its `scratch`
  * when total_dev was NULL */
@@ -325,7 +355,7 @@ ibvh_status ibvh_traverse_pair_bfs(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, i
 /* traverse_rays(bvh, points, directions, BFSTraversal()) — raytrace/breadth_first/
  * breadth_first.jl:1-66. */
 ibvh_status ibvh_traverse_rays_bfs(const ibvh_bvh *bvh, const void *points, const void *directions,
-                                   int64_t num_rays, int64_t start_level, void *bvtt1, void *bvtt2,
+                                   int64_t num_rays, int64_t start_level, int32_t narrow, void *bvtt1, void *bvtt2,
                                    int64_t capacity, void *counters, ibvh_bfs_result *result,
                                    void *stream);
 
@@ -348,11 +378,12 @@ ibvh_status ibvh_dist_unpack_extrema(int32_t flt, const void *vec, void *extrema
 
 /* Stable partition of the local leaves by destination rank (keys in [splitters[r-1], splitters[r]) go to rank r;
  * `splitters`: nranks - 1 ascending keys in HOST memory): perm_out[j] (DEVICE, n x uint32) = source position of the
- * j-th leaf in (destination, source position) order.  nranks <= 256. */
+ * j-th leaf in (destination, source position) order; counts_out (DEVICE, nranks x uint64, optional): leaves per
+ * destination rank — for a caller that does not already know its row of the send matrix.  nranks <= 256. */
 ibvh_status ibvh_dist_partition_scratch_bytes(int64_t n, size_t *bytes_out);
 ibvh_status ibvh_dist_partition(int32_t key_bytes, const void *keys, int64_t n, const uint64_t *splitters,
-                                int32_t nranks, void *perm_out, void *scratch, size_t scratch_bytes,
-                                void *stream);
+                                int32_t nranks, void *perm_out, void *counts_out, void *scratch,
+                                size_t scratch_bytes, void *stream);
 
 /* Digit histograms for the splitter search of the distributed radix sort.  out (DEVICE,
  * max(nprefix,1) x 2^bits uint32, zeroed here): out[j][d] = number of keys whose
@@ -389,6 +420,29 @@ ibvh_status ibvh_generate_spheres_f32(int64_t n, uint64_t seed, int64_t first_in
 ibvh_status ibvh_profile_enable(int32_t on); /* also clears the records */
 ibvh_status ibvh_profile_count(int64_t *count_out);
 ibvh_status ibvh_profile_get(int64_t i, const char **name_out, float *ms_out);
+
+/* Work of ONE counting pass of the leaf-vs-tree walkers (SURVEY.md §8d "touched bytes"; the reference's own counter,
+ * BVHTraversal.num_checks, exists for BFS only: bfs/traverse_single.jl:25,48).  Runs the counting pass of the walk the
+ * ordinary entry points would take — self (bvh2 = points = NULL), pair (bvh2), or rays (points / directions, num_rays) —
+ * in an instantiation that also counts, and leaves in `work_out` (DEVICE, 4 x uint64, zeroed here):
+ *   [0] node tests   (one lane-level box-box / ray-box test against a node volume)
+ *   [1] leaf tests   (one exact leaf-leaf / ray-leaf test)
+ *   [2] node records fetched   [3] leaf records fetched
+ * `counts`: per-work-item counts as for the _count calls (max(n1, n2) / num_rays / n entries), not scanned.
+ * Measurement only; instantiated for BSphere{Float32} leaves, BBox{Float32} nodes, Int32 indices, default start
+ * levels, no `narrow` (anything else: IBVH_ERR_UNSUPPORTED). */
+ibvh_status ibvh_lvt_work_counters(const ibvh_bvh *bvh, const ibvh_bvh *bvh2, const void *points,
+                                   const void *directions, int64_t num_rays, void *counts, void *work_out,
+                                   void *stream);
+
+/* Development knobs, for measurements and tests only (the defaults are the shipped behaviour; results never depend
+ * on them, only speed and which code path is taken).  One process-wide table: set a knob BEFORE the calls it should
+ * affect and not concurrently with them.  The library never reads the environment.  Names: "ray_block", "lvt_wide",
+ * "lvt_xcd", "sort_tile", "sort_lsd", "sort_msd_avg", "bucket_tpb", "msd", "msd_bits", "msd_cap", "msd_tile",
+ * "msd_ftpb", "msd_avg", "msd_range" (meanings: csrc/ibvh_common.hpp, struct Tuning).  Unknown name:
+ * IBVH_ERR_INVALID_ARG. */
+ibvh_status ibvh_set_tuning(const char *name, int32_t value);
+ibvh_status ibvh_get_tuning(const char *name, int32_t *value_out);
 
 /* Library / device introspection. */
 const char *ibvh_version(void);

@@ -7,6 +7,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <mutex>
 #include <thread>
 
 using namespace orc;
@@ -179,6 +180,59 @@ int build_impl(const ibvh_build_desc &d, const void *volumes, void *leaves_v, vo
     return IBVH_OK;
 }
 
+// Fork-join over `threads` contiguous ranges on the OpenMP runtime (persistent team, spinning barriers): the phases
+// of the baseline are short (a tree level, a radix pass) and spawning 256 std::threads for each of them cost more
+// than the work itself.  Every logical range is executed exactly once whatever team size the runtime grants.
+template <class F> static void parallel_ranges(int64_t n, int threads, F &&f) {
+    if (threads <= 1 || n < 2 * threads) {
+        f(0, int64_t(0), n);
+        return;
+    }
+#pragma omp parallel for schedule(static, 1) num_threads(threads)
+    for (int t = 0; t < threads; ++t) f(t, n * t / threads, n * (t + 1) / threads);
+}
+// The same, with the range cut into chunks that the threads take as they become free (the leaf-vs-tree walk of one
+// leaf costs anything from a few node tests to hundreds: equal contiguous shares leave threads idle at the end).
+// Results do not depend on who processes which chunk: every leaf writes its own count / its own output range.
+template <class F> static void parallel_chunks(int64_t n, int threads, int64_t chunk, F &&f) {
+    if (threads <= 1 || n < 2 * threads) {
+        f(0, int64_t(0), n);
+        return;
+    }
+    const int64_t nchunks = (n + chunk - 1) / chunk;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+    for (int64_t c = 0; c < nchunks; ++c) f(0, c * chunk, (c + 1) * chunk < n ? (c + 1) * chunk : n);
+}
+
+// Work counters of the walk (SURVEY.md §8d "touched bytes"): node tests = calls of the node predicate (one node volume
+// fetched and tested), leaf tests = leaves reached (one leaf record fetched and tested).  The reference has such a
+// counter for BFS only (num_checks, bfs/traverse_single.jl:25,48); this is the same idea for the leaf-vs-tree walk.
+struct TestCounts {
+    int64_t node = 0, leaf = 0;
+};
+template <class P> struct CountingPolicy {
+    P &p;
+    TestCounts &tc;
+    bool skip(int64_t inode, int64_t ilevel) const { return p.skip(inode, ilevel); }
+    void leaf(int64_t pos) const {
+        ++tc.leaf;
+        p.leaf(pos);
+    }
+    bool node(int64_t mem) const {
+        ++tc.node;
+        return p.node(mem);
+    }
+};
+template <class I, class ViewT, class Policy> inline void lvt_walk(const ViewT &bvh, int64_t start_level, Policy &&pol);
+template <class I, class ViewT, class P> inline void lvt_walk_counted(const ViewT &bvh, int64_t start_level, P &p, TestCounts *tc) {
+    if (tc) {
+        CountingPolicy<P> cp{p, *tc};
+        lvt_walk<I>(bvh, start_level, cp);
+    } else {
+        lvt_walk<I>(bvh, start_level, p);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // LVT walkers — lvt/traverse_single.jl:136-208, lvt/traverse_pair.jl:176-244,
 //               raytrace/leaf_vs_tree/leaf_vs_tree.jl:170-228
@@ -215,7 +269,8 @@ template <class I, class ViewT, class Policy> inline void lvt_walk(const ViewT &
 
 // traverse_lvt_single! for leaf `ileaf` (1-based).  emit(first, second) per contact, in order.
 template <class L, class N, class I, class M, class Emit>
-inline void lvt_single_leaf(const View<L, N, I, M> &bvh, int64_t ileaf, int64_t start_level, int narrow, Emit &&emit) {
+inline void lvt_single_leaf(const View<L, N, I, M> &bvh, int64_t ileaf, int64_t start_level, int narrow, Emit &&emit,
+                            TestCounts *tc = nullptr) {
     const auto &bv = bvh.leaves[ileaf - 1];
     // bv_node = bv.volume isa NodeType ? bv.volume : NodeType(bv.volume) — traverse_single.jl:154-155
     N bv_node = convert_to(bv.volume, (N *)nullptr);
@@ -239,13 +294,13 @@ inline void lvt_single_leaf(const View<L, N, I, M> &bvh, int64_t ileaf, int64_t 
         }
         bool node(int64_t mem) const { return iscontact(bv_node, bvh.nodes[mem - 1]); }
     } p{bvh, bv, bv_node, ileaf, narrow, emit};
-    lvt_walk<I>(bvh, start_level, p);
+    lvt_walk_counted<I>(bvh, start_level, p, tc);
 }
 
 // traverse_lvt_pair! — bv from the driving BVH against the other tree; FLIP restores order.
 template <class L, class N, class I, class M, class Emit>
 inline void lvt_pair_leaf(const BoundingVolume<L, I, M> &bv, const View<L, N, I, M> &bvh, int64_t start_level,
-                          int narrow, bool flip, Emit &&emit) {
+                          int narrow, bool flip, Emit &&emit, TestCounts *tc = nullptr) {
     N bv_node = convert_to(bv.volume, (N *)nullptr);
     struct P {
         const View<L, N, I, M> &bvh;
@@ -265,13 +320,13 @@ inline void lvt_pair_leaf(const BoundingVolume<L, I, M> &bv, const View<L, N, I,
         }
         bool node(int64_t mem) const { return iscontact(bv_node, bvh.nodes[mem - 1]); }
     } p{bvh, bv, bv_node, narrow, flip, emit};
-    lvt_walk<I>(bvh, start_level, p);
+    lvt_walk_counted<I>(bvh, start_level, p, tc);
 }
 
 // traverse_ray_lvt!
 template <class L, class N, class I, class M, class Emit>
 inline void lvt_ray(const typename L::elt *point, const typename L::elt *dir, int64_t iray,
-                    const View<L, N, I, M> &bvh, int64_t start_level, Emit &&emit) {
+                    const View<L, N, I, M> &bvh, int64_t start_level, Emit &&emit, TestCounts *tc = nullptr) {
     struct P {
         const View<L, N, I, M> &bvh;
         const typename L::elt *p;
@@ -285,7 +340,7 @@ inline void lvt_ray(const typename L::elt *point, const typename L::elt *dir, in
         }
         bool node(int64_t mem) const { return isintersection(bvh.nodes[mem - 1], p, d); }
     } p{bvh, point, dir, iray, emit};
-    lvt_walk<I>(bvh, start_level, p);
+    lvt_walk_counted<I>(bvh, start_level, p, tc);
 }
 
 // check + inclusive scan of counts (AK.accumulate!, traverse_single.jl:57) with overflow guard
@@ -795,7 +850,7 @@ int oracle_traverse_lvt_write(const ibvh_bvh *bvh, int64_t start_level, int32_t 
 }
 
 static int pair_lvt(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, int64_t sl1, int64_t sl2, int32_t narrow,
-                    void *counts, int64_t *total_out, void *contacts) {
+                    void *counts, int64_t *total_out, void *contacts, int threads = 1, TestCounts *tc_out = nullptr) {
     if (int e = check_levels(*bvh1, sl1, true)) return e;
     if (int e = check_levels(*bvh2, sl2, true)) return e;
     if (!same_types(bvh1->types, bvh2->types)) return IBVH_ERR_UNSUPPORTED;
@@ -812,21 +867,34 @@ static int pair_lvt(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, int64_t sl1, int
         auto vo = view_of<L, N, I, M>(*oth);
         I *c = (I *)counts;
         int64_t n = drv->tree.real_leaves;
+        // (threads > 1: contiguous chunks handed out dynamically, lvt/traverse_pair.jl:119-173's task ranges; every
+        // driving leaf writes its own count / its own output range, so the result does not depend on the team)
         if (!contacts) {
-            for (int64_t i = 1; i <= n; ++i) {
-                int64_t cnt = 0;
-                auto emit = [&](I, I) { ++cnt; };
-                lvt_pair_leaf(vd.leaves[i - 1], vo, sl_other, narrow, flip, emit);
-                c[i - 1] = I(cnt);
-            }
+            std::mutex mu;
+            parallel_chunks(n, threads, 2048, [&](int, int64_t lo, int64_t hi) {
+                TestCounts tc;
+                for (int64_t i = lo + 1; i <= hi; ++i) {
+                    int64_t cnt = 0;
+                    auto emit = [&](I, I) { ++cnt; };
+                    lvt_pair_leaf(vd.leaves[i - 1], vo, sl_other, narrow, flip, emit, tc_out ? &tc : nullptr);
+                    c[i - 1] = I(cnt);
+                }
+                if (tc_out) {
+                    std::lock_guard<std::mutex> g(mu);
+                    tc_out->node += tc.node;
+                    tc_out->leaf += tc.leaf;
+                }
+            });
             return scan_counts(c, n, total_out);
         }
         IndexPair<I> *out = (IndexPair<I> *)contacts;
-        for (int64_t i = 1; i <= n; ++i) {
-            int64_t w = (i == 1) ? 0 : (int64_t)c[i - 2];
-            auto emit = [&](I a, I b) { out[w++] = {a, b}; };
-            lvt_pair_leaf(vd.leaves[i - 1], vo, sl_other, narrow, flip, emit);
-        }
+        parallel_chunks(n, threads, 2048, [&](int, int64_t lo, int64_t hi) {
+            for (int64_t i = lo + 1; i <= hi; ++i) {
+                int64_t w = (i == 1) ? 0 : (int64_t)c[i - 2];
+                auto emit = [&](I a, I b) { out[w++] = {a, b}; };
+                lvt_pair_leaf(vd.leaves[i - 1], vo, sl_other, narrow, flip, emit);
+            }
+        });
         return IBVH_OK;
     });
 }
@@ -842,7 +910,7 @@ int oracle_traverse_pair_lvt_write(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, i
 }
 
 static int rays_lvt(const ibvh_bvh *bvh, const void *points, const void *dirs, int64_t num_rays, int64_t sl,
-                    void *counts, int64_t *total_out, void *contacts) {
+                    void *counts, int64_t *total_out, void *contacts, int threads = 1, TestCounts *tc_out = nullptr) {
     if (int e = check_levels(*bvh, sl, true)) return e;
     // isintersection(::BBox{T}, ::NTuple{3,T}, ...) needs one float type (isintersection.jl:1-5)
     if (bvh->types.leaf_float != bvh->types.node_float) return IBVH_ERR_UNSUPPORTED;
@@ -859,20 +927,31 @@ static int rays_lvt(const ibvh_bvh *bvh, const void *points, const void *dirs, i
             const T *p = (const T *)points, *d = (const T *)dirs;
             I *c = (I *)counts;
             if (!contacts) {
-                for (int64_t i = 1; i <= num_rays; ++i) {
-                    int64_t cnt = 0;
-                    auto emit = [&](I, I) { ++cnt; };
-                    lvt_ray(p + 3 * (i - 1), d + 3 * (i - 1), i, v, sl, emit);
-                    c[i - 1] = I(cnt);
-                }
+                std::mutex mu;
+                parallel_chunks(num_rays, threads, 1024, [&](int, int64_t lo, int64_t hi) {
+                    TestCounts tc;
+                    for (int64_t i = lo + 1; i <= hi; ++i) {
+                        int64_t cnt = 0;
+                        auto emit = [&](I, I) { ++cnt; };
+                        lvt_ray(p + 3 * (i - 1), d + 3 * (i - 1), i, v, sl, emit, tc_out ? &tc : nullptr);
+                        c[i - 1] = I(cnt);
+                    }
+                    if (tc_out) {
+                        std::lock_guard<std::mutex> g(mu);
+                        tc_out->node += tc.node;
+                        tc_out->leaf += tc.leaf;
+                    }
+                });
                 return scan_counts(c, num_rays, total_out);
             }
             IndexPair<I> *out = (IndexPair<I> *)contacts;
-            for (int64_t i = 1; i <= num_rays; ++i) {
-                int64_t w = (i == 1) ? 0 : (int64_t)c[i - 2];
-                auto emit = [&](I a, I b) { out[w++] = {a, b}; };
-                lvt_ray(p + 3 * (i - 1), d + 3 * (i - 1), i, v, sl, emit);
-            }
+            parallel_chunks(num_rays, threads, 1024, [&](int, int64_t lo, int64_t hi) {
+                for (int64_t i = lo + 1; i <= hi; ++i) {
+                    int64_t w = (i == 1) ? 0 : (int64_t)c[i - 2];
+                    auto emit = [&](I a, I b) { out[w++] = {a, b}; };
+                    lvt_ray(p + 3 * (i - 1), d + 3 * (i - 1), i, v, sl, emit);
+                }
+            });
             return IBVH_OK;
         }
     });
@@ -1058,29 +1137,6 @@ int oracle_generate_spheres_f32(int64_t n, uint64_t seed, int64_t first_index, c
 // ranges the way the reference's CPU path is (AK.itask_partition, lvt/traverse_single.jl:94-111):
 // extrema, encode, chunked stable sort + stable merges, per-level merges, two-pass LVT.
 } // extern "C"
-// Fork-join over `threads` contiguous ranges on the OpenMP runtime (persistent team, spinning barriers): the phases
-// of the baseline are short (a tree level, a radix pass) and spawning 256 std::threads for each of them cost more
-// than the work itself.  Every logical range is executed exactly once whatever team size the runtime grants.
-template <class F> static void parallel_ranges(int64_t n, int threads, F &&f) {
-    if (threads <= 1 || n < 2 * threads) {
-        f(0, int64_t(0), n);
-        return;
-    }
-#pragma omp parallel for schedule(static, 1) num_threads(threads)
-    for (int t = 0; t < threads; ++t) f(t, n * t / threads, n * (t + 1) / threads);
-}
-// The same, with the range cut into chunks that the threads take as they become free (the leaf-vs-tree walk of one
-// leaf costs anything from a few node tests to hundreds: equal contiguous shares leave threads idle at the end).
-// Results do not depend on who processes which chunk: every leaf writes its own count / its own output range.
-template <class F> static void parallel_chunks(int64_t n, int threads, int64_t chunk, F &&f) {
-    if (threads <= 1 || n < 2 * threads) {
-        f(0, int64_t(0), n);
-        return;
-    }
-    const int64_t nchunks = (n + chunk - 1) / chunk;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
-    for (int64_t c = 0; c < nchunks; ++c) f(0, c * chunk, (c + 1) * chunk < n ? (c + 1) * chunk : n);
-}
 extern "C" {
 
 // SphereF32 leaves / BBoxF32 nodes / I32 / U32 — the bench types (benchmark/bvh_contact.jl:21-27)
@@ -1229,6 +1285,75 @@ int oracle_bench_build_traverse_f32(const void *volumes, int64_t n, int threads,
     *t_build_s = std::chrono::duration<double>(t1 - t0).count();
     *t_traverse_s = std::chrono::duration<double>(t2 - t1).count();
     return total <= contacts_capacity ? IBVH_OK : IBVH_ERR_CAPACITY;
+}
+
+// ---- timed CPU baselines of the pair and ray traversals (bench.py's cpu_baseline legs for configs 3 and 4) ----------
+// The reference's two-pass protocol on `threads` OpenMP threads with dynamically handed-out chunks
+// (lvt/traverse_pair.jl:40-116, raytrace/leaf_vs_tree/leaf_vs_tree.jl:1-90): count -> inclusive scan -> write.
+// Protocol of benchmark/bvh_contact_pair.jl:38-46 / bvh_rays.jl:36-58: the BVHs are built beforehand.
+int oracle_bench_pair_lvt(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, int64_t sl1, int64_t sl2, int threads, void *counts,
+                          void *contacts, int64_t capacity, int64_t *num_contacts, double *t_s) {
+    auto t0 = std::chrono::steady_clock::now();
+    int64_t total = 0;
+    if (int e = pair_lvt(bvh1, bvh2, sl1, sl2, 0, counts, &total, nullptr, threads)) return e;
+    *num_contacts = total;
+    if (total > capacity) return IBVH_ERR_CAPACITY;
+    if (int e = pair_lvt(bvh1, bvh2, sl1, sl2, 0, counts, &total, contacts, threads)) return e;
+    *t_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return IBVH_OK;
+}
+int oracle_bench_rays_lvt(const ibvh_bvh *bvh, const void *points, const void *dirs, int64_t num_rays, int64_t sl, int threads,
+                          void *counts, void *contacts, int64_t capacity, int64_t *num_contacts, double *t_s) {
+    auto t0 = std::chrono::steady_clock::now();
+    int64_t total = 0;
+    if (int e = rays_lvt(bvh, points, dirs, num_rays, sl, counts, &total, nullptr, threads)) return e;
+    *num_contacts = total;
+    if (total > capacity) return IBVH_ERR_CAPACITY;
+    if (int e = rays_lvt(bvh, points, dirs, num_rays, sl, counts, &total, contacts, threads)) return e;
+    *t_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return IBVH_OK;
+}
+
+// ---- work counters of the reference's leaf-vs-tree walk: node tests and leaf tests of ONE pass ------
+// bvh2 != NULL: pair walk (the BVH with more leaves drives); points != NULL: rays; otherwise the self walk.
+// counts: scratch for the per-item counts (max(n1, n2) / num_rays / n entries of the index type).
+int oracle_lvt_test_counts(const ibvh_bvh *bvh, const ibvh_bvh *bvh2, const void *points, const void *dirs, int64_t num_rays,
+                           int64_t sl1, int64_t sl2, int threads, void *counts, int64_t *node_tests, int64_t *leaf_tests,
+                           int64_t *num_contacts) {
+    TestCounts tc;
+    int64_t total = 0;
+    int rc = IBVH_OK;
+    if (points) {
+        rc = rays_lvt(bvh, points, dirs, num_rays, sl1, counts, &total, nullptr, threads, &tc);
+    } else if (bvh2) {
+        rc = pair_lvt(bvh, bvh2, sl1, sl2, 0, counts, &total, nullptr, threads, &tc);
+    } else {
+        if (int e = check_levels(*bvh, sl1, true)) return e;
+        if (bvh->tree.real_nodes > 1)
+            rc = dispatch_all(bvh->types, [&](auto lt, auto nt, auto it, auto mt) -> int {
+                using L = typename decltype(lt)::type;
+                using N = typename decltype(nt)::type;
+                using I = typename decltype(it)::type;
+                using M = typename decltype(mt)::type;
+                auto v = view_of<L, N, I, M>(*bvh);
+                std::mutex mu;
+                parallel_chunks(bvh->tree.real_leaves, threads, 2048, [&](int, int64_t lo, int64_t hi) {
+                    TestCounts t;
+                    int64_t cnt = 0;
+                    auto emit = [&](I, I) { ++cnt; };
+                    for (int64_t i = lo + 1; i <= hi; ++i) lvt_single_leaf(v, i, sl1, 0, emit, &t);
+                    std::lock_guard<std::mutex> g(mu);
+                    tc.node += t.node;
+                    tc.leaf += t.leaf;
+                    total += cnt;
+                });
+                return IBVH_OK;
+            });
+    }
+    *node_tests = tc.node;
+    *leaf_tests = tc.leaf;
+    *num_contacts = total;
+    return rc;
 }
 
 int oracle_hardware_threads(void) { return (int)std::thread::hardware_concurrency(); }

@@ -368,7 +368,8 @@ def load_native():
         subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), "native"], stdout=subprocess.DEVNULL,
                               stderr=subprocess.DEVNULL, timeout=600)
         nat = C.CDLL(so)
-        nat.oracle_bench_build_traverse_f32.restype = C.c_int
+        for name in ("oracle_bench_build_traverse_f32", "oracle_bench_pair_lvt", "oracle_bench_rays_lvt", "oracle_lvt_test_counts"):
+            getattr(nat, name).restype = C.c_int
         return nat
     except Exception:
         return None
@@ -393,6 +394,72 @@ def bench_build_traverse_f32(volumes, threads, native=None):
     abi.check(st)
     bvh = HostBVH(types, tree, 1, leaves, nodes, skips, None)
     return bvh, contacts[:nc.value], tb.value, tt.value
+
+
+def bench_pair_lvt(bvh1, bvh2, threads, native=None, capacity=None):
+    """Timed two-pass LVT pair traversal of two pre-built host BVHs on `threads` OpenMP threads (the cpu_baseline leg of
+    config 4; protocol of benchmark/bvh_contact_pair.jl:38-46).  Returns (num_contacts, seconds)."""
+    s1, s2 = bvh1.struct(), bvh2.struct()
+    n = max(bvh1.tree.real_leaves, bvh2.tree.real_leaves)
+    counts = np.zeros(n, abi.INDEX_DTYPES[bvh1.types.index_type])
+    cap = int(capacity or max(4 * n, 1024))
+    while True:
+        contacts = np.zeros(cap, abi.pair_dtype(bvh1.types))
+        nc, ts = C.c_int64(), C.c_double()
+        st = (native or lib).oracle_bench_pair_lvt(C.byref(s1), C.byref(s2), C.c_int64(max(1, bvh1.built_level)),
+                                                   C.c_int64(max(1, bvh2.built_level)), int(threads), _p(counts), _p(contacts),
+                                                   C.c_int64(cap), C.byref(nc), C.byref(ts))
+        if st == abi.ERR_CAPACITY:
+            cap = nc.value
+            continue
+        abi.check(st)
+        return nc.value, ts.value
+
+
+def bench_rays_lvt(bvh, points, directions, threads, native=None, capacity=None):
+    """Timed two-pass LVT ray traversal on `threads` OpenMP threads (cpu_baseline leg of config 3; protocol of
+    benchmark/bvh_rays.jl:36-58).  Returns (num_hits, seconds)."""
+    p, d = _rays(bvh, points, directions)
+    s = bvh.struct()
+    counts = np.zeros(len(p), abi.INDEX_DTYPES[bvh.types.index_type])
+    cap = int(capacity or max(32 * len(p), 1024))
+    while True:
+        contacts = np.zeros(cap, abi.pair_dtype(bvh.types))
+        nc, ts = C.c_int64(), C.c_double()
+        st = (native or lib).oracle_bench_rays_lvt(C.byref(s), _p(p), _p(d), C.c_int64(len(p)), C.c_int64(1), int(threads),
+                                                   _p(counts), _p(contacts), C.c_int64(cap), C.byref(nc), C.byref(ts))
+        if st == abi.ERR_CAPACITY:
+            cap = nc.value
+            continue
+        abi.check(st)
+        return nc.value, ts.value
+
+
+def lvt_test_counts(bvh, bvh2=None, points=None, directions=None, threads=1, start_level=None, start_level2=None, native=None):
+    """Work of the reference's leaf-vs-tree walk (one pass): (node tests, leaf tests, contacts) — SURVEY.md §8d
+    "touched bytes" = 24 B x (node tests + leaf tests) for the bench types."""
+    s = bvh.struct()
+    sl1 = max(1, bvh.built_level) if start_level is None else start_level
+    nt, lt, nc = C.c_int64(), C.c_int64(), C.c_int64()
+    idt = abi.INDEX_DTYPES[bvh.types.index_type]
+    f = (native or lib).oracle_lvt_test_counts
+    if points is not None:
+        p, d = _rays(bvh, points, directions)
+        counts = np.zeros(len(p), idt)
+        st = f(C.byref(s), C.c_void_p(0), _p(p), _p(d), C.c_int64(len(p)), C.c_int64(sl1 if start_level is not None else 1),
+               C.c_int64(0), int(threads), _p(counts), C.byref(nt), C.byref(lt), C.byref(nc))
+    elif bvh2 is not None:
+        s2 = bvh2.struct()
+        sl2 = max(1, bvh2.built_level) if start_level2 is None else start_level2
+        counts = np.zeros(max(bvh.tree.real_leaves, bvh2.tree.real_leaves), idt)
+        st = f(C.byref(s), C.byref(s2), C.c_void_p(0), C.c_void_p(0), C.c_int64(0), C.c_int64(sl1), C.c_int64(sl2), int(threads),
+               _p(counts), C.byref(nt), C.byref(lt), C.byref(nc))
+    else:
+        counts = np.zeros(1, idt)
+        st = f(C.byref(s), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), C.c_int64(0), C.c_int64(sl1), C.c_int64(0), int(threads),
+               _p(counts), C.byref(nt), C.byref(lt), C.byref(nc))
+    abi.check(st)
+    return nt.value, lt.value, nc.value
 
 
 def pairs_as_tuples(contacts):

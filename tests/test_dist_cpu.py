@@ -172,6 +172,55 @@ def test_gloo_world2_matches_single_device_build(kind, flt, morton, n):
     assert abs(len(leaves[0]) - len(leaves[1])) <= max(8, n // 100)  # balanced within the splitter tolerance
 
 
+def ragged_clustered_cloud(n, seed):
+    """Three tight Gaussian clusters + a thin uniform background + exact duplicates: crowded Morton cells, splitters
+    that need refinement, ties across ranks."""
+    rng = np.random.default_rng(seed)
+    centres = rng.random((3, 3)) * 8 - 2
+    which = rng.integers(0, 3, n)
+    c = centres[which] + rng.normal(0, 0.01, (n, 3))
+    bg = rng.random(n) < 0.1
+    c[bg] = rng.random((int(bg.sum()), 3)) * 10 - 3
+    c[n // 2: n // 2 + 200] = c[0]  # duplicates of one leaf, spread over ranks by the ragged sharding below
+    return np.concatenate([c, 0.005 + 0.01 * rng.random((n, 1))], axis=1).astype(np.float32)
+
+
+def _worker_ragged(rank, world, path, n, seed, bounds, init_file):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    try:
+        vols = ragged_clustered_cloud(n, seed)
+        local = torch.from_numpy(vols[bounds[rank]:bounds[rank + 1]].copy())
+        builder = ibd.DistributedBuilder(ibd.TorchComm(), engine=OracleEngine())
+        bvh = builder.build(local)
+        np.save(os.path.join(path, f"leaves_{rank}.npy"), bvh.leaves)
+        np.save(os.path.join(path, f"send_{rank}.npy"), np.asarray(builder.last["send_counts"]))
+        np.save(os.path.join(path, f"recv_{rank}.npy"), np.asarray(builder.last["recv_counts"]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world4_ragged_clustered_shards():
+    """Four real processes over gloo, shards of very different sizes (one of them EMPTY: it still takes part in every
+    collective), clustered keys with duplicates: concatenated slices == the single-device build, and the exchange sizes
+    every rank derived are consistent (send[r][d] == recv[d][r])."""
+    world, n, seed = 4, 24_019, 77
+    bounds = [0, 0, 301, 16_000, n]  # rank 0 holds nothing, rank 1 a handful, rank 2 most
+    with tempfile.TemporaryDirectory() as tmp:
+        init_file = os.path.join(tmp, "rendezvous")
+        mp.spawn(_worker_ragged, args=(world, tmp, n, seed, bounds, init_file), nprocs=world, join=True)
+        leaves = [np.load(os.path.join(tmp, f"leaves_{r}.npy")) for r in range(world)]
+        send = np.stack([np.load(os.path.join(tmp, f"send_{r}.npy")) for r in range(world)])
+        recv = np.stack([np.load(os.path.join(tmp, f"recv_{r}.npy")) for r in range(world)])
+    vols = ragged_clustered_cloud(n, seed)
+    check_against_single_build(vols, abi.make_types(), leaves)
+    assert np.array_equal(send, recv.T)
+    assert send[0].sum() == 0 and send.sum() == n
+    sizes = [len(x) for x in leaves]
+    assert min(sizes) >= 1 and max(sizes) - min(sizes) <= max(8, n // 50)
+
+
 @pytest.mark.parametrize("world", [1, 3, 8])
 def test_virtual_ranks_cpu(world):
     n = 30011

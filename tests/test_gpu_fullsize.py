@@ -14,25 +14,11 @@ import implicitbvh_amd as ibvh  # noqa: E402
 from implicitbvh_amd import abi  # noqa: E402
 
 
+from implicitbvh_amd.synthetic import torus_mesh  # noqa: E402  (shared with bench.py and tools/)
+
+
 def contacts_np(trav):
     return trav.contacts.cpu().numpy().astype(np.int64)
-
-
-def torus_mesh(u=1898, v=1897):
-    """Deterministic surrogate for xyzrgb_dragon.obj (absent from the reference repo, benchmark/README.md:3):
-    a displaced torus tessellation with 2*u*v ~ 7.2 M triangles, i.e. a 2-manifold leaf distribution."""
-    a = (np.arange(u, dtype=np.float64) / u * 2 * np.pi)[:, None]
-    b = (np.arange(v, dtype=np.float64) / v * 2 * np.pi)[None, :]
-    r = 0.35 + 0.05 * np.sin(7 * a) * np.cos(5 * b)
-    x = ((1.0 + r * np.cos(b)) * np.cos(a)).astype(np.float32)
-    y = ((1.0 + r * np.cos(b)) * np.sin(a)).astype(np.float32)
-    z = (r * np.sin(b) + 0 * a).astype(np.float32)
-    p = np.stack([x, y, z], axis=-1)
-    p00, p10 = p, np.roll(p, -1, axis=0)
-    p01, p11 = np.roll(p, -1, axis=1), np.roll(np.roll(p, -1, axis=0), -1, axis=1)
-    t1 = np.stack([p00, p10, p11], axis=2).reshape(-1, 3, 3)
-    t2 = np.stack([p00, p11, p01], axis=2).reshape(-1, 3, 3)
-    return np.concatenate([t1, t2]).reshape(-1, 9)
 
 
 def test_config3_mesh_rays_full_size():

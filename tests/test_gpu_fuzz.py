@@ -13,13 +13,14 @@ def test_random_configurations_match_the_oracle(seed):
 
 def test_64_bit_queue_entries_match_the_oracle():
     """The BBox-node walker's 64-bit queue entries (trees of 29 .. 31 levels, > 134 M leaves) cannot be reached with an
-    oracle-sized input; IBVH_LVT_WIDE=1 forces them for every tree.  The knob is read once per process, so the fuzzer
-    runs in a child process (started, not exec'ed: this process has initialised the GPU)."""
+    oracle-sized input; the development knob lvt_wide = 1 (ibvh_set_tuning, applied by the binding from IBVH_TUNING when the
+    library is loaded) forces them for every tree.  The knob is process-wide, so the fuzzer runs in a child process
+    (started, not exec'ed: this process has initialised the GPU)."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, IBVH_LVT_WIDE="1")
+    env = dict(os.environ, IBVH_TUNING="lvt_wide=1")
     out = subprocess.run([sys.executable, os.path.join(here, "fuzz_gpu.py"), "10", "7", "light"], cwd=here, env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]

@@ -270,7 +270,7 @@ def test_build_every_sort_route_at_every_partition_depth(shape):
         assert bool(int(g._skew[0])) == expect_skew
         node_type = TOKENS[types.node_kind](torch.float32 if types.node_float == abi.F32 else torch.float64)
         dev = cuda(vols.astype(NP_F[types.leaf_float]))
-        for pretend in (0, 1, 2, 3):                   # what "the previous build" left: launches 0, 2, 3, 4 extra levels
+        for pretend in (0, 1, 2, 3):                   # what "the previous build" left: launches 1, 2, 3, 4 extra levels
             g._skew[0] = pretend
             g = ibvh.BVH(dev, node_type, options=make_options(types), cache=g)
             assert_bvh_equal(o, g)
@@ -278,7 +278,21 @@ def test_build_every_sort_route_at_every_partition_depth(shape):
             used = int(g._skew[0])
             assert (used > 0) == expect_skew and used <= abi.MAX_SORT_LEVELS
             if pretend == 0 and expect_skew:
+                assert used <= 2                       # one extra level ran: it can ask for at most one more
+        # no extra level at all (a raw C caller may pass sort_levels = 0): everything crowded takes the one-workgroup path
+        from implicitbvh_amd import api
+        saved = api.COLD_SORT_LEVELS
+        try:
+            api.COLD_SORT_LEVELS = 0
+            g0 = ibvh.BVH(dev, node_type, options=make_options(types))
+            assert_bvh_equal(o, g0)
+            torch.cuda.synchronize()
+            used = int(g0._skew[0])
+            assert (used > 0) == expect_skew
+            if expect_skew:
                 assert used == 1                       # no extra level ran: all it can know is that one is needed
+        finally:
+            api.COLD_SORT_LEVELS = saved
 
 
 @pytest.mark.parametrize("levels", [-1, 99])
@@ -485,8 +499,8 @@ def test_lvt_enqueue_without_host_sync_matches_the_two_call_protocol():
     # large enough
     cap = len(exp) + 100
     contacts = torch.full((cap, 2), -7, dtype=torch.int32, device="cuda")
-    lib.call("ibvh_traverse_lvt_enqueue", C.byref(s), 1, 0, counts.data_ptr(), contacts.data_ptr(), cap, None, scratch.data_ptr(),
-             scratch.numel(), stream)  # total_dev = NULL: the total stays in the scratch header
+    lib.call("ibvh_traverse_lvt_enqueue", C.byref(s), 1, 0, counts.data_ptr(), contacts.data_ptr(), cap, None, None,
+             scratch.data_ptr(), scratch.numel(), stream)  # total_dev = total_host = NULL: the total stays in the scratch header
     total = C.c_int64()
     lib.call("ibvh_lvt_total", scratch.data_ptr(), C.byref(total), stream)
     assert total.value == len(exp)
@@ -497,8 +511,16 @@ def test_lvt_enqueue_without_host_sync_matches_the_two_call_protocol():
     for cap, written in ((len(exp), True), (len(exp) - 1, False)):
         contacts = torch.full((len(exp), 2), -7, dtype=torch.int32, device="cuda")
         tdev = torch.full((3,), -1, dtype=torch.int64, device="cuda")  # the caller's own total word (middle one)
+        # ... and a word of mapped pinned host memory that the scan kernel fills as well (total_host): polled, no sync
+        thost = torch.full((3,), -5, dtype=torch.int64).pin_memory()
         lib.call("ibvh_traverse_lvt_enqueue", C.byref(s), 1, 0, counts.data_ptr(), contacts.data_ptr(), cap,
-                 tdev.data_ptr() + 8, scratch.data_ptr(), scratch.numel(), stream)
+                 tdev.data_ptr() + 8, thost.data_ptr() + 8, scratch.data_ptr(), scratch.numel(), stream)
+        import time
+        t_end = time.time() + 30
+        view = thost.numpy()
+        while int(view[1]) == -5 and time.time() < t_end:
+            pass
+        assert view.tolist() == [-5, len(exp), -5]
         lib.call("ibvh_lvt_total", tdev.data_ptr() + 8, C.byref(total), stream)
         assert tdev.cpu().tolist() == [-1, len(exp), -1]
         assert total.value == len(exp)
@@ -508,7 +530,7 @@ def test_lvt_enqueue_without_host_sync_matches_the_two_call_protocol():
              scratch.numel(), stream)
     assert (contacts.cpu().numpy() == exp).all()
     # capacity 0: counting only
-    lib.call("ibvh_traverse_lvt_enqueue", C.byref(s), 1, 0, counts.data_ptr(), None, 0, None, scratch.data_ptr(), scratch.numel(), stream)
+    lib.call("ibvh_traverse_lvt_enqueue", C.byref(s), 1, 0, counts.data_ptr(), None, 0, None, None, scratch.data_ptr(), scratch.numel(), stream)
     lib.call("ibvh_lvt_total", scratch.data_ptr(), C.byref(total), stream)
     assert total.value == len(exp)
 
@@ -697,8 +719,169 @@ def test_narrow_menu_bfs_equals_lvt():
         bfs = ibvh.traverse(g, ibvh.BFSTraversal(), narrow=ibvh.NARROW_MORTON_LT)
         assert (contacts_np(lvt) == exp).all()
         assert sorted(map(tuple, contacts_np(bfs).tolist())) == sorted(map(tuple, exp.tolist()))
-    with pytest.raises(NotImplementedError):
-        ibvh.traverse(g, narrow=lambda a, b: True)
+    with pytest.raises(TypeError):
+        ibvh.traverse(g, narrow="morton")
+    with pytest.raises(ValueError):
+        ibvh.traverse(g, narrow=ibvh.NARROW_RAY_ORIGIN_OUTSIDE)  # a ray predicate is not on the pair menu
+
+
+def _positions(leaves):
+    """user index -> 1-based position in the sorted leaf array (indices are a permutation of 1..n in these tests)"""
+    idx = leaves["index"].astype(np.int64)
+    pos = np.zeros(idx.max() + 1, np.int64)
+    pos[idx] = np.arange(1, len(idx) + 1)
+    return pos
+
+
+@pytest.mark.parametrize("combo", [ALL_COMBOS[0], ALL_COMBOS[1], ALL_COMBOS[4]], ids=str)
+def test_contact_positions_option_and_callable_narrow(combo):
+    """IBVH_OUTPUT_POSITIONS (include/ibvh.h): the same contact list with leaf positions instead of user indices, query /
+    bvh1 first — what a host needs to evaluate ANY pure `narrow` itself (the reference only ever uses it as
+    `iscontact(...) && narrow(...)` at leaf level: lvt/traverse_single.jl:170, bfs/traverse_single_gpu.jl:187).  The
+    Python mirror does exactly that for a callable: it must give what the device menu gives for the same predicate
+    (runtests.jl:1230-1270, gputests.jl:251-288), LVT in the reference's order, BFS as a set."""
+    rng = np.random.default_rng(41)
+    types = abi.make_types(*combo)
+    f = NP_F[combo[1]]
+    for n, n2 in ((2, 3), (61, 200), (3000, 1700)):
+        v1, v2 = random_volumes(rng, n, combo[0], combo[1]), random_volumes(rng, n2, combo[0], combo[1])
+        (o1, g1), (o2, g2) = build_both(v1, types), build_both(v2, types)
+        P1, P2 = _positions(o1.leaves), _positions(o2.leaves)
+        # self: (query position, partner position), query = the smaller position
+        exp = oracle_pairs(orc.traverse_lvt(o1)[0]).astype(np.int64).reshape(-1, 2)
+        want = np.stack([np.minimum(P1[exp[:, 0]], P1[exp[:, 1]]), np.maximum(P1[exp[:, 0]], P1[exp[:, 1]])], 1)
+        for alg in (ibvh.LVTTraversal(), ibvh.BFSTraversal()):
+            got = contacts_np(ibvh.api._traverse_lvt_single(g1, 1, abi.OUTPUT_POSITIONS, None) if isinstance(alg, ibvh.LVTTraversal)
+                              else ibvh.api._traverse_bfs_single(g1, max(o1.tree.levels // 2, 1), abi.OUTPUT_POSITIONS, None)).reshape(-1, 2)
+            if isinstance(alg, ibvh.LVTTraversal):
+                assert (got == want).all()
+            else:
+                assert sorted(map(tuple, got.tolist())) == sorted(map(tuple, want.tolist()))
+        # pair: (position in bvh1, position in bvh2), both argument orders (the larger BVH drives: flip)
+        for (oa, ga, Pa), (ob, gb, Pb) in (((o1, g1, P1), (o2, g2, P2)), ((o2, g2, P2), (o1, g1, P1))):
+            exp = oracle_pairs(orc.traverse_pair_lvt(oa, ob)[0]).astype(np.int64).reshape(-1, 2)
+            want = np.stack([Pa[exp[:, 0]], Pb[exp[:, 1]]], 1)
+            got = contacts_np(ibvh.api._traverse_lvt_pair(ga, gb, 1, 1, abi.OUTPUT_POSITIONS, None)).reshape(-1, 2)
+            assert (got == want).all()
+            gotb = contacts_np(ibvh.api._traverse_bfs_pair(ga, gb, max(oa.tree.levels // 2, 1), max(ob.tree.levels // 2, 1),
+                                                         abi.OUTPUT_POSITIONS, None)).reshape(-1, 2)
+            assert sorted(map(tuple, gotb.tolist())) == sorted(map(tuple, want.tolist()))
+        # a callable narrow == the device menu entry with the same meaning, and == the oracle
+        for code, fn in ((ibvh.NARROW_MORTON_LT, lambda a, b: a.morton < b.morton), (ibvh.NARROW_INDEX_LT, lambda a, b: a.index < b.index)):
+            exp = oracle_pairs(orc.traverse_lvt(o1, narrow=code)[0]).reshape(-1, 2)
+            assert (contacts_np(ibvh.traverse(g1, narrow=fn)).reshape(-1, 2) == exp).all()
+            assert (contacts_np(ibvh.traverse(g1, narrow=code)).reshape(-1, 2) == exp).all()
+            bfs = contacts_np(ibvh.traverse(g1, ibvh.BFSTraversal(), narrow=fn)).reshape(-1, 2)
+            assert sorted(map(tuple, bfs.tolist())) == sorted(map(tuple, exp.tolist()))
+            expp = oracle_pairs(orc.traverse_pair_lvt(o1, o2, narrow=code)[0]).reshape(-1, 2)
+            assert (contacts_np(ibvh.traverse(g1, g2, narrow=fn)).reshape(-1, 2) == expp).all()
+            bfsp = contacts_np(ibvh.traverse(g1, g2, ibvh.BFSTraversal(), narrow=fn)).reshape(-1, 2)
+            assert sorted(map(tuple, bfsp.tolist())) == sorted(map(tuple, expp.tolist()))
+        # a predicate that is on no menu: volumes are visible to the callable
+        if combo[0] == abi.BSPHERE:
+            fn = lambda a, b: a.volume[:, 3] > b.volume[:, 3]  # noqa: E731  (query radius larger than the partner's)
+            exp = oracle_pairs(orc.traverse_lvt(o1)[0]).astype(np.int64).reshape(-1, 2)
+            rad = o1.leaves["volume"]["r"]
+            qpos, ppos = np.minimum(P1[exp[:, 0]], P1[exp[:, 1]]), np.maximum(P1[exp[:, 0]], P1[exp[:, 1]])
+            keep = rad[qpos - 1] > rad[ppos - 1]
+            assert (contacts_np(ibvh.traverse(g1, narrow=fn)).reshape(-1, 2) == exp[keep]).all()
+    with pytest.raises(ValueError):
+        ibvh.traverse(g1, narrow=lambda a, b: a.index[:1] > 0)  # one bool per candidate is required
+
+
+def test_ray_narrow_menu_and_positions():
+    """traverse_rays(...; narrow) (raytrace/raytrace.jl:76, raytrace/leaf_vs_tree/leaf_vs_tree.jl:194: `isintersection(...) &&
+    narrow(leaf, p, d)`): the device menu entry IBVH_NARROW_RAY_ORIGIN_OUTSIDE, a callable doing the same on the host side of
+    the boundary, and the positions option — all against the oracle's hit list filtered by the predicate (a pure narrow is
+    a post-filter)."""
+    rng = np.random.default_rng(42)
+    for combo in ((abi.BSPHERE, abi.F32, abi.BBOX, abi.F32), (abi.BBOX, abi.F64, abi.BBOX, abi.F64)):
+        types = abi.make_types(*combo)
+        f = NP_F[combo[1]]
+        for n in (1, 9, 1500):
+            vols = random_volumes(rng, n, combo[0], combo[1], scale=4.0)
+            o, g = build_both(vols, types)
+            nr = 700
+            p = (5 * rng.random((nr, 3)) - 0.5).astype(f)
+            p[::3] = vols[rng.integers(0, n, len(p[::3])), :3].astype(f) if combo[0] == abi.BSPHERE else \
+                (0.5 * (vols[rng.integers(0, n, len(p[::3])), :3] + vols[rng.integers(0, n, len(p[::3])), 3:])).astype(f)  # origins INSIDE leaves
+            d = (rng.random((nr, 3)) - 0.5).astype(f)
+            exp = oracle_pairs(orc.traverse_rays_lvt(o, p, d)[0]).astype(np.int64).reshape(-1, 2)
+            P = _positions(o.leaves)
+            lv = o.leaves["volume"][P[exp[:, 0]] - 1]
+            pp = p[exp[:, 1] - 1]
+            if combo[0] == abi.BSPHERE:
+                dd = pp - lv["x"]
+                outside = dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1] + dd[:, 2] * dd[:, 2] > lv["r"] * lv["r"]
+            else:
+                outside = ((pp < lv["lo"]) | (pp > lv["up"])).any(axis=1)
+            assert 0 < outside.sum() < len(exp) or n == 1
+            P_, D_ = cuda(p).t(), cuda(d).t()
+            got = contacts_np(ibvh.traverse_rays(g, P_, D_, narrow=ibvh.NARROW_RAY_ORIGIN_OUTSIDE)).reshape(-1, 2)
+            assert (got == exp[outside]).all()
+            bfs = contacts_np(ibvh.traverse_rays(g, P_, D_, ibvh.BFSTraversal(), narrow=ibvh.NARROW_RAY_ORIGIN_OUTSIDE)).reshape(-1, 2)
+            assert sorted(map(tuple, bfs.tolist())) == sorted(map(tuple, exp[outside].tolist()))
+            # cached (enqueue) path keeps the narrow
+            t1 = ibvh.traverse_rays(g, P_, D_, narrow=ibvh.NARROW_RAY_ORIGIN_OUTSIDE)
+            t2 = ibvh.traverse_rays(g, P_, D_, narrow=ibvh.NARROW_RAY_ORIGIN_OUTSIDE, cache=t1)
+            assert (contacts_np(t2).reshape(-1, 2) == exp[outside]).all()
+            # callable: hits whose ray index is even and whose leaf index is odd
+            fn = lambda bv, pts, dirs: (bv.index % 2 == 1) & (pts[:, 0] == pts[:, 0])  # noqa: E731
+            keep = exp[:, 0] % 2 == 1
+            assert (contacts_np(ibvh.traverse_rays(g, P_, D_, narrow=fn)).reshape(-1, 2) == exp[keep]).all()
+            bfs = contacts_np(ibvh.traverse_rays(g, P_, D_, ibvh.BFSTraversal(), narrow=fn)).reshape(-1, 2)
+            assert sorted(map(tuple, bfs.tolist())) == sorted(map(tuple, exp[keep].tolist()))
+    with pytest.raises(ValueError):
+        ibvh.traverse_rays(g, P_, D_, narrow=ibvh.NARROW_MORTON_LT)  # a pair predicate is not on the ray menu
+
+
+def test_work_counters_rays_equal_the_reference_walk():
+    """ibvh_lvt_work_counters: the ray walker tests both children of every node it enters, exactly the nodes and leaves the
+    reference's stack walk tests (raytrace/leaf_vs_tree/leaf_vs_tree.jl:187-225) -> identical counts; the BBox-node leaf
+    walkers enumerate candidates differently (conservative union boxes), so there only sanity bounds hold."""
+    n = 60_000
+    r0 = 0.5 * (3 * 8 / (4 * np.pi * n)) ** (1 / 3)
+    host = orc.generate_spheres_f32(n, 42, r0=r0)
+    o, g = build_both(host, abi.make_types())
+    rng = np.random.default_rng(3)
+    p, d = rng.random((5000, 3)).astype(np.float32), (rng.random((5000, 3)) - 0.3).astype(np.float32)
+    w = ibvh.lvt_work_counters(g, points=cuda(p).t(), directions=cuda(d).t())
+    nt, lt, nc = orc.lvt_test_counts(o, points=p, directions=d)
+    assert (w["node_tests"], w["leaf_tests"], w["contacts_counted"]) == (nt, lt, nc)
+    assert w["node_fetches"] == nt and w["leaf_fetches"] == lt
+    ws = ibvh.lvt_work_counters(g)
+    nts, lts, ncs = orc.lvt_test_counts(o)
+    assert ws["contacts_counted"] == ncs == ibvh.traverse(g).num_contacts
+    assert ws["leaf_tests"] >= ncs and 0.5 * lts <= ws["leaf_tests"] <= 4 * lts
+    assert ws["node_fetches"] < nts  # a wave shares its node fetches: far fewer records than one walk per leaf
+    o2, g2 = build_both(orc.generate_spheres_f32(n, 45, origin=(0.9, 0, 0), r0=r0), abi.make_types())
+    wp = ibvh.lvt_work_counters(g, g2)
+    ntp, ltp, ncp = orc.lvt_test_counts(o, o2)
+    assert wp["contacts_counted"] == ncp and wp["leaf_tests"] >= ncp
+
+
+def test_more_contacts_than_int32_is_an_overflow_error():
+    """IBVH_ERR_OVERFLOW (include/ibvh.h; SURVEY.md §8a trap 9: the reference has no guard, its Int32 prefix sum wraps):
+    70,000 identical spheres touch pairwise — 2.45e9 > 2^31 - 1 contacts; the COUNT call must say so instead of returning
+    a wrapped total, and the Python mirror raises OverflowError."""
+    n = 70_000
+    vols = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    vols[:, :3] = torch.rand((n, 3), device="cuda") * 1e-3
+    vols[:, 3] = 1.0
+    g = ibvh.BVH(vols)
+    with pytest.raises(OverflowError):
+        ibvh.traverse(g)
+    # the same cloud with Int64 indices counts them all
+    g64 = ibvh.BVH(vols, options=ibvh.BVHOptions(index=np.int64))
+    s = g64.struct()
+    need = C.c_size_t()
+    lib.call("ibvh_lvt_scratch_bytes", C.byref(g64.types), n, 0, C.byref(need))
+    scratch = torch.zeros(need.value, dtype=torch.uint8, device="cuda")
+    counts = torch.zeros(n, dtype=torch.int64, device="cuda")
+    total = C.c_int64()
+    lib.call("ibvh_traverse_lvt_count", C.byref(s), 1, 0, counts.data_ptr(), C.byref(total), scratch.data_ptr(), scratch.numel(),
+             torch.cuda.current_stream().cuda_stream)
+    assert total.value == n * (n - 1) // 2
 
 
 # ---------------------------------------------------------------------------------------------

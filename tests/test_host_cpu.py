@@ -157,12 +157,13 @@ def test_julia_ccall_signatures_match_the_ctypes_binding():
           "Ref{IbvhBuildDesc}": C.POINTER(abi.BuildDesc), "Ref{IbvhBfsResult}": C.POINTER(abi.BfsResult)}
     seen = set()
     for name, ret, args in calls:
-        assert ret == "Cint", name
+        assert ret == ("Int32" if name == "ibvh_abi_version" else "Cint"), name
         got = [jl[a.strip()] for a in args.split(",") if a.strip()]
         assert got == lib.SIGNATURES[name], (name, args)
         seen.add(name)
     # the whole hot-path surface is bound: build + 3 LVT shapes x (count, write, enqueue) + 3 BFS shapes
-    want = {"ibvh_build", "ibvh_build_scratch_bytes", "ibvh_lvt_scratch_bytes", "ibvh_lvt_total", "ibvh_bfs_counters_bytes"}
+    want = {"ibvh_build", "ibvh_build_scratch_bytes", "ibvh_lvt_scratch_bytes", "ibvh_lvt_total", "ibvh_bfs_counters_bytes",
+            "ibvh_abi_version"}
     for shape in ("", "_pair", "_rays"):
         want |= {f"ibvh_traverse{shape}_lvt_{k}" for k in ("count", "write", "enqueue")}
         want |= {f"ibvh_traverse{shape}_bfs", f"ibvh_bfs{shape}_initial_capacity"}

@@ -121,7 +121,7 @@ out["config2_skew"] = {"leaves": n2, "build_uniform_ms": round(ms_warm, 3), "bui
 del v2, s2, t_lvt, t_bfs, clustered, sorted_vols, sc, ss
 torch.cuda.empty_cache()
 # ---- config 3 -------------------------------------------------------------------------------
-from test_gpu_fullsize import torus_mesh
+from implicitbvh_amd.synthetic import torus_mesh
 # IBVH_MESH=/path/to/xyzrgb_dragon.obj (benchmark/bvh_contact.jl:30-36): the real mesh when it is there,
 # the 7.2 M-triangle torus surrogate otherwise
 mesh_path = os.environ.get("IBVH_MESH", "")

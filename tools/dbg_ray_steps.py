@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np, torch
 import implicitbvh_amd as ibvh
 from implicitbvh_amd import lib, api
-from test_gpu_fullsize import torus_mesh
+from implicitbvh_amd.synthetic import torus_mesh
 tris = torch.from_numpy(torus_mesh()).cuda()
 vols = ibvh.bounding_volumes_from_triangles(tris)
 bvh = ibvh.BVH(vols)

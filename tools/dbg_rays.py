@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import implicitbvh_amd as ibvh
-from test_gpu_fullsize import torus_mesh
+from implicitbvh_amd.synthetic import torus_mesh
 tris = torch.from_numpy(torus_mesh()).cuda()
 vols = ibvh.bounding_volumes_from_triangles(tris)
 bvh = ibvh.BVH(vols)

@@ -23,7 +23,7 @@ elif case == "dups":
 elif case == "uniform":
     v = ibvh.generate_spheres(n, 42, r0=0.5 * (3 * 8 / (4 * math.pi * n)) ** (1 / 3))
 elif case == "mesh":
-    from test_gpu_fullsize import torus_mesh
+    from implicitbvh_amd.synthetic import torus_mesh
     tris = torch.from_numpy(torus_mesh()).cuda()
     v = ibvh.bounding_volumes_from_triangles(tris); n = v.shape[0]
 b = ibvh.BVH(v)
