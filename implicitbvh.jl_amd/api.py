@@ -211,6 +211,29 @@ def isvirtual(tree, implicit_index):
     return bool(out.value)
 
 
+# Per-(types, n) constants of a build / traversal (tree shape, record layout, scratch sizes): pure functions of their key,
+# asked of the library once.  A time-stepping caller rebuilds the same shape every step; on the step's critical path
+# (the host reads the contact count, then enqueues the next build) every avoided ctypes round trip counts.
+_shape_memo = {}
+
+
+def _memo(key, make):
+    v = _shape_memo.get(key)
+    if v is None:
+        if len(_shape_memo) > 256:
+            _shape_memo.clear()
+        v = _shape_memo[key] = make()
+    return v
+
+
+def _layout_of(types):
+    def make():
+        lay = abi.Layout()
+        lib.call("ibvh_layout_of", C.byref(types), C.byref(lay))
+        return lay
+    return _memo(("layout", types.key()), make)
+
+
 # ---------------------------------------------------------------------------------------------
 # BoundingVolumes: Vector{BoundingVolume{V,I,M}} in device memory
 # ---------------------------------------------------------------------------------------------
@@ -221,8 +244,7 @@ class BoundingVolumes:
         torch = _torch()
         self.types = types
         self.n = int(n)
-        lay = abi.Layout()
-        lib.call("ibvh_layout_of", C.byref(types), C.byref(lay))
+        lay = _layout_of(types)
         self.layout = lay
         if buf is None:
             buf = torch.zeros(self.n * lay.leaf_bytes, dtype=torch.uint8, device="cuda")
@@ -397,7 +419,7 @@ class BVH:
         types = abi.make_types(kind, flt, node_type.kind, node_type.flt, options.index_code, options.morton_code)
         if not abi.combo_supported(types):
             raise ValueError(f"no conversion from {'BSphere' if kind == abi.BSPHERE else 'BBox'} leaves to {node_type!r}")
-        self.tree = ImplicitTree(n)  # DomainError for n < 1
+        self.tree = _memo(("tree", int(n)), lambda: ImplicitTree(n))  # DomainError for n < 1
         tree = self.tree
         # compute_build_level (build.jl:309-325)
         if isinstance(built_level, (int, np.integer)):
@@ -428,13 +450,16 @@ class BVH:
             self.skips = cache.skips if cache.skips.numel() == tree.levels else torch.empty(tree.levels, dtype=idt, device="cuda")
             self.nodes = cache.nodes if cache.nodes.shape[0] == num_nodes else torch.empty((num_nodes, nw), dtype=ndt, device="cuda")
             self._scratch = cache._scratch
-        need = C.c_size_t()
-        lib.call("ibvh_build_scratch_bytes", C.byref(types), n, C.byref(need))
-        if self._scratch is None or self._scratch.numel() < need.value:
-            self._scratch = torch.empty(need.value, dtype=torch.uint8, device="cuda")
+        def scratch_need():
+            need = C.c_size_t()
+            lib.call("ibvh_build_scratch_bytes", C.byref(types), n, C.byref(need))
+            return need.value
+        need = _memo(("build_scratch", types.key(), int(n)), scratch_need)
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(need, dtype=torch.uint8, device="cuda")
         if wrapped and _out_of_place:
             # source records stay untouched, the sorted records go to a (reused) buffer of their own
-            nbytes = n * abi.leaf_dtype(types).itemsize
+            nbytes = n * int(_layout_of(types).leaf_bytes)
             reuse = cache is not None and cache.leaves.buf.numel() == nbytes and cache.leaves.buf.data_ptr() != bounding_volumes.buf.data_ptr()
             self.leaves = BoundingVolumes(types, n, cache.leaves.buf if reuse else torch.empty(nbytes, dtype=torch.uint8, device="cuda"))
             vol_ptr = _ptr(bounding_volumes.buf)
@@ -446,7 +471,7 @@ class BVH:
             # raw volumes: the wrapped, sorted leaves are this BVH's own array — the cached one when it has the right size
             # and type (the reference allocates a new one every time, build.jl:345-349; with cache= a time step then
             # allocates nothing at all: nodes, skips, leaves, extrema and scratch are all reused)
-            nbytes = n * abi.leaf_dtype(types).itemsize
+            nbytes = n * int(_layout_of(types).leaf_bytes)
             reuse = (cache is not None and cache.leaves.buf.numel() == nbytes and cache.leaves.types.key() == types.key()
                      and cache.leaves.buf.data_ptr() != bounding_volumes.data_ptr())
             self.leaves = BoundingVolumes(types, n, cache.leaves.buf if reuse else torch.empty(nbytes, dtype=torch.uint8, device="cuda"))
@@ -687,8 +712,8 @@ class _LvtScratch:
     after later traversals have reused — and rewritten — the scratch buffer (header, tile sums and contact cache
     alike).  So the totals do NOT live in the scratch: every call hands the library its own int64 word of a separate
     64-entry ring (`total_dev` of include/ibvh.h), which nothing else writes until the ring wraps, 64 calls later; a
-    total that was never read by then raises instead of returning another call's number.  An event recorded on the
-    launch stream orders the late read against the launch even when the current stream has changed."""
+    total that was never read by then raises instead of returning another call's number.  The host normally gets
+    the total from the pinned mirror word the scan kernel fills (`total_host`), without touching the stream."""
     SLOTS = 64
 
     def __init__(self, nbytes):
@@ -724,9 +749,7 @@ class _PendingTotal:
         self.event = None
 
     def launched(self):
-        torch = _torch()
-        self.event = torch.cuda.Event()
-        self.event.record(torch.cuda.current_stream())
+        """(nothing to record: the pinned word is polled; the fallback below synchronises the whole device)"""
         return self
 
     def item(self):
@@ -743,8 +766,7 @@ class _PendingTotal:
                 v = int(words[k])
                 if v != _HostWords.PENDING:
                     return v
-        if self.event is not None:
-            self.event.synchronize()
+        _torch().cuda.synchronize()  # the word never arrived (not expected): wait for everything, read the device copy
         return int(self.owner.totals[self.slot].item())
 
 
@@ -763,13 +785,16 @@ def _cache_slots(cache, n_items, default):
 
 
 def _lvt_scratch(cache, types, n_items, slots=None):
-    torch = _torch()
-    need = C.c_size_t()
-    lib.call("ibvh_lvt_scratch_bytes", C.byref(types), int(n_items), _cache_slots(cache, n_items, LVT_CACHE_SLOTS if slots is None else slots),
-             C.byref(need))
+    k = _cache_slots(cache, n_items, LVT_CACHE_SLOTS if slots is None else slots)
+
+    def scratch_need():
+        need = C.c_size_t()
+        lib.call("ibvh_lvt_scratch_bytes", C.byref(types), int(n_items), k, C.byref(need))
+        return need.value
+    need = _memo(("lvt_scratch", types.key(), int(n_items), k), scratch_need)
     s = cache._scratch if cache is not None else None
-    if not isinstance(s, _LvtScratch) or s.capacity() < need.value:
-        s = _LvtScratch(need.value)
+    if not isinstance(s, _LvtScratch) or s.capacity() < need:
+        s = _LvtScratch(need)
     return s
 
 

@@ -87,6 +87,19 @@ IBVH_D bool narrow_eval(int narrow, uint64_t ma, int64_t ia, uint64_t mb, int64_
 // A policy = check(pair, result) (does the pair pass at its level? `result`: what goes into the queue — the pair
 // itself, or the contact at leaf level) + children(pair, out) (the next level's pairs of a passing pair).
 // ------------------------------------------------------------------------------------------
+// Register storage for a node volume OR a leaf volume, whichever the launch's (uniform) level flag says: what a lane
+// prefetches for a child stays as small as the larger of the two instead of holding both.
+template <class A, class B> struct Either {
+    static constexpr int W = (int)((sizeof(A) > sizeof(B) ? sizeof(A) : sizeof(B)) / 4);
+    uint32_t w[W];
+    template <class X> IBVH_D void set(const X &x) { __builtin_memcpy(w, &x, sizeof(X)); }
+    template <class X> IBVH_D X get() const {
+        X x;
+        __builtin_memcpy(&x, w, sizeof(X));
+        return x;
+    }
+};
+
 template <class I> struct Identity { // the initial queue: "children" of nothing, still to be checked
     static constexpr int MAXOUT = 1;
     IBVH_D int children(IndexPair<I> s, IndexPair<I> *out) const {
@@ -104,22 +117,42 @@ template <class L, class N, class I> struct SelfStep {
     int self_checks; // (nodes) :44
     int narrow;      // (leaves) menu code
     int positions;   // (leaves) IBVH_OUTPUT_POSITIONS: 1-based leaf positions instead of user indices, left leaf first
-    IBVH_D bool check(IndexPair<I> s, IndexPair<I> &res) const {
+    // What one check needs from memory, fetched UNCONDITIONALLY (`s` is always a valid pair of this level: the kernel
+    // hands over a real child or safe()): every lane's loads for all its <= 4 children are in flight before the first
+    // test — four dependent round trips per lane otherwise, and the kernel is bound by exactly that latency.
+    struct Loaded {
+        Either<N, L> a, b;
+        I ia, ib;
+    };
+    IBVH_D IndexPair<I> safe() const { const I f = I(int64_t(1) << (t.level - 1)); return {f, f}; } // the level's first node: always real
+    IBVH_D Loaded load(IndexPair<I> s) const {
+        Loaded x{};
         if (leaf) {
             const char *r1 = t.leaf_rec(s.a), *r2 = t.leaf_rec(s.b);
-            if (!iscontact(load_vol<L>(r1), load_vol<L>(r2))) return false;
-            I i1 = load_index<I>(r1, t.lay), i2 = load_index<I>(r2, t.lay);
-            if (narrow != IBVH_NARROW_NONE) {
-                uint64_t m1 = narrow == IBVH_NARROW_MORTON_LT ? load_morton(r1, t.lay) : 0;
-                uint64_t m2 = narrow == IBVH_NARROW_MORTON_LT ? load_morton(r2, t.lay) : 0;
-                if (!narrow_eval(narrow, m1, i1, m2, i2)) return false;
+            x.a.set(load_vol<L>(r1));
+            x.b.set(load_vol<L>(r2));
+            x.ia = load_index<I>(r1, t.lay);
+            x.ib = load_index<I>(r2, t.lay);
+        } else {
+            x.a.set(t.node(s.a));
+            x.b.set(t.node(s.b));
+        }
+        return x;
+    }
+    IBVH_D bool test(IndexPair<I> s, const Loaded &x, IndexPair<I> &res) const {
+        if (leaf) {
+            if (!iscontact(x.a.template get<L>(), x.b.template get<L>())) return false;
+            if (narrow != IBVH_NARROW_NONE) { // (the Morton codes are fetched only here: the menu predicates are the rare case)
+                const uint64_t m1 = narrow == IBVH_NARROW_MORTON_LT ? load_morton(t.leaf_rec(s.a), t.lay) : 0;
+                const uint64_t m2 = narrow == IBVH_NARROW_MORTON_LT ? load_morton(t.leaf_rec(s.b), t.lay) : 0;
+                if (!narrow_eval(narrow, m1, x.ia, m2, x.ib)) return false;
             }
             if (positions) res = {I(s.a - t.leaf_first + 1), I(s.b - t.leaf_first + 1)}; // (a is left of b)
-            else res = i1 > i2 ? IndexPair<I>{i2, i1} : IndexPair<I>{i1, i2};
+            else res = x.ia > x.ib ? IndexPair<I>{x.ib, x.ia} : IndexPair<I>{x.ia, x.ib};
             return true;
         }
         res = s;
-        return s.a == s.b || iscontact(t.node(s.a), t.node(s.b)); // (a node against itself is not tested, :52-70)
+        return s.a == s.b || iscontact(x.a.template get<N>(), x.b.template get<N>()); // (a node against itself is not tested, :52-70)
     }
     IBVH_D int children(IndexPair<I> s, IndexPair<I> *out) const {
         const I a = s.a, b = s.b;
@@ -158,25 +191,47 @@ template <class L, class N, class I> struct PairStep {
     TreeRef<L, N> t1, t2;
     int narrow, positions;
     int leaf1, leaf2, d1, d2;
-    IBVH_D bool check(IndexPair<I> s, IndexPair<I> &res) const {
+    struct Loaded { // (see SelfStep::Loaded)
+        Either<N, L> a, b;
+        I ia, ib;
+    };
+    IBVH_D IndexPair<I> safe() const { return {I(int64_t(1) << (t1.level - 1)), I(int64_t(1) << (t2.level - 1))}; }
+    IBVH_D Loaded load(IndexPair<I> s) const {
+        Loaded x{};
+        const I a = s.a, b = s.b;
+        if (leaf1) {
+            const char *r1 = t1.leaf_rec(a);
+            x.a.set(load_vol<L>(r1));
+            if (leaf2) x.ia = load_index<I>(r1, t1.lay);
+        } else {
+            x.a.set(t1.node(a));
+        }
+        if (leaf2) {
+            const char *r2 = t2.leaf_rec(b);
+            x.b.set(load_vol<L>(r2));
+            if (leaf1) x.ib = load_index<I>(r2, t2.lay);
+        } else {
+            x.b.set(t2.node(b));
+        }
+        return x;
+    }
+    IBVH_D bool test(IndexPair<I> s, const Loaded &x, IndexPair<I> &res) const {
         const I a = s.a, b = s.b;
         res = s;
         if (leaf1 && leaf2) {
             // _traverse_leaves_pair_gpu! (:556-609): (leaf1.index, leaf2.index), not re-ordered
-            const char *r1 = t1.leaf_rec(a), *r2 = t2.leaf_rec(b);
-            if (!iscontact(load_vol<L>(r1), load_vol<L>(r2))) return false;
-            I i1 = load_index<I>(r1, t1.lay), i2 = load_index<I>(r2, t2.lay);
+            if (!iscontact(x.a.template get<L>(), x.b.template get<L>())) return false;
             if (narrow != IBVH_NARROW_NONE) {
-                uint64_t m1 = narrow == IBVH_NARROW_MORTON_LT ? load_morton(r1, t1.lay) : 0;
-                uint64_t m2 = narrow == IBVH_NARROW_MORTON_LT ? load_morton(r2, t2.lay) : 0;
-                if (!narrow_eval(narrow, m1, i1, m2, i2)) return false;
+                const uint64_t m1 = narrow == IBVH_NARROW_MORTON_LT ? load_morton(t1.leaf_rec(a), t1.lay) : 0;
+                const uint64_t m2 = narrow == IBVH_NARROW_MORTON_LT ? load_morton(t2.leaf_rec(b), t2.lay) : 0;
+                if (!narrow_eval(narrow, m1, x.ia, m2, x.ib)) return false;
             }
-            res = positions ? IndexPair<I>{I(a - t1.leaf_first + 1), I(b - t2.leaf_first + 1)} : IndexPair<I>{i1, i2};
+            res = positions ? IndexPair<I>{I(a - t1.leaf_first + 1), I(b - t2.leaf_first + 1)} : IndexPair<I>{x.ia, x.ib};
             return true;
         }
-        if (leaf1) return iscontact(load_vol<L>(t1.leaf_rec(a)), t2.node(b)); // iscontact(leaf1.volume, node2), :461-527
-        if (leaf2) return iscontact(t1.node(a), load_vol<L>(t2.leaf_rec(b))); // :360-426
-        return iscontact(t1.node(a), t2.node(b));
+        if (leaf1) return iscontact(x.a.template get<L>(), x.b.template get<N>()); // iscontact(leaf1.volume, node2), :461-527
+        if (leaf2) return iscontact(x.a.template get<N>(), x.b.template get<L>()); // :360-426
+        return iscontact(x.a.template get<N>(), x.b.template get<N>());
     }
     IBVH_D int children(IndexPair<I> s, IndexPair<I> *out) const {
         const I a = s.a, b = s.b;
@@ -219,20 +274,40 @@ template <class L, class N, class I> struct RayStep {
     const T *points, *dirs;
     int leaf;
     int narrow, positions;
-    IBVH_D bool check(IndexPair<I> s, IndexPair<I> &res) const {
+    struct Loaded { // (see SelfStep::Loaded)
+        T p[3], d[3];
+        Either<N, L> v;
+        I idx;
+    };
+    IBVH_D IndexPair<I> safe() const { return {I(int64_t(1) << (t.level - 1)), I(1)}; } // (num_rays >= 1 whenever a level runs)
+    IBVH_D Loaded load(IndexPair<I> s) const {
+        Loaded x{};
+        const int64_t r0 = 3 * ((int64_t)s.b - 1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            x.p[k] = points[r0 + k];
+            x.d[k] = dirs[r0 + k];
+        }
+        if (leaf) {
+            const char *r = t.leaf_rec(s.a);
+            x.v.set(load_vol<L>(r));
+            x.idx = load_index<I>(r, t.lay);
+        } else {
+            x.v.set(t.node(s.a));
+        }
+        return x;
+    }
+    IBVH_D bool test(IndexPair<I> s, const Loaded &x, IndexPair<I> &res) const {
         const I a = s.a, iray = s.b;
-        const T p[3] = {points[3 * ((int64_t)iray - 1)], points[3 * ((int64_t)iray - 1) + 1], points[3 * ((int64_t)iray - 1) + 2]};
-        const T d[3] = {dirs[3 * ((int64_t)iray - 1)], dirs[3 * ((int64_t)iray - 1) + 1], dirs[3 * ((int64_t)iray - 1) + 2]};
         res = s;
         if (leaf) {
-            const char *r = t.leaf_rec(a);
-            const L leaf_vol = load_vol<L>(r);
-            if (!isintersection(leaf_vol, p, d)) return false;
-            if (narrow == IBVH_NARROW_RAY_ORIGIN_OUTSIDE && !origin_outside(leaf_vol, p)) return false; // raytrace_gpu.jl:159
-            res = {positions ? I(a - t.leaf_first + 1) : load_index<I>(r, t.lay), iray};
+            const L lv = x.v.template get<L>();
+            if (!isintersection(lv, x.p, x.d)) return false;
+            if (narrow == IBVH_NARROW_RAY_ORIGIN_OUTSIDE && !origin_outside(lv, x.p)) return false; // raytrace_gpu.jl:159
+            res = {positions ? I(a - t.leaf_first + 1) : x.idx, iray};
             return true;
         }
-        return isintersection(t.node(a), p, d);
+        return isintersection(x.v.template get<N>(), x.p, x.d);
     }
     IBVH_D int children(IndexPair<I> s, IndexPair<I> *out) const {
         out[0] = {I(2 * s.a), s.b};
@@ -278,10 +353,19 @@ __global__ __launch_bounds__(TPB) void level_kernel(const IndexPair<I> *__restri
         int nk = 0, k = 0;
         if (i < num_src) nk = pa.children(src[i], kids);
         generated += (unsigned long long)nk;
+        // all loads of all children first (unconditional: a slot without a child fetches the level's first node), then the
+        // tests: one memory round trip per lane and chunk instead of one per child
+        typename PolB::Loaded ld[MAXOUT];
+        const IndexPair<I> safe = pb.safe();
+#pragma unroll
+        for (int j = 0; j < MAXOUT; ++j) {
+            if (j >= nk) kids[j] = safe;
+            ld[j] = pb.load(kids[j]);
+        }
 #pragma unroll
         for (int j = 0; j < MAXOUT; ++j) {
             IndexPair<I> r;
-            if (j < nk && pb.check(kids[j], r)) out[k++] = r;
+            if (j < nk && pb.test(kids[j], ld[j], r)) out[k++] = r;
         }
 
         // exclusive offset inside the wave from ballots over the bit planes of k (k <= 4)

@@ -32,6 +32,7 @@ namespace build {
 
 constexpr int EXT_TPB = 256;
 constexpr int EXT_MAX_BLOCKS = 2048;
+constexpr int EXT_FOLD_BLOCKS = 512; // ibvh_build: the partials are folded by every encode workgroup (ExtremaFold)
 
 // ------------------------------------------------------------------------------------------
 // M1: extrema of the centres — morton/utils.jl:1-72
@@ -184,16 +185,70 @@ __global__ __launch_bounds__(256) void encode_kernel(const char *__restrict__ re
 // Same, fused with the radix sort's first per-tile digit histogram: the workgroup encodes exactly the
 // keys of one sort tile and counts their lowest digit in LDS, so the sort's first hist pass (a 4 B/leaf
 // re-read of the keys plus a launch) disappears.
+// The fold of the extrema partials rides along (ExtremaFold): every workgroup folds the <= EXT_FOLD_BLOCKS partial results
+// itself (a few KB of L2 hits) and applies the epsilon expansion — the identical operations in every workgroup, min / max
+// being order-free — instead of waiting for a one-workgroup launch in between (extrema_final_kernel: ~6 us of pure
+// launch / dependency latency at 1e6 leaves); workgroup 0 also publishes the result (the build's `extrema` output) and
+// writes the skips.
+template <class T> struct ExtremaFold {
+    const T *partials; // nullptr: `ext` already holds the bounds
+    int nparts;
+    T *out, *out2;
+    SkipsOut so;
+};
 template <class V, class K>
 __global__ __launch_bounds__(1024) void encode_hist_kernel(const char *__restrict__ recs, int64_t stride, int64_t n,
                                                           const typename V::elt *__restrict__ ext, int morton_type,
                                                           K *__restrict__ keys, int tile_elems, int shift, uint32_t mask,
-                                                          uint32_t *__restrict__ tile_hist, int num_tiles, int tile_major) {
+                                                          uint32_t *__restrict__ tile_hist, int num_tiles, int tile_major,
+                                                          ExtremaFold<typename V::elt> fold) {
     using T = typename V::elt;
     extern __shared__ uint32_t h[]; // mask + 1 counters
+    __shared__ T s_fold[16][6];
+    __shared__ T s_ext[6];
     for (int i = threadIdx.x; i <= (int)mask; i += blockDim.x) h[i] = 0;
+    if (fold.partials != nullptr) {
+        if (blockIdx.x == 0) write_skips(fold.so);
+        T mn[3] = {float_max<T>(), float_max<T>(), float_max<T>()};
+        T mx[3] = {float_min_normal<T>(), float_min_normal<T>(), float_min_normal<T>()};
+        for (int i = threadIdx.x; i < fold.nparts; i += blockDim.x) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const T a = fold.partials[i * 6 + k], b = fold.partials[i * 6 + 3 + k];
+                mn[k] = mn[k] < a ? mn[k] : a;
+                mx[k] = mx[k] > b ? mx[k] : b;
+            }
+        }
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const T a = wave_min(mn[k]), b = wave_max(mx[k]);
+            if (lane == 0) {
+                s_fold[w][k] = a;
+                s_fold[w][3 + k] = b;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            T v = s_fold[0][threadIdx.x];
+            for (int i = 1; i < (int)(blockDim.x >> 6); ++i) {
+                const T t = s_fold[i][threadIdx.x];
+                v = threadIdx.x < 3 ? (v < t ? v : t) : (v > t ? v : t);
+            }
+            // bounding_volumes_extrema (utils.jl:63-69): x -/+ rp*abs(x) -/+ floatmin, two roundings a side
+            const T rp = relative_precision<T>(), fm = float_min_normal<T>();
+            const T a = rp * ibvh_abs(v);
+            v = threadIdx.x < 3 ? (v - a) - fm : (v + a) + fm;
+            s_ext[threadIdx.x] = v;
+            if (blockIdx.x == 0) {
+                fold.out[threadIdx.x] = v;
+                if (fold.out2) fold.out2[threadIdx.x] = v;
+            }
+        }
+    }
     __syncthreads();
-    const T mins[3] = {ext[0], ext[1], ext[2]}, maxs[3] = {ext[3], ext[4], ext[5]};
+    const T *bounds = fold.partials != nullptr ? s_ext : ext;
+    const T mins[3] = {bounds[0], bounds[1], bounds[2]}, maxs[3] = {bounds[3], bounds[4], bounds[5]};
     const int64_t base = (int64_t)blockIdx.x * tile_elems;
     for (int j = threadIdx.x; j < tile_elems; j += blockDim.x) {
         const int64_t i = base + j;
@@ -421,6 +476,14 @@ inline Scratch carve(char *base, int64_t n, int key_bytes, int64_t leaf_bytes, i
     return s;
 }
 
+// the first half alone: per-workgroup partial extrema for a consumer that folds them itself (encode_hist_kernel)
+template <class V> int extrema_partials(const char *recs, int64_t stride, int64_t n, char *partials, hipStream_t st, int *nparts) {
+    using T = typename V::elt;
+    const int blocks = grid_for(n, EXT_TPB * 4, EXT_FOLD_BLOCKS);
+    IBVH_LAUNCH((extrema_partial_kernel<V>), dim3(blocks), dim3(EXT_TPB), 0, st, recs, stride, n, (T *)partials);
+    *nparts = blocks;
+    return IBVH_OK;
+}
 template <class V>
 int extrema(const char *recs, int64_t stride, int64_t n, int expand, typename V::elt *out, char *partials, hipStream_t st,
             typename V::elt *out2 = nullptr, SkipsOut so = SkipsOut{TreeDev{0, 0, 0}, nullptr, 4}) {
@@ -544,8 +607,13 @@ ibvh_status ibvh_build(const ibvh_build_desc *desc, const void *volumes, void *l
         TreeDev td{tree.levels, tree.real_leaves, tree.virtual_leaves};
         const SkipsOut so{td, skips, ty.index_type == IBVH_I32 ? 4 : 8};
         // extrema (or caller-fixed bounds: morton/default.jl:52-57)
+        ExtremaFold<T> fold{nullptr, 0, ext, (T *)extrema_out, so};
         if (desc->compute_extrema) {
-            if (int e = extrema<L>(src, src_stride, n, 1, ext, sc.partials, st, (T *)extrema_out, so)) return e;
+            // partial extrema only: the encode kernel's workgroups fold them (one launch less on the critical path)
+            int nparts = 0;
+            if (int e = extrema_partials<L>(src, src_stride, n, sc.partials, st, &nparts)) return e;
+            fold.partials = (const T *)sc.partials;
+            fold.nparts = nparts;
         } else {
             IBVH_LAUNCH((extrema_set_kernel<T>), dim3(1), dim3(64), 0, st, ext, (T *)extrema_out, desc->mins[0], desc->mins[1],
                                desc->mins[2], desc->maxs[0], desc->maxs[1], desc->maxs[2], so);
@@ -559,11 +627,11 @@ ibvh_status ibvh_build(const ibvh_build_desc *desc, const void *volumes, void *l
         if (key_bytes == 8)
             IBVH_LAUNCH((encode_hist_kernel<L, uint64_t>), dim3(plan.num_tiles), dim3(plan.tpb), ((size_t)plan.mask + 1) * 4, st,
                         src, src_stride, n, ext, ty.morton_type, (uint64_t *)sc.keys, plan.tpb * plan.ipt, plan.shift, plan.mask,
-                        plan.tile_hist, plan.num_tiles, mp.bits ? 1 : 0);
+                        plan.tile_hist, plan.num_tiles, mp.bits ? 1 : 0, fold);
         else
             IBVH_LAUNCH((encode_hist_kernel<L, uint32_t>), dim3(plan.num_tiles), dim3(plan.tpb), ((size_t)plan.mask + 1) * 4, st,
                         src, src_stride, n, ext, ty.morton_type, (uint32_t *)sc.keys, plan.tpb * plan.ipt, plan.shift, plan.mask,
-                        plan.tile_hist, plan.num_tiles, mp.bits ? 1 : 0);
+                        plan.tile_hist, plan.num_tiles, mp.bits ? 1 : 0, fold);
         IBVH_LAUNCH_CHECK();
         if (mp.bits) {
             // the default: ONE partition of the finished records by the top bits of their key, buckets finished in LDS

@@ -136,7 +136,10 @@ template <class I> struct PairCache {
     int32_t K;
 };
 
-constexpr int BRUTE_DEPTH = 7;   // 2^7 = 128 leaves, 64 leaf-parents (one per lane) per brute-forced subtree
+#ifndef IBVH_BRUTE_DEPTH
+#define IBVH_BRUTE_DEPTH 7
+#endif
+constexpr int BRUTE_DEPTH = IBVH_BRUTE_DEPTH; // 2^7 = 128 leaves, 64 leaf-parents (one per lane) per brute-forced subtree
 constexpr int FRONTIER_CAP = 256; // frontier entries per wave and level (LDS); overflow -> exact walk
 
 // Per-lane query state + the emission rules shared by both kernels.
@@ -171,12 +174,15 @@ template <class L, class N, class I, int MODE, bool WRITE, bool NARROW> struct Q
         w = 0;
         cnt = 0;
         if (valid) {
-            const char *rec = a.items + item * a.items_lay.stride;
+            // (SELF: the work items ARE the walked tree's leaves — naming them through a.leaves / a.lay lets the compiler drop
+            // a.items / a.items_lay, six scalar registers that would otherwise stay live through the whole kernel)
+            const LeafLayout &il = MODE == MODE_SELF ? a.lay : a.items_lay;
+            const char *rec = (MODE == MODE_SELF ? a.leaves : a.items) + item * il.stride;
             q_leaf = load_vol<L>(rec);
             q_node = convert_to(q_leaf, (N *)nullptr); // traverse_single.jl:154-155
-            q_index = load_index<I>(rec, a.items_lay);
+            q_index = load_index<I>(rec, il);
             if constexpr (NARROW)
-                if (a.narrow == IBVH_NARROW_MORTON_LT) q_morton = load_morton(rec, a.items_lay);
+                if (a.narrow == IBVH_NARROW_MORTON_LT) q_morton = load_morton(rec, il);
         }
         lane_on = valid;
     }
@@ -334,6 +340,50 @@ template <class T> IBVH_D T wave_max_all(T v) {
     return v;
 }
 
+// Inclusive prefix min / max over the 64 lanes of a wave with DPP (lane k: min / max of lanes 0 .. k): four row_shr steps
+// inside each row of 16 lanes, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 — six VALU
+// instructions per value (the DPP operand rides on the v_min / v_max itself) where __shfl_up costs a ds_bpermute, its
+// address arithmetic and a compare-select per step.  Lanes without a valid source are write-disabled and keep their own
+// value.  Inputs are finite (the callers sanitise NaN), so v_min_f32 / v_max_f32 are exact here; all 64 lanes are active.
+// Written as ONE assembly block over twelve independent values (six minima, six maxima), step by step across all of
+// them: a DPP operand must not have been written by one of the two preceding VALU instructions, and with eleven other
+// instructions between two steps of the same value no s_nop is needed.  (Through __builtin_amdgcn_update_dpp the compiler
+// emits v_mov_b32_dpp + canonicalising v_max + v_min + a copy per step: four instructions instead of one.)
+#define IBVH_DPP_STEP(CTRL)                              \
+    "v_min_f32_dpp %0, %0, %0 " CTRL "\n\t"              \
+    "v_min_f32_dpp %1, %1, %1 " CTRL "\n\t"              \
+    "v_min_f32_dpp %2, %2, %2 " CTRL "\n\t"              \
+    "v_min_f32_dpp %3, %3, %3 " CTRL "\n\t"              \
+    "v_min_f32_dpp %4, %4, %4 " CTRL "\n\t"              \
+    "v_min_f32_dpp %5, %5, %5 " CTRL "\n\t"              \
+    "v_max_f32_dpp %6, %6, %6 " CTRL "\n\t"              \
+    "v_max_f32_dpp %7, %7, %7 " CTRL "\n\t"              \
+    "v_max_f32_dpp %8, %8, %8 " CTRL "\n\t"              \
+    "v_max_f32_dpp %9, %9, %9 " CTRL "\n\t"              \
+    "v_max_f32_dpp %10, %10, %10 " CTRL "\n\t"           \
+    "v_max_f32_dpp %11, %11, %11 " CTRL "\n\t"
+IBVH_D void wave_prefix_scans_dpp(float (&mn)[6], float (&mx)[6]) {
+    asm volatile("s_nop 1\n\t" IBVH_DPP_STEP("row_shr:1 row_mask:0xf bank_mask:0xf") IBVH_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+                     IBVH_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xf") IBVH_DPP_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+                         IBVH_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf") IBVH_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(mn[0]), "+v"(mn[1]), "+v"(mn[2]), "+v"(mn[3]), "+v"(mn[4]), "+v"(mn[5]), "+v"(mx[0]), "+v"(mx[1]), "+v"(mx[2]),
+                   "+v"(mx[3]), "+v"(mx[4]), "+v"(mx[5]));
+}
+#undef IBVH_DPP_STEP
+// wave minimum of one value (every lane of the result's lane 63 holds it; read with v_readlane): one dependent chain,
+// so each step waits out the DPP hazard with an s_nop
+IBVH_D float wave_min_dpp_lane63(float v) {
+    asm volatile("s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(v));
+    return v;
+}
+
 // ---- (2) BBox nodes: frontier descent + candidate-pair queue ----------------------------------------
 // Stage c in detail: each lane gathers the two leaves of its pair (48 contiguous bytes for BSphere{Float32}
 // records), runs the exact leaf tests and ranks its hits among the lanes that hold the same query (6-ballot
@@ -411,10 +461,17 @@ constexpr int QUEUE_CAP = 512; // candidate pairs per wave (LDS); drained whenev
 #define IBVH_QUEUE_WAVES 1
 #endif
 constexpr int QUEUE_WAVES = IBVH_QUEUE_WAVES; // waves per workgroup (they share nothing: a workgroup is only a unit of dispatch)
+#ifndef IBVH_QUEUE_MINWAVES
+#define IBVH_QUEUE_MINWAVES 8
+#endif
+#ifndef IBVH_LVT_STRAIGHT
+#define IBVH_LVT_STRAIGHT 7 // bit 0: descent loads, bit 1: leaf-parent loads, bit 2: leaf loads of the pair step — straight-line (clamped) instead of exec-masked
+#endif
+constexpr int QUEUE_MINWAVES = IBVH_QUEUE_MINWAVES; // waves per SIMD the register allocator has to leave room for (8: 64 VGPRs)
 
 // WIDE: 64-bit queue entries for trees of 29 .. 31 levels (leaf-parent indices beyond 2^26), see launch().
 template <class L, class N, class I, int MODE, bool WRITE, bool NARROW, bool WIDE, bool COUNT = false>
-__global__ __launch_bounds__(64 * QUEUE_WAVES, 8) void lvt_queue_kernel(Args<L, N, I> a, PairCache<I> cache, int cut_level) {
+__global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_kernel(Args<L, N, I> a, PairCache<I> cache, int cut_level) {
     using TN = typename N::elt;
     Work<COUNT> work; // (COUNT: one lane-level box / sphere test = one count; lane 0 carries the wave-uniform parts)
     using Q = Query<L, N, I, MODE, WRITE, NARROW>;
@@ -510,36 +567,8 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, 8) void lvt_queue_kernel(Args<L, 
         bool use = q.lane_on; // NaN boxes touch nothing and must not poison the min / max
 #pragma unroll
         for (int k = 0; k < 3; ++k) use = use && q.q_node.lo[k] == q.q_node.lo[k] && q.q_node.up[k] == q.q_node.up[k];
-        N pre, suf;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            pre.lo[k] = suf.lo[k] = use ? q.q_node.lo[k] : big;
-            pre.up[k] = suf.up[k] = use ? q.q_node.up[k] : -big;
-        }
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { // lanes without a source keep their own value: min / max are idempotent
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                TN t = __shfl_up(pre.lo[k], o, 64);
-                pre.lo[k] = pre.lo[k] < t ? pre.lo[k] : t;
-                t = __shfl_up(pre.up[k], o, 64);
-                pre.up[k] = pre.up[k] > t ? pre.up[k] : t;
-                t = __shfl_down(suf.lo[k], o, 64);
-                suf.lo[k] = suf.lo[k] < t ? suf.lo[k] : t;
-                t = __shfl_down(suf.up[k], o, 64);
-                suf.up[k] = suf.up[k] > t ? suf.up[k] : t;
-            }
-        }
-        N nxt_suf; // box of lanes lane+1 .. 63
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            nxt_suf.lo[k] = __shfl_down(suf.lo[k], 1, 64);
-            nxt_suf.up[k] = __shfl_down(suf.up[k], 1, 64);
-            if (lane == 63) {
-                nxt_suf.lo[k] = big;
-                nxt_suf.up[k] = -big;
-            }
-        }
+        N pre, nxt_suf; // box of lanes 0 .. lane / of lanes lane+1 .. 63
+        float cost;
         auto half_area = [](const N &b) {
             float d[3];
 #pragma unroll
@@ -549,18 +578,94 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, 8) void lvt_queue_kernel(Args<L, 
             }
             return d[0] * d[1] + d[1] * d[2] + d[0] * d[2];
         };
-        float cost = half_area(pre) + half_area(nxt_suf);
-        cost = cost == cost ? cost : __builtin_inff();
-        // argmin over the lanes: non-negative floats order like their bit patterns
-        uint64_t key = ((uint64_t)__float_as_uint(cost) << 32) | (uint32_t)lane;
+        int ksplit;
+        if constexpr (std::is_same<TN, float>::value) {
+            // DPP scans (wave_prefix_dpp).  The suffix boxes come from the same prefix scan run on the lane-reversed
+            // values: rsuf in lane j = box of lanes 63-j .. 63, so the box of lanes k+1 .. 63 sits in lane 62-k; only its
+            // half-area has to travel back (one ds_bpermute), and the chosen boxes are read with v_readlane.
+            N rev, rsuf;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const uint64_t t = (uint64_t)__shfl_xor((long long)key, o, 64);
-            key = t < key ? t : key;
+            for (int k = 0; k < 3; ++k) {
+                pre.lo[k] = use ? q.q_node.lo[k] : big;
+                pre.up[k] = use ? q.q_node.up[k] : -big;
+                rev.lo[k] = __shfl(pre.lo[k], 63 - lane, 64);
+                rev.up[k] = __shfl(pre.up[k], 63 - lane, 64);
+            }
+            {
+                float mn[6] = {pre.lo[0], pre.lo[1], pre.lo[2], rev.lo[0], rev.lo[1], rev.lo[2]};
+                float mx[6] = {pre.up[0], pre.up[1], pre.up[2], rev.up[0], rev.up[1], rev.up[2]};
+                wave_prefix_scans_dpp(mn, mx);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    pre.lo[k] = mn[k];
+                    pre.up[k] = mx[k];
+                    rsuf.lo[k] = mn[3 + k];
+                    rsuf.up[k] = mx[3 + k];
+                }
+            }
+            // cost(k) = area(lanes 0 .. k) + area(lanes k+1 .. 63); the latter is rsuf's area in lane 62-k (nothing for k = 63)
+            const float ra = half_area(rsuf);
+            float sa = __shfl(ra, 62 - lane, 64);
+            sa = lane == 63 ? 0.0f : sa;
+            cost = half_area(pre) + sa;
+            cost = cost == cost ? cost : __builtin_inff();
+            // argmin: wave min of the cost with the same DPP steps, then the first lane that attains it
+            const float m = wave_min_dpp_lane63(cost);
+            const float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
+            const uint64_t at = __builtin_amdgcn_ballot_w64(cost == best);
+            ksplit = at != 0 ? (int)__builtin_ctzll(at) : 0;
+            ubox_a = broadcast_from_lane(pre, ksplit);
+            ubox_b = broadcast_from_lane(rsuf, ksplit == 63 ? 0 : 62 - ksplit);
+            if (ksplit == 63) { // nothing to the right of the split: the empty box
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    ubox_b.lo[k] = big;
+                    ubox_b.up[k] = -big;
+                }
+            }
+        } else {
+            N suf;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                pre.lo[k] = suf.lo[k] = use ? q.q_node.lo[k] : big;
+                pre.up[k] = suf.up[k] = use ? q.q_node.up[k] : -big;
+            }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { // lanes without a source keep their own value: min / max are idempotent
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    TN t = __shfl_up(pre.lo[k], o, 64);
+                    pre.lo[k] = pre.lo[k] < t ? pre.lo[k] : t;
+                    t = __shfl_up(pre.up[k], o, 64);
+                    pre.up[k] = pre.up[k] > t ? pre.up[k] : t;
+                    t = __shfl_down(suf.lo[k], o, 64);
+                    suf.lo[k] = suf.lo[k] < t ? suf.lo[k] : t;
+                    t = __shfl_down(suf.up[k], o, 64);
+                    suf.up[k] = suf.up[k] > t ? suf.up[k] : t;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                nxt_suf.lo[k] = __shfl_down(suf.lo[k], 1, 64);
+                nxt_suf.up[k] = __shfl_down(suf.up[k], 1, 64);
+                if (lane == 63) {
+                    nxt_suf.lo[k] = big;
+                    nxt_suf.up[k] = -big;
+                }
+            }
+            cost = half_area(pre) + half_area(nxt_suf);
+            cost = cost == cost ? cost : __builtin_inff();
+            // argmin over the lanes: non-negative floats order like their bit patterns
+            uint64_t key = ((uint64_t)__float_as_uint(cost) << 32) | (uint32_t)lane;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint64_t t = (uint64_t)__shfl_xor((long long)key, o, 64);
+                key = t < key ? t : key;
+            }
+            ksplit = (int)(key & 63u);
+            ubox_a = broadcast_from_lane(pre, ksplit);
+            ubox_b = broadcast_from_lane(nxt_suf, ksplit);
         }
-        const int ksplit = (int)(key & 63u);
-        ubox_a = broadcast_from_lane(pre, ksplit);
-        ubox_b = broadcast_from_lane(nxt_suf, ksplit);
     }
     auto touches_wave = [&](const N &b) { return (bool)((int)iscontact(ubox_a, b) | (int)iscontact(ubox_b, b)); };
     const int lp = levels - 1;
@@ -572,6 +677,25 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, 8) void lvt_queue_kernel(Args<L, 
     // c: leaf tests of queue[off, off + avail), one pair per lane
     auto pair_step = [&](int off, int avail) {
         const bool v = lane < avail;
+        // (straight-line loads: lanes beyond the step re-read its first entry, a pair without a right leaf re-reads the left
+        // one; both are masked by v / has_b afterwards)
+#if IBVH_LVT_STRAIGHT & 4
+        const QE e = queue[off + (v ? lane : 0)];
+        const int qi = (int)(e & 63u);
+        const uint32_t pos = 2u * (uint32_t)(e >> 6); // 0-based position of the pair's left leaf
+        const bool has_b = v & (pos + 1u < n_leaves);
+        uint64_t mor_a = 0, mor_b = 0;
+        const char *rec = a.leaves + (int64_t)pos * a.lay.stride;
+        const char *rec_b = (pos + 1u < n_leaves) ? rec + a.lay.stride : rec;
+        const L leaf_a = load_vol<L>(rec), leaf_b = load_vol<L>(rec_b);
+        const I idx_a = load_index<I>(rec, a.lay), idx_b = load_index<I>(rec_b, a.lay);
+        if constexpr (NARROW) {
+            if (a.narrow == IBVH_NARROW_MORTON_LT) {
+                mor_a = load_morton(rec, a.lay);
+                mor_b = load_morton(rec_b, a.lay);
+            }
+        }
+#else
         const QE e = v ? queue[off + lane] : (QE)0;
         const int qi = (int)(e & 63u);
         const uint32_t pos = 2u * (uint32_t)(e >> 6); // 0-based position of the pair's left leaf
@@ -592,6 +716,7 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, 8) void lvt_queue_kernel(Args<L, 
             if constexpr (NARROW)
                 if (a.narrow == IBVH_NARROW_MORTON_LT) mor_b = load_morton(rec + a.lay.stride, a.lay);
         }
+#endif
         const L ql = shuffle_from(q.q_leaf, qi);
         const I qidx = __shfl(q.q_index, qi, 64);
         const uint32_t item_q = wave_item0 + (uint32_t)qi;
@@ -674,6 +799,12 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, 8) void lvt_queue_kernel(Args<L, 
         uint32_t last = first32 + (1u << (lp - cut_level));
         last = last < lp_real ? last : lp_real;
         const int np = (int)(last - first32); // <= 64
+        // lanes without a parent (a ragged last subtree) re-read the last one and stay out of box_mask: whatever they
+        // compute below is masked (straight-line load: no exec-masked region, no "empty box" to materialise)
+#if IBVH_LVT_STRAIGHT & 2
+        const N mybox = load_vol<N>(lp_nodes + (first32 + (uint32_t)(lane < np ? lane : np - 1)));
+        const bool mine = lane < np;
+#else
         N mybox; // lanes without a parent hold the empty box: it matches nothing
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -681,16 +812,18 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, 8) void lvt_queue_kernel(Args<L, 
             mybox.up[k] = -float_max<TN>();
         }
         if (lane < np) mybox = load_vol<N>(lp_nodes + (first32 + (uint32_t)lane));
+        const bool mine = true;
+#endif
         work.add(2, lane < np);
         work.add(0, lane < np ? 2u : 0u); // against the wave's two boxes
         const uint32_t right_leaf = 2u * (first32 + (uint32_t)lane) + 1u; // of this lane's parent
-        bool box_on = touches_wave(mybox);
+        bool box_on = mine & touches_wave(mybox);
         if constexpr (MODE == MODE_SELF) box_on = box_on & (right_leaf > wave_item0);
         const uint64_t box_mask = __builtin_amdgcn_ballot_w64(box_on);
         // shorter of the two loops: lanes = queries over the parents that touch the wave's boxes, or
         // lanes = parents over the active queries.  (Measured alternative: lanes = (query, parent) pairs
         // pulled together with ds_bpermute — as many steps as this loop has iterations, and slower.)
-        const bool by_box = (int)__popcll(box_mask) < (int)__popcll(on_mask); // (int: keeps the compare on the scalar unit)
+        const bool by_box = __builtin_amdgcn_readfirstlane((int)__popcll(box_mask)) < __builtin_amdgcn_readfirstlane((int)__popcll(on_mask)); // (uniform 32-bit: a scalar compare)
         const QE e_box = (QE)lane | ((QE)first32 << 6);             // + (u << 6)
         const QE e_qry = (QE)(first32 + (uint32_t)lane) << 6;       // | u
         if constexpr (std::is_same<TN, float>::value && !WIDE) {
@@ -771,16 +904,25 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, 8) void lvt_queue_kernel(Args<L, 
             int next_count = 0;
             for (int base = 0; base < count; base += 64) {
                 const bool have = base + lane < count;
+                // (straight-line: lanes beyond the frontier re-read its first entry and are masked afterwards — no exec-masked
+                // region around the loads, and the ballot below is the compare mask itself)
+                work.add(2, have);
+                work.add(0, have ? 2u : 0u);
+#if IBVH_LVT_STRAIGHT & 1
+                const uint32_t idx = cur[have ? base + lane : base];
+                const N box = load_vol<N>(lvl_nodes + (idx - lvl_first));
+                bool hit = have & touches_wave(box);
+                if constexpr (MODE == MODE_SELF) hit = hit & !((idx + 1u) <= (wave_next >> (levels - lvl)));
+#else
                 const uint32_t idx = have ? cur[base + lane] : 0u;
                 N box;
                 bool hit = false;
-                work.add(2, have);
-                work.add(0, have ? 2u : 0u);
                 if (have) {
                     box = load_vol<N>(lvl_nodes + (idx - lvl_first));
                     hit = touches_wave(box);
                     if constexpr (MODE == MODE_SELF) hit = hit & !((idx + 1u) <= (wave_next >> (levels - lvl)));
                 }
+#endif
                 const uint64_t hm = __builtin_amdgcn_ballot_w64(hit);
                 if (lvl == cut_level) {
                     for (uint64_t todo = hm; todo != 0; todo &= todo - 1) {
