@@ -784,14 +784,20 @@ def _cache_slots(cache, n_items, default):
     return max(default, min(64, want))
 
 
-def _lvt_scratch(cache, types, n_items, slots=None):
+def _lvt_scratch(cache, types, n_items, slots=None, rays_bvh=None):
     k = _cache_slots(cache, n_items, LVT_CACHE_SLOTS if slots is None else slots)
 
     def scratch_need():
         need = C.c_size_t()
-        lib.call("ibvh_lvt_scratch_bytes", C.byref(types), int(n_items), k, C.byref(need))
+        if rays_bvh is not None:  # rays: room for the walker's shadow of the node levels as well (include/ibvh.h)
+            s = rays_bvh.struct()
+            lib.call("ibvh_rays_scratch_bytes", C.byref(s), int(n_items), k, C.byref(need))
+        else:
+            lib.call("ibvh_lvt_scratch_bytes", C.byref(types), int(n_items), k, C.byref(need))
         return need.value
-    need = _memo(("lvt_scratch", types.key(), int(n_items), k), scratch_need)
+    key = ("lvt_scratch", types.key(), int(n_items), k) if rays_bvh is None else \
+        ("rays_scratch", types.key(), int(n_items), k, len(rays_bvh.leaves), rays_bvh.built_level)
+    need = _memo(key, scratch_need)
     s = cache._scratch if cache is not None else None
     if not isinstance(s, _LvtScratch) or s.capacity() < need:
         s = _LvtScratch(need)
@@ -996,7 +1002,7 @@ def traverse_rays(bvh, points, directions, alg=None, start_level=1, narrow=None,
     s = bvh.struct()
     if lvt:
         counts = _cache_tensor(cache.cache2 if cache else None, nr, 0, idt, "cache2")
-        scratch = _lvt_scratch(cache, bvh.types, nr, slots=RAY_CACHE_SLOTS)
+        scratch = _lvt_scratch(cache, bvh.types, nr, slots=RAY_CACHE_SLOTS, rays_bvh=bvh)
         sp, sn = _ptr(scratch), scratch.numel()
         spec = _speculative_buffer(cache, idt)
         if spec is not None:

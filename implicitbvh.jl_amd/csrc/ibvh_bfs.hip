@@ -102,6 +102,7 @@ template <class A, class B> struct Either {
 
 template <class I> struct Identity { // the initial queue: "children" of nothing, still to be checked
     static constexpr int MAXOUT = 1;
+    static constexpr bool kIdentity = true;
     IBVH_D int children(IndexPair<I> s, IndexPair<I> *out) const {
         out[0] = s;
         return 1;
@@ -111,6 +112,8 @@ template <class I> struct Identity { // the initial queue: "children" of nothing
 // _traverse_nodes_gpu! — bfs/traverse_single_gpu.jl:30-120 (same rules as traverse_single_cpu.jl:64-133) — and
 // _traverse_leaves_gpu! — :153-211
 template <class L, class N, class I> struct SelfStep {
+    using leaf_t = L;
+    using node_t = N;
     static constexpr int MAXOUT = 4;
     TreeRef<L, N> t;
     int leaf;        // entries are leaf pairs
@@ -154,6 +157,44 @@ template <class L, class N, class I> struct SelfStep {
         res = s;
         return s.a == s.b || iscontact(x.a.template get<N>(), x.b.template get<N>()); // (a node against itself is not tested, :52-70)
     }
+    // The children of a source pair (a, b) are combinations of {2a, 2a+1} x {2b, 2b+1}: FOUR volumes (two adjacent
+    // pairs in memory) serve all of them — fetched once per source pair instead of twice per child pair.
+    // (called on the CHILD level's policy with the parent-level source pair)
+    static constexpr bool kIdentity = false;
+    struct Sides {
+        Either<N, L> v[2][2]; // [side a / b][left / right child]
+        I idx[2][2];
+    };
+    IBVH_D Sides load_sides(IndexPair<I> s, const SelfStep &) const {
+        Sides x{};
+        const int64_t first = int64_t(1) << (t.level - 1), nreal = level_num_real(t.levels, t.virtual_leaves, t.level);
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int64_t c0 = 2 * (int64_t)(side ? s.b : s.a);
+            const int64_t c1 = (c0 + 1 - first) < nreal ? c0 + 1 : c0; // a virtual right child re-reads the left one (never selected)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int64_t c = k ? c1 : c0;
+                if (leaf) {
+                    const char *r = t.leaf_rec(c);
+                    x.v[side][k].set(load_vol<L>(r));
+                    x.idx[side][k] = load_index<I>(r, t.lay);
+                } else {
+                    x.v[side][k].set(t.node(c));
+                }
+            }
+        }
+        return x;
+    }
+    IBVH_D bool test_sides(IndexPair<I> s, const Sides &x, IndexPair<I> &res) const {
+        const int ka = (int)(s.a & 1), kb = (int)(s.b & 1);
+        Loaded y;
+        y.a = ka ? x.v[0][1] : x.v[0][0];
+        y.b = kb ? x.v[1][1] : x.v[1][0];
+        y.ia = ka ? x.idx[0][1] : x.idx[0][0];
+        y.ib = kb ? x.idx[1][1] : x.idx[1][0];
+        return test(s, y, res);
+    }
     IBVH_D int children(IndexPair<I> s, IndexPair<I> *out) const {
         const I a = s.a, b = s.b;
         if (a == b) {
@@ -187,6 +228,8 @@ template <class L, class N, class I> struct SelfStep {
 // The six pair kernels of bfs/traverse_pair_gpu.jl:34-609 in one policy: which side is at leaf level
 // (leaf1 / leaf2) and which side descends (d1 / d2).
 template <class L, class N, class I> struct PairStep {
+    using leaf_t = L;
+    using node_t = N;
     static constexpr int MAXOUT = 4;
     TreeRef<L, N> t1, t2;
     int narrow, positions;
@@ -233,6 +276,44 @@ template <class L, class N, class I> struct PairStep {
         if (leaf2) return iscontact(x.a.template get<N>(), x.b.template get<L>()); // :360-426
         return iscontact(x.a.template get<N>(), x.b.template get<N>());
     }
+    static constexpr bool kIdentity = false;
+    struct Sides { // (see SelfStep::Sides; a side that did not descend in the parent step holds its one node twice)
+        Either<N, L> v[2][2];
+        I idx[2][2];
+    };
+    IBVH_D Sides load_sides(IndexPair<I> s, const PairStep &parent) const {
+        Sides x{};
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const TreeRef<L, N> &t = side ? t2 : t1;
+            const bool is_leaf = side ? leaf2 : leaf1, descended = side ? parent.d2 : parent.d1;
+            const int64_t p = (int64_t)(side ? s.b : s.a);
+            const int64_t first = int64_t(1) << (t.level - 1), nreal = level_num_real(t.levels, t.virtual_leaves, t.level);
+            const int64_t c0 = descended ? 2 * p : p;
+            const int64_t c1 = (descended && (c0 + 1 - first) < nreal) ? c0 + 1 : c0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int64_t c = k ? c1 : c0;
+                if (is_leaf) {
+                    const char *r = t.leaf_rec(c);
+                    x.v[side][k].set(load_vol<L>(r));
+                    x.idx[side][k] = load_index<I>(r, t.lay);
+                } else {
+                    x.v[side][k].set(t.node(c));
+                }
+            }
+        }
+        return x;
+    }
+    IBVH_D bool test_sides(IndexPair<I> s, const Sides &x, IndexPair<I> &res, const PairStep &parent) const {
+        const int ka = parent.d1 ? (int)(s.a & 1) : 0, kb = parent.d2 ? (int)(s.b & 1) : 0;
+        Loaded y;
+        y.a = ka ? x.v[0][1] : x.v[0][0];
+        y.b = kb ? x.v[1][1] : x.v[1][0];
+        y.ia = ka ? x.idx[0][1] : x.idx[0][0];
+        y.ib = kb ? x.idx[1][1] : x.idx[1][0];
+        return test(s, y, res);
+    }
     IBVH_D int children(IndexPair<I> s, IndexPair<I> *out) const {
         const I a = s.a, b = s.b;
         if (d1 && d2) { // _traverse_nodes_pair_gpu! (:34-119)
@@ -268,6 +349,8 @@ template <class L, class N, class I> struct PairStep {
 
 // _traverse_rays_nodes_gpu! / _traverse_rays_leaves_gpu! — raytrace/breadth_first/raytrace_gpu.jl:26-179
 template <class L, class N, class I> struct RayStep {
+    using leaf_t = L;
+    using node_t = N;
     static constexpr int MAXOUT = 2;
     using T = typename L::elt;
     TreeRef<L, N> t;
@@ -309,6 +392,47 @@ template <class L, class N, class I> struct RayStep {
         }
         return isintersection(x.v.template get<N>(), x.p, x.d);
     }
+    static constexpr bool kIdentity = false;
+    struct Sides { // the ray once + the two children of its node
+        T p[3], d[3];
+        Either<N, L> v[2];
+        I idx[2];
+    };
+    IBVH_D Sides load_sides(IndexPair<I> s, const RayStep &) const {
+        Sides x{};
+        const int64_t r0 = 3 * ((int64_t)s.b - 1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            x.p[k] = points[r0 + k];
+            x.d[k] = dirs[r0 + k];
+        }
+        const int64_t first = int64_t(1) << (t.level - 1), nreal = level_num_real(t.levels, t.virtual_leaves, t.level);
+        const int64_t c0 = 2 * (int64_t)s.a, c1 = (c0 + 1 - first) < nreal ? c0 + 1 : c0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int64_t c = k ? c1 : c0;
+            if (leaf) {
+                const char *r = t.leaf_rec(c);
+                x.v[k].set(load_vol<L>(r));
+                x.idx[k] = load_index<I>(r, t.lay);
+            } else {
+                x.v[k].set(t.node(c));
+            }
+        }
+        return x;
+    }
+    IBVH_D bool test_sides(IndexPair<I> s, const Sides &x, IndexPair<I> &res) const {
+        const int k = (int)(s.a & 1);
+        Loaded y;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            y.p[j] = x.p[j];
+            y.d[j] = x.d[j];
+        }
+        y.v = k ? x.v[1] : x.v[0];
+        y.idx = k ? x.idx[1] : x.idx[0];
+        return test(s, y, res);
+    }
     IBVH_D int children(IndexPair<I> s, IndexPair<I> *out) const {
         out[0] = {I(2 * s.a), s.b};
         if (t.right_child_virtual(s.a)) return 1;
@@ -334,10 +458,19 @@ __global__ __launch_bounds__(TPB) void level_kernel(const IndexPair<I> *__restri
                                                     int64_t capacity, unsigned long long *__restrict__ counters, int step, int chk,
                                                     PolA pa, PolB pb) {
     constexpr int MAXOUT = PolA::MAXOUT;
-    __shared__ IndexPair<I> staged[MAXOUT * TPB];
-    __shared__ int wave_tot[TPB / 64];
+    // Results of MANY chunks are collected in LDS and leave in one coalesced run behind ONE global atomic on the level's
+    // tail (round 2 took that atomic per chunk: every chunk of a workgroup then waited out a ~2 us round trip to L2 —
+    // ~34 chunks a workgroup and level at 1e6 leaves, most of the 1.4 ms of config 2).  A wave reserves its share of the
+    // staging area with one LDS atomic (no workgroup barrier for the prefix); one barrier per chunk tells everybody
+    // whether the area could overflow with the next chunk and must be flushed first.
+    constexpr int STAGE = (sizeof(I) == 4 ? 24 : 48) * 1024 / (int)sizeof(IndexPair<I>); // 3,072 pairs: six workgroups a CU (the registers allow five)
+    static_assert(STAGE >= 2 * MAXOUT * TPB, "the staging area holds at least two worst-case chunks");
+    __shared__ IndexPair<I> staged[STAGE];
+    __shared__ int s_fill;
     __shared__ unsigned long long s_base;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) s_fill = 0;
+    lds_barrier();
     // an EARLIER step overflowed: its destination (our source) is incomplete.  The step that overflows itself keeps going
     // in every workgroup — also those that start, or reach their next chunk, after a sibling raised the flag — so that
     // counters[2 + step] ends as the exact number of pairs the step produces (required_capacity).
@@ -347,56 +480,67 @@ __global__ __launch_bounds__(TPB) void level_kernel(const IndexPair<I> *__restri
     if (num_src > capacity) return;   // (defensive: the flag covers this)
     const uint64_t lt = ((uint64_t)1 << lane) - 1;
     unsigned long long generated = 0;
-    for (int64_t chunk = blockIdx.x; chunk * TPB < num_src; chunk += gridDim.x) {
-        const int64_t i = chunk * TPB + threadIdx.x;
-        IndexPair<I> kids[MAXOUT], out[MAXOUT];
-        int nk = 0, k = 0;
-        if (i < num_src) nk = pa.children(src[i], kids);
-        generated += (unsigned long long)nk;
-        // all loads of all children first (unconditional: a slot without a child fetches the level's first node), then the
-        // tests: one memory round trip per lane and chunk instead of one per child
-        typename PolB::Loaded ld[MAXOUT];
-        const IndexPair<I> safe = pb.safe();
-#pragma unroll
-        for (int j = 0; j < MAXOUT; ++j) {
-            if (j >= nk) kids[j] = safe;
-            ld[j] = pb.load(kids[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < MAXOUT; ++j) {
-            IndexPair<I> r;
-            if (j < nk && pb.test(kids[j], ld[j], r)) out[k++] = r;
-        }
-
-        // exclusive offset inside the wave from ballots over the bit planes of k (k <= 4)
-        uint64_t b0 = __ballot(k & 1), b1 = __ballot(k & 2), b2 = __ballot(k & 4);
-        int wave_prefix = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
-        int wave_sum = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
-        if (lane == 0) wave_tot[w] = wave_sum;
-        lds_barrier();
-        int block_prefix = 0, total = 0;
-#pragma unroll
-        for (int j = 0; j < TPB / 64; ++j) {
-            int t = wave_tot[j];
-            if (j < w) block_prefix += t;
-            total += t;
-        }
-        const int at = block_prefix + wave_prefix;
-#pragma unroll
-        for (int j = 0; j < MAXOUT; ++j)
-            if (j < k) staged[at + j] = out[j];
-        if (threadIdx.x == 0) s_base = total ? atomicAdd(&counters[2 + step], (unsigned long long)total) : 0ull;
-        lds_barrier();
-        const unsigned long long base = s_base;
+    // staging area -> destination queue: one global atomic for everything collected since the last flush
+    auto flush = [&]() {
+        const int total = s_fill; // (all waves are behind a barrier: stable)
         if (total > 0) {
+            if (threadIdx.x == 0) s_base = atomicAdd(&counters[2 + step], (unsigned long long)total);
+            lds_barrier();
+            const unsigned long long base = s_base;
             if (base + (unsigned long long)total > (unsigned long long)capacity) {
                 if (threadIdx.x == 0) atomicMax(&counters[0], (unsigned long long)(1 + step)); // the tail keeps counting
             } else {
                 for (int p = threadIdx.x; p < total; p += TPB) dst[base + p] = staged[p];
             }
         }
-        lds_barrier(); // staged / wave_tot / s_base are reused by the next chunk (LDS only: the stores above stay in flight)
+        lds_barrier();
+        if (threadIdx.x == 0) s_fill = 0;
+        lds_barrier(); // staged / s_fill / s_base are reused (LDS only: the stores above stay in flight)
+    };
+    for (int64_t chunk = blockIdx.x; chunk * TPB < num_src; chunk += gridDim.x) {
+        const int64_t i = chunk * TPB + threadIdx.x;
+        // (results stay in registers, statically indexed: `out[k++]` would put the array into scratch memory)
+        IndexPair<I> kids[MAXOUT], res[MAXOUT];
+        uint32_t okm = 0; // bit j: child j passed
+        int nk = 0;
+        if (i < num_src) nk = pa.children(src[i], kids);
+        generated += (unsigned long long)nk;
+        // ALL loads first, unconditionally (a lane without a source pair fetches for the level's first node), then the
+        // tests: one memory round trip per lane and chunk instead of one per child pair
+        if constexpr (PolA::kIdentity) {
+            const IndexPair<I> kid = nk > 0 ? kids[0] : pb.safe();
+            const typename PolB::Loaded ld = pb.load(kid);
+            if (nk > 0 && pb.test(kid, ld, res[0])) okm = 1u;
+        } else {
+            // the source pair's children share their volumes: {2a, 2a+1} x {2b, 2b+1} (or one side kept): four volume
+            // fetches per lane serve up to four checks
+            const IndexPair<I> s0 = i < num_src ? src[i] : pa.safe();
+            const typename PolB::Sides sides = pb.load_sides(s0, pa);
+#pragma unroll
+            for (int j = 0; j < MAXOUT; ++j) {
+                bool ok;
+                if constexpr (std::is_same<PolB, PairStep<typename PolB::leaf_t, typename PolB::node_t, I>>::value) ok = j < nk && pb.test_sides(kids[j], sides, res[j], pa);
+                else ok = j < nk && pb.test_sides(kids[j], sides, res[j]);
+                okm |= ok ? (1u << j) : 0u;
+            }
+        }
+        const int k = __popc(okm);
+
+        // exclusive offset inside the wave from ballots over the bit planes of k (k <= 4)
+        uint64_t b0 = __ballot(k & 1), b1 = __ballot(k & 2), b2 = __ballot(k & 4);
+        int wave_prefix = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
+        int wave_sum = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+        int wave_base = 0;
+        if (lane == 0 && wave_sum > 0) wave_base = atomicAdd(&s_fill, wave_sum); // (LDS atomic: the wave's share of the staging area)
+        wave_base = __builtin_amdgcn_readfirstlane(wave_base);
+        const int at = wave_base + wave_prefix;
+#pragma unroll
+        for (int j = 0; j < MAXOUT; ++j)
+            if ((okm >> j) & 1u) staged[at + __popc(okm & ((1u << j) - 1u))] = res[j];
+        lds_barrier(); // every wave's share is reserved and written
+        if (s_fill > STAGE - MAXOUT * TPB) flush(); // (uniform: read after the barrier) the next chunk might not fit
     }
+    flush();
     // pairs checked by this workgroup
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) generated += __shfl_xor(generated, o, 64);

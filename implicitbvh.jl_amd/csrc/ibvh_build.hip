@@ -608,12 +608,17 @@ ibvh_status ibvh_build(const ibvh_build_desc *desc, const void *volumes, void *l
         const SkipsOut so{td, skips, ty.index_type == IBVH_I32 ? 4 : 8};
         // extrema (or caller-fixed bounds: morton/default.jl:52-57)
         ExtremaFold<T> fold{nullptr, 0, ext, (T *)extrema_out, so};
-        if (desc->compute_extrema) {
-            // partial extrema only: the encode kernel's workgroups fold them (one launch less on the critical path)
+        // Small builds are launch-latency bound: the encode kernel's workgroups fold the partial extrema themselves (one
+        // launch less on the critical path: -6 us at 1e6 leaves).  With thousands of encode workgroups the redundant folds
+        // cost more than the launch they save (1e7 leaves: encode 35 -> 45 us), so large builds keep the one-workgroup fold.
+        const bool fold_in_encode = n <= (int64_t)1 << 21;
+        if (desc->compute_extrema && fold_in_encode) {
             int nparts = 0;
             if (int e = extrema_partials<L>(src, src_stride, n, sc.partials, st, &nparts)) return e;
             fold.partials = (const T *)sc.partials;
             fold.nparts = nparts;
+        } else if (desc->compute_extrema) {
+            if (int e = extrema<L>(src, src_stride, n, 1, ext, sc.partials, st, (T *)extrema_out, so)) return e;
         } else {
             IBVH_LAUNCH((extrema_set_kernel<T>), dim3(1), dim3(64), 0, st, ext, (T *)extrema_out, desc->mins[0], desc->mins[1],
                                desc->mins[2], desc->maxs[0], desc->maxs[1], desc->maxs[2], so);

@@ -44,6 +44,11 @@ template <class L, class N, class I> struct Args {
     // *guard_total <= guard_capacity (guard_total == nullptr: unguarded)
     const int64_t *guard_total;
     int64_t guard_capacity;
+    // RAYS: the quantised 8-wide shadow of the node levels (RayShadow below; nullptr: the binary walk) and which rays a
+    // launch serves: 0 all, 1 only IRREGULAR ones (a zero / non-finite direction component or a non-finite origin: the
+    // slab test is not monotone under box inclusion for them), 2 only regular ones
+    const char *shadow;
+    int32_t rays_filter;
     // ibvh_lvt_work_counters only (COUNT instantiations): [0] node tests, [1] leaf tests, [2] node records fetched,
     // [3] leaf records fetched, summed over the launch
     unsigned long long *work;
@@ -456,13 +461,23 @@ IBVH_D uint64_t test_and_append_f32(uint64_t init, float slo0, float slo1, float
     return hm;
 }
 
-constexpr int QUEUE_CAP = 512; // candidate pairs per wave (LDS); drained whenever fewer than 64 slots are free
+#ifndef IBVH_QUEUE_CAP
+#define IBVH_QUEUE_CAP 512
+#endif
+constexpr int QUEUE_CAP = IBVH_QUEUE_CAP; // candidate pairs per wave (LDS); drained whenever fewer than 64 slots are free
 #ifndef IBVH_QUEUE_WAVES
 #define IBVH_QUEUE_WAVES 1
 #endif
 constexpr int QUEUE_WAVES = IBVH_QUEUE_WAVES; // waves per workgroup (they share nothing: a workgroup is only a unit of dispatch)
+// Waves per SIMD the register allocator has to leave room for.  Round 3, measured on MI355X with the DPP prologue and
+// the straight-line loads below (count pass, 1e6 / 1e7 leaves): 8 waves (64 VGPRs: 36 SGPR + 6 VGPR spills, 28 B of
+// scratch per lane) 0.188 / 1.75 ms; 7 waves (70 VGPRs, 15 SGPR spills to VGPR lanes, NO scratch) 0.156 / 1.37 ms; the
+// round-2 kernel at 8 waves (31 + 4 spills, 20 B of scratch) 0.165 / 1.42 ms.  (profiles/r03_lvt_variants.txt)
 #ifndef IBVH_QUEUE_MINWAVES
-#define IBVH_QUEUE_MINWAVES 8
+#define IBVH_QUEUE_MINWAVES 7
+#endif
+#ifndef IBVH_LVT_QTABLE
+#define IBVH_LVT_QTABLE 0
 #endif
 #ifndef IBVH_LVT_STRAIGHT
 #define IBVH_LVT_STRAIGHT 7 // bit 0: descent loads, bit 1: leaf-parent loads, bit 2: leaf loads of the pair step — straight-line (clamped) instead of exec-masked
@@ -480,8 +495,20 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
     using QE = typename std::conditional<WIDE, uint64_t, uint32_t>::type; // queue entry: query lane | leaf-parent index << 6
     __shared__ QE s_queue[QUEUE_WAVES][QUEUE_CAP];
     __shared__ Cnt s_cnt[QUEUE_WAVES][64];
+#if IBVH_LVT_QTABLE
+    // The wave's 64 query leaves (volume, index) in LDS: the leaf-test step fetches its candidate's query with one or two
+    // ds_read instead of five ds_bpermute out of registers, and the volume / index need not stay in VGPRs through the loops.
+    struct QRec {
+        L vol;
+        I idx;
+    };
+    __shared__ QRec s_query[QUEUE_WAVES][64];
+#endif
     Q q(a, cache);
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // (uniform: LDS bases stay scalar)
+#if IBVH_LVT_QTABLE
+    s_query[wv][lane] = QRec{q.q_leaf, q.q_index};
+#endif
     // Wave-dense contact cache.  The wave owns the scratch bytes its 64 items own in the slot-major layout of the
     // other walkers ([item0 * K, (item0 + 64) * K) pairs) but fills them densely, in discovery order, with
     // (pair, query lane | position within that query's list << 6) entries behind a 16-byte header {fill}: the
@@ -717,8 +744,14 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
                 if (a.narrow == IBVH_NARROW_MORTON_LT) mor_b = load_morton(rec + a.lay.stride, a.lay);
         }
 #endif
+#if IBVH_LVT_QTABLE
+        const QRec qr = s_query[wv][qi];
+        const L ql = qr.vol;
+        const I qidx = qr.idx;
+#else
         const L ql = shuffle_from(q.q_leaf, qi);
         const I qidx = __shfl(q.q_index, qi, 64);
+#endif
         const uint32_t item_q = wave_item0 + (uint32_t)qi;
         bool hit_a = v & iscontact(ql, leaf_a), hit_b = has_b & iscontact(ql, leaf_b);
         work.add(1, (uint32_t)v + (uint32_t)has_b);
@@ -1010,6 +1043,20 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
 // (Tried and dropped in round 2: the top 10 levels of the tree in LDS — a third code path per step, no gain.)
 constexpr int RAY_BITS = 10, RAY_BLOCK_MAX = 1 << RAY_BITS;
 
+// a ray the shadow walk may serve: finite origin, finite non-zero direction with finite reciprocal
+template <class T> IBVH_D bool ray_is_regular(const T *p, const T *d, const T *inv) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const T big = float_max<T>();
+        ok = ok && (p[k] >= -big && p[k] <= big) && (d[k] >= -big && d[k] <= big) && d[k] != T(0) && (inv[k] >= -big && inv[k] <= big) &&
+             inv[k] != T(0);
+    }
+    return ok;
+}
+
+
+
 template <class L, class N, class I, bool WRITE, bool COUNT = false>
 __global__ __launch_bounds__(64) void lvt_rays_kernel(Args<L, N, I> a, PairCache<I> cache, int ray_block) {
     using T = typename L::elt;
@@ -1091,8 +1138,8 @@ __global__ __launch_bounds__(64) void lvt_rays_kernel(Args<L, N, I> a, PairCache
         if (idle != 0 && next < items_here) {
             const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             const int mine = next + rank;
+            bool took = false;
             if (ray < 0 && mine < items_here) {
-                ray = mine;
                 const int64_t item = first_item + mine;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
@@ -1100,6 +1147,12 @@ __global__ __launch_bounds__(64) void lvt_rays_kernel(Args<L, N, I> a, PairCache
                     d[k] = a.dirs[3 * item + k];
                     inv[k] = T(1) / d[k];
                 }
+                // (behind the shadow walker this kernel serves the irregular rays only: Args::rays_filter)
+                took = !(a.rays_filter == 1 && ray_is_regular(p, d, inv));
+            }
+            if (took) {
+                const int64_t item = first_item + mine;
+                ray = mine;
                 pi = 0;
                 inode = pfirst;
                 level = plevel;
@@ -1110,7 +1163,10 @@ __global__ __launch_bounds__(64) void lvt_rays_kernel(Args<L, N, I> a, PairCache
             const int taken = __popcll(idle);
             next = next + taken < items_here ? next + taken : items_here;
         }
-        if (__builtin_amdgcn_ballot_w64(ray >= 0) == 0) break;
+        if (__builtin_amdgcn_ballot_w64(ray >= 0) == 0) {
+            if (next >= items_here) break;
+            continue; // (a whole draw of rays that are not this launch's: draw again)
+        }
         // ---- walk: every busy lane advances its ray until a quarter of the wave has gone idle (or the block is used up
         // and everybody is done)
         for (;;) {
@@ -1241,6 +1297,297 @@ __global__ __launch_bounds__(64) void lvt_rays_kernel(Args<L, N, I> a, PairCache
     }
 }
 
+// ---- (3b) rays over a quantised 8-wide SHADOW of the node levels --------------------------------------------------
+// What bounds the binary ray walk is the number of dependent ~48-byte fetches (config 3: 206 node fetches per ray) and the
+// bytes they move.  For a ray whose direction components are all finite and non-zero (and whose origin is finite) the slab
+// test of isintersection.jl:1-33 is MONOTONE under box inclusion — every operation in it, (lo - p) * inv, min, max, is a
+// weakly monotone function of its operands in floating point — and a BBox node is the exact min / max of its children
+// (merge.jl:30-40), so such a ray reaches leaf j in the reference's walk (raytrace/leaf_vs_tree/leaf_vs_tree.jl:187-225)
+// iff it hits the box of j's PARENT (that implies every ancestor) and then the leaf itself.  Any conservative enumeration
+// of leaf parents followed by those two exact tests, in ascending leaf order, therefore reproduces the reference's hit
+// list including its order — the interior levels only prune.  The enumeration used here is a shadow copy of the node
+// levels in which ONE entry describes a node and its (up to) eight descendants three levels down:
+//     { float lo[3], step[3]; uint32 valid; uint8 q[8][6] }   (80 bytes, 16-byte aligned)
+// child c's box relative to the node's own exact box, 8 bits a coordinate, rounded OUTWARDS and verified against the very
+// expression the walk evaluates (lo + float(q) * step, no contraction): dequantised boxes contain the exact ones, so by the
+// same monotonicity a ray that hits an exact box hits its dequantised superset when the SAME slab function is applied.
+// One 80-byte fetch thus replaces three levels of 48-byte fetches (config 3: 57 wide + 19 leaf-parent fetches per ray
+// instead of 206), the children of an entry are tested from registers, and the walk is a depth-first visit in ascending
+// child order whose stack is one byte per wide level (the tree is implicit: a child's index is (index << 3) | c).
+// At the bottom a candidate leaf parent's exact box (24 bytes) and its two leaves (48 bytes) are fetched together and
+// tested exactly.  Irregular rays (a zero or non-finite direction component, ...) are left to the binary walker, which is
+// launched behind this kernel for them alone (Args::rays_filter) — config 3 has none, a launch that finds none returns at once.
+// The shadow is rebuilt by every counting call (one streaming pass over the nodes: 0.05 ms for 7.2 M leaves) into the
+// caller's scratch (ibvh_rays_scratch_bytes), so nothing outlives the call and a BVH needs no extra field.
+constexpr int SHADOW_ENTRY_BYTES = 80;
+constexpr int SHADOW_MAX_DEPTHS = 8; // wide levels: trees of up to 26 levels (the per-lane stack is one uint64)
+struct RayShadow {
+    int32_t depths;                       // wide levels K (0: no shadow)
+    int32_t d0;                           // binary levels the top entry spans (1 .. 3); every other entry spans 3
+    uint32_t base[SHADOW_MAX_DEPTHS + 1]; // first entry of wide level k (in entries); base[K] = total
+};
+IBVH_HD int shadow_level(const RayShadow &sh, int k) { return k == 0 ? 1 : 1 + sh.d0 + 3 * (k - 1); } // binary level of wide level k
+inline RayShadow make_ray_shadow(const ibvh_tree &tree) {
+    RayShadow sh{};
+    const int64_t lp = tree.levels - 1; // leaf parents: the children of the bottom wide level
+    if (lp < 7) return sh;
+    const int K = (int)((lp - 1 + 2) / 3);
+    if (K > SHADOW_MAX_DEPTHS) return sh;
+    sh.depths = K;
+    sh.d0 = (int)((lp - 1) - 3 * (K - 1));
+    uint64_t run = 0;
+    for (int k = 0; k < K; ++k) {
+        sh.base[k] = (uint32_t)run;
+        run += (uint64_t)level_num_real(tree.levels, tree.virtual_leaves, shadow_level(sh, k));
+    }
+    if (run >= ((uint64_t)1 << 32)) return RayShadow{};
+    sh.base[K] = (uint32_t)run;
+    return sh;
+}
+struct ShadowEntry {
+    float lo[3], step[3];
+    uint32_t valid;
+    uint8_t q[8][6]; // child c: lo.x lo.y lo.z up.x up.y up.z
+    uint32_t pad_;
+};
+static_assert(sizeof(ShadowEntry) == SHADOW_ENTRY_BYTES, "shadow entry layout");
+// the ONE dequantisation expression (build-time verification and walk must agree bit for bit)
+IBVH_D float shadow_dequant(float lo, float step, uint32_t q) { return lo + (float)q * step; }
+
+template <class N>
+__global__ __launch_bounds__(256) void ray_shadow_build_kernel(const N *__restrict__ nodes, TreeDev tree, RayShadow sh, ShadowEntry *__restrict__ out) {
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= sh.base[sh.depths]) return;
+    int k = 0;
+    while (k + 1 < sh.depths && e >= sh.base[k + 1]) ++k;
+    const int level = shadow_level(sh, k), dep = k == 0 ? sh.d0 : 3, clevel = level + dep;
+    const int64_t first = int64_t(1) << (level - 1), cfirst = int64_t(1) << (clevel - 1);
+    const int64_t idx = first + (int64_t)(e - sh.base[k]); // implicit index of the node
+    const N self = load_vol<N>(nodes + (idx - level_skips(tree.levels, tree.virtual_leaves, level) - 1));
+    const int64_t creal = level_num_real(tree.levels, tree.virtual_leaves, clevel);
+    const int64_t cskips = level_skips(tree.levels, tree.virtual_leaves, clevel);
+    ShadowEntry en{};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float lo = (float)self.lo[a], up = (float)self.up[a];
+        float step = (up - lo) / 255.0f;
+        if (!(step >= 0.0f) || !(step <= 3.0e38f)) step = 0.0f; // (NaN / inf boxes: every child dequantises to NaN / lo: see below)
+        // the top of the frame must reach the node's own upper bound despite the roundings
+        for (int it = 0; it < 64 && shadow_dequant(lo, step, 255u) < up; ++it) step = __int_as_float(__float_as_int(step) + 1); // (next float up: step is finite and >= 0)
+        en.lo[a] = lo;
+        en.step[a] = step;
+    }
+    uint32_t valid = 0;
+    for (int c = 0; c < (1 << dep); ++c) {
+        const int64_t ci = (idx << dep) | c;
+        if (ci - cfirst >= creal) continue; // virtual child
+        const N ch = load_vol<N>(nodes + (ci - cskips - 1));
+        bool ok = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float lo = en.lo[a], step = en.step[a];
+            const float clo = (float)ch.lo[a], cup = (float)ch.up[a];
+            // largest q with dequant(q) <= clo, smallest q with dequant(q) >= cup (verified with the walk's own expression)
+            int ql = step > 0.0f ? (int)((clo - lo) / step) : 0;
+            ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql);
+            while (ql > 0 && !(shadow_dequant(lo, step, (uint32_t)ql) <= clo)) --ql;
+            int qu = step > 0.0f ? (int)((cup - lo) / step) : 0;
+            qu = qu < 0 ? 0 : (qu > 255 ? 255 : qu);
+            while (qu < 255 && !(shadow_dequant(lo, step, (uint32_t)qu) >= cup)) ++qu;
+            // a frame that cannot bracket the child (NaN or infinite coordinates): the entry says so and the walk treats
+            // the child as hit unconditionally (conservative)
+            ok = ok && shadow_dequant(lo, step, (uint32_t)ql) <= clo && shadow_dequant(lo, step, (uint32_t)qu) >= cup;
+            en.q[c][a] = (uint8_t)ql;
+            en.q[c][3 + a] = (uint8_t)qu;
+        }
+        valid |= 1u << c;
+        if (!ok) valid |= 1u << (8 + c); // bits 8 .. 15: "always descend"
+    }
+    en.valid = valid;
+    out[e] = en;
+}
+
+template <class L, class N, class I, bool WRITE>
+__global__ __launch_bounds__(64) void lvt_rays_wide_kernel(Args<L, N, I> a, PairCache<I> cache, int ray_block, RayShadow sh) {
+    using T = typename L::elt;
+    static_assert(std::is_same<T, float>::value && std::is_same<typename N::elt, float>::value, "the shadow is single precision");
+    struct Entry {
+        IndexPair<I> pair;
+        I meta;
+    };
+    __shared__ int s_fill;
+    const int lane = threadIdx.x;
+    const int64_t first_item = (int64_t)blockIdx.x * ray_block;
+    const int64_t left = a.n_items - first_item;
+    const int items_here = (int)(left < ray_block ? left : ray_block);
+    char *region = cache.K > 0 && items_here > 0 ? (char *)(cache.slots + first_item * (int64_t)cache.K) : nullptr;
+    const int entry_cap = region ? (int)(((int64_t)items_here * cache.K * (int64_t)sizeof(IndexPair<I>) - 16) / (int64_t)sizeof(Entry)) : 0;
+    Entry *entries = (Entry *)(region + 16);
+    if (lane == 0) s_fill = 0;
+    __builtin_amdgcn_wave_barrier();
+    if constexpr (WRITE) {
+        if (a.guard_total != nullptr && load_total_uniform(a.guard_total) > a.guard_capacity) return;
+        const int fill = region ? __builtin_amdgcn_readfirstlane(*(const int *)region) : -1;
+        if (fill >= 0) { // serve the whole block from its cache (the hits of its REGULAR rays; the others are the binary walker's)
+            for (int t = lane; t < fill; t += 64) {
+                const Entry e = entries[t];
+                const int64_t ray = first_item + (int64_t)(e.meta & (RAY_BLOCK_MAX - 1));
+                const int64_t w0 = ray > 0 ? (int64_t)a.counts[ray - 1] : 0;
+                a.contacts[w0 + (int64_t)(e.meta >> RAY_BITS)] = e.pair;
+            }
+            return;
+        }
+    }
+    const int levels = (int)a.tree.levels, lp = levels - 1, K = sh.depths;
+    const uint32_t vl = (uint32_t)a.tree.virtual_leaves;
+    const uint32_t lp_first = 1u << (lp - 1);
+    const uint32_t lp_real = lp_first - (vl >> 1);
+    const uint32_t lp_skips = [&] {
+        const uint32_t v = vl >> 2; // level_skips(lp) = 2v - popcount(v), v = vl >> (levels - (lp - 1))
+        return 2u * v - (uint32_t)__builtin_popcount(v);
+    }();
+    const N *lp_nodes = a.nodes + ((int64_t)lp_first - (int64_t)lp_skips - 1);
+    const uint32_t n_leaves = (uint32_t)a.tree.real_leaves;
+    const ShadowEntry *shadow = (const ShadowEntry *)a.shadow;
+
+    // per-lane ray state
+    T p[3] = {0, 0, 0}, d[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
+    int ray = -1;        // ray-in-block this lane walks (-1: idle)
+    int k = 0;           // wide level of the current entry
+    uint32_t idx = 1;    // its node's implicit (binary) index
+    uint32_t todo = 0;   // children of the current entry still to visit (bit c)
+    uint64_t pend = 0;   // byte j: children of the path's entry at wide level j still to visit
+    bool fetch = false;  // the current entry has not been fetched yet
+    int64_t w = 0, cnt = 0;
+    bool meta_bad = false;
+    int next = 0;
+
+    auto emit = [&](I lidx, uint32_t lpos) {
+        const IndexPair<I> c2{a.positions ? (I)(lpos + 1u) : lidx, (I)(first_item + ray + 1)};
+        if constexpr (WRITE) {
+            a.contacts[w++] = c2;
+        } else {
+            if (region) {
+                const int slot = atomicAdd(&s_fill, 1);
+                if (cnt >= ((int64_t)1 << (sizeof(I) * 8 - 1 - RAY_BITS))) meta_bad = true;
+                if (slot < entry_cap) entries[slot] = Entry{c2, (I)((I)ray | ((I)cnt << RAY_BITS))};
+            }
+            ++cnt;
+        }
+    };
+
+    for (;;) {
+        // ---- refill: idle lanes take the next rays of the block (irregular ones are skipped here: the binary walker's)
+        const uint64_t idle = __builtin_amdgcn_ballot_w64(ray < 0);
+        if (idle != 0 && next < items_here) {
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            const int mine = next + rank;
+            if (ray < 0 && mine < items_here) {
+                const int64_t item = first_item + mine;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    p[j] = a.points[3 * item + j];
+                    d[j] = a.dirs[3 * item + j];
+                    inv[j] = T(1) / d[j];
+                }
+                if (ray_is_regular(p, d, inv)) {
+                    ray = mine;
+                    k = 0;
+                    idx = 1u;
+                    todo = 0;
+                    pend = 0;
+                    fetch = true;
+                    cnt = 0;
+                    if constexpr (WRITE) w = item > 0 ? (int64_t)a.counts[item - 1] : 0;
+                }
+            }
+            const int taken = __popcll(idle);
+            next = next + taken < items_here ? next + taken : items_here;
+        }
+        if (__builtin_amdgcn_ballot_w64(ray >= 0) == 0) {
+            if (next >= items_here) break;
+            continue; // (every lane drew an irregular ray: draw again)
+        }
+        // ---- walk
+        for (;;) {
+            if (ray >= 0) {
+                if (fetch) {
+                    // one 80-byte entry: the node's frame and its (up to) eight descendants three levels down
+                    fetch = false;
+                    const ShadowEntry en = shadow[sh.base[k] + (idx - (1u << (shadow_level(sh, k) - 1)))];
+                    uint32_t hits = 0;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        N b;
+#pragma unroll
+                        for (int ax = 0; ax < 3; ++ax) {
+                            b.lo[ax] = shadow_dequant(en.lo[ax], en.step[ax], en.q[c][ax]);
+                            b.up[ax] = shadow_dequant(en.lo[ax], en.step[ax], en.q[c][3 + ax]);
+                        }
+                        const bool h = isintersection_inv(b, p, inv); // (the reference's slab function: monotone, see above)
+                        hits |= (h || ((en.valid >> (8 + c)) & 1u)) ? (1u << c) : 0u;
+                    }
+                    todo = hits & en.valid & 0xffu;
+                }
+                if (todo != 0) {
+                    const int c = __builtin_ctz(todo);
+                    todo &= todo - 1;
+                    const int dep = k == 0 ? sh.d0 : 3;
+                    const uint32_t child = (idx << dep) | (uint32_t)c;
+                    if (k + 1 < K) { // descend: remember what is left here
+                        pend = (pend & ~((uint64_t)0xff << (8 * k))) | ((uint64_t)todo << (8 * k));
+                        k += 1;
+                        idx = child;
+                        fetch = true;
+                    } else {
+                        // a candidate leaf parent: its EXACT box and its two leaves, fetched together, tested exactly
+                        const uint32_t j = child - lp_first; // within level lp (real: the entry's valid mask)
+                        const N pb = load_vol<N>(lp_nodes + j);
+                        const uint32_t pos = 2u * j;
+                        const bool has_b = pos + 1u < n_leaves;
+                        const char *rec = a.leaves + (int64_t)pos * a.lay.stride;
+                        const char *rec_b = has_b ? rec + a.lay.stride : rec;
+                        const L la = load_vol<L>(rec), lb = load_vol<L>(rec_b);
+                        const I ia = load_index<I>(rec, a.lay), ib = load_index<I>(rec_b, a.lay);
+                        if (isintersection_inv(pb, p, inv)) { // raytrace/lvt:205-221 at the leaf parents' level
+                            bool h0 = isintersection(la, p, d), h1 = has_b && isintersection(lb, p, d);
+                            if (a.narrow == IBVH_NARROW_RAY_ORIGIN_OUTSIDE) {
+                                h0 = h0 && origin_outside(la, p);
+                                h1 = h1 && origin_outside(lb, p);
+                            }
+                            if (h0) emit(ia, pos);
+                            if (h1) emit(ib, pos + 1u);
+                        }
+                    }
+                } else if (!fetch) {
+                    // this entry is exhausted: back to the deepest ancestor with children left
+                    while (k > 0 && ((pend >> (8 * (k - 1))) & 0xffu) == 0) {
+                        idx >>= (k - 1 == 0 ? sh.d0 : 3);
+                        k -= 1;
+                    }
+                    if (k == 0) { // ray finished
+                        if constexpr (!WRITE) a.counts[first_item + ray] = (I)cnt;
+                        ray = -1;
+                    } else {
+                        idx >>= (k - 1 == 0 ? sh.d0 : 3);
+                        k -= 1;
+                        todo = (uint32_t)(pend >> (8 * k)) & 0xffu;
+                        pend &= ~((uint64_t)0xff << (8 * k));
+                    }
+                }
+            }
+            const uint64_t idle_now = __builtin_amdgcn_ballot_w64(ray < 0);
+            if (idle_now == ~(uint64_t)0) break;
+            if (next < items_here && __popcll(idle_now) >= 16) break;
+        }
+    }
+    if constexpr (!WRITE) {
+        __builtin_amdgcn_wave_barrier();
+        const bool ok = __builtin_amdgcn_ballot_w64(meta_bad) == 0;
+        if (region && lane == 0) *(int *)region = (s_fill <= entry_cap && ok) ? s_fill : -1;
+    }
+}
+
 // ---- inclusive scan of the per-item counts (AK.accumulate!, traverse_single.jl:57) ---------------
 constexpr int SCAN_TPB = 256, SCAN_IPT = 16, SCAN_TILE = SCAN_TPB * SCAN_IPT;
 
@@ -1277,6 +1624,14 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_apply_kernel(I *c, int64_t n, c
     int64_t before = 0;
     for (int64_t j = threadIdx.x; j < (int64_t)blockIdx.x; j += SCAN_TPB) before += partials[j];
     const int64_t tile_offset = block_sum(before, s_p);
+    // The grand total is known to the last workgroup before it scans anything (the tile sums are all there): publish it
+    // FIRST — the host may be polling its pinned copy (total_host), and every microsecond it learns the count earlier is
+    // a microsecond more of the next step's launch work hidden behind this step's writing pass.
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        const int64_t total = tile_offset + partials[blockIdx.x];
+        totals[0] = total;
+        if (total_host) __hip_atomic_store(total_host, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // thread owns SCAN_IPT consecutive items so the in-thread running sum is in memory order
     int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_IPT;
     int64_t v[SCAN_IPT], sum = 0;
@@ -1333,11 +1688,6 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_apply_kernel(I *c, int64_t n, c
             run += v[j];
             if (i < n) c[i] = (I)run;
         }
-    }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_TPB - 1) {
-        totals[0] = run; // inclusive value of the last item
-        // the host's copy (mapped pinned memory, polled by the caller instead of a stream sync + D2H copy)
-        if (total_host) __hip_atomic_store(total_host, run, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1410,6 +1760,26 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
         const int forced_block = g_tuning.ray_block;
         if (forced_block >= 64 && forced_block <= RAY_BLOCK_MAX && (forced_block & (forced_block - 1)) == 0) ray_block = forced_block;
         const unsigned rblocks = (unsigned)ceil_div(a.n_items, (int64_t)ray_block);
+        if constexpr (std::is_same<typename L::elt, float>::value && std::is_same<N, BBox<float>>::value) {
+            if (a.shadow != nullptr && !count_work) {
+                // regular rays over the 8-wide shadow; the irregular ones (if any) by the binary walker behind it, without
+                // a cache of its own (the block headers belong to the shadow walker)
+                const ibvh_tree t{a.tree.levels, a.tree.real_leaves, 0, a.tree.virtual_leaves, 0};
+                const RayShadow sh = make_ray_shadow(t);
+                Args<L, N, I> irr = a;
+                irr.rays_filter = 1;
+                const PairCache<I> none{nullptr, 0};
+                if (write) {
+                    IBVH_LAUNCH((lvt_rays_wide_kernel<L, N, I, true>), dim3(rblocks), dim3(64), 0, st, a, cache, ray_block, sh);
+                    IBVH_LAUNCH((lvt_rays_kernel<L, N, I, true>), dim3(rblocks), dim3(64), 0, st, irr, none, ray_block);
+                } else {
+                    IBVH_LAUNCH((lvt_rays_wide_kernel<L, N, I, false>), dim3(rblocks), dim3(64), 0, st, a, cache, ray_block, sh);
+                    IBVH_LAUNCH((lvt_rays_kernel<L, N, I, false>), dim3(rblocks), dim3(64), 0, st, irr, none, ray_block);
+                }
+                IBVH_LAUNCH_CHECK();
+                return IBVH_OK;
+            }
+        }
         if constexpr (kWorkTypes<L, N, I>) {
             if (count_work) {
                 IBVH_LAUNCH((lvt_rays_kernel<L, N, I, false, true>), dim3(rblocks), dim3(64), 0, st, a, cache, ray_block);
@@ -1478,6 +1848,17 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
     return IBVH_OK;
 }
 
+// Bytes of the quantised shadow a ray traversal of `bvh` with `num_rays` rays uses, 0 when the binary walk serves it:
+// single-precision leaves under BBox{Float32} nodes, a fully built tree of 8 .. 26 levels, and enough rays for the one
+// streaming pass over the nodes that builds the shadow to pay (at least one ray per 64 leaves).
+inline size_t rays_shadow_bytes(const ibvh_bvh &bvh, int64_t num_rays) {
+    if (bvh.types.node_kind != IBVH_BBOX || bvh.types.node_float != IBVH_F32 || bvh.types.leaf_float != IBVH_F32) return 0;
+    if (!g_tuning.rays_shadow) return 0; // (development knob, off: see the note at the kernel)
+    if (bvh.built_level > 1 || num_rays * 64 < bvh.tree.real_leaves) return 0;
+    const RayShadow sh = make_ray_shadow(bvh.tree);
+    return sh.depths ? (size_t)sh.base[sh.depths] * SHADOW_ENTRY_BYTES : 0;
+}
+
 // shared driver of the six entry points
 template <int MODE>
 int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const void *dirs, int64_t n_items,
@@ -1498,7 +1879,16 @@ int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const voi
     dl = wl;
     if (drv && !layout_of(drv->types, lay, &dl)) return IBVH_ERR_UNSUPPORTED;
     if (!work && (!scratch || scratch_bytes < scan_scratch_bytes(n_items))) return IBVH_ERR_SCRATCH;
-    const int K = work ? 0 : cache_slots_for(scratch_bytes, n_items, lay.pair_bytes);
+    // RAYS: the quantised shadow of the node levels lives at the END of the scratch when the caller sized it with
+    // ibvh_rays_scratch_bytes (and the walk qualifies: rays_shadow_bytes); the contact cache gets what lies in between
+    size_t shadow_bytes = 0;
+    if (MODE == MODE_RAYS && !work) {
+        shadow_bytes = rays_shadow_bytes(*walk, n_items);
+        if (scratch_bytes < scan_scratch_bytes(n_items) + shadow_bytes + 256) shadow_bytes = 0;
+    }
+    const size_t cache_room = scratch_bytes - (shadow_bytes ? shadow_bytes + 256 : 0);
+    char *shadow_ptr = shadow_bytes ? (char *)scratch + ((scratch_bytes - shadow_bytes) & ~(size_t)255) : nullptr;
+    const int K = work ? 0 : cache_slots_for(cache_room, n_items, lay.pair_bytes);
     return dispatch_leaf_node(walk->types, [&](auto lt, auto nt) -> int {
         using L = typename decltype(lt)::type;
         using N = typename decltype(nt)::type;
@@ -1529,6 +1919,15 @@ int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const voi
                 a.guard_total = nullptr;
                 a.guard_capacity = 0;
                 a.work = work;
+                a.shadow = shadow_ptr;
+                a.rays_filter = 0;
+                if constexpr (MODE == MODE_RAYS && std::is_same<N, BBox<float>>::value && std::is_same<typename L::elt, float>::value) {
+                    if (shadow_ptr && !write) { // (the writing pass of a _count / _write pair finds the shadow where the count left it)
+                        const RayShadow sh = make_ray_shadow(walk->tree);
+                        IBVH_LAUNCH((ray_shadow_build_kernel<N>), dim3((unsigned)ceil_div((int64_t)sh.base[sh.depths], 256)), dim3(256), 0, st,
+                                    a.nodes, a.tree, sh, (ShadowEntry *)shadow_ptr);
+                    }
+                }
                 PairCache<I> cache{K ? (IndexPair<I> *)((char *)scratch + scan_scratch_bytes(n_items)) : nullptr, K};
                 if (int e = launch<L, N, I, MODE>(a, cache, write, st)) return e;
                 if (write || work) return (int)IBVH_OK;
@@ -1562,6 +1961,17 @@ ibvh_status ibvh_lvt_scratch_bytes(const ibvh_types *types, int64_t n_items, int
     if (!layout_of(*types, lay)) return IBVH_ERR_UNSUPPORTED;
     if (cache_slots > MAX_CACHE_SLOTS) cache_slots = MAX_CACHE_SLOTS;
     *bytes_out = scan_scratch_bytes(n_items) + (size_t)cache_slots * (size_t)n_items * (size_t)lay.pair_bytes;
+    return IBVH_OK;
+}
+
+// Scratch for the ray traversal entry points: ibvh_lvt_scratch_bytes for num_rays work items plus room for the shadow
+// of the node levels the ray walker builds for itself (see include/ibvh.h).
+ibvh_status ibvh_rays_scratch_bytes(const ibvh_bvh *bvh, int64_t num_rays, int32_t cache_slots, size_t *bytes_out) {
+    if (!bvh || !bytes_out || num_rays < 0) return IBVH_ERR_INVALID_ARG;
+    size_t base = 0;
+    if (ibvh_status e = ibvh_lvt_scratch_bytes(&bvh->types, num_rays, cache_slots, &base)) return e;
+    const size_t sh = rays_shadow_bytes(*bvh, num_rays);
+    *bytes_out = sh ? (size_t)align_up((int64_t)base, 256) + sh + 512 : base;
     return IBVH_OK;
 }
 

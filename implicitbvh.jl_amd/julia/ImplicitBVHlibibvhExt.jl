@@ -211,6 +211,10 @@ c_traverse_pair_lvt_enqueue(bvh1, bvh2, sl1, sl2, narrow, counts, contacts, capa
     ccall((:ibvh_traverse_pair_lvt_enqueue, libibvh), Cint,
           (Ref{IbvhBvh}, Ref{IbvhBvh}, Int64, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
           bvh1, bvh2, sl1, sl2, narrow, counts, contacts, capacity, total_dev, total_host, scratch, sb, stream)
+c_rays_scratch_bytes(bvh, num_rays, slots, out) =
+    ccall((:ibvh_rays_scratch_bytes, libibvh), Cint,
+          (Ref{IbvhBvh}, Int64, Int32, Ref{Csize_t}),
+          bvh, num_rays, slots, out)
 c_traverse_rays_lvt_count(bvh, points, dirs, num_rays, sl, narrow, counts, total, scratch, sb, stream) =
     ccall((:ibvh_traverse_rays_lvt_count, libibvh), Cint,
           (Ref{IbvhBvh}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int32, Ptr{Cvoid}, Ref{Int64}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
@@ -319,10 +323,14 @@ cached(cache, field::Symbol, ::Type{T}, n, like) where {T} =
     end
 
 # `count`, `write`, `enqueue`: closures over the entry points of one traversal shape; they take the buffers only.
-function lvt_two_pass(::Type{I}, like, n_items, types, slots, cache, count, write, enqueue) where {I}
+function lvt_two_pass(::Type{I}, like, n_items, types, slots, cache, count, write, enqueue; rays_of=nothing) where {I}
     counts = cached(cache, :cache2, I, n_items, like)
     need = Ref{Csize_t}(0)
-    check(c_lvt_scratch_bytes(types, n_items, slots, need), "ibvh_lvt_scratch_bytes")
+    if isnothing(rays_of)
+        check(c_lvt_scratch_bytes(types, n_items, slots, need), "ibvh_lvt_scratch_bytes")
+    else   # rays: room for the walker's quantised shadow of the node levels as well (include/ibvh.h)
+        check(c_rays_scratch_bytes(rays_of, n_items, slots, need), "ibvh_rays_scratch_bytes")
+    end
     scratch = scratch!(:lvt, need[])
     total = Ref{Int64}(0)
     if !isnothing(cache) && length(cache.cache1) > 0
@@ -442,7 +450,8 @@ function ImplicitBVH.traverse_rays(
     total, contacts, counts = lvt_two_pass(I, bvh.nodes, nr, d.types, RAY_CACHE_SLOTS, cache,
         (cn, tot, sc, sb) -> c_traverse_rays_lvt_count(d, devptr(p), devptr(dr), nr, start_level, code, devptr(cn), tot, devptr(sc), sb, s),
         (cn, ct, sc, sb) -> c_traverse_rays_lvt_write(d, devptr(p), devptr(dr), nr, start_level, code, devptr(cn), devptr(ct), devptr(sc), sb, s),
-        (cn, ct, cap, td, th, sc, sb) -> c_traverse_rays_lvt_enqueue(d, devptr(p), devptr(dr), nr, start_level, code, devptr(cn), devptr(ct), cap, td, th, devptr(sc), sb, s))
+        (cn, ct, cap, td, th, sc, sb) -> c_traverse_rays_lvt_enqueue(d, devptr(p), devptr(dr), nr, start_level, code, devptr(cn), devptr(ct), cap, td, th, devptr(sc), sb, s);
+        rays_of=d)
     BVHTraversal(Int(start_level), 0, total, contacts, counts)
 end
 

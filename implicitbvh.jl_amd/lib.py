@@ -37,6 +37,7 @@ SIGNATURES = {
     "ibvh_traverse_lvt_write": [_P(abi.Bvh), _i64, _i32, _vp, _vp, _vp, _sz, _vp],
     "ibvh_traverse_pair_lvt_count": [_P(abi.Bvh), _P(abi.Bvh), _i64, _i64, _i32, _vp, _P(_i64), _vp, _sz, _vp],
     "ibvh_traverse_pair_lvt_write": [_P(abi.Bvh), _P(abi.Bvh), _i64, _i64, _i32, _vp, _vp, _vp, _sz, _vp],
+    "ibvh_rays_scratch_bytes": [_P(abi.Bvh), _i64, _i32, _P(_sz)],
     "ibvh_traverse_rays_lvt_count": [_P(abi.Bvh), _vp, _vp, _i64, _i64, _i32, _vp, _P(_i64), _vp, _sz, _vp],
     "ibvh_traverse_rays_lvt_write": [_P(abi.Bvh), _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _sz, _vp],
     "ibvh_traverse_lvt_enqueue": [_P(abi.Bvh), _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp],

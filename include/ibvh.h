@@ -263,7 +263,14 @@ ibvh_status ibvh_traverse_pair_lvt_write(const ibvh_bvh *bvh1, const ibvh_bvh *b
 
 /* traverse_rays(bvh, points, directions, LVTTraversal()) — raytrace/leaf_vs_tree/
  * leaf_vs_tree.jl:1-228.  points/directions: (3, num_rays) column-major arrays of the leaf
- * float type; contacts are (leaf.index, iray). */
+ * float type; contacts are (leaf.index, iray); `narrow`: IBVH_NARROW_NONE / _RAY_ORIGIN_OUTSIDE (| IBVH_OUTPUT_POSITIONS).
+ * Scratch: ibvh_rays_scratch_bytes() = ibvh_lvt_scratch_bytes(num_rays work items) — plus, ONLY while the development
+ * knob "rays_shadow" is set (off by default: measured slower than the binary walk), room for a quantised
+ * 8-wide shadow of the node levels that the counting call builds for itself and walks instead of the binary tree (one
+ * 80-byte fetch per three levels; leaf parents' exact boxes and leaves still tested exactly: the hit list, order
+ * included, is unchanged — csrc/ibvh_lvt.hip "(3b)").  Pass the SAME scratch buffer and size to a _count call and its
+ * _write call. */
+ibvh_status ibvh_rays_scratch_bytes(const ibvh_bvh *bvh, int64_t num_rays, int32_t cache_slots, size_t *bytes_out);
 ibvh_status ibvh_traverse_rays_lvt_count(const ibvh_bvh *bvh, const void *points,
                                          const void *directions, int64_t num_rays,
                                          int64_t start_level, int32_t narrow, void *counts,
@@ -439,7 +446,7 @@ ibvh_status ibvh_lvt_work_counters(const ibvh_bvh *bvh, const ibvh_bvh *bvh2, co
  * on them, only speed and which code path is taken).  One process-wide table: set a knob BEFORE the calls it should
  * affect and not concurrently with them.  The library never reads the environment.  Names: "ray_block", "lvt_wide",
  * "lvt_xcd", "sort_tile", "sort_lsd", "sort_msd_avg", "bucket_tpb", "msd", "msd_bits", "msd_cap", "msd_tile",
- * "msd_ftpb", "msd_avg", "msd_range" (meanings: csrc/ibvh_common.hpp, struct Tuning).  Unknown name:
+ * "msd_ftpb", "msd_avg", "msd_range", "rays_shadow" (meanings: csrc/ibvh_common.hpp, struct Tuning).  Unknown name:
  * IBVH_ERR_INVALID_ARG. */
 ibvh_status ibvh_set_tuning(const char *name, int32_t value);
 ibvh_status ibvh_get_tuning(const char *name, int32_t *value_out);

@@ -4,4 +4,4 @@
 out="$GRAFT_REPO_ROOT/gpurun_out/$1"; ctrs="$2"; shift 2
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $ctrs --output-format csv -d "$out" -o run -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --extra-n 0 "$@" > "$out/bench.log" 2>&1
+rocprofv3 --pmc $ctrs --output-format csv -d "$out" -o run -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-configs --extra-n 0 "$@" > "$out/bench.log" 2>&1

@@ -13,8 +13,11 @@ import os
 import shutil
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_sha
+
 COMMENT = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no tracing) of `python3 bench.py --n {n} --steps 5 "
-           "--warmup 2 --no-cpu-baseline --extra-n 0`, per-launch averages in KiB as reported. Per MI355X_MICROARCH.md §HBM: "
+           "--warmup 2 --no-cpu-baseline --no-configs --extra-n 0`, per-launch averages in KiB as reported. Per MI355X_MICROARCH.md §HBM: "
            "FETCH_SIZE on gfx950 reports 1/2 of the bytes of wide coalesced streaming reads (so hbm_read_bytes ~= "
            "2*FETCH_SIZE*1024 for those; other access widths uncalibrated; calibrated here on extrema_partial_kernel, "
            "which streams 16 B/leaf); WRITE_SIZE is exact for streaming stores. Infinity-Cache hits are counted, so "
@@ -51,7 +54,9 @@ def main():
             kernels[name] = {"launches": max(f[1], w[1]),
                              "FETCH_SIZE_KiB_avg": round(f[0] / f[1], 2) if f[1] else None,
                              "WRITE_SIZE_KiB_avg": round(w[0] / w[1], 2) if w[1] else None}
-        json.dump({"_comment": COMMENT.format(n=n), "kernels": kernels},
+        # csrc_sha: the state of the kernel sources these counters belong to (run this script BEFORE touching csrc/ again);
+        # bench.py quotes the figures only while the hash still matches
+        json.dump({"_comment": COMMENT.format(n=n), "csrc_sha": csrc_sha(), "kernels": kernels},
                   open(f"profiles/{tag}_pmc_fetch_write_{label}.json", "w"), indent=1)
         print("wrote", label, len(kernels), "kernels")
 

@@ -5,10 +5,10 @@
 #   write*/ rocprofv3 --pmc WRITE_SIZE
 # at n = 1e6 (the bench default) and n = 1e7 (the north-star size) into gpurun_out/prof_<tag>/.
 # tools/pmc_traffic.py turns them into the profiles/ files.
-tag=${1:-r01}
+tag=${1:-r03}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$tag
 mkdir -p "$O"; cd /tmp; export TMPDIR=/tmp
-common="--no-cpu-baseline --extra-n 0"
+common="--no-cpu-baseline --no-configs --extra-n 0"
 for n in 1000000 10000000; do
   s=$([ $n = 1000000 ] && echo "" || echo "_1e7")
   rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt$s" -o r -- python3 "$R/bench.py" --n $n $common > "$O/kt$s.log" 2>&1

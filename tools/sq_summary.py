@@ -14,7 +14,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import pmc_key
+from bench import csrc_sha, pmc_key
 
 
 def main():
@@ -46,8 +46,8 @@ def main():
         out[k] = e
     os.makedirs("profiles", exist_ok=True)
     json.dump({"_comment": "rocprofv3 --pmc SQ counter passes (three separate passes, no tracing flags) of `python3 bench.py "
-                           "--no-cpu-baseline --extra-n 0 --steps 3 --warmup 1` (1e6 leaves), per-launch averages; made by "
-                           "tools/profile_sq.sh + tools/sq_summary.py", "kernels": out},
+                           "--no-cpu-baseline --no-configs --extra-n 0 --steps 3 --warmup 1` (1e6 leaves), per-launch averages; made by "
+                           "tools/profile_sq.sh + tools/sq_summary.py", "csrc_sha": csrc_sha(), "kernels": out},
               open(f"profiles/{tag}_sq_counters_n1e6.json", "w"), indent=1)
     print("wrote", len(out), "kernels")
 
