@@ -405,39 +405,41 @@ IBVH_D float wave_min_dpp_lane63(float v) {
 // `init`; the surviving lanes append their entry `e` to the LDS queue at lds_base + 4 * (number of surviving lanes
 // below).  v_cmpx narrows EXEC directly, so the chain needs no s_and per compare and the append runs under the
 // result mask without a saveexec — 17 VALU + 4 SALU where the compiler's version took 21 + 14.  Returns the mask.
-template <bool THR_GT>
-IBVH_D uint64_t test_and_append_f32(uint64_t init, float slo0, float slo1, float slo2, float sup0, float sup1, float sup2,
-                                     float vlo0, float vlo1, float vlo2, float vup0, float vup1, float vup2, uint32_t sthr,
-                                     uint32_t vcmp, uint32_t e, uint32_t lds_base) {
-    uint64_t hm, saved;
-    uint32_t tmp;
-    if constexpr (THR_GT) {
-        asm volatile("s_nop 1\n\t"
-                     "s_mov_b64 %[sv], exec\n\t"
-                     "s_mov_b64 exec, %[init]\n\t"
+// Round 3: the step also advances the queue's LDS byte address itself (s_bcnt1 + s_lshl2_add: the caller no longer keeps
+// a count that has to be shifted and added to a base every time), EXEC is restored to all-ones instead of being saved (the
+// kernel's control flow is wave-uniform: all 64 lanes are active wherever this is called), and the self walk's prune in the
+// parent-major loop compares the parent index itself (p >= (item + 1) >> 1  <=>  2p + 1 > item): 30 instructions per loop
+// iteration where round 2 took 42 — and the loops are bound by the scalar instructions around the seven v_cmpx
+// (count pass 0.155 -> 0.146 ms at 1e6 for the first five of them, measured).
+template <bool THR_GE>
+IBVH_D void test_and_append_f32(uint64_t init, float slo0, float slo1, float slo2, float sup0, float sup1, float sup2, float vlo0,
+                                 float vlo1, float vlo2, float vup0, float vup1, float vup2, uint32_t sthr, uint32_t vcmp, uint32_t e,
+                                 uint32_t &lds_addr) {
+    uint32_t tmp, cnt;
+    if constexpr (THR_GE) {
+        asm volatile("s_mov_b64 exec, %[init]\n\t"
                      "v_cmpx_le_f32 %[slo0], %[vup0]\n\t"
                      "v_cmpx_ge_f32 %[sup0], %[vlo0]\n\t"
                      "v_cmpx_le_f32 %[slo1], %[vup1]\n\t"
                      "v_cmpx_ge_f32 %[sup1], %[vlo1]\n\t"
                      "v_cmpx_le_f32 %[slo2], %[vup2]\n\t"
                      "v_cmpx_ge_f32 %[sup2], %[vlo2]\n\t"
-                     "v_cmpx_gt_u32 %[sthr], %[vcmp]\n\t"
-                     "s_mov_b64 %[hm], exec\n\t"
-                     "s_nop 1\n\t"
+                     "v_cmpx_ge_u32 %[sthr], %[vcmp]\n\t"
+                     "s_nop 2\n\t"
                      "v_mbcnt_lo_u32_b32 %[tmp], exec_lo, 0\n\t"
                      "v_mbcnt_hi_u32_b32 %[tmp], exec_hi, %[tmp]\n\t"
-                     "v_lshl_add_u32 %[tmp], %[tmp], 2, %[base]\n\t"
+                     "v_lshl_add_u32 %[tmp], %[tmp], 2, %[addr]\n\t"
                      "ds_write_b32 %[tmp], %[e]\n\t"
-                     "s_mov_b64 exec, %[sv]"
-                     : [hm] "=&s"(hm), [sv] "=&s"(saved), [tmp] "=&v"(tmp)
+                     "s_bcnt1_i32_b64 %[cnt], exec\n\t"
+                     "s_mov_b64 exec, -1\n\t"
+                     "s_lshl2_add_u32 %[addr], %[cnt], %[addr]"
+                     : [tmp] "=&v"(tmp), [cnt] "=&s"(cnt), [addr] "+s"(lds_addr)
                      : [init] "s"(init), [slo0] "s"(slo0), [slo1] "s"(slo1), [slo2] "s"(slo2), [sup0] "s"(sup0), [sup1] "s"(sup1),
                        [sup2] "s"(sup2), [vlo0] "v"(vlo0), [vlo1] "v"(vlo1), [vlo2] "v"(vlo2), [vup0] "v"(vup0), [vup1] "v"(vup1),
-                       [vup2] "v"(vup2), [sthr] "s"(sthr), [vcmp] "v"(vcmp), [e] "v"(e), [base] "s"(lds_base)
-                     : "vcc", "memory");
+                       [vup2] "v"(vup2), [sthr] "s"(sthr), [vcmp] "v"(vcmp), [e] "v"(e)
+                     : "vcc", "scc", "memory");
     } else {
-        asm volatile("s_nop 1\n\t"
-                     "s_mov_b64 %[sv], exec\n\t"
-                     "s_mov_b64 exec, %[init]\n\t"
+        asm volatile("s_mov_b64 exec, %[init]\n\t"
                      "v_cmpx_le_f32 %[slo0], %[vup0]\n\t"
                      "v_cmpx_ge_f32 %[sup0], %[vlo0]\n\t"
                      "v_cmpx_le_f32 %[slo1], %[vup1]\n\t"
@@ -445,20 +447,43 @@ IBVH_D uint64_t test_and_append_f32(uint64_t init, float slo0, float slo1, float
                      "v_cmpx_le_f32 %[slo2], %[vup2]\n\t"
                      "v_cmpx_ge_f32 %[sup2], %[vlo2]\n\t"
                      "v_cmpx_lt_u32 %[sthr], %[vcmp]\n\t"
-                     "s_mov_b64 %[hm], exec\n\t"
-                     "s_nop 1\n\t"
+                     "s_nop 2\n\t"
                      "v_mbcnt_lo_u32_b32 %[tmp], exec_lo, 0\n\t"
                      "v_mbcnt_hi_u32_b32 %[tmp], exec_hi, %[tmp]\n\t"
-                     "v_lshl_add_u32 %[tmp], %[tmp], 2, %[base]\n\t"
+                     "v_lshl_add_u32 %[tmp], %[tmp], 2, %[addr]\n\t"
                      "ds_write_b32 %[tmp], %[e]\n\t"
-                     "s_mov_b64 exec, %[sv]"
-                     : [hm] "=&s"(hm), [sv] "=&s"(saved), [tmp] "=&v"(tmp)
+                     "s_bcnt1_i32_b64 %[cnt], exec\n\t"
+                     "s_mov_b64 exec, -1\n\t"
+                     "s_lshl2_add_u32 %[addr], %[cnt], %[addr]"
+                     : [tmp] "=&v"(tmp), [cnt] "=&s"(cnt), [addr] "+s"(lds_addr)
                      : [init] "s"(init), [slo0] "s"(slo0), [slo1] "s"(slo1), [slo2] "s"(slo2), [sup0] "s"(sup0), [sup1] "s"(sup1),
                        [sup2] "s"(sup2), [vlo0] "v"(vlo0), [vlo1] "v"(vlo1), [vlo2] "v"(vlo2), [vup0] "v"(vup0), [vup1] "v"(vup1),
-                       [vup2] "v"(vup2), [sthr] "s"(sthr), [vcmp] "v"(vcmp), [e] "v"(e), [base] "s"(lds_base)
-                     : "vcc", "memory");
+                       [vup2] "v"(vup2), [sthr] "s"(sthr), [vcmp] "v"(vcmp), [e] "v"(e)
+                     : "vcc", "scc", "memory");
     }
-    return hm;
+}
+
+// `init` & iscontact(S, V) for the 64 lanes at once, S wave-uniform (scalar registers), V per lane: six v_cmpx narrow EXEC
+// from `init` — 6 VALU + 3 SALU where the compiler's six v_cmp into SGPR pairs need five s_and on top, and the result is a
+// scalar mask straight away (a ballot of a bool that crossed a branch is re-materialised with v_cndmask + v_cmp_ne).
+// All 64 lanes are active at every call site (wave-uniform control flow): EXEC is restored to all-ones.
+IBVH_D uint64_t contact_mask_f32(uint64_t init, const BBox<float> &S, const BBox<float> &V) {
+    uint64_t m;
+    asm volatile("s_mov_b64 exec, %[init]\n\t"
+                 "v_cmpx_le_f32 %[slo0], %[vup0]\n\t"
+                 "v_cmpx_ge_f32 %[sup0], %[vlo0]\n\t"
+                 "v_cmpx_le_f32 %[slo1], %[vup1]\n\t"
+                 "v_cmpx_ge_f32 %[sup1], %[vlo1]\n\t"
+                 "v_cmpx_le_f32 %[slo2], %[vup2]\n\t"
+                 "v_cmpx_ge_f32 %[sup2], %[vlo2]\n\t"
+                 "s_mov_b64 %[m], exec\n\t"
+                 "s_mov_b64 exec, -1"
+                 : [m] "=&s"(m)
+                 : [init] "s"(init), [slo0] "s"(S.lo[0]), [slo1] "s"(S.lo[1]), [slo2] "s"(S.lo[2]), [sup0] "s"(S.up[0]), [sup1] "s"(S.up[1]),
+                   [sup2] "s"(S.up[2]), [vlo0] "v"(V.lo[0]), [vlo1] "v"(V.lo[1]), [vlo2] "v"(V.lo[2]), [vup0] "v"(V.up[0]), [vup1] "v"(V.up[1]),
+                   [vup2] "v"(V.up[2])
+                 : "vcc");
+    return m;
 }
 
 #ifndef IBVH_QUEUE_CAP
@@ -581,6 +606,7 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
     Cnt *cnts = s_cnt[wv];
     cnts[lane] = WRITE ? q.w : (Cnt)0; // next output offset (WRITE) / contacts so far (count pass) of query `lane`
     int qn = 0;                        // wave-uniform: queued pairs
+    const uint64_t lane_on_mask = __builtin_amdgcn_ballot_w64(q.lane_on); // (fixed from here on)
 
     // Two boxes instead of one union box: 64 consecutive Morton-sorted leaves regularly straddle a big jump of
     // the Z-curve, and the single union box of such a wave spans a large part of the scene (measured at 1e6
@@ -823,10 +849,19 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
 
     // b: candidates of the subtree rooted at node c (level cut_level) whose box is `cbox`
     auto brute = [&](uint32_t c, const N &cbox) {
-        bool on = q.lane_on & iscontact(q.q_node, cbox);
         work.add(0, q.lane_on);
-        if constexpr (MODE == MODE_SELF) on = on & !((c + 1u) <= (self_next >> (levels - cut_level)));
-        const uint64_t on_mask = __builtin_amdgcn_ballot_w64(on);
+        uint64_t on_mask;
+        bool on; // (per lane: only the generic loop below reads it)
+        if constexpr (std::is_same<TN, float>::value) {
+            uint64_t init = lane_on_mask;
+            if constexpr (MODE == MODE_SELF) init &= __builtin_amdgcn_ballot_w64(!((c + 1u) <= (self_next >> (levels - cut_level))));
+            on_mask = contact_mask_f32(init, cbox, q.q_node);
+            on = (on_mask >> lane) & 1u;
+        } else {
+            on = q.lane_on & iscontact(q.q_node, cbox);
+            if constexpr (MODE == MODE_SELF) on = on & !((c + 1u) <= (self_next >> (levels - cut_level)));
+            on_mask = __builtin_amdgcn_ballot_w64(on);
+        }
         if (on_mask == 0) return;
         const uint32_t first32 = (c - (1u << (cut_level - 1))) << (lp - cut_level); // 0-based, within level lp
         uint32_t last = first32 + (1u << (lp - cut_level));
@@ -850,9 +885,18 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
         work.add(2, lane < np);
         work.add(0, lane < np ? 2u : 0u); // against the wave's two boxes
         const uint32_t right_leaf = 2u * (first32 + (uint32_t)lane) + 1u; // of this lane's parent
-        bool box_on = mine & touches_wave(mybox);
-        if constexpr (MODE == MODE_SELF) box_on = box_on & (right_leaf > wave_item0);
-        const uint64_t box_mask = __builtin_amdgcn_ballot_w64(box_on);
+        uint64_t box_mask;
+        bool box_on; // (per lane: only the generic loop below reads it)
+        if constexpr (std::is_same<TN, float>::value) {
+            uint64_t init = __builtin_amdgcn_ballot_w64(mine);
+            if constexpr (MODE == MODE_SELF) init &= __builtin_amdgcn_ballot_w64(right_leaf > wave_item0);
+            box_mask = contact_mask_f32(init, ubox_a, mybox) | contact_mask_f32(init, ubox_b, mybox);
+            box_on = (box_mask >> lane) & 1u;
+        } else {
+            box_on = mine & touches_wave(mybox);
+            if constexpr (MODE == MODE_SELF) box_on = box_on & (right_leaf > wave_item0);
+            box_mask = __builtin_amdgcn_ballot_w64(box_on);
+        }
         // shorter of the two loops: lanes = queries over the parents that touch the wave's boxes, or
         // lanes = parents over the active queries.  (Measured alternative: lanes = (query, parent) pairs
         // pulled together with ds_bpermute — as many steps as this loop has iterations, and slower.)
@@ -860,38 +904,50 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
         const QE e_box = (QE)lane | ((QE)first32 << 6);             // + (u << 6)
         const QE e_qry = (QE)(first32 + (uint32_t)lane) << 6;       // | u
         if constexpr (std::is_same<TN, float>::value && !WIDE) {
-            // hand-scheduled step (test_and_append_f32); the pair walk has no prune: thresholds that always pass
+            // hand-scheduled step (test_and_append_f32); the pair walk has no prune: thresholds that always pass.  The loops
+            // keep the queue's LDS byte address (the step advances it) instead of the entry count.
             const uint32_t queue_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)queue;
+            const uint32_t drain_at = queue_lds + 4u * (uint32_t)(QUEUE_CAP - 64);
+            uint32_t qaddr = queue_lds + 4u * (uint32_t)qn;
+            auto drain_if_full = [&]() {
+                if (qaddr > drain_at) {
+                    qn = (int)((qaddr - queue_lds) >> 2);
+                    drain(false);
+                    qaddr = queue_lds + 4u * (uint32_t)qn;
+                }
+            };
             if (by_box) {
-                for (uint64_t todo = box_mask; todo != 0; todo &= todo - 1) {
-                    if (qn > QUEUE_CAP - 64) drain(false);
+                // 2p + 1 > item  <=>  p >= (item + 1) >> 1: the parent index itself is the scalar operand
+                const uint32_t half_item = MODE == MODE_SELF ? (my_item + 1u) >> 1 : 0u;
+                for (uint64_t todo = box_mask; todo != 0;) {
+                    drain_if_full();
                     const int u = __builtin_ctzll(todo);
+                    asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(u)); // (todo &= todo - 1 costs three scalar instructions)
                     // (the parent box comes straight from memory with scalar loads — it is L2-hot, lane u just loaded it —
-                    // instead of six v_readlane out of `mybox`: 3 % fewer VALU cycles, measured)
-                    const N p = load_vol_uniform<N>(lp_nodes + (first32 + (uint32_t)u));
+                    // instead of six v_readlane out of `mybox`: 3 % fewer VALU cycles, measured; 32-bit byte offset: leaf-parent
+                    // indices stay below 2^26 here, and a 64-bit product costs four scalar instructions instead of one)
+                    const uint32_t pidx = first32 + (uint32_t)u;
+                    const N p = load_vol_uniform<N>((const char *)lp_nodes + pidx * (uint32_t)sizeof(N));
                     work.add(0, (uint32_t)(on_mask >> lane) & 1u);
                     work.add(2, lane == 0);
-                    const uint32_t thr = MODE == MODE_SELF ? 2u * (first32 + (uint32_t)u) + 1u : 0xffffffffu; // > my_item
-                    const uint64_t hm = test_and_append_f32<true>(on_mask, p.lo[0], p.lo[1], p.lo[2], p.up[0], p.up[1], p.up[2],
-                                                                  q.q_node.lo[0], q.q_node.lo[1], q.q_node.lo[2], q.q_node.up[0],
-                                                                  q.q_node.up[1], q.q_node.up[2], thr, MODE == MODE_SELF ? my_item : 0u,
-                                                                  e_box + ((uint32_t)u << 6), queue_lds + 4u * (uint32_t)qn);
-                    qn += (int)__popcll(hm);
+                    test_and_append_f32<true>(on_mask, p.lo[0], p.lo[1], p.lo[2], p.up[0], p.up[1], p.up[2], q.q_node.lo[0], q.q_node.lo[1],
+                                              q.q_node.lo[2], q.q_node.up[0], q.q_node.up[1], q.q_node.up[2], pidx, half_item,
+                                              e_box + ((uint32_t)u << 6), qaddr);
                 }
             } else {
-                for (uint64_t todo = on_mask; todo != 0; todo &= todo - 1) {
-                    if (qn > QUEUE_CAP - 64) drain(false);
+                for (uint64_t todo = on_mask; todo != 0;) {
+                    drain_if_full();
                     const int u = __builtin_ctzll(todo);
+                    asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(u));
                     const N qb = broadcast_from_lane(q.q_node, u);
                     work.add(0, (uint32_t)(box_mask >> lane) & 1u);
                     const uint32_t thr = MODE == MODE_SELF ? wave_item0 + (uint32_t)u : 0u; // < right_leaf
-                    const uint64_t hm = test_and_append_f32<false>(box_mask, qb.lo[0], qb.lo[1], qb.lo[2], qb.up[0], qb.up[1], qb.up[2],
-                                                                   mybox.lo[0], mybox.lo[1], mybox.lo[2], mybox.up[0], mybox.up[1],
-                                                                   mybox.up[2], thr, MODE == MODE_SELF ? right_leaf : 1u,
-                                                                   e_qry | (uint32_t)u, queue_lds + 4u * (uint32_t)qn);
-                    qn += (int)__popcll(hm);
+                    test_and_append_f32<false>(box_mask, qb.lo[0], qb.lo[1], qb.lo[2], qb.up[0], qb.up[1], qb.up[2], mybox.lo[0], mybox.lo[1],
+                                               mybox.lo[2], mybox.up[0], mybox.up[1], mybox.up[2], thr, MODE == MODE_SELF ? right_leaf : 1u,
+                                               e_qry | (uint32_t)u, qaddr);
                 }
             }
+            qn = (int)((qaddr - queue_lds) >> 2);
         } else {
             for (uint64_t todo = by_box ? box_mask : on_mask; todo != 0; todo &= todo - 1) {
                 if (qn > QUEUE_CAP - 64) drain(false);
@@ -944,8 +1000,19 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
 #if IBVH_LVT_STRAIGHT & 1
                 const uint32_t idx = cur[have ? base + lane : base];
                 const N box = load_vol<N>(lvl_nodes + (idx - lvl_first));
-                bool hit = have & touches_wave(box);
-                if constexpr (MODE == MODE_SELF) hit = hit & !((idx + 1u) <= (wave_next >> (levels - lvl)));
+                bool hit;
+                uint64_t hit_mask;
+                if constexpr (std::is_same<TN, float>::value) {
+                    bool pre = have;
+                    if constexpr (MODE == MODE_SELF) pre = pre & !((idx + 1u) <= (wave_next >> (levels - lvl)));
+                    const uint64_t init = __builtin_amdgcn_ballot_w64(pre);
+                    hit_mask = contact_mask_f32(init, ubox_a, box) | contact_mask_f32(init, ubox_b, box);
+                    hit = (hit_mask >> lane) & 1u;
+                } else {
+                    hit = have & touches_wave(box);
+                    if constexpr (MODE == MODE_SELF) hit = hit & !((idx + 1u) <= (wave_next >> (levels - lvl)));
+                    hit_mask = __builtin_amdgcn_ballot_w64(hit);
+                }
 #else
                 const uint32_t idx = have ? cur[base + lane] : 0u;
                 N box;
@@ -955,8 +1022,9 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
                     hit = touches_wave(box);
                     if constexpr (MODE == MODE_SELF) hit = hit & !((idx + 1u) <= (wave_next >> (levels - lvl)));
                 }
+                const uint64_t hit_mask = __builtin_amdgcn_ballot_w64(hit);
 #endif
-                const uint64_t hm = __builtin_amdgcn_ballot_w64(hit);
+                const uint64_t hm = hit_mask;
                 if (lvl == cut_level) {
                     for (uint64_t todo = hm; todo != 0; todo &= todo - 1) {
                         const int src = __builtin_ctzll(todo);
