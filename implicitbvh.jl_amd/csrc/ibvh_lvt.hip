@@ -486,6 +486,36 @@ IBVH_D uint64_t contact_mask_f32(uint64_t init, const BBox<float> &S, const BBox
     return m;
 }
 
+// `init` & (iscontact(A, V) | iscontact(B, V)): the wave's two query boxes against a per-lane box, in one block (the
+// second chain starts from `init` again; the masks are OR-ed on the scalar unit)
+IBVH_D uint64_t contact_mask2_f32(uint64_t init, const BBox<float> &A, const BBox<float> &B, const BBox<float> &V) {
+    uint64_t m, ma;
+    asm volatile("s_mov_b64 exec, %[init]\n\t"
+                 "v_cmpx_le_f32 %[alo0], %[vup0]\n\t"
+                 "v_cmpx_ge_f32 %[aup0], %[vlo0]\n\t"
+                 "v_cmpx_le_f32 %[alo1], %[vup1]\n\t"
+                 "v_cmpx_ge_f32 %[aup1], %[vlo1]\n\t"
+                 "v_cmpx_le_f32 %[alo2], %[vup2]\n\t"
+                 "v_cmpx_ge_f32 %[aup2], %[vlo2]\n\t"
+                 "s_mov_b64 %[ma], exec\n\t"
+                 "s_mov_b64 exec, %[init]\n\t"
+                 "v_cmpx_le_f32 %[blo0], %[vup0]\n\t"
+                 "v_cmpx_ge_f32 %[bup0], %[vlo0]\n\t"
+                 "v_cmpx_le_f32 %[blo1], %[vup1]\n\t"
+                 "v_cmpx_ge_f32 %[bup1], %[vlo1]\n\t"
+                 "v_cmpx_le_f32 %[blo2], %[vup2]\n\t"
+                 "v_cmpx_ge_f32 %[bup2], %[vlo2]\n\t"
+                 "s_or_b64 %[m], %[ma], exec\n\t"
+                 "s_mov_b64 exec, -1"
+                 : [m] "=&s"(m), [ma] "=&s"(ma)
+                 : [init] "s"(init), [alo0] "s"(A.lo[0]), [alo1] "s"(A.lo[1]), [alo2] "s"(A.lo[2]), [aup0] "s"(A.up[0]), [aup1] "s"(A.up[1]),
+                   [aup2] "s"(A.up[2]), [blo0] "s"(B.lo[0]), [blo1] "s"(B.lo[1]), [blo2] "s"(B.lo[2]), [bup0] "s"(B.up[0]), [bup1] "s"(B.up[1]),
+                   [bup2] "s"(B.up[2]), [vlo0] "v"(V.lo[0]), [vlo1] "v"(V.lo[1]), [vlo2] "v"(V.lo[2]), [vup0] "v"(V.up[0]), [vup1] "v"(V.up[1]),
+                   [vup2] "v"(V.up[2])
+                 : "vcc", "scc");
+    return m;
+}
+
 #ifndef IBVH_QUEUE_CAP
 #define IBVH_QUEUE_CAP 512
 #endif
@@ -500,6 +530,9 @@ constexpr int QUEUE_WAVES = IBVH_QUEUE_WAVES; // waves per workgroup (they share
 // round-2 kernel at 8 waves (31 + 4 spills, 20 B of scratch) 0.165 / 1.42 ms.  (profiles/r03_lvt_variants.txt)
 #ifndef IBVH_QUEUE_MINWAVES
 #define IBVH_QUEUE_MINWAVES 7
+#endif
+#ifndef IBVH_LVT_UNCHECKED
+#define IBVH_LVT_UNCHECKED 0 // 1: a second copy of the candidate loops without the queue-full check for subtrees that are certain to fit (measured: slower — more scalar spills)
 #endif
 #ifndef IBVH_LVT_QTABLE
 #define IBVH_LVT_QTABLE 0
@@ -890,7 +923,7 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
         if constexpr (std::is_same<TN, float>::value) {
             uint64_t init = __builtin_amdgcn_ballot_w64(mine);
             if constexpr (MODE == MODE_SELF) init &= __builtin_amdgcn_ballot_w64(right_leaf > wave_item0);
-            box_mask = contact_mask_f32(init, ubox_a, mybox) | contact_mask_f32(init, ubox_b, mybox);
+            box_mask = contact_mask2_f32(init, ubox_a, ubox_b, mybox);
             box_on = (box_mask >> lane) & 1u;
         } else {
             box_on = mine & touches_wave(mybox);
@@ -900,7 +933,8 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
         // shorter of the two loops: lanes = queries over the parents that touch the wave's boxes, or
         // lanes = parents over the active queries.  (Measured alternative: lanes = (query, parent) pairs
         // pulled together with ds_bpermute — as many steps as this loop has iterations, and slower.)
-        const bool by_box = __builtin_amdgcn_readfirstlane((int)__popcll(box_mask)) < __builtin_amdgcn_readfirstlane((int)__popcll(on_mask)); // (uniform 32-bit: a scalar compare)
+        const uint32_t n_box = (uint32_t)__builtin_popcountll(box_mask), n_on = (uint32_t)__builtin_popcountll(on_mask);
+        const bool by_box = n_box < n_on; // (32-bit and uniform: a scalar compare)
         const QE e_box = (QE)lane | ((QE)first32 << 6);             // + (u << 6)
         const QE e_qry = (QE)(first32 + (uint32_t)lane) << 6;       // | u
         if constexpr (std::is_same<TN, float>::value && !WIDE) {
@@ -916,11 +950,23 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
                     qaddr = queue_lds + 4u * (uint32_t)qn;
                 }
             };
-            if (by_box) {
-                // 2p + 1 > item  <=>  p >= (item + 1) >> 1: the parent index itself is the scalar operand
-                const uint32_t half_item = MODE == MODE_SELF ? (my_item + 1u) >> 1 : 0u;
+            // (n_box * n_on bounds what this subtree can append: when that fits the queue as it stands — after a drain if need
+            // be — the loops run without the per-iteration check: two scalar instructions less per iteration)
+#if IBVH_LVT_UNCHECKED
+            if (qaddr + 4u * n_box * n_on > queue_lds + 4u * (uint32_t)QUEUE_CAP) {
+                qn = (int)((qaddr - queue_lds) >> 2);
+                drain(false);
+                qaddr = queue_lds + 4u * (uint32_t)qn;
+            }
+            const bool checked = qaddr + 4u * n_box * n_on > queue_lds + 4u * (uint32_t)QUEUE_CAP;
+#else
+            constexpr bool checked = true;
+#endif
+            // 2p + 1 > item  <=>  p >= (item + 1) >> 1: the parent index itself is the scalar operand
+            const uint32_t half_item = MODE == MODE_SELF ? (my_item + 1u) >> 1 : 0u;
+            auto loop_by_box = [&](auto chk) {
                 for (uint64_t todo = box_mask; todo != 0;) {
-                    drain_if_full();
+                    if constexpr (decltype(chk)::value) drain_if_full();
                     const int u = __builtin_ctzll(todo);
                     asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(u)); // (todo &= todo - 1 costs three scalar instructions)
                     // (the parent box comes straight from memory with scalar loads — it is L2-hot, lane u just loaded it —
@@ -934,9 +980,10 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
                                               q.q_node.lo[2], q.q_node.up[0], q.q_node.up[1], q.q_node.up[2], pidx, half_item,
                                               e_box + ((uint32_t)u << 6), qaddr);
                 }
-            } else {
+            };
+            auto loop_by_query = [&](auto chk) {
                 for (uint64_t todo = on_mask; todo != 0;) {
-                    drain_if_full();
+                    if constexpr (decltype(chk)::value) drain_if_full();
                     const int u = __builtin_ctzll(todo);
                     asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(u));
                     const N qb = broadcast_from_lane(q.q_node, u);
@@ -946,7 +993,19 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
                                                mybox.lo[2], mybox.up[0], mybox.up[1], mybox.up[2], thr, MODE == MODE_SELF ? right_leaf : 1u,
                                                e_qry | (uint32_t)u, qaddr);
                 }
+            };
+#if IBVH_LVT_UNCHECKED
+            if (by_box) {
+                if (checked) loop_by_box(std::true_type{});
+                else loop_by_box(std::false_type{});
+            } else {
+                if (checked) loop_by_query(std::true_type{});
+                else loop_by_query(std::false_type{});
             }
+#else
+            if (by_box) loop_by_box(std::true_type{});
+            else loop_by_query(std::true_type{});
+#endif
             qn = (int)((qaddr - queue_lds) >> 2);
         } else {
             for (uint64_t todo = by_box ? box_mask : on_mask; todo != 0; todo &= todo - 1) {
@@ -1006,7 +1065,7 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
                     bool pre = have;
                     if constexpr (MODE == MODE_SELF) pre = pre & !((idx + 1u) <= (wave_next >> (levels - lvl)));
                     const uint64_t init = __builtin_amdgcn_ballot_w64(pre);
-                    hit_mask = contact_mask_f32(init, ubox_a, box) | contact_mask_f32(init, ubox_b, box);
+                    hit_mask = contact_mask2_f32(init, ubox_a, ubox_b, box);
                     hit = (hit_mask >> lane) & 1u;
                 } else {
                     hit = have & touches_wave(box);
