@@ -825,20 +825,31 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
             hit_a = hit_a && (fl ? narrow_eval(a.narrow, mor_a, idx_a, qm, qidx) : narrow_eval(a.narrow, qm, qidx, mor_a, idx_a));
             hit_b = hit_b && (fl ? narrow_eval(a.narrow, mor_b, idx_b, qm, qidx) : narrow_eval(a.narrow, qm, qidx, mor_b, idx_b));
         }
-        // lanes holding the same query (match-any on the 6-bit lane id)
-        uint64_t same = __builtin_amdgcn_ballot_w64(v);
+        // lanes holding the same query (match-any on the 6-bit lane id).  Written on the 32-bit halves with the
+        // three-input boolean op — same &= ~(ballot(bit) ^ -bit), table 0x90 = a & ~(b ^ c) — and with v_mbcnt as "popcount
+        // below this lane": the compiler's 64-bit per-lane version of this block was 90 VALU instructions, this is 40.
+        uint32_t same_lo, same_hi;
+        {
+            const uint64_t vm = avail >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << avail) - 1); // = ballot(v), scalar
+            same_lo = (uint32_t)vm;
+            same_hi = (uint32_t)(vm >> 32);
+        }
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
-            const bool bit = (qi >> b) & 1;
-            const uint64_t m = __builtin_amdgcn_ballot_w64(bit);
-            same &= bit ? m : ~m;
+            const int x = (int)((uint32_t)qi << (31 - b)) >> 31; // -bit
+            const uint64_t m = __builtin_amdgcn_ballot_w64(x != 0);
+            same_lo = __builtin_amdgcn_bitop3_b32(same_lo, (uint32_t)m, (uint32_t)x, 0x90);
+            same_hi = __builtin_amdgcn_bitop3_b32(same_hi, (uint32_t)(m >> 32), (uint32_t)x, 0x90);
         }
         const uint64_t m_a = __builtin_amdgcn_ballot_w64(hit_a), m_b = __builtin_amdgcn_ballot_w64(hit_b);
-        const int rank = __popcll(same & lt_mask & m_a) + __popcll(same & lt_mask & m_b);
-        const int tot = __popcll(same & m_a) + __popcll(same & m_b);
+        const uint32_t sa_lo = same_lo & (uint32_t)m_a, sa_hi = same_hi & (uint32_t)(m_a >> 32);
+        const uint32_t sb_lo = same_lo & (uint32_t)m_b, sb_hi = same_hi & (uint32_t)(m_b >> 32);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi(sb_hi, __builtin_amdgcn_mbcnt_lo(sb_lo, __builtin_amdgcn_mbcnt_hi(sa_hi, __builtin_amdgcn_mbcnt_lo(sa_lo, 0u))));
+        const int tot = __builtin_popcount(sa_lo) + __builtin_popcount(sa_hi) + __builtin_popcount(sb_lo) + __builtin_popcount(sb_hi);
+        const bool group_first = __builtin_amdgcn_mbcnt_hi(same_hi, __builtin_amdgcn_mbcnt_lo(same_lo, 0u)) == 0u;
         const Cnt base = cnts[qi];
         __builtin_amdgcn_wave_barrier();
-        if (v && (same & lt_mask) == 0 && tot > 0) cnts[qi] = base + (Cnt)tot;
+        if (v && group_first && tot > 0) cnts[qi] = base + (Cnt)tot;
         __builtin_amdgcn_wave_barrier();
         // WRITE: straight to the output; counting pass: appended to the wave's dense cache (slot = running fill +
         // number of hitting lanes below this one, a-hits of the step before its b-hits)
