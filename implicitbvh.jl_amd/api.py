@@ -877,6 +877,7 @@ def _traverse_lvt_pair(bvh1, bvh2, sl1, sl2, narrow, cache):
 
 
 BFS_INITIAL_FACTOR = 4  # queues start at 4x the initial pair count (bfs/traverse_single.jl:73)
+_last_bfs_counters = None
 BFS_GROWTH = 4          # and grow at least 4x when a level does not fit (deeper levels need more still: 2x cost twice the resumes)
 
 
@@ -913,6 +914,8 @@ def _bfs_run(entry, types, initial_capacity, cache, levels_hint, *args):
         abi.check(st, entry)
         if res.contacts_in == 2:
             q1, q2 = q2, q1
+        global _last_bfs_counters
+        _last_bfs_counters = (counters, int(levels_hint))  # (tools/dbg_bfs_levels.py reads the per-step counts)
         return res, q1, q2
 
 

@@ -20,6 +20,7 @@ namespace ibvh {
 namespace bfs {
 
 constexpr int TPB = 256;
+constexpr int GEN_SLOTS = 16; // words per step the workgroups spread their check counts over (level_kernel)
 
 // Workgroup barrier that orders LDS accesses only: __syncthreads() also drains every outstanding global store and
 // load (s_waitcnt vmcnt(0)), which would make a workgroup wait for its queue writes before it may read its next chunk.
@@ -448,7 +449,11 @@ template <class L, class N, class I> struct RayStep {
 // counters[0]          overflow flag: 0, or 1 + the index of the first step whose destination queue was too small
 // counters[1 + s]      entries in the SOURCE queue of step s (counters[1] = the initial queue; step s produces
 //                      counters[2 + s], counting on past `capacity` so that the exact need is known)
-// counters[chk + s]    pairs step s generated and checked (num_checks is their sum)
+// counters[chk * (1 + k) + s]   pairs step s generated and checked, slot k < GEN_SLOTS (num_checks is their sum; chk =
+//                      total_levels + 8 = the length of one block).  Same-address global atomics are serialised at
+//                      ~11 ns each on this part (measured: a level's time was 11 ns x (workgroups + waves) whatever
+//                      its size — 108 us for 0.5 M source pairs, 140 us for 5.2 M), so a workgroup adds its count
+//                      ONCE, to the slot blockIdx % GEN_SLOTS (different cache lines), not once per wave to one word
 // No host read between the levels: a step takes its source count from the device word the previous step
 // accumulated, so the grid is a fixed number of workgroups that stride over the source queue; once a step has
 // overflowed, the later steps (already enqueued) return at once and the caller resumes from that step with larger
@@ -467,9 +472,12 @@ __global__ __launch_bounds__(TPB) void level_kernel(const IndexPair<I> *__restri
     static_assert(STAGE >= 2 * MAXOUT * TPB, "the staging area holds at least two worst-case chunks");
     __shared__ IndexPair<I> staged[STAGE];
     __shared__ int s_fill;
-    __shared__ unsigned long long s_base;
+    __shared__ unsigned long long s_base, s_gen;
     const int lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) s_fill = 0;
+    if (threadIdx.x == 0) {
+        s_fill = 0;
+        s_gen = 0ull;
+    }
     lds_barrier();
     // an EARLIER step overflowed: its destination (our source) is incomplete.  The step that overflows itself keeps going
     // in every workgroup — also those that start, or reach their next chunk, after a sibling raised the flag — so that
@@ -497,30 +505,45 @@ __global__ __launch_bounds__(TPB) void level_kernel(const IndexPair<I> *__restri
         if (threadIdx.x == 0) s_fill = 0;
         lds_barrier(); // staged / s_fill / s_base are reused (LDS only: the stores above stay in flight)
     };
-    for (int64_t chunk = blockIdx.x; chunk * TPB < num_src; chunk += gridDim.x) {
+    // Software pipeline over the workgroup's chunks (round 3): the source pair of chunk c + 2 and the volumes of chunk
+    // c + 1 are in flight while chunk c is tested, staged and flushed.  A chunk used to be three DEPENDENT round trips
+    // (source pair -> volumes -> tail atomic of a flush), with nothing else for the workgroup's waves to do meanwhile: the
+    // level kernels were ~82 % waiting.  Lanes beyond the queue's end carry safe() (a valid pair of the level), so every
+    // load is unconditional; vmcnt counts in order, so the wait for chunk c + 1's volumes sits at the register rotation at
+    // the end of the body, a whole test-and-stage phase after they were requested.
+    using Fetched = typename std::conditional<PolA::kIdentity, typename PolB::Loaded, typename PolB::Sides>::type;
+    const int64_t stride = (int64_t)gridDim.x;
+    auto source_of = [&](int64_t chunk) -> IndexPair<I> {
         const int64_t i = chunk * TPB + threadIdx.x;
+        if constexpr (PolA::kIdentity) return i < num_src ? src[i] : pb.safe();
+        else return i < num_src ? src[i] : pa.safe();
+    };
+    auto fetch = [&](IndexPair<I> sp) -> Fetched {
+        if constexpr (PolA::kIdentity) return pb.load(sp);
+        else return pb.load_sides(sp, pa);
+    };
+    IndexPair<I> s_cur = source_of((int64_t)blockIdx.x), s_nxt = source_of((int64_t)blockIdx.x + stride);
+    Fetched f_cur = fetch(s_cur);
+    for (int64_t chunk = blockIdx.x; chunk * TPB < num_src; chunk += stride) {
+        const int64_t i = chunk * TPB + threadIdx.x;
+        const Fetched f_nxt = fetch(s_nxt);
+        const IndexPair<I> s_nn = source_of(chunk + 2 * stride);
         // (results stay in registers, statically indexed: `out[k++]` would put the array into scratch memory)
         IndexPair<I> kids[MAXOUT], res[MAXOUT];
         uint32_t okm = 0; // bit j: child j passed
         int nk = 0;
-        if (i < num_src) nk = pa.children(src[i], kids);
+        if (i < num_src) nk = pa.children(s_cur, kids);
         generated += (unsigned long long)nk;
-        // ALL loads first, unconditionally (a lane without a source pair fetches for the level's first node), then the
-        // tests: one memory round trip per lane and chunk instead of one per child pair
         if constexpr (PolA::kIdentity) {
-            const IndexPair<I> kid = nk > 0 ? kids[0] : pb.safe();
-            const typename PolB::Loaded ld = pb.load(kid);
-            if (nk > 0 && pb.test(kid, ld, res[0])) okm = 1u;
+            if (nk > 0 && pb.test(s_cur, f_cur, res[0])) okm = 1u;
         } else {
             // the source pair's children share their volumes: {2a, 2a+1} x {2b, 2b+1} (or one side kept): four volume
             // fetches per lane serve up to four checks
-            const IndexPair<I> s0 = i < num_src ? src[i] : pa.safe();
-            const typename PolB::Sides sides = pb.load_sides(s0, pa);
 #pragma unroll
             for (int j = 0; j < MAXOUT; ++j) {
                 bool ok;
-                if constexpr (std::is_same<PolB, PairStep<typename PolB::leaf_t, typename PolB::node_t, I>>::value) ok = j < nk && pb.test_sides(kids[j], sides, res[j], pa);
-                else ok = j < nk && pb.test_sides(kids[j], sides, res[j]);
+                if constexpr (std::is_same<PolB, PairStep<typename PolB::leaf_t, typename PolB::node_t, I>>::value) ok = j < nk && pb.test_sides(kids[j], f_cur, res[j], pa);
+                else ok = j < nk && pb.test_sides(kids[j], f_cur, res[j]);
                 okm |= ok ? (1u << j) : 0u;
             }
         }
@@ -539,12 +562,17 @@ __global__ __launch_bounds__(TPB) void level_kernel(const IndexPair<I> *__restri
             if ((okm >> j) & 1u) staged[at + __popc(okm & ((1u << j) - 1u))] = res[j];
         lds_barrier(); // every wave's share is reserved and written
         if (s_fill > STAGE - MAXOUT * TPB) flush(); // (uniform: read after the barrier) the next chunk might not fit
+        s_cur = s_nxt;
+        f_cur = f_nxt;
+        s_nxt = s_nn;
     }
     flush();
     // pairs checked by this workgroup
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) generated += __shfl_xor(generated, o, 64);
-    if (lane == 0 && generated != 0ull) atomicAdd(&counters[chk + step], generated);
+    if (lane == 0 && generated != 0ull) atomicAdd(&s_gen, generated); // (LDS)
+    lds_barrier();
+    if (threadIdx.x == 0 && s_gen != 0ull) atomicAdd(&counters[chk * (1 + (int)(blockIdx.x % GEN_SLOTS)) + step], s_gen);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -602,7 +630,7 @@ inline int level_grid() {
     static const int g = [] {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return cus * 8;
+        return cus * 4; // one resident round at four workgroups a CU; every workgroup costs a serialised tail atomic per flush
     }();
     return g;
 }
@@ -619,7 +647,7 @@ template <class I, class PolA, class PolB> int step(Run &r, const PolA &pa, cons
 }
 
 // flag + per-step queue counts, then per-step check counts
-inline size_t counters_bytes(int64_t total_levels) { return (size_t)(total_levels + 8) * 8 * 2; }
+inline size_t counters_bytes(int64_t total_levels) { return (size_t)(total_levels + 8) * 8 * (1 + GEN_SLOTS); }
 
 // fresh run: counters zeroed, counters[1] = initial queue size.  Resume (res->resume_step > 0): the queue the
 // overflowed step reads — res->contacts_in says which buffer — still holds res->resume_num entries; the flag and
@@ -641,7 +669,8 @@ inline int begin(Run &r, void *bvtt1, void *bvtt2, int64_t capacity, void *count
         IBVH_HIP_CHECK(hipMemsetAsync(counters, 0, 8, st));
         IBVH_HIP_CHECK(hipMemsetAsync((char *)counters + keep, 0, half - keep, st));
         // the checks of steps 0 .. first - 1 stay; step `first` runs again from the start
-        IBVH_HIP_CHECK(hipMemsetAsync((char *)counters + half + (size_t)r.first * 8, 0, half - (size_t)r.first * 8, st));
+        for (int k = 0; k < GEN_SLOTS; ++k)
+            IBVH_HIP_CHECK(hipMemsetAsync((char *)counters + half * (size_t)(1 + k) + (size_t)r.first * 8, 0, half - (size_t)r.first * 8, st));
         return IBVH_OK;
     }
     IBVH_HIP_CHECK(hipMemsetAsync(counters, 0, counters_bytes(total_levels), st));
@@ -652,10 +681,10 @@ inline int begin(Run &r, void *bvtt1, void *bvtt2, int64_t capacity, void *count
 
 // the one blocking read: flag + all counts
 inline int finish(const Run &r, ibvh_bfs_result *res) {
-    unsigned long long host[160];
+    unsigned long long host[80 * (1 + GEN_SLOTS)];
     const int nsteps = r.step;
-    if (nsteps + 2 > 80 || r.chk + nsteps > 160) return IBVH_ERR_INVALID_ARG;
-    IBVH_HIP_CHECK(hipMemcpyAsync(host, r.counters, (size_t)(r.chk + nsteps) * 8, hipMemcpyDeviceToHost, r.st));
+    if (nsteps + 2 > r.chk || r.chk > 80) return IBVH_ERR_INVALID_ARG;
+    IBVH_HIP_CHECK(hipMemcpyAsync(host, r.counters, (size_t)r.chk * (1 + GEN_SLOTS) * 8, hipMemcpyDeviceToHost, r.st));
     IBVH_HIP_CHECK(hipStreamSynchronize(r.st));
     const unsigned long long flag = host[0];
     if (flag != 0ull) {
@@ -674,7 +703,8 @@ inline int finish(const Run &r, ibvh_bfs_result *res) {
     // is one check — the initial queue plus each node-level result, i.e. every pair a step here generated and checked;
     // what passes the last (leaf) step is the contact list
     int64_t checks = 0;
-    for (int s = 0; s < nsteps; ++s) checks += (int64_t)host[r.chk + s];
+    for (int k = 0; k < GEN_SLOTS; ++k)
+        for (int s = 0; s < nsteps; ++s) checks += (int64_t)host[r.chk * (1 + k) + s];
     res->num_contacts = (int64_t)host[1 + nsteps];
     res->num_checks = checks;
     res->contacts_in = r.swapped ? 2 : 1;
