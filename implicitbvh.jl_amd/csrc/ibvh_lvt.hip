@@ -516,6 +516,36 @@ IBVH_D uint64_t contact_mask2_f32(uint64_t init, const BBox<float> &A, const BBo
     return m;
 }
 
+// Diagnostic build only (-DIBVH_PHASE_STAMPS, tools/phase_stamps.sh + tools/lvt_stamps.py): s_memtime ticks a wave of
+// lvt_queue_kernel spends per section, summed over the launch's waves into a buffer no product code reads.  Coarse: a
+// lap is a scalar memory round trip itself, and the per-subtree sections take ~70 of them per wave.
+#ifdef IBVH_PHASE_STAMPS
+__device__ unsigned long long g_lvt_ticks[8];
+struct Sections {
+    unsigned long long t0, acc[6] = {0, 0, 0, 0, 0, 0};
+    IBVH_D void start() { t0 = __builtin_amdgcn_s_memtime(); }
+    IBVH_D void lap(int k) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        acc[k] += t - t0;
+        t0 = t;
+    }
+    IBVH_D void flush() {
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) atomicAdd(&g_lvt_ticks[k], acc[k]);
+            atomicAdd(&g_lvt_ticks[7], 1ull);
+        }
+    }
+};
+#else
+struct Sections {
+    IBVH_D void start() {}
+    IBVH_D void lap(int) {}
+    IBVH_D void flush() {}
+};
+#endif
+enum { SEC_PROLOGUE = 0, SEC_DESCENT = 1, SEC_SUBTREE = 2, SEC_LOOPS = 3, SEC_LEAVES = 4, SEC_EPILOGUE = 5 };
+
 #ifndef IBVH_QUEUE_CAP
 #define IBVH_QUEUE_CAP 512
 #endif
@@ -562,6 +592,8 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
     };
     __shared__ QRec s_query[QUEUE_WAVES][64];
 #endif
+    Sections sec;
+    sec.start();
     Q q(a, cache);
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // (uniform: LDS bases stay scalar)
 #if IBVH_LVT_QTABLE
@@ -875,6 +907,7 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
     };
     // drain the full 64-pair steps (all == false) or everything (all == true); a remainder moves to the front
     auto drain = [&](bool all) {
+        sec.lap(SEC_LOOPS);
         int done = 0;
         while (qn - done >= 64 || (all && qn - done > 0)) {
             const int avail = qn - done < 64 ? qn - done : 64;
@@ -889,10 +922,12 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
             __builtin_amdgcn_wave_barrier();
         }
         qn = __builtin_amdgcn_readfirstlane(rem);
+        sec.lap(SEC_LEAVES);
     };
 
     // b: candidates of the subtree rooted at node c (level cut_level) whose box is `cbox`
     auto brute = [&](uint32_t c, const N &cbox) {
+        sec.lap(SEC_DESCENT);
         work.add(0, q.lane_on);
         uint64_t on_mask;
         bool on; // (per lane: only the generic loop below reads it)
@@ -906,7 +941,10 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
             if constexpr (MODE == MODE_SELF) on = on & !((c + 1u) <= (self_next >> (levels - cut_level)));
             on_mask = __builtin_amdgcn_ballot_w64(on);
         }
-        if (on_mask == 0) return;
+        if (on_mask == 0) {
+            sec.lap(SEC_SUBTREE);
+            return;
+        }
         const uint32_t first32 = (c - (1u << (cut_level - 1))) << (lp - cut_level); // 0-based, within level lp
         uint32_t last = first32 + (1u << (lp - cut_level));
         last = last < lp_real ? last : lp_real;
@@ -946,6 +984,7 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
         // pulled together with ds_bpermute — as many steps as this loop has iterations, and slower.)
         const uint32_t n_box = (uint32_t)__builtin_popcountll(box_mask), n_on = (uint32_t)__builtin_popcountll(on_mask);
         const bool by_box = n_box < n_on; // (32-bit and uniform: a scalar compare)
+        sec.lap(SEC_SUBTREE);
         const QE e_box = (QE)lane | ((QE)first32 << 6);             // + (u << 6)
         const QE e_qry = (QE)(first32 + (uint32_t)lane) << 6;       // | u
         if constexpr (std::is_same<TN, float>::value && !WIDE) {
@@ -1042,8 +1081,10 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
                 qn = __builtin_amdgcn_readfirstlane(qn + __popcll(hm));
             }
         }
+        sec.lap(SEC_LOOPS);
     };
 
+    sec.lap(SEC_PROLOGUE);
     // a: frontier descent from the start level to the cut level.  Roots are taken in chunks so the first
     // frontier always fits; chunks and frontier entries stay in increasing node order.
     uint32_t *fr0 = s_frontier[wv][0], *fr1 = s_frontier[wv][1];
@@ -1143,6 +1184,7 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
             if (region && lane == 0) *(int *)region = -1;
         return;
     }
+    sec.lap(SEC_DESCENT);
     drain(true);
     work.flush(a.work);
     if constexpr (!WRITE) {
@@ -1152,6 +1194,8 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
         const bool meta_ok = __builtin_amdgcn_ballot_w64((int64_t)cnts[lane] >= ((int64_t)1 << (sizeof(I) * 8 - 7))) == 0;
         if (region && lane == 0) *(int *)region = (wfill <= entry_cap && meta_ok) ? wfill : -1;
     }
+    sec.lap(SEC_EPILOGUE);
+    sec.flush();
 }
 
 // ---- (3) rays: per-lane walks, lanes refilled from the wave's block of rays -------------------------------
@@ -2271,3 +2315,13 @@ ibvh_status ibvh_traverse_rays_lvt_enqueue(const ibvh_bvh *bvh, const void *poin
 }
 
 } // extern "C"
+
+#ifdef IBVH_PHASE_STAMPS
+extern "C" int ibvh_debug_lvt_ticks(unsigned long long *out /* 8 */, int reset) {
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(ibvh::lvt::g_lvt_ticks), z, sizeof(z));
+    }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ibvh::lvt::g_lvt_ticks), sizeof(unsigned long long) * 8);
+}
+#endif
