@@ -369,7 +369,11 @@ class _HintWord:
         return _host_words().ptr(self.slot)
 
     def __getitem__(self, i):
-        return int(_host_words().words[self.slot]) & 0xffffffff  # (the GPU writes the low 4 bytes)
+        return int(_host_words().words[self.slot]) & 0xff  # extra levels the last build would have used (include/ibvh.h, skew_flag)
+
+    def occupancy(self):
+        """Fullest coarse cell of the last build in 1/128 of what one finish workgroup sorts (second byte of the word)."""
+        return (int(_host_words().words[self.slot]) >> 8) & 0xff
 
     def __setitem__(self, i, v):
         _host_words().words[self.slot] = int(v)
@@ -500,10 +504,15 @@ class BVH:
             d.mins[:] = [float(v) for v in alg.mins]
             d.maxs[:] = [float(v) for v in alg.maxs]
         used = self._skew[0]
-        # at least ONE extra level also after a uniform cloud: if the next input is clustered (or the cache is reused for
-        # another scene) that level splits every crowded cell 256 ways before anything reaches the one-workgroup slow
-        # path — a handful of near-empty launches per step against a ~100x latency spike on the step where the input changes
-        d.sort_levels = COLD_SORT_LEVELS if cache is None else min(used + 1, abi.MAX_SORT_LEVELS)
+        # A SPARE extra level (four launches that find nothing to do: ~15 us per step at 1e6 leaves) whenever the chain is
+        # anywhere near needing one: the previous build used extra levels, or its fullest cell was beyond SPARE_OCCUPANCY
+        # of what a finish workgroup sorts — a cloud that contracts or clusters over many steps reaches that long before
+        # a cell overflows.  Only an input that changes ABRUPTLY from comfortably uniform to clustered meets no extra
+        # level: its crowded cells take the one-workgroup slow path on that one step (correct; 17 ms at 1e6 leaves,
+        # ~0.1 s at 1e7, tools/dbg_spike.py) and the hint it leaves fixes the next.  SPARE_OCCUPANCY = 0 restores
+        # "always one spare level".
+        spare = used > 0 or self._skew.occupancy() >= SPARE_OCCUPANCY
+        d.sort_levels = COLD_SORT_LEVELS if cache is None else min(used + (1 if spare else 0), abi.MAX_SORT_LEVELS)
         d.skew_flag = self._skew.ptr()
         lib.call("ibvh_build", C.byref(d), vol_ptr, _ptr(self.leaves.buf), _ptr(self.nodes), _ptr(self.skips),
                  _ptr(self.extrema), _ptr(self._scratch), self._scratch.numel(), _stream())
@@ -688,6 +697,7 @@ def _cache_tensor(cache_t, need_rows, cols, dtype, what):
 
 
 COLD_SORT_LEVELS = 2  # extra partition levels a build without cache= launches (include/ibvh.h, sort_levels)
+SPARE_OCCUPANCY = 96  # (of 128) fullest coarse cell from which a cached build launches a spare extra level (BVH.__init__)
 LVT_CACHE_SLOTS = 8  # contacts per work item kept from the counting pass (include/ibvh.h)
 RAY_CACHE_SLOTS = 32  # hits per ray kept from the counting pass
 

@@ -142,12 +142,13 @@ __global__ __launch_bounds__(PLAN_TPB) void plan_kernel(Tables tb, int radix, ui
     __shared__ uint32_t s_nover, s_ntiles;
     const Level L = tb.lvl[0];
     const int lo = threadIdx.x * PER;
-    uint32_t tot[PER], sum = 0, nov = 0, nt = 0;
+    uint32_t tot[PER], sum = 0, nov = 0, nt = 0, biggest = 0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int d = lo + k;
         tot[k] = d < radix ? tb.cell_total[d] : 0u;
         sum += tot[k];
+        biggest = tot[k] > biggest ? tot[k] : biggest;
         if (tot[k] > cap) {
             nov += 1;
             nt += segment_tiles(tot[k], tile);
@@ -157,6 +158,13 @@ __global__ __launch_bounds__(PLAN_TPB) void plan_kernel(Tables tb, int radix, ui
     uint32_t run = block_exclusive_scan<PLAN_TPB>(sum, wave_tot, &total_n);
     uint32_t kk = block_exclusive_scan<PLAN_TPB>(nov, wave_tot, &total_over);
     uint32_t tt = block_exclusive_scan<PLAN_TPB>(nt, wave_tot, &total_tiles);
+    // the fullest cell, in 1/128 of what a finish workgroup sorts (saturating at 255): the second byte of the caller's hint
+    // word — how close a so far uniform input is to needing an extra level (include/ibvh.h, skew_flag)
+    __shared__ uint32_t s_biggest;
+    if (threadIdx.x == 0) s_biggest = 0;
+    __syncthreads();
+    atomicMax(&s_biggest, biggest);
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int d = lo + k;
@@ -182,6 +190,10 @@ __global__ __launch_bounds__(PLAN_TPB) void plan_kernel(Tables tb, int radix, ui
         tb.cell_start[radix] = total_n;
         s_tbase[total_over] = total_tiles;
         *tb.needed = total_over > 0 ? 1u : 0u;
+        {
+            const uint64_t occ = ((uint64_t)s_biggest * 128u + cap - 1) / cap;
+            tb.needed[1] = (uint32_t)(occ > 255 ? 255 : occ);
+        }
         if (levels <= 0) total_over = total_tiles = 0; // the finish kernel sorts crowded cells by itself
 #pragma unroll
         for (int l = 0; l < MAX_LEVELS; ++l) tb.lvl[l].hdr[0] = tb.lvl[l].hdr[1] = 0;
@@ -928,7 +940,7 @@ __global__ __launch_bounds__(TPB) void finish_kernel(Tables tb, int radix, Finis
     extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
     const FinishLds<K, TPB, IPT> l(bsm);
     IBVH_STAMP(1, 0);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && fa.skew_flag) *fa.skew_flag = (int32_t)*tb.needed;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && fa.skew_flag) *fa.skew_flag = (int32_t)(tb.needed[0] | (tb.needed[1] << 8));
     if ((int)blockIdx.x < radix) {
         const uint32_t d = blockIdx.x;
         const uint32_t start = uni(tb.cell_start[d]), m = uni(tb.cell_start[d + 1]) - start;

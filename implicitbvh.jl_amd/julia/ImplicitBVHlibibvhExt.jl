@@ -300,8 +300,9 @@ function ImplicitBVH.BVH(
                          Float64.(alg.mins), Float64.(alg.maxs),   # NB alg.mins/maxs, not options.mins (default.jl:55-56)
                          # sort_levels = 2: always launch two extra partition levels (robust against clustered clouds; a
                          # few per cent of a uniform 1e6-leaf build).  A shim that rebuilds every time step can hand the
-                         # library a mapped pinned host word as skew_flag and pass the value the previous build left there,
-                         # plus one (include/ibvh.h).
+                         # library a mapped pinned host word as skew_flag and pass the level count the previous build left
+                         # in its low byte, plus a spare one when that is not 0 or the second byte (fullest cell, in 1/128 of
+                         # a workgroup's capacity) is close to 128 (include/ibvh.h).
                          Int32(2), Int32(0), Ptr{Cvoid}(C_NULL))
     check(c_build(desc, wrapped ? C_NULL : devptr(bounding_volumes), devptr(leaves), devptr(nodes), devptr(skips),
                   C_NULL, devptr(scratch), need[], stream_ptr()), "ibvh_build")

@@ -143,10 +143,12 @@ typedef struct ibvh_build_desc {
      *   sort_levels = k (0 .. IBVH_MAX_SORT_LEVELS; negative or larger = all): launch k extra levels.  Whatever is
      *   still crowded after them is sorted by one workgroup per piece — always correct, slow when pieces are large.
      * skew_flag (optional, may be NULL): 4 bytes the GPU can write — device memory or mapped pinned host memory.  Every
-     * build stores there how many extra levels its input would have used (0 for a uniform cloud; at most one more than
-     * it was given), so a caller that rebuilds every time step can pass sort_levels = (the value the previous build
-     * left, plus one spare level when it is not 0) without ever synchronising (build.jl:109-126 reuse pattern); a cold
-     * build should pass 2 or more. */
+     * build stores there, in the low byte, how many extra levels its input would have used (0 for a uniform cloud; at
+     * most one more than it was given) and, in the second byte, how full the fullest cell of the coarse grid was, in
+     * 1/128 of what one workgroup sorts (128 = exactly full, saturating at 255), so a caller that rebuilds every time
+     * step can pass sort_levels = (the levels the previous build reported, plus one spare level when that is not 0 or
+     * the fullest cell was close to full) without ever synchronising (build.jl:109-126 reuse pattern); a cold build
+     * should pass 2 or more. */
     int32_t sort_levels;
     int32_t reserved_;
     void *skew_flag;

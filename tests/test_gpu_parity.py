@@ -270,7 +270,9 @@ def test_build_every_sort_route_at_every_partition_depth(shape):
         assert bool(int(g._skew[0])) == expect_skew
         node_type = TOKENS[types.node_kind](torch.float32 if types.node_float == abi.F32 else torch.float64)
         dev = cuda(vols.astype(NP_F[types.leaf_float]))
-        for pretend in (0, 1, 2, 3):                   # what "the previous build" left: launches 1, 2, 3, 4 extra levels
+        # what "the previous build" left in the hint word (levels | fullest cell << 8): launches 0 extra levels (a comfortable
+        # uniform cloud before), 1 (a nearly full cell before: the spare level), 2, 3, 4
+        for pretend in (0, 127 << 8, 1, 2, 3):
             g._skew[0] = pretend
             g = ibvh.BVH(dev, node_type, options=make_options(types), cache=g)
             assert_bvh_equal(o, g)
@@ -278,6 +280,8 @@ def test_build_every_sort_route_at_every_partition_depth(shape):
             used = int(g._skew[0])
             assert (used > 0) == expect_skew and used <= abi.MAX_SORT_LEVELS
             if pretend == 0 and expect_skew:
+                assert used == 1                       # no extra level ran: all it can know is that one is needed
+            if pretend == 127 << 8 and expect_skew:
                 assert used <= 2                       # one extra level ran: it can ask for at most one more
         # no extra level at all (a raw C caller may pass sort_levels = 0): everything crowded takes the one-workgroup path
         from implicitbvh_amd import api
@@ -293,6 +297,58 @@ def test_build_every_sort_route_at_every_partition_depth(shape):
                 assert used == 1                       # no extra level ran: all it can know is that one is needed
         finally:
             api.COLD_SORT_LEVELS = saved
+
+
+def _kernels_of_one_cached_build(dev, cache):
+    lib.call("ibvh_profile_enable", 1)
+    g = ibvh.BVH(dev, cache=cache)
+    torch.cuda.synchronize()
+    cnt = C.c_int64()
+    lib.call("ibvh_profile_count", C.byref(cnt))
+    names = set()
+    for i in range(cnt.value):
+        name, ms = C.c_char_p(), C.c_float()
+        lib.call("ibvh_profile_get", i, C.byref(name), C.byref(ms))
+        names.add(name.value.decode())
+    lib.call("ibvh_profile_enable", 0)
+    return g, " ".join(sorted(names))
+
+
+def test_spare_sort_level_follows_the_fullest_cell(monkeypatch):
+    """The hint word's second byte is the fullest coarse cell in 1/128 of a finish workgroup's capacity; a cached build
+    launches the spare extra level (four more kernels) only from api.SPARE_OCCUPANCY on, or when the chain used extra levels."""
+    from implicitbvh_amd import api
+    rng = np.random.default_rng(11)
+    n = 300_000
+    vols = np.concatenate([rng.random((n, 3)), 1e-4 * np.ones((n, 1))], axis=1).astype(np.float32)
+    o = orc.build(vols, abi.make_types())
+    dev = cuda(vols)
+    g = ibvh.BVH(dev)
+    torch.cuda.synchronize()
+    assert int(g._skew[0]) == 0 and 32 <= g._skew.occupancy() < 128     # uniform: the average cell is 30 - 60 % full
+    occ = g._skew.occupancy()
+    monkeypatch.setattr(api, "SPARE_OCCUPANCY", occ + 1)                 # comfortably below: no extra level
+    g, names = _kernels_of_one_cached_build(dev, g)
+    assert "hist_level_kernel" not in names and "finish_kernel" in names
+    assert_bvh_equal(o, g)
+    monkeypatch.setattr(api, "SPARE_OCCUPANCY", occ)                     # at the threshold: the spare level runs
+    g, names = _kernels_of_one_cached_build(dev, g)
+    assert "hist_level_kernel" in names
+    assert_bvh_equal(o, g)
+    assert g._skew.occupancy() == occ
+    # a clustered cloud through the same chain while the hint says "comfortable": no extra level, still exact; the hint it
+    # leaves turns the levels on for the build after
+    monkeypatch.setattr(api, "SPARE_OCCUPANCY", 128)
+    c = rng.random((5, 3))[rng.integers(0, 5, n)] + rng.normal(0, 2e-4, (n, 3))
+    clustered = np.concatenate([c, 1e-4 * np.ones((n, 1))], axis=1).astype(np.float32)
+    oc = orc.build(clustered, abi.make_types())
+    g, names = _kernels_of_one_cached_build(cuda(clustered), g)
+    assert "hist_level_kernel" not in names
+    assert_bvh_equal(oc, g)
+    assert int(g._skew[0]) == 1 and g._skew.occupancy() == 255
+    g, names = _kernels_of_one_cached_build(cuda(clustered), g)
+    assert "hist_level_kernel" in names
+    assert_bvh_equal(oc, g)
 
 
 @pytest.mark.parametrize("levels", [-1, 99])
