@@ -163,7 +163,12 @@ __global__ __launch_bounds__(PLAN_TPB) void plan_kernel(Tables tb, int radix, ui
     __shared__ uint32_t s_biggest;
     if (threadIdx.x == 0) s_biggest = 0;
     __syncthreads();
-    atomicMax(&s_biggest, biggest);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { // (one LDS atomic per wave: 1,024 same-address ones cost 3 us)
+        const uint32_t t = (uint32_t)__shfl_xor((int)biggest, o, 64);
+        biggest = t > biggest ? t : biggest;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(&s_biggest, biggest);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
