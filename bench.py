@@ -268,6 +268,13 @@ def run_configs(args, ibvh, lib, torch, cpu):
         return s3["r"]
     ms_r3, r3 = _timed(torch, rays3, 3)
     dom_r, avg_r, ks_r = _dominant(lib, torch, rays3)
+    s3["rb"] = None
+
+    def rays3_bfs():  # the reference's benchmark times both algorithms (benchmark/bvh_rays.jl:54-57)
+        s3["rb"] = ibvh.traverse_rays(s3["b"], p, d, ibvh.BFSTraversal(), cache=s3["rb"])
+        return s3["rb"]
+    ms_rb3, rb3 = _timed(torch, rays3_bfs, 3)
+    _, _, ks_rb = _dominant(lib, torch, rays3_bfs)
     c3 = {"workload": f"{mesh_name}: BSphere{{Float32}} leaves from triangles, build, self-traverse, traverse_rays with {nr} random rays "
                       "(benchmark/bvh_rays.jl:36-58)",
           "triangles": n3, "volumes_ms": round(ms_vol, 4),
@@ -280,7 +287,13 @@ def run_configs(args, ibvh, lib, torch, cpu):
           "rays": {"ms": round(ms_r3, 4), "rays": nr, "hits": r3.num_contacts, "mrays_per_s": round(nr / ms_r3 / 1e3, 2),
                    "kernels_ms": ks_r,
                    "roofline": _roof(dom_r, avg_r, 24.0 * nr + 4.0 * nr + 48.0 * n3 + 8.0 * r3.num_contacts,
-                                     "counting pass: rays 24 + counts 4 per ray, tree (leaves 24 + nodes 24 per leaf) once, 8 per cached hit")}}
+                                     "counting pass: rays 24 + counts 4 per ray, tree (leaves 24 + nodes 24 per leaf) once, 8 per cached hit")},
+          "rays_bfs": {"ms": round(ms_rb3, 4), "rays": nr, "hits": rb3.num_contacts, "num_checks": rb3.num_checks,
+                       "mrays_per_s": round(nr / ms_rb3 / 1e3, 2), "kernels_ms": ks_rb,
+                       "roofline": _roof("whole traversal (%d level launches)" % max(len(ks_rb), 1), ms_rb3,
+                                         24.0 * nr + 48.0 * n3 + 8.0 * rb3.num_contacts,
+                                         "rays 24 per ray, tree (leaves 24 + nodes 24 per leaf) once, 8 per hit (queue traffic is the implementation's)")}}
+    s3["rb"] = None
     if orc is not None:
         # CPU legs on a bounded sample: the same mesh's volumes (from the GPU: the triangle kernel is bit-exact against the
         # oracle, tests/test_gpu_parity.py), the oracle's multi-threaded build, then the two-pass LVT ray walk on the first

@@ -627,12 +627,15 @@ struct Run {
 };
 
 inline int level_grid() {
-    static const int g = [] {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return cus * 4; // one resident round at four workgroups a CU; every workgroup costs a serialised tail atomic per flush
+    static const int cus = [] {
+        int dev = 0, c = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+        return c;
     }();
-    return g;
+    // (default 4 a CU: one resident round at the self / pair kernels' occupancy; every workgroup costs a serialised tail
+    // atomic per flush)
+    const int per = g_tuning.bfs_wg_per_cu < 1 ? 1 : (g_tuning.bfs_wg_per_cu > 16 ? 16 : g_tuning.bfs_wg_per_cu);
+    return cus * per;
 }
 
 template <class I, class PolA, class PolB> int step(Run &r, const PolA &pa, const PolB &pb) {
