@@ -227,7 +227,7 @@ def run_configs(args, ibvh, lib, torch, cpu):
     out["config2_bfs"] = {"workload": "1e6 random BSphere{Float32} leaves, traverse(bvh, BFSTraversal(); cache)", "ms": round(ms, 4),
                           "contacts": t.num_contacts, "num_checks": t.num_checks,
                           "mcontacts_per_s": round(t.num_contacts / ms / 1e3, 1), "kernels_ms": ks,
-                          "roofline": _roof("whole traversal (%d level launches)" % max(len(ks), 1), ms, cbytes,
+                          "roofline": _roof("whole traversal (one level kernel launch per tree level)", ms, cbytes,
                                             "leaves 24 + nodes 24 per leaf, each once + 8 per contact (queue traffic is the implementation's)")}
     del v2, b2, t, st
     torch.cuda.empty_cache()
@@ -290,7 +290,7 @@ def run_configs(args, ibvh, lib, torch, cpu):
                                      "counting pass: rays 24 + counts 4 per ray, tree (leaves 24 + nodes 24 per leaf) once, 8 per cached hit")},
           "rays_bfs": {"ms": round(ms_rb3, 4), "rays": nr, "hits": rb3.num_contacts, "num_checks": rb3.num_checks,
                        "mrays_per_s": round(nr / ms_rb3 / 1e3, 2), "kernels_ms": ks_rb,
-                       "roofline": _roof("whole traversal (%d level launches)" % max(len(ks_rb), 1), ms_rb3,
+                       "roofline": _roof("whole traversal (one level kernel launch per tree level)", ms_rb3,
                                          24.0 * nr + 48.0 * n3 + 8.0 * rb3.num_contacts,
                                          "rays 24 per ray, tree (leaves 24 + nodes 24 per leaf) once, 8 per hit (queue traffic is the implementation's)")}}
     s3["rb"] = None
