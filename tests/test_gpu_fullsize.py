@@ -208,6 +208,66 @@ def test_skewed_ten_million_leaf_builds_properties(shape):
     assert b2.leaves.to_numpy().tobytes() == leaves.tobytes()
 
 
+def _timed_build(v, cache):
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    b = ibvh.BVH(v, cache=cache)
+    torch.cuda.synchronize()
+    return b, (time.perf_counter() - t0) * 1e3
+
+
+def test_ten_million_leaves_changing_under_a_cache_chain_time_bounds(monkeypatch):
+    """the step on which a `cache=` chain's input changes.  (1) A cloud that contracts by 2 % per step — how
+    inputs become clustered in a simulation — never meets a slow step: the build reports its fullest cell and the
+    spare sort level comes on before a cell overflows.  (2) With the spare level always on (api.SPARE_OCCUPANCY = 0) an
+    ABRUPT change from uniform to one tight cluster stays within a few normal steps.  (3) With the default policy that
+    one step takes the one-workgroup path (correct, slow) and the step after is normal again.  Generous bounds: the
+    measured figures are 0.86 ms (1), 0.64 ms (2), 118 ms then 0.78 ms (3) against a uniform step of 0.6 ms."""
+    from implicitbvh_amd import api
+    n = 10_000_000
+    g = torch.Generator(device="cuda").manual_seed(3)
+    uniform = torch.rand((n, 4), generator=g, device="cuda") * torch.tensor([1, 1, 1, 1e-4], device="cuda")
+    one = torch.empty((n, 4), device="cuda")
+    one[:, :3] = 0.5 + 0.001 * torch.randn((n, 3), generator=g, device="cuda")
+    one[:, 3] = 1e-4
+    one[0, :3] = 100.0
+    b = None
+    for _ in range(4):
+        b, t_uniform = _timed_build(uniform, b)
+    assert int(b._skew[0]) == 0 and 0 < b._skew.occupancy() < api.SPARE_OCCUPANCY
+    # (1) gradual
+    v = uniform.clone()
+    worst = 0.0
+    for step in range(40):
+        v[:, :3] = 0.5 + (v[:, :3] - 0.5) * 0.98
+        v[0, :3] = 0.0  # two fixed outliers keep the grid's extent: the cloud really gets denser in it
+        v[1, :3] = 1.0
+        b, t = _timed_build(v, b)
+        if step >= 2:
+            worst = max(worst, t)
+    m = b.leaves.morton
+    assert bool((m[1:] >= m[:-1]).all()) and int(b._skew[0]) >= 1
+    assert worst < 8 * t_uniform + 2.0, (worst, t_uniform)
+    # (2) abrupt, spare level always on
+    monkeypatch.setattr(api, "SPARE_OCCUPANCY", 0)
+    for _ in range(3):
+        b, _ = _timed_build(uniform, b)
+    b, t_change = _timed_build(one, b)
+    m = b.leaves.morton
+    assert bool((m[1:] >= m[:-1]).all())
+    assert t_change < 8 * t_uniform + 2.0, (t_change, t_uniform)
+    # (3) abrupt, default policy: slow once, right, and normal on the next step
+    monkeypatch.setattr(api, "SPARE_OCCUPANCY", 96)
+    for _ in range(3):
+        b, _ = _timed_build(uniform, b)
+    b, t_slow = _timed_build(one, b)
+    m = b.leaves.morton
+    assert bool((m[1:] >= m[:-1]).all()) and int(b._skew[0]) >= 1
+    b, t_next = _timed_build(one, b)
+    assert t_next < 8 * t_uniform + 2.0, (t_next, t_slow, t_uniform)
+
+
 @pytest.mark.parametrize("n", [12_500_000, 13_500_000])
 def test_build_properties_where_the_sort_changes_geometry(n):
     """config 5's per-GPU size (the 8,192-record finish workgroup at 75 % average fill) and the first size sorted with
