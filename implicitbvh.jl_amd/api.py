@@ -540,9 +540,10 @@ class BVH:
         # of what a finish workgroup sorts — a cloud that contracts or clusters over many steps reaches that long before
         # a cell overflows.  Only an input that changes ABRUPTLY from comfortably uniform to clustered meets no extra
         # level: its crowded cells take the one-workgroup slow path on that one step (correct; 17 ms at 1e6 leaves,
-        # ~0.1 s at 1e7, tools/dbg_spike.py) and the hint it leaves fixes the next.  SPARE_OCCUPANCY = 0 restores
-        # "always one spare level".
-        spare = used > 0 or self._skew.occupancy() >= SPARE_OCCUPANCY
+        # tools/dbg_spike.py) and the hint it leaves fixes the next.  That path's cost grows with the cell (~0.1 s at 1e7
+        # leaves) while the idle level's share of a step shrinks (1 % at 1e7), so builds of SPARE_ALWAYS_FROM leaves and
+        # more always launch the spare level.  SPARE_OCCUPANCY = 0 restores "always" at every size.
+        spare = used > 0 or self._skew.occupancy() >= SPARE_OCCUPANCY or n >= SPARE_ALWAYS_FROM
         d.sort_levels = COLD_SORT_LEVELS if cache is None else min(used + (1 if spare else 0), abi.MAX_SORT_LEVELS)
         d.skew_flag = self._skew.ptr()
         lib.call("ibvh_build", C.byref(d), vol_ptr, _ptr(self.leaves.buf), _ptr(self.nodes), _ptr(self.skips),
@@ -729,6 +730,8 @@ def _cache_tensor(cache_t, need_rows, cols, dtype, what):
 
 COLD_SORT_LEVELS = 2  # extra partition levels a build without cache= launches (include/ibvh.h, sort_levels)
 SPARE_OCCUPANCY = 96  # (of 128) fullest coarse cell from which a cached build launches a spare extra level (BVH.__init__)
+SPARE_ALWAYS_FROM = 1 << 24  # leaves from which a cached build always launches it (the slow path it avoids grows with the input,
+                             # the idle level's share of a step shrinks: 0.7 % at 1.7e7 leaves)
 LVT_CACHE_SLOTS = 8  # contacts per work item kept from the counting pass (include/ibvh.h)
 RAY_CACHE_SLOTS = 32  # hits per ray kept from the counting pass
 

@@ -219,11 +219,12 @@ def _timed_build(v, cache):
 
 def test_ten_million_leaves_changing_under_a_cache_chain_time_bounds(monkeypatch):
     """the step on which a `cache=` chain's input changes.  (1) A cloud that contracts by 2 % per step — how
-    inputs become clustered in a simulation — never meets a slow step: the build reports its fullest cell and the
-    spare sort level comes on before a cell overflows.  (2) With the spare level always on (api.SPARE_OCCUPANCY = 0) an
-    ABRUPT change from uniform to one tight cluster stays within a few normal steps.  (3) With the default policy that
-    one step takes the one-workgroup path (correct, slow) and the step after is normal again.  Generous bounds: the
-    measured figures are 0.86 ms (1), 0.64 ms (2), 118 ms then 0.78 ms (3) against a uniform step of 0.6 ms."""
+    inputs become clustered in a simulation — never meets a slow step, also without the always-on spare level of large
+    builds: the build reports its fullest cell and the level comes on before a cell overflows.  (2) The policy of builds
+    of api.SPARE_ALWAYS_FROM leaves and more (the spare level is always launched), forced here: an ABRUPT change from
+    uniform to one tight cluster stays within a few normal steps.  (3) Occupancy policy alone: that one step takes the one-workgroup path
+    (correct, slow) and the step after is normal again.  Generous bounds: the measured figures are 0.86 ms (1), 0.64 ms
+    (2), 118 ms then 0.78 ms (3) against a uniform step of 0.6 ms."""
     from implicitbvh_amd import api
     n = 10_000_000
     g = torch.Generator(device="cuda").manual_seed(3)
@@ -236,7 +237,10 @@ def test_ten_million_leaves_changing_under_a_cache_chain_time_bounds(monkeypatch
     for _ in range(4):
         b, t_uniform = _timed_build(uniform, b)
     assert int(b._skew[0]) == 0 and 0 < b._skew.occupancy() < api.SPARE_OCCUPANCY
-    # (1) gradual
+    # (1) gradual, by the occupancy policy alone
+    monkeypatch.setattr(api, "SPARE_ALWAYS_FROM", 1 << 62)
+    for _ in range(2):
+        b, _ = _timed_build(uniform, b)
     v = uniform.clone()
     worst = 0.0
     for step in range(40):
@@ -249,16 +253,16 @@ def test_ten_million_leaves_changing_under_a_cache_chain_time_bounds(monkeypatch
     m = b.leaves.morton
     assert bool((m[1:] >= m[:-1]).all()) and int(b._skew[0]) >= 1
     assert worst < 8 * t_uniform + 2.0, (worst, t_uniform)
-    # (2) abrupt, spare level always on
-    monkeypatch.setattr(api, "SPARE_OCCUPANCY", 0)
+    # (2) abrupt, with the policy of the largest builds (SPARE_ALWAYS_FROM leaves and more): the spare level is always there
+    monkeypatch.setattr(api, "SPARE_ALWAYS_FROM", 1 << 22)
     for _ in range(3):
         b, _ = _timed_build(uniform, b)
     b, t_change = _timed_build(one, b)
     m = b.leaves.morton
     assert bool((m[1:] >= m[:-1]).all())
     assert t_change < 8 * t_uniform + 2.0, (t_change, t_uniform)
-    # (3) abrupt, default policy: slow once, right, and normal on the next step
-    monkeypatch.setattr(api, "SPARE_OCCUPANCY", 96)
+    # (3) abrupt, occupancy policy alone (what smaller builds get): slow once, right, and normal on the next step
+    monkeypatch.setattr(api, "SPARE_ALWAYS_FROM", 1 << 62)
     for _ in range(3):
         b, _ = _timed_build(uniform, b)
     b, t_slow = _timed_build(one, b)
