@@ -48,6 +48,7 @@ namespace msd {
 using rsort::block_exclusive_scan;
 using rsort::lds_barrier;
 using rsort::lds_exclusive_scan;
+using rsort::lds_exclusive_scan_pair;
 using rsort::lds_radix_pass;
 using rsort::RecordArgs;
 using rsort::wave_rank;
@@ -566,12 +567,17 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
     // (straight-line, unconditional loads with clamped indices: the compiler can then wait for exactly the values it
     // needs — s_waitcnt vmcnt(N) — instead of draining everything before the first use)
     uint32_t tile_off_a[DPT], tile_off_b[DPT];
+    // Level 1 without extra levels (li < 0): no plan_kernel ran — a launch that depends on its predecessor costs ~5 us.  The
+    // digit starts are the exclusive prefix of the <= 4,096 cell totals: every workgroup scans them for itself, in the same
+    // sweep (shared barriers) as its tile-local digit bases; workgroup 0 also leaves the starts and the hint words where
+    // the finish kernel reads them.
+    const bool own_starts = !L2 && li < 0;
 #pragma unroll
     for (int k = 0; k < DPT; ++k) {
         const int d = k * TPB + threadIdx.x;
         const int dc = d < radix ? d : radix - 1;
         tile_off_a[k] = scan_row[dc];
-        tile_off_b[k] = digit_start[dc];
+        tile_off_b[k] = own_starts ? tb.cell_total[dc] : digit_start[dc];
     }
     for (int rp = 0; rp < (L2 ? reps : 1); ++rp, tile_base += TILE) {
     if (L2 && tile_base >= end) break;
@@ -629,16 +635,48 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
             }
             local_base[d] = run;
             tile_cnt[k] = run;
+            if (own_starts) delta[d] = tile_off_b[k]; // (the cell's total)
         }
     }
     lds_barrier();
     IBVH_STAMP(0, 3);
-    lds_exclusive_scan<TPB, true>(local_base, radix, wave_tot);
+    if (own_starts) {
+        lds_exclusive_scan_pair<TPB, true>(local_base, delta, radix, wave_tot);
+        if (blockIdx.x == 0) { // what plan_kernel would have left for the finish kernel
+            uint32_t biggest = 0;
+#pragma unroll
+            for (int k = 0; k < DPT; ++k) {
+                const int d = k * TPB + threadIdx.x;
+                if (d < radix) {
+                    tb.cell_start[d] = delta[d];
+                    biggest = tile_off_b[k] > biggest ? tile_off_b[k] : biggest;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t t = (uint32_t)__shfl_xor((int)biggest, o, 64);
+                biggest = t > biggest ? t : biggest;
+            }
+            if (lane == 0) wave_tot[w] = biggest;
+            lds_barrier();
+            if (threadIdx.x == 0) {
+                for (int i = 1; i < W; ++i) biggest = wave_tot[i] > biggest ? wave_tot[i] : biggest;
+                const uint32_t cap = (uint32_t)-li; // (li = -(what a finish workgroup sorts) says "no plan")
+                const uint64_t occ = ((uint64_t)biggest * 128u + cap - 1) / cap;
+                tb.cell_start[radix] = (uint32_t)n;
+                tb.needed[0] = biggest > cap ? 1u : 0u;
+                tb.needed[1] = (uint32_t)(occ > 255 ? 255 : occ);
+            }
+            lds_barrier(); // (wave_tot is reused)
+        }
+    } else {
+        lds_exclusive_scan<TPB, true>(local_base, radix, wave_tot);
+    }
     IBVH_STAMP(0, 4);
 #pragma unroll
     for (int k = 0; k < DPT; ++k) {
         const int d = k * TPB + threadIdx.x;
-        if (d < radix) delta[d] = tile_off_a[k] + tile_off_b[k] + dst_first - local_base[d]; // mod 2^32
+        if (d < radix) delta[d] = tile_off_a[k] + (own_starts ? delta[d] : tile_off_b[k]) + dst_first - local_base[d]; // mod 2^32
     }
     uint32_t pos[IPT];
 #pragma unroll
@@ -1139,7 +1177,7 @@ static int launch_partitions(const Plan &p, const K *keys, int64_t n, const Reco
     const uint32_t words = (uint32_t)ra.lay.stride / 8u;
     const uint32_t inv_words = (uint32_t)((((uint64_t)1 << 32) + words - 1) / words);
     IBVH_LAUNCH((partition_kernel<K, PT, PI, false>), dim3(p.num_tiles), dim3(PT), smem, st, keys, n, p.shift, p.bits, p.tb,
-                p.num_tiles, ra, inv_words, p.bits, 0, out, levels > 0 ? side0 : (K *)nullptr);
+                p.num_tiles, ra, inv_words, p.bits, levels > 0 ? 0 : -(p.ftpb * p.fipt), out, levels > 0 ? side0 : (K *)nullptr);
     if (levels <= 0) return IBVH_OK;
     // extra levels: only the segments the level before found crowded (none for a uniform cloud: every workgroup
     // returns at once)
@@ -1193,8 +1231,11 @@ int sort_records(const Plan &p, int key_bytes, const void *keys, int64_t n, cons
         chunks = (p.num_tiles + rows - 1) / rows;
         IBVH_LAUNCH((scan_tiles_kernel), dim3(ndb * chunks), dim3(SCAN_TPB), 0, st, p.tb.tile_hist, p.tb.tile_scan, p.num_tiles, radix, rows,
                     p.tb.cell_total);
-        IBVH_LAUNCH((plan_kernel), dim3(1), dim3(PLAN_TPB), 0, st, p.tb, radix, (uint32_t)(p.ftpb * p.fipt), (uint32_t)(p.ptpb * p.pipt),
-                    levels, p.shift);
+        // (no extra levels: nothing but the cell starts and the hint would come out of the plan, and the partition kernel
+        // derives those from the cell totals itself — one dependent launch less)
+        if (levels > 0)
+            IBVH_LAUNCH((plan_kernel), dim3(1), dim3(PLAN_TPB), 0, st, p.tb, radix, (uint32_t)(p.ftpb * p.fipt), (uint32_t)(p.ptpb * p.pipt),
+                        levels, p.shift);
     }
     int rc = IBVH_ERR_INVALID_ARG;
 #define IBVH_PART(K, T, I) \

@@ -114,7 +114,7 @@ IBVH_D void wave_rank(const K (&key)[IPT], int shift, uint32_t mask, int bits, u
 }
 
 // in-place exclusive scans of TWO LDS arrays of `count` values each in one sweep (shared barriers); wave_tot: 2 * TPB/64
-template <int TPB> IBVH_D void lds_exclusive_scan_pair(uint32_t *a, uint32_t *b, int count, uint32_t *wave_tot) {
+template <int TPB, bool LDS_ONLY = false> IBVH_D void lds_exclusive_scan_pair(uint32_t *a, uint32_t *b, int count, uint32_t *wave_tot) {
     constexpr int W = TPB / 64;
     const int per = (count + TPB - 1) / TPB;
     const int lo = threadIdx.x * per;
@@ -138,7 +138,7 @@ template <int TPB> IBVH_D void lds_exclusive_scan_pair(uint32_t *a, uint32_t *b,
         wave_tot[w] = ia;
         wave_tot[W + w] = ib;
     }
-    __syncthreads();
+    wg_barrier<LDS_ONLY>();
     uint32_t ra = ia - sa, rb = ib - sb;
 #pragma unroll
     for (int i = 0; i < W; ++i)
@@ -154,7 +154,7 @@ template <int TPB> IBVH_D void lds_exclusive_scan_pair(uint32_t *a, uint32_t *b,
             ra += va;
             rb += vb;
         }
-    __syncthreads();
+    wg_barrier<LDS_ONLY>();
 }
 
 // grid = radix workgroups; workgroup d turns row d of tile_hist ([radix][num_tiles], digit-major) into its
