@@ -411,57 +411,40 @@ IBVH_D float wave_min_dpp_lane63(float v) {
 // parent-major loop compares the parent index itself (p >= (item + 1) >> 1  <=>  2p + 1 > item): 30 instructions per loop
 // iteration where round 2 took 42 — and the loops are bound by the scalar instructions around the seven v_cmpx
 // (count pass 0.155 -> 0.146 ms at 1e6 for the first five of them, measured).
-template <bool THR_GE>
+// PRUNE = false drops the seventh compare: the pair walk has no prune, and the self walk needs none in a subtree that lies
+// entirely to the right of the wave's own leaves (most of them) — one vector instruction of eleven per iteration, and an
+// iteration's vector instructions are what the pass is bound by (six more of them per parent-major iteration, v_readlane
+// instead of the scalar load: 125 -> 141 us, measured).
+#define IBVH_TEST_AND_APPEND(SEVENTH)                                                                                     \
+    asm volatile("s_mov_b64 exec, %[init]\n\t"                                                                           \
+                 "v_cmpx_le_f32 %[slo0], %[vup0]\n\t"                                                                    \
+                 "v_cmpx_ge_f32 %[sup0], %[vlo0]\n\t"                                                                    \
+                 "v_cmpx_le_f32 %[slo1], %[vup1]\n\t"                                                                    \
+                 "v_cmpx_ge_f32 %[sup1], %[vlo1]\n\t"                                                                    \
+                 "v_cmpx_le_f32 %[slo2], %[vup2]\n\t"                                                                    \
+                 "v_cmpx_ge_f32 %[sup2], %[vlo2]\n\t" SEVENTH "s_nop 2\n\t"                                             \
+                 "v_mbcnt_lo_u32_b32 %[tmp], exec_lo, 0\n\t"                                                             \
+                 "v_mbcnt_hi_u32_b32 %[tmp], exec_hi, %[tmp]\n\t"                                                        \
+                 "v_lshl_add_u32 %[tmp], %[tmp], 2, %[addr]\n\t"                                                         \
+                 "ds_write_b32 %[tmp], %[e]\n\t"                                                                         \
+                 "s_bcnt1_i32_b64 %[cnt], exec\n\t"                                                                      \
+                 "s_mov_b64 exec, -1\n\t"                                                                                \
+                 "s_lshl2_add_u32 %[addr], %[cnt], %[addr]"                                                              \
+                 : [tmp] "=&v"(tmp), [cnt] "=&s"(cnt), [addr] "+s"(lds_addr)                                             \
+                 : [init] "s"(init), [slo0] "s"(slo0), [slo1] "s"(slo1), [slo2] "s"(slo2), [sup0] "s"(sup0), [sup1] "s"(sup1), \
+                   [sup2] "s"(sup2), [vlo0] "v"(vlo0), [vlo1] "v"(vlo1), [vlo2] "v"(vlo2), [vup0] "v"(vup0), [vup1] "v"(vup1), \
+                   [vup2] "v"(vup2), [sthr] "s"(sthr), [vcmp] "v"(vcmp), [e] "v"(e)                                      \
+                 : "vcc", "scc", "memory")
+template <bool THR_GE, bool PRUNE = true>
 IBVH_D void test_and_append_f32(uint64_t init, float slo0, float slo1, float slo2, float sup0, float sup1, float sup2, float vlo0,
                                  float vlo1, float vlo2, float vup0, float vup1, float vup2, uint32_t sthr, uint32_t vcmp, uint32_t e,
                                  uint32_t &lds_addr) {
     uint32_t tmp, cnt;
-    if constexpr (THR_GE) {
-        asm volatile("s_mov_b64 exec, %[init]\n\t"
-                     "v_cmpx_le_f32 %[slo0], %[vup0]\n\t"
-                     "v_cmpx_ge_f32 %[sup0], %[vlo0]\n\t"
-                     "v_cmpx_le_f32 %[slo1], %[vup1]\n\t"
-                     "v_cmpx_ge_f32 %[sup1], %[vlo1]\n\t"
-                     "v_cmpx_le_f32 %[slo2], %[vup2]\n\t"
-                     "v_cmpx_ge_f32 %[sup2], %[vlo2]\n\t"
-                     "v_cmpx_ge_u32 %[sthr], %[vcmp]\n\t"
-                     "s_nop 2\n\t"
-                     "v_mbcnt_lo_u32_b32 %[tmp], exec_lo, 0\n\t"
-                     "v_mbcnt_hi_u32_b32 %[tmp], exec_hi, %[tmp]\n\t"
-                     "v_lshl_add_u32 %[tmp], %[tmp], 2, %[addr]\n\t"
-                     "ds_write_b32 %[tmp], %[e]\n\t"
-                     "s_bcnt1_i32_b64 %[cnt], exec\n\t"
-                     "s_mov_b64 exec, -1\n\t"
-                     "s_lshl2_add_u32 %[addr], %[cnt], %[addr]"
-                     : [tmp] "=&v"(tmp), [cnt] "=&s"(cnt), [addr] "+s"(lds_addr)
-                     : [init] "s"(init), [slo0] "s"(slo0), [slo1] "s"(slo1), [slo2] "s"(slo2), [sup0] "s"(sup0), [sup1] "s"(sup1),
-                       [sup2] "s"(sup2), [vlo0] "v"(vlo0), [vlo1] "v"(vlo1), [vlo2] "v"(vlo2), [vup0] "v"(vup0), [vup1] "v"(vup1),
-                       [vup2] "v"(vup2), [sthr] "s"(sthr), [vcmp] "v"(vcmp), [e] "v"(e)
-                     : "vcc", "scc", "memory");
-    } else {
-        asm volatile("s_mov_b64 exec, %[init]\n\t"
-                     "v_cmpx_le_f32 %[slo0], %[vup0]\n\t"
-                     "v_cmpx_ge_f32 %[sup0], %[vlo0]\n\t"
-                     "v_cmpx_le_f32 %[slo1], %[vup1]\n\t"
-                     "v_cmpx_ge_f32 %[sup1], %[vlo1]\n\t"
-                     "v_cmpx_le_f32 %[slo2], %[vup2]\n\t"
-                     "v_cmpx_ge_f32 %[sup2], %[vlo2]\n\t"
-                     "v_cmpx_lt_u32 %[sthr], %[vcmp]\n\t"
-                     "s_nop 2\n\t"
-                     "v_mbcnt_lo_u32_b32 %[tmp], exec_lo, 0\n\t"
-                     "v_mbcnt_hi_u32_b32 %[tmp], exec_hi, %[tmp]\n\t"
-                     "v_lshl_add_u32 %[tmp], %[tmp], 2, %[addr]\n\t"
-                     "ds_write_b32 %[tmp], %[e]\n\t"
-                     "s_bcnt1_i32_b64 %[cnt], exec\n\t"
-                     "s_mov_b64 exec, -1\n\t"
-                     "s_lshl2_add_u32 %[addr], %[cnt], %[addr]"
-                     : [tmp] "=&v"(tmp), [cnt] "=&s"(cnt), [addr] "+s"(lds_addr)
-                     : [init] "s"(init), [slo0] "s"(slo0), [slo1] "s"(slo1), [slo2] "s"(slo2), [sup0] "s"(sup0), [sup1] "s"(sup1),
-                       [sup2] "s"(sup2), [vlo0] "v"(vlo0), [vlo1] "v"(vlo1), [vlo2] "v"(vlo2), [vup0] "v"(vup0), [vup1] "v"(vup1),
-                       [vup2] "v"(vup2), [sthr] "s"(sthr), [vcmp] "v"(vcmp), [e] "v"(e)
-                     : "vcc", "scc", "memory");
-    }
+    if constexpr (!PRUNE) IBVH_TEST_AND_APPEND("");
+    else if constexpr (THR_GE) IBVH_TEST_AND_APPEND("v_cmpx_ge_u32 %[sthr], %[vcmp]\n\t");
+    else IBVH_TEST_AND_APPEND("v_cmpx_lt_u32 %[sthr], %[vcmp]\n\t");
 }
+#undef IBVH_TEST_AND_APPEND
 
 // `init` & iscontact(S, V) for the 64 lanes at once, S wave-uniform (scalar registers), V per lane: six v_cmpx narrow EXEC
 // from `init` — 6 VALU + 3 SALU where the compiler's six v_cmp into SGPR pairs need five s_and on top, and the result is a
@@ -560,9 +543,6 @@ constexpr int QUEUE_WAVES = IBVH_QUEUE_WAVES; // waves per workgroup (they share
 // round-2 kernel at 8 waves (31 + 4 spills, 20 B of scratch) 0.165 / 1.42 ms.  (profiles/r03_lvt_variants.txt)
 #ifndef IBVH_QUEUE_MINWAVES
 #define IBVH_QUEUE_MINWAVES 7
-#endif
-#ifndef IBVH_LVT_UNCHECKED
-#define IBVH_LVT_UNCHECKED 0 // 1: a second copy of the candidate loops without the queue-full check for subtrees that are certain to fit (measured: slower — more scalar spills)
 #endif
 #ifndef IBVH_LVT_QTABLE
 #define IBVH_LVT_QTABLE 0
@@ -1000,23 +980,11 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
                     qaddr = queue_lds + 4u * (uint32_t)qn;
                 }
             };
-            // (n_box * n_on bounds what this subtree can append: when that fits the queue as it stands — after a drain if need
-            // be — the loops run without the per-iteration check: two scalar instructions less per iteration)
-#if IBVH_LVT_UNCHECKED
-            if (qaddr + 4u * n_box * n_on > queue_lds + 4u * (uint32_t)QUEUE_CAP) {
-                qn = (int)((qaddr - queue_lds) >> 2);
-                drain(false);
-                qaddr = queue_lds + 4u * (uint32_t)qn;
-            }
-            const bool checked = qaddr + 4u * n_box * n_on > queue_lds + 4u * (uint32_t)QUEUE_CAP;
-#else
-            constexpr bool checked = true;
-#endif
             // 2p + 1 > item  <=>  p >= (item + 1) >> 1: the parent index itself is the scalar operand
             const uint32_t half_item = MODE == MODE_SELF ? (my_item + 1u) >> 1 : 0u;
-            auto loop_by_box = [&](auto chk) {
+            auto loop_by_box = [&](auto prune) {
                 for (uint64_t todo = box_mask; todo != 0;) {
-                    if constexpr (decltype(chk)::value) drain_if_full();
+                    drain_if_full();
                     const int u = __builtin_ctzll(todo);
                     asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(u)); // (todo &= todo - 1 costs three scalar instructions)
                     // (the parent box comes straight from memory with scalar loads — it is L2-hot, lane u just loaded it —
@@ -1026,36 +994,30 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
                     const N p = load_vol_uniform<N>((const char *)lp_nodes + pidx * (uint32_t)sizeof(N));
                     work.add(0, (uint32_t)(on_mask >> lane) & 1u);
                     work.add(2, lane == 0);
-                    test_and_append_f32<true>(on_mask, p.lo[0], p.lo[1], p.lo[2], p.up[0], p.up[1], p.up[2], q.q_node.lo[0], q.q_node.lo[1],
+                    test_and_append_f32<true, decltype(prune)::value>(on_mask, p.lo[0], p.lo[1], p.lo[2], p.up[0], p.up[1], p.up[2], q.q_node.lo[0], q.q_node.lo[1],
                                               q.q_node.lo[2], q.q_node.up[0], q.q_node.up[1], q.q_node.up[2], pidx, half_item,
                                               e_box + ((uint32_t)u << 6), qaddr);
                 }
             };
-            auto loop_by_query = [&](auto chk) {
+            auto loop_by_query = [&](auto prune) {
                 for (uint64_t todo = on_mask; todo != 0;) {
-                    if constexpr (decltype(chk)::value) drain_if_full();
+                    drain_if_full();
                     const int u = __builtin_ctzll(todo);
                     asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(u));
                     const N qb = broadcast_from_lane(q.q_node, u);
                     work.add(0, (uint32_t)(box_mask >> lane) & 1u);
                     const uint32_t thr = MODE == MODE_SELF ? wave_item0 + (uint32_t)u : 0u; // < right_leaf
-                    test_and_append_f32<false>(box_mask, qb.lo[0], qb.lo[1], qb.lo[2], qb.up[0], qb.up[1], qb.up[2], mybox.lo[0], mybox.lo[1],
+                    test_and_append_f32<false, decltype(prune)::value>(box_mask, qb.lo[0], qb.lo[1], qb.lo[2], qb.up[0], qb.up[1], qb.up[2], mybox.lo[0], mybox.lo[1],
                                                mybox.lo[2], mybox.up[0], mybox.up[1], mybox.up[2], thr, MODE == MODE_SELF ? right_leaf : 1u,
                                                e_qry | (uint32_t)u, qaddr);
                 }
             };
-#if IBVH_LVT_UNCHECKED
-            if (by_box) {
-                if (checked) loop_by_box(std::true_type{});
-                else loop_by_box(std::false_type{});
-            } else {
-                if (checked) loop_by_query(std::true_type{});
-                else loop_by_query(std::false_type{});
-            }
-#else
-            if (by_box) loop_by_box(std::true_type{});
-            else loop_by_query(std::true_type{});
-#endif
+            // (the pair walk has no prune: its loops carry six compares.  The self walk's prune drops nothing in a subtree
+            // beyond the wave's last item — most of them — but a second copy of the loops for those costs more than the compare
+            // it saves: 128 us against 125, six more SGPR spills; profiles/r03_lvt_variants.txt)
+            using Prune = std::integral_constant<bool, MODE == MODE_SELF>;
+            if (by_box) loop_by_box(Prune{});
+            else loop_by_query(Prune{});
             qn = (int)((qaddr - queue_lds) >> 2);
         } else {
             for (uint64_t todo = by_box ? box_mask : on_mask; todo != 0; todo &= todo - 1) {
