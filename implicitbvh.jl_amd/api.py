@@ -437,6 +437,29 @@ class BVH:
     def __init__(self, bounding_volumes, node_type=None, built_level=1, cache: Optional["BVH"] = None, options=None,
                  _out_of_place=False):
         torch = _require_gpu()
+        # Time-stepping fast path: the same call as the one that built `cache` (raw volumes of the same shape and type,
+        # default options, same node type and built level) repeats nothing but the build itself — every buffer, the tree
+        # shape and the filled-in build descriptor are the cache's.  This is the host's critical path of a loop that reads
+        # the contact count every step: the GPU idles from the moment the host sees the count until this call's first
+        # launch arrives.
+        fast = getattr(cache, "_fast", None) if cache is not None else None
+        if (fast is not None and options is None and not _out_of_place and not isinstance(bounding_volumes, BoundingVolumes)
+                and fast[0] == (bounding_volumes.shape, bounding_volumes.dtype, bounding_volumes.device, node_type, built_level)
+                and bounding_volumes.is_cuda and bounding_volumes.is_contiguous() and cache._skew.valid()
+                and bounding_volumes.data_ptr() != cache.leaves.buf.data_ptr()):
+            d = fast[1]
+            self.tree, self.built_level, self.types = cache.tree, cache.built_level, cache.types
+            self.skips, self.nodes, self._scratch = cache.skips, cache.nodes, cache._scratch
+            self.leaves, self.extrema, self._skew, self._fast = cache.leaves, cache.extrema, cache._skew, fast
+            used = self._skew[0]
+            spare = used > 0 or self._skew.occupancy() >= SPARE_OCCUPANCY or d.n >= SPARE_ALWAYS_FROM
+            d.sort_levels = min(used + (1 if spare else 0), abi.MAX_SORT_LEVELS)
+            lib.call("ibvh_build", C.byref(d), _ptr(bounding_volumes), _ptr(self.leaves.buf), _ptr(self.nodes), _ptr(self.skips),
+                     _ptr(self.extrema), _ptr(self._scratch), self._scratch.numel(), _stream())
+            return
+        fast_key = None
+        if options is None and not _out_of_place and not isinstance(bounding_volumes, BoundingVolumes):
+            fast_key = (bounding_volumes.shape, bounding_volumes.dtype, bounding_volumes.device, node_type, built_level)
         options = options or BVHOptions()
         node_type = node_type or BBox(torch.float32)  # default BBox{Float32} (build.jl:200)
         wrapped = isinstance(bounding_volumes, BoundingVolumes)
@@ -548,6 +571,7 @@ class BVH:
         d.skew_flag = self._skew.ptr()
         lib.call("ibvh_build", C.byref(d), vol_ptr, _ptr(self.leaves.buf), _ptr(self.nodes), _ptr(self.skips),
                  _ptr(self.extrema), _ptr(self._scratch), self._scratch.numel(), _stream())
+        self._fast = (fast_key, d) if fast_key is not None else None
 
     @classmethod
     def from_buffers(cls, types, n, leaves_buf, nodes, built_level=1):
