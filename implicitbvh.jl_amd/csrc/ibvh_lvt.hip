@@ -962,8 +962,11 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
         // shorter of the two loops: lanes = queries over the parents that touch the wave's boxes, or
         // lanes = parents over the active queries.  (Measured alternative: lanes = (query, parent) pairs
         // pulled together with ds_bpermute — as many steps as this loop has iterations, and slower.)
-        const uint32_t n_box = (uint32_t)__builtin_popcountll(box_mask), n_on = (uint32_t)__builtin_popcountll(on_mask);
-        const bool by_box = n_box < n_on; // (32-bit and uniform: a scalar compare)
+        uint32_t n_box = (uint32_t)__builtin_popcountll(box_mask), n_on = (uint32_t)__builtin_popcountll(on_mask);
+        // (opaque to the optimiser: it otherwise compares the two 64-bit popcounts, which the scalar unit cannot do — a v_mov
+        // and a v_cmp_lt_u64 per subtree — and counts the active queries early, parking the number in a vector register)
+        asm volatile("" : "+s"(n_box), "+s"(n_on));
+        const bool by_box = n_box < n_on;
         sec.lap(SEC_SUBTREE);
         const QE e_box = (QE)lane | ((QE)first32 << 6);             // + (u << 6)
         const QE e_qry = (QE)(first32 + (uint32_t)lane) << 6;       // | u
@@ -1102,7 +1105,8 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
                     for (uint64_t todo = hm; todo != 0; todo &= todo - 1) {
                         const int src = __builtin_ctzll(todo);
                         const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)idx, src);
-                        const N cbox = broadcast_from_lane(box, src);
+                        // (the cut node's box by scalar load — L2-hot, lane `src` has just fetched it — instead of six v_readlane)
+                        const N cbox = load_vol_uniform<N>((const char *)lvl_nodes + (c - lvl_first) * (uint32_t)sizeof(N));
                         brute(c, cbox);
                     }
                 } else {
