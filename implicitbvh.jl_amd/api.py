@@ -378,6 +378,11 @@ class _HostWords:
             else:
                 slot = self.next
                 self.next = (self.next + 1) % self.SLOTS
+                if self.next == 0:
+                    # the ring wraps: a scan kernel of the previous lap that is STILL queued would overwrite the new
+                    # owner's PENDING word with its own total.  One device synchronisation per SLOTS
+                    # traversals retires every such kernel before its slot is handed out again.
+                    _torch().cuda.synchronize()
             self.generation[slot] += 1
             gen = self.generation[slot]
         self.words[slot] = initial
@@ -457,9 +462,27 @@ class BVH:
             lib.call("ibvh_build", C.byref(d), _ptr(bounding_volumes), _ptr(self.leaves.buf), _ptr(self.nodes), _ptr(self.skips),
                      _ptr(self.extrema), _ptr(self._scratch), self._scratch.numel(), _stream())
             return
+        # The reference's literal time-stepping loop — `bvh = BVH(bvh.leaves, N; cache=bvh)` after the leaves were moved IN
+        # PLACE (build.jl:109-126, README.md:84-95): pre-wrapped records, user indices kept, the record array is input and
+        # output.  Same idea: nothing but the build call itself is repeated.
+        if (fast is not None and options is None and not _out_of_place and isinstance(bounding_volumes, BoundingVolumes)
+                and bounding_volumes is cache.leaves and fast[0] == ("in place", bounding_volumes.buf.data_ptr(), len(bounding_volumes),
+                                                                     node_type, built_level) and cache._skew.valid()):
+            d = fast[1]
+            self.tree, self.built_level, self.types = cache.tree, cache.built_level, cache.types
+            self.skips, self.nodes, self._scratch = cache.skips, cache.nodes, cache._scratch
+            self.leaves, self.extrema, self._skew, self._fast = cache.leaves, cache.extrema, cache._skew, fast
+            used = self._skew[0]
+            spare = used > 0 or self._skew.occupancy() >= SPARE_OCCUPANCY or d.n >= SPARE_ALWAYS_FROM
+            d.sort_levels = min(used + (1 if spare else 0), abi.MAX_SORT_LEVELS)
+            lib.call("ibvh_build", C.byref(d), C.c_void_p(0), _ptr(self.leaves.buf), _ptr(self.nodes), _ptr(self.skips),
+                     _ptr(self.extrema), _ptr(self._scratch), self._scratch.numel(), _stream())
+            return
         fast_key = None
         if options is None and not _out_of_place and not isinstance(bounding_volumes, BoundingVolumes):
             fast_key = (bounding_volumes.shape, bounding_volumes.dtype, bounding_volumes.device, node_type, built_level)
+        elif options is None and not _out_of_place:
+            fast_key = ("in place", bounding_volumes.buf.data_ptr(), len(bounding_volumes), node_type, built_level)
         options = options or BVHOptions()
         node_type = node_type or BBox(torch.float32)  # default BBox{Float32} (build.jl:200)
         wrapped = isinstance(bounding_volumes, BoundingVolumes)
@@ -645,7 +668,9 @@ class BVHTraversal:
             return
         total_t, capacity, finish = self._pending
         self._pending = None
-        total = int(total_t.item())  # the blocking read
+        total = int(total_t.item())  # the blocking read (the pinned word: published before the scan / writing pass finish)
+        if hasattr(total_t, "order_current_stream"):
+            total_t.order_current_stream()  # a consumer on another stream waits for the launch stream
         if self._cache1.dtype == _torch().int32 and total > 2**31 - 1:
             raise OverflowError("more than typemax(Int32) contacts")
         if total > capacity:
@@ -817,8 +842,26 @@ class _PendingTotal:
         self.event = None
 
     def launched(self):
-        """(nothing to record: the pinned word is polled; the fallback below synchronises the whole device)"""
+        """Remember the stream the traversal was enqueued on (the raw handle: no event is recorded on the hot path).  The
+        pinned word is published BEFORE the scan and the guarded writing pass have finished, so a consumer on ANOTHER
+        stream must be ordered behind this one explicitly: order_current_stream()."""
+        self.stream = _stream().value or 0
         return self
+
+    def order_current_stream(self):
+        """Make torch's current stream wait for everything enqueued on the launch stream so far (a no-op when they are the
+        same stream: in-order).  Called by BVHTraversal._resolve before the writing pass is re-launched or the contacts
+        are handed out."""
+        stream = getattr(self, "stream", None)
+        if stream is None:
+            return
+        cur = _stream().value or 0
+        if cur == stream:
+            return
+        torch = _torch()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.ExternalStream(stream) if stream else torch.cuda.default_stream())
+        torch.cuda.current_stream().wait_event(ev)
 
     def item(self):
         if self.owner.calls - self.calls >= self.owner.SLOTS:
@@ -834,7 +877,13 @@ class _PendingTotal:
                 v = int(words[k])
                 if v != _HostWords.PENDING:
                     return v
-        _torch().cuda.synchronize()  # the word never arrived (not expected): wait for everything, read the device copy
+        # the word never arrived (not expected): wait for the launch stream, read the device copy
+        stream = getattr(self, "stream", None)
+        torch = _torch()
+        if stream:
+            torch.cuda.ExternalStream(stream).synchronize()
+        else:
+            torch.cuda.synchronize()
         return int(self.owner.totals[self.slot].item())
 
 

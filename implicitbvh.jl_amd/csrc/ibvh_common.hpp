@@ -506,6 +506,7 @@ IBVH_HD int64_t ceil_div_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
 struct Tuning {
     int ray_block = 0;      // rays per wave of lvt_rays_kernel (0 = chosen from the batch size; a power of two, 64 .. 1024)
     int lvt_wide = 0;       // 1 = 64-bit queue entries for every tree (otherwise only for 29 .. 31 levels)
+    int lvt_dual = 0;       // 1 = BBox-node leaf queries take the dual descent (lvt_dual_kernel: fewer box tests, no overflow path; measured 7 - 25 % slower than lvt_queue_kernel in round 4), 0 = lvt_queue_kernel
     int lvt_xcd = 64;       // LVT item placement: 0 = round robin, 1 = one range per XCD, n = runs of n workgroups
     int sort_tile = 0;      // LSD path: keys per tile (0 = by size; 2048, 4096, 8192, 16384)
     int sort_lsd = 0;       // 1 = ibvh_sort_pairs always takes the plain LSD passes

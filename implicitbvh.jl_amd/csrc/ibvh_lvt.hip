@@ -1164,6 +1164,767 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_ke
     sec.flush();
 }
 
+
+// ---- (2b) BBox nodes: wave-local DUAL descent + candidate-pair queue ----------------------------------
+// Round 4.  lvt_queue_kernel pairs the wave's 64 queries with the tree in (wave, 128-leaf subtree) tiles: ~23 tiles per
+// wave at 1e6 random spheres, each paying a prologue of ~100 instructions and ~3 loop iterations of 27 for ~14 candidates —
+// 124 lane-level box tests per leaf, 4 % of them hits (profiles/r04_lvt_sections.json: descent 30 %, subtree prologues 19 %,
+// candidate loops 30 % of a wave's time).  This kernel descends BOTH sides instead: the wave's queries get a hierarchy of
+// their own (Q nodes: the lanes of an aligned group of 64 >> (d - 1) lanes on ONE side of the wave's best cut — the two-box
+// split of lvt_queue_kernel is its depth 1 — down to single lanes at depth 7; boxes of depths 1 .. 6 in an LDS table), and
+// the unit of work is a PAIR (Q node, tree node T) whose boxes touch.  A lane pops one pair, fetches T's two children (48
+// contiguous bytes) and Q's two children and tests the <= 4 child pairs at once; passing pairs are appended, in order, to
+// the next segment.  All pairs of a segment sit at the same (Q depth, T level): first only T is split (Q waits at depth 1),
+// the last six steps split both sides, and the pairs that pass the last step are (single query, leaf parent) — exactly the
+// candidates of lvt_queue_kernel, tested with the same exact box test — which the unchanged leaf-test step consumes.
+// tools/sim_lvt_dual.py (the oracle's tree of config 2): 54 lane-level box tests per leaf instead of 124, 23.5 64-lane
+// steps per wave (worst wave 32), 318 candidates per wave.
+//
+// Order.  Every query's candidates must reach the leaf-test step in increasing leaf-parent order.  Invariant: within a
+// segment, the pairs of any fixed Q node appear in increasing T order; a pair's children replace it in place, T-major
+// ((Qa,Ta) (Qb,Ta) (Qa,Tb) (Qb,Tb)), lanes in order — so it holds for the next segment, whatever subset passes.
+//
+// Memory.  Segments live in ONE LDS array used as a double-ended stack: even segments grow up from the bottom, odd ones
+// down from the top; a consumed segment is popped.  While everything fits this is a plain level-synchronous descent
+// (|segment s| + |segment s+1| <= capacity).  When the gap runs short the producer of segment s+1 pauses, segment s+1 is
+// consumed first (recursively: depth-first on demand), popped, and the producer resumes into a fresh segment s+1 — order is
+// preserved because a paused segment's remainder is only expanded after everything before it has left the pipeline.  A
+// reserve of four entries per deeper step guarantees progress (the chunk shrinks to what fits), so there is no overflow
+// path: heavily overlapping input degrades to smaller chunks instead of falling back to the exact walk.
+#ifndef IBVH_DUAL_STACK
+#define IBVH_DUAL_STACK 896
+#endif
+#ifndef IBVH_DUAL_MINWAVES
+#define IBVH_DUAL_MINWAVES 7
+#endif
+constexpr int DUAL_STACK = IBVH_DUAL_STACK;
+constexpr int DUAL_MINWAVES = IBVH_DUAL_MINWAVES;
+constexpr int DUAL_QSLOTS = 70; // depths 1 .. 6: 2^(d-1) groups + 1 (the group the cut falls into has a part on either side) = 69
+// first table slot of depth d (1 .. 6)
+IBVH_D int dual_qoff(int d) { return (1 << (d - 1)) - 1 + (d - 1); }
+
+// The dual step's four box tests for Float32 boxes, hand-scheduled like test_and_append_f32: chain k starts from the lanes in
+// i_k and narrows EXEC with six v_cmpx (iscontact(Q, T): Q.lo <= T.up and Q.up >= T.lo per axis — the same ordered compares
+// as the C++ operators), its surviving lanes are m_k.  All 64 lanes are active at the call site (wave-uniform control flow):
+// EXEC is restored to all-ones.
+#define IBVH_DUAL_CHAIN(I_, M_, Q_, T_)                  \
+    "s_mov_b64 exec, %[" I_ "]\n\t"                      \
+    "v_cmpx_le_f32 %[" Q_ "l0], %[" T_ "u0]\n\t"         \
+    "v_cmpx_ge_f32 %[" Q_ "u0], %[" T_ "l0]\n\t"         \
+    "v_cmpx_le_f32 %[" Q_ "l1], %[" T_ "u1]\n\t"         \
+    "v_cmpx_ge_f32 %[" Q_ "u1], %[" T_ "l1]\n\t"         \
+    "v_cmpx_le_f32 %[" Q_ "l2], %[" T_ "u2]\n\t"         \
+    "v_cmpx_ge_f32 %[" Q_ "u2], %[" T_ "l2]\n\t"         \
+    "s_mov_b64 %[" M_ "], exec\n\t"
+#define IBVH_DUAL_BOX(P_, B_) [P_##l0] "v"(B_.lo[0]), [P_##l1] "v"(B_.lo[1]), [P_##l2] "v"(B_.lo[2]), [P_##u0] "v"(B_.up[0]), [P_##u1] "v"(B_.up[1]), [P_##u2] "v"(B_.up[2])
+IBVH_D void dual_test4_f32(uint64_t i0, uint64_t i1, uint64_t i2, uint64_t i3, const BBox<float> &Qa, const BBox<float> &Qb, const BBox<float> &Ta,
+                           const BBox<float> &Tb, uint64_t &m0, uint64_t &m1, uint64_t &m2, uint64_t &m3) {
+    asm volatile(IBVH_DUAL_CHAIN("i0", "m0", "qa", "ta") IBVH_DUAL_CHAIN("i1", "m1", "qb", "ta") IBVH_DUAL_CHAIN("i2", "m2", "qa", "tb")
+                     IBVH_DUAL_CHAIN("i3", "m3", "qb", "tb") "s_mov_b64 exec, -1"
+                 : [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3)
+                 : [i0] "s"(i0), [i1] "s"(i1), [i2] "s"(i2), [i3] "s"(i3), IBVH_DUAL_BOX(qa, Qa), IBVH_DUAL_BOX(qb, Qb), IBVH_DUAL_BOX(ta, Ta),
+                   IBVH_DUAL_BOX(tb, Tb)
+                 : "vcc");
+}
+// two tests of one Q box (the steps that split only the tree side)
+IBVH_D void dual_test2_f32(uint64_t i0, uint64_t i2, const BBox<float> &Qa, const BBox<float> &Ta, const BBox<float> &Tb, uint64_t &m0, uint64_t &m2) {
+    asm volatile(IBVH_DUAL_CHAIN("i0", "m0", "qa", "ta") IBVH_DUAL_CHAIN("i2", "m2", "qa", "tb") "s_mov_b64 exec, -1"
+                 : [m0] "=&s"(m0), [m2] "=&s"(m2)
+                 : [i0] "s"(i0), [i2] "s"(i2), IBVH_DUAL_BOX(qa, Qa), IBVH_DUAL_BOX(ta, Ta), IBVH_DUAL_BOX(tb, Tb)
+                 : "vcc");
+}
+#undef IBVH_DUAL_CHAIN
+#undef IBVH_DUAL_BOX
+// the lanes of m_k store e_k at consecutive entries from LDS byte address `addr` on (`step` = +-4 bytes per entry, per lane)
+IBVH_D void dual_push4(uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3, uint32_t addr, uint32_t step, uint32_t e0, uint32_t e1, uint32_t e2, uint32_t e3) {
+    asm volatile("s_mov_b64 exec, %[m0]\n\t"
+                 "ds_write_b32 %[addr], %[e0]\n\t"
+                 "v_add_u32 %[addr], %[addr], %[step]\n\t"
+                 "s_mov_b64 exec, %[m1]\n\t"
+                 "ds_write_b32 %[addr], %[e1]\n\t"
+                 "v_add_u32 %[addr], %[addr], %[step]\n\t"
+                 "s_mov_b64 exec, %[m2]\n\t"
+                 "ds_write_b32 %[addr], %[e2]\n\t"
+                 "v_add_u32 %[addr], %[addr], %[step]\n\t"
+                 "s_mov_b64 exec, %[m3]\n\t"
+                 "ds_write_b32 %[addr], %[e3]\n\t"
+                 "s_mov_b64 exec, -1"
+                 : [addr] "+v"(addr)
+                 : [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3), [step] "v"(step), [e0] "v"(e0), [e1] "v"(e1), [e2] "v"(e2), [e3] "v"(e3)
+                 : "memory");
+}
+IBVH_D void dual_push2(uint64_t m0, uint64_t m2, uint32_t addr, uint32_t step, uint32_t e0, uint32_t e2) {
+    asm volatile("s_mov_b64 exec, %[m0]\n\t"
+                 "ds_write_b32 %[addr], %[e0]\n\t"
+                 "v_add_u32 %[addr], %[addr], %[step]\n\t"
+                 "s_mov_b64 exec, %[m2]\n\t"
+                 "ds_write_b32 %[addr], %[e2]\n\t"
+                 "s_mov_b64 exec, -1"
+                 : [addr] "+v"(addr)
+                 : [m0] "s"(m0), [m2] "s"(m2), [step] "v"(step), [e0] "v"(e0), [e2] "v"(e2)
+                 : "memory");
+}
+
+// The lean phase's four tests: the wave's two side boxes A and B (wave-uniform: scalar operands) against a lane's two child
+// boxes Ta (lanes ia) and Tb (lanes ib); same chains as dual_test4_f32.
+#define IBVH_SIDE_CHAIN(I_, M_, S_, T_)                  \
+    "s_mov_b64 exec, %[" I_ "]\n\t"                      \
+    "v_cmpx_le_f32 %[" S_ "l0], %[" T_ "u0]\n\t"         \
+    "v_cmpx_ge_f32 %[" S_ "u0], %[" T_ "l0]\n\t"         \
+    "v_cmpx_le_f32 %[" S_ "l1], %[" T_ "u1]\n\t"         \
+    "v_cmpx_ge_f32 %[" S_ "u1], %[" T_ "l1]\n\t"         \
+    "v_cmpx_le_f32 %[" S_ "l2], %[" T_ "u2]\n\t"         \
+    "v_cmpx_ge_f32 %[" S_ "u2], %[" T_ "l2]\n\t"         \
+    "s_mov_b64 %[" M_ "], exec\n\t"
+#define IBVH_VBOX(P_, B_) [P_##l0] "v"(B_.lo[0]), [P_##l1] "v"(B_.lo[1]), [P_##l2] "v"(B_.lo[2]), [P_##u0] "v"(B_.up[0]), [P_##u1] "v"(B_.up[1]), [P_##u2] "v"(B_.up[2])
+#define IBVH_SBOX(P_, B_) [P_##l0] "s"(B_.lo[0]), [P_##l1] "s"(B_.lo[1]), [P_##l2] "s"(B_.lo[2]), [P_##u0] "s"(B_.up[0]), [P_##u1] "s"(B_.up[1]), [P_##u2] "s"(B_.up[2])
+IBVH_D void dual_sides4_f32(uint64_t ia, uint64_t ib, const BBox<float> &A, const BBox<float> &B, const BBox<float> &Ta, const BBox<float> &Tb,
+                            uint64_t &maa, uint64_t &mba, uint64_t &mab, uint64_t &mbb) {
+    asm volatile(IBVH_SIDE_CHAIN("ia", "maa", "a", "ta") IBVH_SIDE_CHAIN("ia", "mba", "b", "ta") IBVH_SIDE_CHAIN("ib", "mab", "a", "tb")
+                     IBVH_SIDE_CHAIN("ib", "mbb", "b", "tb") "s_mov_b64 exec, -1"
+                 : [maa] "=&s"(maa), [mba] "=&s"(mba), [mab] "=&s"(mab), [mbb] "=&s"(mbb)
+                 : [ia] "s"(ia), [ib] "s"(ib), IBVH_SBOX(a, A), IBVH_SBOX(b, B), IBVH_VBOX(ta, Ta), IBVH_VBOX(tb, Tb)
+                 : "vcc");
+}
+#undef IBVH_SIDE_CHAIN
+#undef IBVH_VBOX
+#undef IBVH_SBOX
+
+// The lane k after which the wave's 64 query boxes are best cut in two (minimum sum of the half-areas of box[0..k] and
+// box[k+1..63]; lvt_queue_kernel's two-box split, see there), wave-uniform.  `box` is empty for lanes without a query.
+template <class N> IBVH_D int dual_choose_cut(const N &box, int lane) {
+    using TN = typename N::elt;
+    const TN big = float_max<TN>();
+    auto half_area = [](const N &b) {
+        float d[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            d[k] = (float)b.up[k] - (float)b.lo[k];
+            d[k] = d[k] > 0.0f ? d[k] : 0.0f; // empty (or NaN) -> 0
+        }
+        return d[0] * d[1] + d[1] * d[2] + d[0] * d[2];
+    };
+    if constexpr (std::is_same<TN, float>::value) {
+        N pre = box, rev, rsuf;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            rev.lo[k] = __shfl(pre.lo[k], 63 - lane, 64);
+            rev.up[k] = __shfl(pre.up[k], 63 - lane, 64);
+        }
+        float mn[6] = {pre.lo[0], pre.lo[1], pre.lo[2], rev.lo[0], rev.lo[1], rev.lo[2]};
+        float mx[6] = {pre.up[0], pre.up[1], pre.up[2], rev.up[0], rev.up[1], rev.up[2]};
+        wave_prefix_scans_dpp(mn, mx);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            pre.lo[k] = mn[k];
+            pre.up[k] = mx[k];
+            rsuf.lo[k] = mn[3 + k];
+            rsuf.up[k] = mx[3 + k];
+        }
+        const float ra = half_area(rsuf);
+        float sa = __shfl(ra, 62 - lane, 64);
+        sa = lane == 63 ? 0.0f : sa;
+        float cost = half_area(pre) + sa;
+        cost = cost == cost ? cost : __builtin_inff();
+        const float m = wave_min_dpp_lane63(cost);
+        const float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
+        const uint64_t at = __builtin_amdgcn_ballot_w64(cost == best);
+        return at != 0 ? (int)__builtin_ctzll(at) : 0;
+    } else {
+        N pre = box, suf = box, nxt_suf;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                TN t = __shfl_up(pre.lo[k], o, 64);
+                pre.lo[k] = pre.lo[k] < t ? pre.lo[k] : t;
+                t = __shfl_up(pre.up[k], o, 64);
+                pre.up[k] = pre.up[k] > t ? pre.up[k] : t;
+                t = __shfl_down(suf.lo[k], o, 64);
+                suf.lo[k] = suf.lo[k] < t ? suf.lo[k] : t;
+                t = __shfl_down(suf.up[k], o, 64);
+                suf.up[k] = suf.up[k] > t ? suf.up[k] : t;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            nxt_suf.lo[k] = __shfl_down(suf.lo[k], 1, 64);
+            nxt_suf.up[k] = __shfl_down(suf.up[k], 1, 64);
+            if (lane == 63) {
+                nxt_suf.lo[k] = big;
+                nxt_suf.up[k] = -big;
+            }
+        }
+        float cost = half_area(pre) + half_area(nxt_suf);
+        cost = cost == cost ? cost : __builtin_inff();
+        uint64_t key = ((uint64_t)__float_as_uint(cost) << 32) | (uint32_t)lane;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint64_t t = (uint64_t)__shfl_xor((long long)key, o, 64);
+            key = t < key ? t : key;
+        }
+        return (int)(key & 63u);
+    }
+}
+
+
+// The schedule of a dual descent, made once per launch on the host (it depends on the tree's shape only): row[cur + 1]
+// describes the step that consumes segment cur (cur = -1: the roots).
+struct DualPlan {
+    int32_t S;        // expansion steps 0 .. S-1 consume segments 0 .. S-1; segment S holds the candidates
+    int32_t roots;    // real nodes of the level the descent starts at
+    int32_t q_first;  // first step that splits the query side (the steps before it split only T)
+    int32_t pad_;
+    uint32_t row[34][8];
+    // row: [0], [1] byte offset (low, high word) of the first node of the level the step's T children live on
+    //      [2] T child b exists for t < this (0: the step does not split T)
+    //      [3] bit 0: the step splits T; bit 1: its Q children are groups of the next depth (table rows / single lanes);
+    //          bit 2: two Q children (four tests); bit 3: they are single lanes; bit 4: the pairs are the roots themselves;
+    //          bits 8-9: code of Q child b - code of Q child a; bits 16-21: levels - (level of the T children);
+    //          bits 24-27: depth of the Q children
+    //      [4] table slot of the first Q child row
+};
+enum { DUAL_TS = 1, DUAL_QS = 2, DUAL_Q2 = 4, DUAL_SINGLES = 8, DUAL_IOTA = 16 };
+inline DualPlan make_dual_plan(int levels, uint32_t vl, int L0, size_t node_bytes) {
+    auto num_real = [&](int level) -> uint32_t { return (1u << (level - 1)) - (vl >> (levels - level)); };
+    auto first_mem = [&](int level) -> uint32_t {
+        const uint32_t v = vl >> (levels - (level - 1));
+        return (1u << (level - 1)) - (2u * v - (uint32_t)__builtin_popcount(v)) - 1u;
+    };
+    DualPlan p{};
+    const int lp = levels - 1, nT = lp - L0;
+    p.S = nT > 6 ? nT : 6;
+    p.roots = (int32_t)num_real(L0);
+    const int t_first = p.S - nT, q_first = p.S - 6; // first step that splits T / Q
+    p.q_first = q_first;
+    for (int cur = -1; cur < p.S; ++cur) {
+        const bool root = cur < 0, split_t = !root && cur >= t_first, split_q = root || cur >= q_first;
+        const int tl_out = L0 + (root ? 0 : (cur >= t_first ? cur - t_first + 1 : 0));
+        const int qd_out = root ? 1 : 1 + (cur >= q_first ? cur - q_first + 1 : 0);
+        const bool qs = split_q && !root;
+        uint32_t *r = p.row[cur + 1];
+        const uint64_t off = (uint64_t)first_mem(tl_out) * node_bytes;
+        r[0] = (uint32_t)off;
+        r[1] = (uint32_t)(off >> 32);
+        r[2] = split_t ? num_real(tl_out) >> 1 : 0u;
+        r[3] = (split_t ? DUAL_TS : 0) | (qs ? DUAL_QS : 0) | (split_q ? DUAL_Q2 : 0) | (qd_out == 7 ? DUAL_SINGLES : 0) | (root ? DUAL_IOTA : 0) |
+               ((root ? 1u : 2u) << 8) | ((uint32_t)(levels - tl_out) << 16) | ((uint32_t)qd_out << 24);
+        r[4] = qs && qd_out <= 6 ? (uint32_t)((1 << (qd_out - 1)) - 1 + (qd_out - 1)) : 0u;
+    }
+    return p;
+}
+// the lanes below m (0 .. 64) as a mask: s_bfm_b64 takes the width modulo 64
+IBVH_D uint64_t dual_mask_below(int m) {
+    uint64_t r;
+    asm("s_bfm_b64 %0, %1, 0" : "=s"(r) : "s"(m));
+    return m >= 64 ? ~(uint64_t)0 : r;
+}
+
+// One butterfly step of the min / max all-reduce over aligned lane groups, on DPP for Float32 (six minima, six maxima in one
+// block: a DPP operand must not have been written by the two preceding VALU instructions).  STEP 0 .. 3 complete the groups of
+// 2, 4, 8 and 16 lanes (quad permutes, then the half-row and row mirrors: any pairing of the two halves of a group will do).
+#define IBVH_DPP12(CTRL)                                                                                                       \
+    asm volatile("s_nop 1\n\t"                                                                                                 \
+                 "v_min_f32_dpp %0, %0, %0 " CTRL "\n\tv_min_f32_dpp %1, %1, %1 " CTRL "\n\tv_min_f32_dpp %2, %2, %2 " CTRL "\n\t"   \
+                 "v_min_f32_dpp %3, %3, %3 " CTRL "\n\tv_min_f32_dpp %4, %4, %4 " CTRL "\n\tv_min_f32_dpp %5, %5, %5 " CTRL "\n\t"   \
+                 "v_max_f32_dpp %6, %6, %6 " CTRL "\n\tv_max_f32_dpp %7, %7, %7 " CTRL "\n\tv_max_f32_dpp %8, %8, %8 " CTRL "\n\t"   \
+                 "v_max_f32_dpp %9, %9, %9 " CTRL "\n\tv_max_f32_dpp %10, %10, %10 " CTRL "\n\tv_max_f32_dpp %11, %11, %11 " CTRL      \
+                 : "+v"(mn[0]), "+v"(mn[1]), "+v"(mn[2]), "+v"(mn[3]), "+v"(mn[4]), "+v"(mn[5]), "+v"(mx[0]), "+v"(mx[1]), "+v"(mx[2]), \
+                   "+v"(mx[3]), "+v"(mx[4]), "+v"(mx[5]))
+template <int STEP> IBVH_D void group_reduce_step_dpp(float (&mn)[6], float (&mx)[6]) {
+    if constexpr (STEP == 0) IBVH_DPP12("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    else if constexpr (STEP == 1) IBVH_DPP12("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    else if constexpr (STEP == 2) IBVH_DPP12("row_half_mirror row_mask:0xf bank_mask:0xf");
+    else IBVH_DPP12("row_mirror row_mask:0xf bank_mask:0xf");
+}
+#undef IBVH_DPP12
+
+template <class L, class N, class I, int MODE, bool WRITE, bool NARROW, bool WIDE, bool COUNT = false>
+__global__ __launch_bounds__(64, DUAL_MINWAVES) void lvt_dual_kernel(Args<L, N, I> a, PairCache<I> cache, DualPlan plan) {
+    using TN = typename N::elt;
+    Work<COUNT> work;
+    using Q = Query<L, N, I, MODE, WRITE, NARROW>;
+    using Cnt = typename Q::Cnt;
+    using QE = typename std::conditional<WIDE, uint64_t, uint32_t>::type; // pair: Q node (7 bits) | T index within its level << 7
+    constexpr int CAP = WIDE ? DUAL_STACK / 2 : DUAL_STACK;
+    __shared__ QE s_stack[CAP];
+    constexpr int NW = (int)(sizeof(N) / 8); // a node box as 8-byte words
+    __shared__ __attribute__((aligned(16))) uint64_t s_qtab[DUAL_QSLOTS * NW];
+    __shared__ Cnt s_cnt[64];
+    Q q(a, cache);
+    const int lane = threadIdx.x;
+    // wave-dense contact cache: see lvt_queue_kernel
+    struct Entry {
+        IndexPair<I> pair;
+        I meta;
+    };
+    const int64_t first_item = q.item - lane;
+    const int64_t items_here = a.n_items - first_item < 64 ? a.n_items - first_item : 64;
+    char *region = cache.K > 0 && items_here > 0 ? (char *)(cache.slots + first_item * (int64_t)cache.K) : nullptr;
+    const int entry_cap = region ? (int)(((int64_t)items_here * cache.K * (int64_t)sizeof(IndexPair<I>) - 16) / (int64_t)sizeof(Entry)) : 0;
+    Entry *entries = (Entry *)(region + 16);
+    int wfill = 0;
+    if constexpr (WRITE) {
+        if (a.guard_total != nullptr && load_total_uniform(a.guard_total) > a.guard_capacity) return;
+        q.w = (q.valid && q.item > 0) ? (Cnt)a.counts[q.item - 1] : 0;
+        const int fill = region ? __builtin_amdgcn_readfirstlane(*(const int *)region) : -1;
+        if (fill >= 0) {
+            s_cnt[lane] = q.w;
+            __builtin_amdgcn_wave_barrier();
+            for (int t = lane; t < fill; t += 64) {
+                const Entry e = entries[t];
+                const int64_t dest = (int64_t)s_cnt[(int)(e.meta & 63)] + (int64_t)(e.meta >> 6);
+                a.contacts[dest] = e.pair;
+            }
+            return;
+        }
+        q.lane_on = q.valid;
+    }
+    if constexpr (MODE == MODE_PAIR) {
+        if (a.built_level <= 1 && a.tree.levels >= 2) {
+            const N root = load_vol_uniform<N>(a.nodes);
+            work.add(0, q.lane_on);
+            work.add(2, lane == 0);
+            if (__builtin_amdgcn_ballot_w64(q.lane_on & iscontact(q.q_node, root)) == 0) {
+                work.flush(a.work);
+                if constexpr (!WRITE) {
+                    if (q.valid) a.counts[q.item] = (I)0;
+                    if (region && lane == 0) *(int *)region = 0;
+                }
+                return;
+            }
+        }
+    }
+
+    // (wave-uniform arithmetic is 32-bit on purpose, see lvt_queue_kernel)
+    const int levels = (int)a.tree.levels;
+    const uint32_t vl = (uint32_t)a.tree.virtual_leaves;
+    auto num_real = [&](int level) -> uint32_t { return (1u << (level - 1)) - (vl >> (levels - level)); };
+    auto first_mem = [&](int level) -> uint32_t {
+        const uint32_t v = vl >> (levels - (level - 1));
+        return (1u << (level - 1)) - (2u * v - (uint32_t)__builtin_popcount(v)) - 1u;
+    };
+    const uint32_t my_item = (uint32_t)q.item;
+    const uint32_t wave_item0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_item);
+    const uint32_t n_leaves = (uint32_t)a.tree.real_leaves;
+    Cnt *cnts = s_cnt;
+    cnts[lane] = WRITE ? q.w : (Cnt)0;
+
+    // ---- the wave's own hierarchy ----
+    N qbox; // this lane's query as a node box; empty for lanes without a query (NaN boxes touch nothing)
+    {
+        const TN big = float_max<TN>();
+        bool use = q.lane_on;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) use = use && q.q_node.lo[k] == q.q_node.lo[k] && q.q_node.up[k] == q.q_node.up[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            qbox.lo[k] = use ? q.q_node.lo[k] : big;
+            qbox.up[k] = use ? q.q_node.up[k] : -big;
+        }
+    }
+    const int ksplit = dual_choose_cut(qbox, lane); // side A = lanes 0 .. ksplit, side B = the rest
+    N side_a, side_b_;
+    {
+        const TN big = float_max<TN>();
+        const bool side_b = lane > ksplit;
+        // the part of this lane's aligned group on side A (0 .. 2) / on side B (3 .. 5), minima and maxima
+        TN mn[6], mx[6];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = side_b ? big : qbox.lo[k];
+            mx[k] = side_b ? -big : qbox.up[k];
+            mn[3 + k] = side_b ? qbox.lo[k] : big;
+            mx[3 + k] = side_b ? qbox.up[k] : -big;
+        }
+        auto store = [&](int slot, int part) { // (8-byte words: ds_write_b64)
+            N b;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                b.lo[k] = mn[3 * part + k];
+                b.up[k] = mx[3 * part + k];
+            }
+            uint64_t w[NW];
+            __builtin_memcpy(w, &b, sizeof(N));
+#pragma unroll
+            for (int k = 0; k < NW; ++k) s_qtab[slot * NW + k] = w[k];
+        };
+        auto step = [&](auto dtag) {
+            constexpr int d = decltype(dtag)::value; // depth whose groups (64 >> (d-1) lanes) are complete after this step
+            constexpr int o = 1 << (6 - d);
+            bool done = false;
+            if constexpr (std::is_same<TN, float>::value && o <= 8) {
+                group_reduce_step_dpp<6 - d>(mn, mx);
+                done = true;
+            }
+            if (!done) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    TN t = __shfl_xor(mn[k], o, 64);
+                    mn[k] = mn[k] < t ? mn[k] : t;
+                    t = __shfl_xor(mx[k], o, 64);
+                    mx[k] = mx[k] > t ? mx[k] : t;
+                }
+            }
+            const int j = lane >> (7 - d), sidx = ksplit >> (7 - d);
+            if ((lane & (2 * o - 1)) == 0) {
+                if (j <= sidx) store(dual_qoff(d) + j, 0);
+                if (j >= sidx) store(dual_qoff(d) + j + 1, 1);
+            }
+        };
+        step(std::integral_constant<int, 6>{});
+        step(std::integral_constant<int, 5>{});
+        step(std::integral_constant<int, 4>{});
+        step(std::integral_constant<int, 3>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 1>{});
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { // every lane now holds the two side boxes
+            side_a.lo[k] = mn[k];
+            side_a.up[k] = mx[k];
+            side_b_.lo[k] = mn[3 + k];
+            side_b_.up[k] = mx[3 + k];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- schedule ----
+    const int S = plan.S;               // expansion steps 0 .. S-1 consume segments 0 .. S-1; segment S holds the candidates
+    const int roots = plan.roots;
+    int lo_ptr = 0, hi_ptr = CAP;       // free entries: [lo_ptr, hi_ptr)
+    auto seg_dir = [](int s) { return (s & 1) ? -1 : 1; };
+    const uint32_t stack_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) QE *)s_stack;
+    auto below = [](uint64_t mk, uint32_t acc) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, acc)); };
+
+    // leaf tests of `avail` candidates (entries hd .. of the segment at org, direction dir), one pair per lane
+    // (lvt_queue_kernel's stage c)
+    auto pair_step = [&](int org, int dir, int hd, int avail) {
+        const bool v = lane < avail;
+        const QE e = s_stack[org + dir * (hd + (v ? lane : 0))];
+        const int qi = (int)((uint32_t)(e >> 1) & 63u);
+        const uint32_t pos = 2u * (uint32_t)(e >> 7);
+        const bool has_b = v & (pos + 1u < n_leaves);
+        uint64_t mor_a = 0, mor_b = 0;
+        const char *rec = a.leaves + (int64_t)pos * a.lay.stride;
+        const char *rec_b = (pos + 1u < n_leaves) ? rec + a.lay.stride : rec;
+        const L leaf_a = load_vol<L>(rec), leaf_b = load_vol<L>(rec_b);
+        const I idx_a = load_index<I>(rec, a.lay), idx_b = load_index<I>(rec_b, a.lay);
+        if constexpr (NARROW) {
+            if (a.narrow == IBVH_NARROW_MORTON_LT) {
+                mor_a = load_morton(rec, a.lay);
+                mor_b = load_morton(rec_b, a.lay);
+            }
+        }
+        const L ql = shuffle_from(q.q_leaf, qi);
+        const I qidx = __shfl(q.q_index, qi, 64);
+        const uint32_t item_q = wave_item0 + (uint32_t)qi;
+        bool hit_a = v & iscontact(ql, leaf_a), hit_b = has_b & iscontact(ql, leaf_b);
+        work.add(1, (uint32_t)v + (uint32_t)has_b);
+        work.add(3, (uint32_t)v + (uint32_t)has_b);
+        if constexpr (MODE == MODE_SELF) {
+            hit_a = hit_a & (pos > item_q);
+            hit_b = hit_b & (pos + 1u > item_q);
+        }
+        if constexpr (NARROW) {
+            const uint64_t qm = (uint64_t)__shfl((long long)q.q_morton, qi, 64);
+            const bool fl = MODE == MODE_PAIR && a.flip;
+            hit_a = hit_a && (fl ? narrow_eval(a.narrow, mor_a, idx_a, qm, qidx) : narrow_eval(a.narrow, qm, qidx, mor_a, idx_a));
+            hit_b = hit_b && (fl ? narrow_eval(a.narrow, mor_b, idx_b, qm, qidx) : narrow_eval(a.narrow, qm, qidx, mor_b, idx_b));
+        }
+        uint32_t same_lo, same_hi;
+        {
+            const uint64_t vm = dual_mask_below(avail);
+            same_lo = (uint32_t)vm;
+            same_hi = (uint32_t)(vm >> 32);
+        }
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const int x = (int)((uint32_t)qi << (31 - b)) >> 31;
+            const uint64_t m = __builtin_amdgcn_ballot_w64(x != 0);
+            same_lo = __builtin_amdgcn_bitop3_b32(same_lo, (uint32_t)m, (uint32_t)x, 0x90);
+            same_hi = __builtin_amdgcn_bitop3_b32(same_hi, (uint32_t)(m >> 32), (uint32_t)x, 0x90);
+        }
+        const uint64_t m_a = __builtin_amdgcn_ballot_w64(hit_a), m_b = __builtin_amdgcn_ballot_w64(hit_b);
+        const uint32_t sa_lo = same_lo & (uint32_t)m_a, sa_hi = same_hi & (uint32_t)(m_a >> 32);
+        const uint32_t sb_lo = same_lo & (uint32_t)m_b, sb_hi = same_hi & (uint32_t)(m_b >> 32);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi(sb_hi, __builtin_amdgcn_mbcnt_lo(sb_lo, __builtin_amdgcn_mbcnt_hi(sa_hi, __builtin_amdgcn_mbcnt_lo(sa_lo, 0u))));
+        const int tot = __builtin_popcount(sa_lo) + __builtin_popcount(sa_hi) + __builtin_popcount(sb_lo) + __builtin_popcount(sb_hi);
+        const bool group_first = __builtin_amdgcn_mbcnt_hi(same_hi, __builtin_amdgcn_mbcnt_lo(same_lo, 0u)) == 0u;
+        const Cnt base = cnts[qi];
+        __builtin_amdgcn_wave_barrier();
+        if (v && group_first && tot > 0) cnts[qi] = base + (Cnt)tot;
+        __builtin_amdgcn_wave_barrier();
+        auto put = [&](Cnt at, I lidx, int slot, uint32_t lpos) {
+            IndexPair<I> c2;
+            if (a.positions) {
+                const I qp = (I)(item_q + 1u), lpp = (I)(lpos + 1u);
+                c2 = (MODE == MODE_PAIR && a.flip) ? IndexPair<I>{lpp, qp} : IndexPair<I>{qp, lpp};
+            } else if constexpr (MODE == MODE_SELF) c2 = qidx > lidx ? IndexPair<I>{lidx, qidx} : IndexPair<I>{qidx, lidx};
+            else c2 = a.flip ? IndexPair<I>{lidx, qidx} : IndexPair<I>{qidx, lidx};
+            if constexpr (WRITE) {
+                a.contacts[(int64_t)at] = c2;
+            } else {
+                if (slot < entry_cap) entries[slot] = Entry{c2, (I)((I)qi | ((I)(at - 0) << 6))};
+            }
+        };
+        const Cnt at = base + (Cnt)rank;
+        const int n_a = __popcll(m_a);
+        if (hit_a) put(at, idx_a, wfill + (int)below(m_a, 0u), pos);
+        if (hit_b) put(at + (hit_a ? 1 : 0), idx_b, wfill + n_a + (int)below(m_b, 0u), pos + 1u);
+        if constexpr (!WRITE) wfill = __builtin_amdgcn_readfirstlane(wfill + n_a + __popcll(m_b));
+    };
+
+    // ---- scheduler (wave-uniform): breadth-first while the segments fit, depth-first on demand ----
+    // cur = the segment being consumed (-1: the roots), its state in scalar registers.  A segment that has to wait
+    // half-consumed (space ran short: what it produced so far is consumed first) parks its state in lane cur + 1 of sg_*.
+    int cur = -1, c_org = 0, c_cnt = roots, c_head = 0;
+    uint32_t paused = 0;                // bit s + 1: segment s is parked
+    int sg_head = 0, sg_cnt = 0, sg_org = 0;
+
+    // ---- lean phase: while only T is split and the frontier fits the wave's 64 lanes, it lives in registers (lane j: the
+    // j-th node, at most 64), both side boxes are tested at once from scalar registers and a node that touches either side
+    // is kept ONCE; no segment bookkeeping.  The step that leaves the phase (the next step splits Q, or more than 64 nodes
+    // pass) pushes (side, node) pairs into the segment the general scheduler continues from. ----
+    if (roots <= 64) {
+        const N A = broadcast_from_lane(side_a, 0), B = broadcast_from_lane(side_b_, 0);
+        uint32_t ft = (uint32_t)lane; // the frontier: T index within its level
+        int fcnt = roots;
+        for (int s = -1;; ++s) {      // the step that consumes "segment" s
+            const uint32_t *row = plan.row[s + 1];
+            const uint32_t flags = row[3], tb_lim = row[2];
+            const int ts = (int)(flags & DUAL_TS);
+            const int sh = (int)((flags >> 16) & 63u);
+            const char *lvl = (const char *)a.nodes + (((uint64_t)row[1] << 32) | row[0]);
+            const uint64_t vm = dual_mask_below(fcnt);
+            const uint32_t t = lane < fcnt ? ft : 0u;
+            const uint64_t tbm = __builtin_amdgcn_ballot_w64(t < tb_lim);
+            const uint32_t offa = t * ((uint32_t)sizeof(N) << ts);
+            const uint32_t offb = (t < tb_lim) ? offa + (uint32_t)sizeof(N) : offa;
+            const N Ta = load_vol<N>(lvl + offa);
+            const N Tb = load_vol<N>(lvl + offb);
+            work.add(2, lane < fcnt ? ((t < tb_lim) ? 2u : 1u) : 0u);
+            uint64_t ia = vm, ib = vm & tbm;
+            if constexpr (MODE == MODE_SELF) {
+                const uint32_t thr = (wave_item0 + 1u) >> sh;
+                ia &= __builtin_amdgcn_ballot_w64(t >= (ts ? (thr + 1u) >> 1 : thr));
+                ib &= __builtin_amdgcn_ballot_w64(t >= (thr >> 1));
+            }
+            work.add(0, 2u * ((uint32_t)((ia >> lane) & 1u) + (uint32_t)((ib >> lane) & 1u)));
+            uint64_t maa, mba, mab, mbb;
+            if constexpr (std::is_same<TN, float>::value) dual_sides4_f32(ia, ib, A, B, Ta, Tb, maa, mba, mab, mbb);
+            else {
+                maa = ia & __builtin_amdgcn_ballot_w64(iscontact(A, Ta));
+                mba = ia & __builtin_amdgcn_ballot_w64(iscontact(B, Ta));
+                mab = ib & __builtin_amdgcn_ballot_w64(iscontact(A, Tb));
+                mbb = ib & __builtin_amdgcn_ballot_w64(iscontact(B, Tb));
+            }
+            const uint64_t ma = maa | mba, mb = mab | mbb;
+            const int n_merged = __popcll(ma) + __popcll(mb);
+            const uint32_t ta = t << ts;
+            if (s + 1 < plan.q_first && n_merged <= 64) {
+                // stay: compact the surviving children (child a before child b, lanes in order) through the bottom of the stack
+                if (n_merged == 0) {
+                    cur = -2; // nothing touches the wave: done
+                    break;
+                }
+                const uint32_t rank = below(mb, below(ma, 0u));
+                if ((ma >> lane) & 1u) s_stack[rank] = (QE)ta;
+                if ((mb >> lane) & 1u) s_stack[rank + (uint32_t)((ma >> lane) & 1u)] = (QE)(ta + 1u);
+                __builtin_amdgcn_wave_barrier();
+                ft = (uint32_t)s_stack[lane];
+                __builtin_amdgcn_wave_barrier();
+                fcnt = n_merged;
+                continue;
+            }
+            // leave: (side, node) pairs into segment s + 1, T-major
+            const int n_out = __popcll(maa) + __popcll(mba) + __popcll(mab) + __popcll(mbb);
+            const int ddir = seg_dir(s + 1);
+            const int d_org = ddir > 0 ? lo_ptr : hi_ptr - 1;
+            const uint32_t rank = below(mbb, below(mab, below(mba, below(maa, 0u))));
+            const QE e0 = (QE)ta << 7, e1 = e0 + 1u, e2 = e0 + 128u, e3 = e2 + 1u;
+            if constexpr (!WIDE) {
+                const uint32_t vstep = (uint32_t)(ddir * 4);
+                dual_push4(maa, mba, mab, mbb, stack_lds + (uint32_t)(d_org * 4) + rank * vstep, vstep, e0, e1, e2, e3);
+            } else {
+                int j = (int)rank;
+                if ((maa >> lane) & 1u) s_stack[d_org + ddir * j++] = e0;
+                if ((mba >> lane) & 1u) s_stack[d_org + ddir * j++] = e1;
+                if ((mab >> lane) & 1u) s_stack[d_org + ddir * j++] = e2;
+                if ((mbb >> lane) & 1u) s_stack[d_org + ddir * j++] = e3;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (ddir > 0) lo_ptr += n_out;
+            else hi_ptr -= n_out;
+            cur = n_out > 0 ? s + 1 : -2;
+            c_org = d_org;
+            c_cnt = n_out;
+            c_head = 0;
+            break;
+        }
+    }
+    while (cur >= -1) {
+        if (c_head == c_cnt) { // consumed (and popped): continue with the deepest parked segment, if any
+            if (paused == 0) break;
+            cur = 30 - __builtin_clz(paused);
+            paused &= ~(1u << (cur + 1));
+            c_org = __builtin_amdgcn_readlane(sg_org, cur + 1);
+            c_cnt = __builtin_amdgcn_readlane(sg_cnt, cur + 1);
+            c_head = __builtin_amdgcn_readlane(sg_head, cur + 1);
+            continue;
+        }
+        if (cur == S) {
+            for (; c_head < c_cnt; c_head += 64) pair_step(c_org, seg_dir(S), c_head, c_cnt - c_head < 64 ? c_cnt - c_head : 64);
+            if (seg_dir(S) > 0) lo_ptr = c_org;
+            else hi_ptr = c_org + 1;
+            c_head = c_cnt = 0;
+            continue;
+        }
+        // the step that consumes segment cur
+        const uint32_t *row = plan.row[cur + 1];
+        const uint32_t flags = row[3], tb_lim = row[2];
+        const int ts = (int)(flags & DUAL_TS), qs = (int)((flags >> 1) & 1u);
+        const uint32_t dq = (flags >> 8) & 3u;
+        const int sh = (int)((flags >> 16) & 63u), qd_out = (int)((flags >> 24) & 15u);
+        const char *lvl = (const char *)a.nodes + (((uint64_t)row[1] << 32) | row[0]);
+        uint32_t thr_a = 0, thr_b = 0; // self walk: T child a / b is kept for t >= thr_a / thr_b (something right of the wave's first item below it)
+        if constexpr (MODE == MODE_SELF) {
+            const uint32_t thr = (wave_item0 + 1u) >> sh;
+            thr_a = ts ? (thr + 1u) >> 1 : thr;
+            thr_b = thr >> 1;
+        }
+        // Q children that do not exist: only the group the cut falls into has a part on either side
+        uint32_t bad_a = ~0u, bad_b = ~0u;
+        if (qs) {
+            const uint32_t sidx_in = (uint32_t)ksplit >> (8 - qd_out), bit = ((uint32_t)ksplit >> (7 - qd_out)) & 1u;
+            bad_a = (bit || qd_out == 7) ? 2u * sidx_in + 1u : ~0u; // side B of that group: its child a lies on side A
+            bad_b = bit ? ~0u : 2u * sidx_in;                      // side A of that group: its child b lies on side B
+        }
+        const uint32_t qrow = row[4] * (uint32_t)NW; // first word of the Q children's table row
+        const int fan_shift = ts + ((flags & DUAL_Q2) ? 1 : 0);
+        const int res = 4 * (S - 1 - cur);
+        const int need_full = res + (64 << fan_shift);
+        const int sdir = cur < 0 ? 1 : seg_dir(cur), ddir = seg_dir(cur + 1);
+        const int d_org = ddir > 0 ? lo_ptr : hi_ptr - 1; // (the segment this step produces is fresh: nothing deeper is pending)
+        int d_cnt = 0, gap = hi_ptr - lo_ptr;
+        const uint32_t vstep = (uint32_t)(ddir * (int)sizeof(QE));
+        bool descend = false;
+        auto chunks = [&](auto kind_tag) {
+            constexpr int KIND = decltype(kind_tag)::value;
+            while (c_head < c_cnt) {
+                int m = c_cnt - c_head < 64 ? c_cnt - c_head : 64;
+                if (gap < need_full) {
+                    const int room = (gap - res) >> fan_shift;
+                    if (room < m) {
+                        if (d_cnt > 0) { // short of space: what this step produced so far is consumed first
+                            descend = true;
+                            break;
+                        }
+                        m = room;
+                    }
+                }
+                const uint64_t vm = dual_mask_below(m);
+                const int src = c_head + (lane < m ? lane : 0);
+                uint32_t qn = 0, t = (uint32_t)src;
+                if (KIND != 1 || !(flags & DUAL_IOTA)) {
+                    const QE e = s_stack[c_org + sdir * src];
+                    qn = (uint32_t)e & 127u;
+                    t = (uint32_t)(e >> 7);
+                }
+                // tree side: the two children of T (or T itself while only Q is split); a missing child b re-reads child a
+                const uint64_t tbm = __builtin_amdgcn_ballot_w64(t < tb_lim);
+                const uint32_t offa = t * ((uint32_t)sizeof(N) << (KIND == 0 ? 1 : ts));
+                const uint32_t offb = (t < tb_lim) ? offa + (uint32_t)sizeof(N) : offa;
+                const N Ta = load_vol<N>(lvl + offa);
+                const N Tb = load_vol<N>(lvl + offb);
+                work.add(2, lane < m ? ((t < tb_lim) ? 2u : 1u) : 0u);
+                // query side: the two children of Q (or Q itself while it waits at depth 1; a root meets both sides)
+                N Qa, Qb;
+                if constexpr (KIND == 2) {
+                    const int la = (int)(qn & ~1u);
+                    Qa = shuffle_from(qbox, la);
+                    Qb = shuffle_from(qbox, la + 1);
+                } else {
+                    uint64_t w[2 * NW];
+                    const uint32_t w0 = qrow + qn * (uint32_t)NW;
+#pragma unroll
+                    for (int k = 0; k < (KIND == 0 ? NW : 2 * NW); ++k) w[k] = s_qtab[w0 + k];
+                    __builtin_memcpy(&Qa, w, sizeof(N));
+                    if constexpr (KIND == 0) Qb = Qa;
+                    else __builtin_memcpy(&Qb, w + NW, sizeof(N));
+                }
+                uint64_t am = vm, bm = 0;
+                if constexpr (KIND != 0) {
+                    am = vm & __builtin_amdgcn_ballot_w64(qn != bad_a);
+                    bm = vm & __builtin_amdgcn_ballot_w64(qn != bad_b);
+                }
+                uint64_t ka = ~(uint64_t)0, kb = tbm;
+                if constexpr (MODE == MODE_SELF) {
+                    ka = __builtin_amdgcn_ballot_w64(t >= thr_a);
+                    kb &= __builtin_amdgcn_ballot_w64(t >= thr_b);
+                }
+                const uint64_t i0 = am & ka, i1 = bm & ka, i2 = am & kb, i3 = bm & kb;
+                work.add(0, (uint32_t)((i0 >> lane) & 1u) + (uint32_t)((i1 >> lane) & 1u) + (uint32_t)((i2 >> lane) & 1u) + (uint32_t)((i3 >> lane) & 1u));
+                uint64_t m0, m1 = 0, m2, m3 = 0;
+                if constexpr (std::is_same<TN, float>::value) {
+                    if constexpr (KIND == 0) dual_test2_f32(i0, i2, Qa, Ta, Tb, m0, m2);
+                    else dual_test4_f32(i0, i1, i2, i3, Qa, Qb, Ta, Tb, m0, m1, m2, m3);
+                } else {
+                    m0 = i0 & __builtin_amdgcn_ballot_w64(iscontact(Qa, Ta));
+                    m2 = i2 & __builtin_amdgcn_ballot_w64(iscontact(Qa, Tb));
+                    if constexpr (KIND != 0) {
+                        m1 = i1 & __builtin_amdgcn_ballot_w64(iscontact(Qb, Ta));
+                        m3 = i3 & __builtin_amdgcn_ballot_w64(iscontact(Qb, Tb));
+                    }
+                }
+                const int n_out = __popcll(m0) + __popcll(m2) + (KIND != 0 ? __popcll(m1) + __popcll(m3) : 0);
+                // entries: Q code | T index << 7
+                const uint32_t qa = KIND == 0 ? qn : (KIND == 2 ? 2u * qn - (qn & 1u) : (qn << qs) - (qn & (uint32_t)qs));
+                const QE e0 = ((QE)t << (7 + (KIND == 0 ? 1 : ts))) | (QE)qa, e1 = e0 + dq, e2 = e0 + 128u, e3 = e2 + dq;
+                const uint32_t rank = KIND != 0 ? below(m3, below(m2, below(m1, below(m0, 0u)))) : below(m2, below(m0, 0u));
+                if constexpr (!WIDE) {
+                    const uint32_t addr = stack_lds + (uint32_t)((d_org + ddir * d_cnt) * 4) + rank * vstep;
+                    if constexpr (KIND != 0) dual_push4(m0, m1, m2, m3, addr, vstep, e0, e1, e2, e3);
+                    else dual_push2(m0, m2, addr, vstep, e0, e2);
+                } else {
+                    int j = d_cnt + (int)rank;
+                    if ((m0 >> lane) & 1u) s_stack[d_org + ddir * j++] = e0;
+                    if ((m1 >> lane) & 1u) s_stack[d_org + ddir * j++] = e1;
+                    if ((m2 >> lane) & 1u) s_stack[d_org + ddir * j++] = e2;
+                    if ((m3 >> lane) & 1u) s_stack[d_org + ddir * j++] = e3;
+                }
+                d_cnt += n_out;
+                gap -= n_out;
+                c_head += m;
+                __builtin_amdgcn_wave_barrier();
+            }
+        };
+        if (flags & DUAL_SINGLES) chunks(std::integral_constant<int, 2>{});
+        else if (flags & DUAL_Q2) chunks(std::integral_constant<int, 1>{});
+        else chunks(std::integral_constant<int, 0>{});
+        if (ddir > 0) lo_ptr = d_org + d_cnt;
+        else hi_ptr = d_org + 1 - d_cnt;
+        if (descend) { // park this segment with its remainder
+            sg_org = (lane == cur + 1) ? c_org : sg_org;
+            sg_cnt = (lane == cur + 1) ? c_cnt : sg_cnt;
+            sg_head = (lane == cur + 1) ? c_head : sg_head;
+            paused |= 1u << (cur + 1);
+        } else if (cur >= 0) { // consumed: pop it (everything deeper than cur + 1 is empty)
+            if (sdir > 0) lo_ptr = c_org;
+            else hi_ptr = c_org + 1;
+        }
+        ++cur;
+        c_org = d_org;
+        c_cnt = d_cnt;
+        c_head = 0;
+    }
+    work.flush(a.work);
+    if constexpr (!WRITE) {
+        if (q.valid) a.counts[q.item] = (I)cnts[lane];
+        const bool meta_ok = __builtin_amdgcn_ballot_w64((int64_t)cnts[lane] >= ((int64_t)1 << (sizeof(I) * 8 - 7))) == 0;
+        if (region && lane == 0) *(int *)region = (wfill <= entry_cap && meta_ok) ? wfill : -1;
+    }
+}
+
 // ---- (3) rays: per-lane walks, lanes refilled from the wave's block of rays -------------------------------
 // The rays of a wave are not spatially coherent, so every lane walks its own ray — leaner than the reference's loop
 // (raytrace/leaf_vs_tree/leaf_vs_tree.jl:187-225): a step tests BOTH children of the current node (adjacent in
@@ -1957,6 +2718,34 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
                     int64_t top = a.built_level > 7 ? a.built_level : 7; // level 7: 64 nodes, one 64-lane step
                     if (top > a.tree.levels - 1) top = a.tree.levels - 1;
                     aq.start_level = top; // also when the caller named a HIGHER level: levels 1..6 hold < 64 nodes each
+                    if (g_tuning.lvt_dual) {
+                        // the dual descent (lvt_dual_kernel): pairs pack (T index within its level << 7 | Q node): 32 bits up to 27 levels
+                        const bool dwide = force_wide || a.tree.levels > 27;
+                        const DualPlan dplan = make_dual_plan((int)aq.tree.levels, (uint32_t)aq.tree.virtual_leaves, (int)aq.start_level, sizeof(N));
+                        if constexpr (kWorkTypes<L, N, I>) {
+                            if (count_work) {
+                                if (dwide || aq.narrow != IBVH_NARROW_NONE) return IBVH_ERR_UNSUPPORTED;
+                                IBVH_LAUNCH((lvt_dual_kernel<L, N, I, MODE, false, false, false, true>), dim3(qblocks), dim3(64), 0, st, aq, cache, dplan);
+                                IBVH_LAUNCH_CHECK();
+                                return IBVH_OK;
+                            }
+                        }
+                        const int dvariant = (write ? 1 : 0) | (aq.narrow != IBVH_NARROW_NONE ? 2 : 0) | (dwide ? 4 : 0);
+#define IBVH_DUAL_LAUNCH(W_, N_, D_) IBVH_LAUNCH((lvt_dual_kernel<L, N, I, MODE, W_, N_, D_>), dim3(qblocks), dim3(64), 0, st, aq, cache, dplan)
+                        switch (dvariant) {
+                        case 0: IBVH_DUAL_LAUNCH(false, false, false); break;
+                        case 1: IBVH_DUAL_LAUNCH(true, false, false); break;
+                        case 2: IBVH_DUAL_LAUNCH(false, true, false); break;
+                        case 3: IBVH_DUAL_LAUNCH(true, true, false); break;
+                        case 4: IBVH_DUAL_LAUNCH(false, false, true); break;
+                        case 5: IBVH_DUAL_LAUNCH(true, false, true); break;
+                        case 6: IBVH_DUAL_LAUNCH(false, true, true); break;
+                        default: IBVH_DUAL_LAUNCH(true, true, true); break;
+                        }
+#undef IBVH_DUAL_LAUNCH
+                        IBVH_LAUNCH_CHECK();
+                        return IBVH_OK;
+                    }
                     const int64_t c = aq.tree.levels - BRUTE_DEPTH;
                     const int cut = (int)(c > aq.start_level ? c : aq.start_level);
                     if constexpr (kWorkTypes<L, N, I>) {
@@ -2180,6 +2969,7 @@ ibvh_status ibvh_lvt_work_counters(const ibvh_bvh *bvh, const ibvh_bvh *bvh2, co
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(work_out, 0, 4 * sizeof(unsigned long long), st) != hipSuccess) return IBVH_ERR_HIP;
     const int64_t sl = bvh->built_level > 1 ? bvh->built_level : 1;
+    if (int e = check_levels(*bvh, sl)) return (ibvh_status)e; // (all three shapes: levels <= 32, built_level <= start level)
     if (points) {
         if (!directions || num_rays <= 0) return IBVH_ERR_INVALID_ARG;
         return (ibvh_status)run<MODE_RAYS>(nullptr, bvh, points, directions, num_rays, sl, 0, 0, counts, nullptr, nullptr, nullptr,
@@ -2190,6 +2980,7 @@ ibvh_status ibvh_lvt_work_counters(const ibvh_bvh *bvh, const ibvh_bvh *bvh2, co
         const bool flip = !(bvh->tree.real_leaves >= bvh2->tree.real_leaves); // the BVH with more leaves drives (:15-36)
         const ibvh_bvh *drv = flip ? bvh2 : bvh, *oth = flip ? bvh : bvh2;
         const int64_t slo = oth->built_level > 1 ? oth->built_level : 1;
+        if (int e = check_levels(*oth, slo)) return (ibvh_status)e;
         return (ibvh_status)run<MODE_PAIR>(drv, oth, nullptr, nullptr, drv->tree.real_leaves, slo, 0, flip ? 1 : 0, counts, nullptr,
                                            nullptr, nullptr, 0, st, false, 0, nullptr, nullptr, (unsigned long long *)work_out);
     }

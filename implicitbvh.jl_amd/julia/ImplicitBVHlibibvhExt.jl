@@ -108,15 +108,20 @@ struct MortonLess end
 "`narrow=IndexLess()`: (a, b) -> a.index < b.index, evaluated on the device (IBVH_NARROW_INDEX_LT)."
 struct IndexLess end
 (::IndexLess)(a, b) = a.index < b.index
-# the device-side menu, or `nothing`: the caller then hands the whole call to the reference's generic method
-narrow_code(f) = f === DEFAULT_NARROW ? Int32(0) : f isa MortonLess ? Int32(1) : f isa IndexLess ? Int32(2) : nothing
+# the device-side menu, or `nothing`: the caller then hands the whole call to the reference's generic method.
+# The default is recognised by identity or by TYPE (a non-capturing closure is a singleton: every value of the default
+# closure's type is the default).  NB an explicit `narrow=(a, b) -> true` written by the caller is a DIFFERENT closure type:
+# it cannot be told apart from any other user predicate and takes the generic KernelAbstractions path of the reference —
+# pass nothing (or `DEFAULT_NARROW`) to stay on the native path.
+is_default_narrow(f, d) = f === d || typeof(f) === typeof(d)
+narrow_code(f) = is_default_narrow(f, DEFAULT_NARROW) ? Int32(0) : f isa MortonLess ? Int32(1) : f isa IndexLess ? Int32(2) : nothing
 "`narrow=OriginOutside()` for traverse_rays: (bv, p, d) -> the ray's origin lies outside bv.volume, evaluated on the device
 (IBVH_NARROW_RAY_ORIGIN_OUTSIDE): drops the leaves a ray starts in."
 struct OriginOutside end
 (::OriginOutside)(bv::BoundingVolume{<:BSphere}, p, d) =
     (p[1] - bv.volume.x[1])^2 + (p[2] - bv.volume.x[2])^2 + (p[3] - bv.volume.x[3])^2 > bv.volume.r * bv.volume.r
 (::OriginOutside)(bv::BoundingVolume{<:BBox}, p, d) = any(p .< bv.volume.lo) || any(p .> bv.volume.up)
-ray_narrow_code(f) = f === DEFAULT_RAY_NARROW ? Int32(0) : f isa OriginOutside ? Int32(3) : nothing
+ray_narrow_code(f) = is_default_narrow(f, DEFAULT_RAY_NARROW) ? Int32(0) : f isa OriginOutside ? Int32(3) : nothing
 # Any other PURE predicate can also be served without the generic path: OR IBVH_OUTPUT_POSITIONS (0x100) into the code
 # and the contact list holds leaf positions ((query, partner) / (bvh1, bvh2) / (leaf, iray), include/ibvh.h) on which the
 # caller evaluates the predicate itself — `narrow` is only ever used as `iscontact(...) && narrow(...)` at leaf level.
@@ -161,9 +166,13 @@ function next_host_word()
     w
 end
 function poll_total(w::Ptr{Int64}, tdev, stream)
-    for _ in 1:50_000_000
-        v = unsafe_load(w)          # (a volatile read of pinned memory: the GPU's store becomes visible here)
+    # An ATOMIC (acquire) load: a plain unsafe_load in a side-effect-free loop may be hoisted or the loop deleted by LLVM,
+    # and the poll would then never see the GPU's store.  Bounded by time, not by iteration count.
+    t0 = time_ns()
+    while time_ns() - t0 < 2_000_000_000
+        v = unsafe_load(w, :acquire)
         v != HOST_PENDING && return v
+        GC.safepoint()
     end
     total = Ref{Int64}(0)           # never arrived (should not happen): the blocking device read
     check(c_lvt_total(tdev, total, stream), "ibvh_lvt_total")
