@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 3  # IBVH_ABI_VERSION of the include/ibvh.h this mirror was written against
+ABI_VERSION = 4  # IBVH_ABI_VERSION of the include/ibvh.h this mirror was written against
 
 # enums ---------------------------------------------------------------------------------------
 BSPHERE, BBOX = 0, 1
@@ -76,6 +76,36 @@ class BuildDesc(C.Structure):
 class BfsResult(C.Structure):
     _fields_ = [("num_contacts", C.c_int64), ("num_checks", C.c_int64), ("contacts_in", C.c_int64),
                 ("required_capacity", C.c_int64), ("resume_step", C.c_int64), ("resume_num", C.c_int64)]
+
+
+# ---- multi-GPU build (include/ibvh.h, "multi-GPU build: the driver") ------------------------------------------
+DIST_MAX_RANKS = 256
+COMM_F64, COMM_I64, COMM_I32 = 0, 1, 2
+COMM_MAX, COMM_SUM, COMM_MIN = 0, 1, 2
+COMM_ALL_REDUCE = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p)
+COMM_ALL_GATHER = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+COMM_ALL_TO_ALL_V = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64), C.c_void_p)
+
+
+class Comm(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int32), ("size", C.c_int32), ("all_reduce", COMM_ALL_REDUCE),
+                ("all_gather", COMM_ALL_GATHER), ("all_to_all_v", COMM_ALL_TO_ALL_V)]
+
+
+class SplitterSearch(C.Structure):
+    _fields_ = [("size", C.c_int32), ("key_bits", C.c_int32), ("decided", C.c_int32), ("all_done", C.c_int32),
+                ("next_bits", C.c_int32), ("next_shift", C.c_int32), ("num_rows", C.c_int32), ("reserved_", C.c_int32),
+                ("n_global", C.c_int64), ("tolerance", C.c_double),
+                ("rows", C.c_uint64 * DIST_MAX_RANKS), ("prefix", C.c_uint64 * DIST_MAX_RANKS),
+                ("splitters", C.c_uint64 * DIST_MAX_RANKS), ("below", C.c_int64 * DIST_MAX_RANKS),
+                ("row_of", C.c_int32 * DIST_MAX_RANKS), ("done", C.c_uint8 * DIST_MAX_RANKS)]
+
+
+class DistPlan(C.Structure):
+    _fields_ = [("size", C.c_int32), ("levels_used", C.c_int32), ("n_local", C.c_int64), ("n_global", C.c_int64),
+                ("base", C.c_int64), ("n_slice", C.c_int64), ("record_bytes", C.c_int64), ("extrema", C.c_double * 6),
+                ("splitters", C.c_uint64 * DIST_MAX_RANKS), ("send_counts", C.c_int64 * DIST_MAX_RANKS),
+                ("recv_counts", C.c_int64 * DIST_MAX_RANKS)]
 
 
 def volume_dtype(kind, flt):

@@ -1,0 +1,423 @@
+// ibvh_distdrv.hip — the distributed build behind the C ABI (north star: "host code stays Julia, calling … through a thin
+// C-ABI (ccall) shim"; the build "shards leaves across the 8 GPUs of one node with RCCL allreduce over xGMI for the global AABB
+// and a distributed radix-sort exchange").  The reference is single-device: there is no reference file for this layer.
+//
+// One process per GPU.  A rank calls
+//   ibvh_dist_plan      local extrema -> ONE all-reduce(MAX) of [-mins, maxs, one-hot leaf counts] -> global AABB (bit-identical
+//                       to the single-device reduce: min / max are exact) -> Morton keys -> 12-bit digit histogram, ALL-GATHERED
+//                       -> ONE device -> host copy -> splitters (refined by further 12-bit levels, one all-reduce(SUM) each, only
+//                       while a splitter's bucket is heavier than `tolerance` of a shard) -> stable partition by destination
+//                       (ibvh_dist_partition) -> how many records this rank sends / receives;
+//   (the caller sizes its record array from plan->n_slice — the reference's "count, then size, then write" protocol)
+//   ibvh_dist_exchange  pack records with GLOBAL 1-based indices, ONE all-to-all over xGMI;
+//   ibvh_build          ordinary local build over the received records (already_wrapped, fixed global extrema): rank r ends
+//                       with the r-th slice of the globally stable-sorted sequence.
+// Collectives go through a small vtable (ibvh_comm): ibvh_comm_from_rccl() fills it for an ncclComm_t (librccl.so is
+// resolved with dlopen on first use: libibvh.so itself does not link RCCL); hosts without RCCL bindings and the CPU /
+// virtual-rank tests inject their own.  The splitter arithmetic is host-only (ibvh_splitter_search_*): the gloo tests on
+// CPU drive the very same code with histograms made by numpy.
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "ibvh_common.hpp"
+
+using namespace ibvh;
+
+namespace {
+
+constexpr int DIGIT_BITS = 12;
+constexpr int MAX_RANKS = IBVH_DIST_MAX_RANKS;
+
+int key_bits_of(const ibvh_types &t) { return t.morton_type == IBVH_U16 ? 15 : (t.morton_type == IBVH_U32 ? 30 : 63); }
+int key_bytes_of(const ibvh_types &t) { return t.morton_type == IBVH_U64 ? 8 : 4; }
+int float_bytes(int flt) { return flt == IBVH_F64 ? 8 : 4; }
+
+__global__ void widen_u32_i64_kernel(const uint32_t *in, long long *out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (long long)in[i];
+}
+
+// where everything lives in the caller's scratch: a function of (types, n_local, size) only, so that ibvh_dist_exchange
+// finds what ibvh_dist_plan left
+struct Layout {
+    size_t ext_local, vec, ext, hist, hist64, allh, cnt, keys, perm, part, records, ext_scratch, total;
+    size_t part_bytes;
+};
+Layout make_layout(const ibvh_types &t, int64_t n, int size) {
+    ibvh_layout lay;
+    layout_of(t, lay);
+    Layout L{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += (size_t)align_up((int64_t)(bytes ? bytes : 8), 256);
+        return at;
+    };
+    L.ext_local = take(64);
+    L.vec = take((size_t)(6 + size) * 8);
+    L.ext = take(64);
+    L.hist = take((size_t)16 * (1 << DIGIT_BITS) * 4);
+    L.hist64 = take((size_t)16 * (1 << DIGIT_BITS) * 8);
+    L.allh = take((size_t)size * (1 << DIGIT_BITS) * 4);
+    L.cnt = take((size_t)4 * size * 8);
+    L.ext_scratch = take((size_t)1 << 17);
+    L.keys = take((size_t)n * key_bytes_of(t));
+    L.perm = take((size_t)n * 4);
+    ibvh_dist_partition_scratch_bytes(n, &L.part_bytes);
+    L.part = take(L.part_bytes);
+    L.records = take((size_t)n * lay.leaf_bytes);
+    L.total = off;
+    return L;
+}
+
+// ---- RCCL, resolved lazily ----------------------------------------------------------------------------------
+struct Rccl {
+    void *lib = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    bool ok = false;
+};
+Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) return;
+        r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
+        r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+        r.Send = (decltype(r.Send))dlsym(r.lib, "ncclSend");
+        r.Recv = (decltype(r.Recv))dlsym(r.lib, "ncclRecv");
+        r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
+        r.ok = r.AllReduce && r.AllGather && r.Send && r.Recv && r.GroupStart && r.GroupEnd;
+    });
+    return r;
+}
+// nccl.h: ncclUint8 = 1, ncclInt32 = 2, ncclInt64 = 4, ncclFloat64 = 8; ncclSum = 0, ncclMax = 2, ncclMin = 3
+struct RcclCtx {
+    void *comm;
+    int rank, size;
+};
+int32_t rccl_all_reduce(void *ctx, void *buf, int64_t count, int32_t dtype, int32_t op, void *stream) {
+    const RcclCtx *c = (const RcclCtx *)ctx;
+    const int dt = dtype == IBVH_COMM_F64 ? 8 : (dtype == IBVH_COMM_I64 ? 4 : 2);
+    const int ro = op == IBVH_COMM_MAX ? 2 : (op == IBVH_COMM_MIN ? 3 : 0);
+    return rccl().AllReduce(buf, buf, (size_t)count, dt, ro, c->comm, (hipStream_t)stream) == 0 ? 0 : IBVH_ERR_HIP;
+}
+int32_t rccl_all_gather(void *ctx, const void *send, void *recv, int64_t bytes, void *stream) {
+    const RcclCtx *c = (const RcclCtx *)ctx;
+    return rccl().AllGather(send, recv, (size_t)bytes, 1, c->comm, (hipStream_t)stream) == 0 ? 0 : IBVH_ERR_HIP;
+}
+int32_t rccl_all_to_all_v(void *ctx, const void *send, const int64_t *send_bytes, void *recv, const int64_t *recv_bytes, void *stream) {
+    const RcclCtx *c = (const RcclCtx *)ctx;
+    Rccl &r = rccl();
+    // grouped point-to-point transfers: xGMI is point-to-point, every pair of GPUs has its own link(s)
+    if (r.GroupStart() != 0) return IBVH_ERR_HIP;
+    size_t so = 0, ro = 0;
+    int bad = 0;
+    for (int p = 0; p < c->size; ++p) {
+        if (send_bytes[p] > 0) bad |= r.Send((const char *)send + so, (size_t)send_bytes[p], 1, p, c->comm, (hipStream_t)stream);
+        if (recv_bytes[p] > 0) bad |= r.Recv((char *)recv + ro, (size_t)recv_bytes[p], 1, p, c->comm, (hipStream_t)stream);
+        so += (size_t)send_bytes[p];
+        ro += (size_t)recv_bytes[p];
+    }
+    bad |= r.GroupEnd();
+    return bad == 0 ? 0 : IBVH_ERR_HIP;
+}
+
+int d2h(void *dst, const void *src, size_t bytes, hipStream_t st) {
+    IBVH_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
+    return IBVH_OK;
+}
+
+} // namespace
+
+#define DIST_HIP_CHECK(expr)                                  \
+    do {                                                      \
+        if ((expr) != hipSuccess) return IBVH_ERR_HIP;        \
+    } while (0)
+
+extern "C" {
+
+ibvh_status ibvh_comm_from_rccl(void *nccl_comm, int32_t rank, int32_t size, ibvh_comm *out) {
+    if (!nccl_comm || !out || size < 1 || rank < 0 || rank >= size) return IBVH_ERR_INVALID_ARG;
+    if (!rccl().ok) return IBVH_ERR_UNSUPPORTED; // librccl.so not found
+    RcclCtx *c = new RcclCtx{nccl_comm, rank, size}; // (a few bytes per communicator, lives as long as the process: no destroy call needed)
+    out->ctx = c;
+    out->rank = rank;
+    out->size = size;
+    out->all_reduce = rccl_all_reduce;
+    out->all_gather = rccl_all_gather;
+    out->all_to_all_v = rccl_all_to_all_v;
+    return IBVH_OK;
+}
+
+// ---- splitter search (host only; identical arithmetic on every rank) ------------------------------------------
+// Keys k_1 <= ... <= k_{P-1}: rank r receives the keys in [k_r, k_{r+1}).  Digit histograms are refined from the top of
+// the key, 12 bits per level.  After a level, splitter s sits on the digit whose cumulative count first exceeds the
+// balanced target s*N/P; it may stop there (k_s = prefix << remaining bits) once the bucket it landed in holds at most
+// tolerance*N/P keys — the imbalance it can cause.  tolerance = 0 refines to full key resolution.
+ibvh_status ibvh_splitter_search_init(ibvh_splitter_search *s, int32_t size, int32_t key_bits, int64_t n_global, double tolerance) {
+    if (!s || size < 1 || size > MAX_RANKS || key_bits < 1 || key_bits > 64 || n_global < 0 || !(tolerance >= 0.0)) return IBVH_ERR_INVALID_ARG;
+    std::memset(s, 0, sizeof(*s));
+    s->size = size;
+    s->key_bits = key_bits;
+    s->n_global = n_global;
+    s->tolerance = tolerance;
+    s->all_done = size == 1 ? 1 : 0;
+    s->next_bits = key_bits < DIGIT_BITS ? key_bits : DIGIT_BITS;
+    s->next_shift = key_bits - s->next_bits;
+    s->num_rows = 0; // level 0: one row over all keys
+    return IBVH_OK;
+}
+
+// hist: max(num_rows, 1) rows of 2^next_bits GLOBAL counts (row j: the keys whose decided prefix is rows[j]; level 0: all keys)
+ibvh_status ibvh_splitter_search_step(ibvh_splitter_search *s, const int64_t *hist) {
+    if (!s || !hist) return IBVH_ERR_INVALID_ARG;
+    if (s->all_done) return IBVH_OK;
+    const int P = s->size, bits = s->next_bits, shift = s->next_shift, width = 1 << bits;
+    const double allowed = s->tolerance * (double)s->n_global / (double)P;
+    for (int k = 0; k < P - 1; ++k) {
+        if (s->done[k]) continue;
+        const int64_t *row = hist + (size_t)(s->decided == 0 ? 0 : s->row_of[k]) * width;
+        const int64_t target = (int64_t)(k + 1) * s->n_global / P;
+        const int64_t rem = target - s->below[k];
+        // first digit whose inclusive cumulative count exceeds rem
+        int64_t cum = 0;
+        int d = 0;
+        for (; d < width; ++d) {
+            if (cum + row[d] > rem) break;
+            cum += row[d];
+        }
+        if (d >= width) {
+            d = width - 1;
+            cum -= row[d];
+        }
+        s->below[k] += cum;
+        s->prefix[k] = (s->prefix[k] << bits) | (uint64_t)d;
+        if (shift == 0 || (double)row[d] <= allowed) {
+            s->done[k] = 1;
+            s->splitters[k] = shift >= 64 ? 0 : s->prefix[k] << shift;
+        }
+    }
+    s->decided += bits;
+    bool all = true;
+    for (int k = 0; k < P - 1; ++k) all = all && s->done[k];
+    s->all_done = (all || s->decided >= s->key_bits) ? 1 : 0;
+    if (!s->all_done) { // the next level: one histogram row per distinct undecided prefix
+        s->next_bits = s->key_bits - s->decided < DIGIT_BITS ? s->key_bits - s->decided : DIGIT_BITS;
+        s->next_shift = s->key_bits - s->decided - s->next_bits;
+        int nr = 0;
+        for (int k = 0; k < P - 1; ++k) {
+            if (s->done[k]) continue;
+            int j = 0;
+            for (; j < nr; ++j)
+                if (s->rows[j] == s->prefix[k]) break;
+            if (j == nr) { // insert sorted (the prefixes of ascending splitters ascend)
+                int at = nr;
+                while (at > 0 && s->rows[at - 1] > s->prefix[k]) {
+                    s->rows[at] = s->rows[at - 1];
+                    --at;
+                }
+                s->rows[at] = s->prefix[k];
+                ++nr;
+            }
+        }
+        s->num_rows = nr;
+        for (int k = 0; k < P - 1; ++k) {
+            s->row_of[k] = 0;
+            if (s->done[k]) continue;
+            for (int j = 0; j < nr; ++j)
+                if (s->rows[j] == s->prefix[k]) s->row_of[k] = j;
+        }
+    }
+    return IBVH_OK;
+}
+
+// ---- the driver --------------------------------------------------------------------------------------------------
+ibvh_status ibvh_dist_scratch_bytes(const ibvh_types *types, int64_t n_local, int32_t size, size_t *bytes_out) {
+    if (!types || !bytes_out || n_local < 0 || size < 1 || size > MAX_RANKS) return IBVH_ERR_INVALID_ARG;
+    ibvh_layout lay;
+    if (!layout_of(*types, lay)) return IBVH_ERR_UNSUPPORTED;
+    *bytes_out = make_layout(*types, n_local, size).total;
+    return IBVH_OK;
+}
+
+ibvh_status ibvh_dist_plan(const ibvh_types *types, const ibvh_comm *comm, const void *volumes, int64_t n_local, double tolerance,
+                           void *scratch, size_t scratch_bytes, ibvh_dist_plan_t *plan, void *stream) {
+    if (!types || !comm || !plan || n_local < 0 || (n_local > 0 && !volumes)) return IBVH_ERR_INVALID_ARG;
+    const int P = comm->size, me = comm->rank;
+    if (P < 1 || P > MAX_RANKS || me < 0 || me >= P || !(tolerance >= 0.0)) return IBVH_ERR_INVALID_ARG;
+    if (P > 1 && (!comm->all_reduce || !comm->all_gather || !comm->all_to_all_v)) return IBVH_ERR_INVALID_ARG;
+    ibvh_layout lay;
+    if (!layout_of(*types, lay) || !combo_ok(*types)) return IBVH_ERR_UNSUPPORTED;
+    const Layout L = make_layout(*types, n_local, P);
+    if (!scratch || scratch_bytes < L.total) return IBVH_ERR_SCRATCH;
+    hipStream_t st = (hipStream_t)stream;
+    char *base = (char *)scratch;
+    const int flt = types->leaf_float, fb = float_bytes(flt);
+    const int kb = key_bytes_of(*types), key_bits = key_bits_of(*types);
+    std::memset(plan, 0, sizeof(*plan));
+    plan->size = P;
+    plan->n_local = n_local;
+    plan->record_bytes = lay.leaf_bytes;
+#define IBVH_TRY(expr)                        \
+    do {                                      \
+        const int e_ = (int)(expr);           \
+        if (e_ != IBVH_OK) return (ibvh_status)e_; \
+    } while (0)
+    // 1. extrema -> [-mins, maxs, one-hot counts] -> ONE all-reduce(MAX) -> global, expanded extrema
+    if (n_local > 0)
+        IBVH_TRY(ibvh_extrema(types, volumes, 0, n_local, 0, base + L.ext_local, base + L.ext_scratch, (size_t)1 << 17, stream));
+    IBVH_TRY(ibvh_dist_pack_extrema(flt, base + L.ext_local, n_local > 0 ? 1 : 0, me, P, n_local, base + L.vec, stream));
+    if (P > 1) IBVH_TRY(comm->all_reduce(comm->ctx, base + L.vec, 6 + P, IBVH_COMM_F64, IBVH_COMM_MAX, stream));
+    IBVH_TRY(ibvh_dist_unpack_extrema(flt, base + L.vec, base + L.ext, stream));
+    // 2. keys, first digit histogram (all-gathered: every rank then knows the whole send matrix when one level suffices)
+    const int bits0 = key_bits < DIGIT_BITS ? key_bits : DIGIT_BITS, shift0 = key_bits - bits0, width0 = 1 << bits0;
+    if (n_local > 0) {
+        IBVH_TRY(ibvh_morton_keys(types, volumes, 0, n_local, base + L.ext, base + L.keys, stream));
+        IBVH_TRY(ibvh_key_histogram(kb, base + L.keys, n_local, shift0, bits0, 64, nullptr, 0, base + L.hist, stream));
+    } else {
+        DIST_HIP_CHECK(hipMemsetAsync(base + L.hist, 0, (size_t)width0 * 4, st));
+    }
+    if (P > 1) IBVH_TRY(comm->all_gather(comm->ctx, base + L.hist, base + L.allh, (int64_t)width0 * 4, stream));
+    else DIST_HIP_CHECK(hipMemcpyAsync(base + L.allh, base + L.hist, (size_t)width0 * 4, hipMemcpyDeviceToDevice, st));
+    // ONE device -> host round trip: the reduced vector (leaf counts), the extrema, every rank's histogram
+    std::vector<double> vec(6 + P);
+    unsigned char ext_raw[48];
+    std::vector<uint32_t> H((size_t)P * width0);
+    IBVH_TRY(d2h(vec.data(), base + L.vec, vec.size() * 8, st));
+    IBVH_TRY(d2h(ext_raw, base + L.ext, (size_t)6 * fb, st));
+    IBVH_TRY(d2h(H.data(), base + L.allh, H.size() * 4, st));
+    DIST_HIP_CHECK(hipStreamSynchronize(st));
+    int64_t n_global = 0, before = 0;
+    for (int r = 0; r < P; ++r) {
+        const int64_t c = (int64_t)std::llround(vec[6 + r]);
+        if (r < me) before += c;
+        n_global += c;
+    }
+    plan->n_global = n_global;
+    plan->base = before;
+    for (int k = 0; k < 6; ++k) plan->extrema[k] = fb == 8 ? ((const double *)ext_raw)[k] : (double)((const float *)ext_raw)[k];
+    if (n_global < P) return IBVH_ERR_DOMAIN; // fewer leaves than ranks
+    // 3. splitters
+    ibvh_splitter_search ss;
+    IBVH_TRY(ibvh_splitter_search_init(&ss, P, key_bits, n_global, tolerance));
+    if (P > 1) {
+        std::vector<int64_t> sum((size_t)width0, 0);
+        for (int r = 0; r < P; ++r)
+            for (int d = 0; d < width0; ++d) sum[d] += H[(size_t)r * width0 + d];
+        IBVH_TRY(ibvh_splitter_search_step(&ss, sum.data()));
+        std::vector<int64_t> rows_host;
+        while (!ss.all_done) { // (rare: a splitter landed in a bucket heavier than the tolerance allows)
+            const int nr = ss.num_rows, width = 1 << ss.next_bits;
+            if (nr > 15) return IBVH_ERR_UNSUPPORTED; // (more than 15 distinct undecided prefixes: > 16 ranks in one bucket chain)
+            if (n_local > 0)
+                IBVH_TRY(ibvh_key_histogram(kb, base + L.keys, n_local, ss.next_shift, ss.next_bits, ss.next_shift + ss.next_bits, ss.rows, nr,
+                                            base + L.hist, stream));
+            else DIST_HIP_CHECK(hipMemsetAsync(base + L.hist, 0, (size_t)nr * width * 4, st));
+            const int64_t cnt = (int64_t)nr * width;
+            widen_u32_i64_kernel<<<dim3((unsigned)ceil_div(cnt, 256)), dim3(256), 0, st>>>((const uint32_t *)(base + L.hist), (long long *)(base + L.hist64), cnt);
+            IBVH_TRY(comm->all_reduce(comm->ctx, base + L.hist64, cnt, IBVH_COMM_I64, IBVH_COMM_SUM, stream));
+            rows_host.resize((size_t)cnt);
+            IBVH_TRY(d2h(rows_host.data(), base + L.hist64, (size_t)cnt * 8, st));
+            DIST_HIP_CHECK(hipStreamSynchronize(st));
+            IBVH_TRY(ibvh_splitter_search_step(&ss, rows_host.data()));
+        }
+    }
+    plan->levels_used = ss.decided;
+    for (int k = 0; k < P - 1; ++k) plan->splitters[k] = ss.splitters[k];
+    // 4. who sends what to whom
+    bool matrix_known = P > 1 && ss.decided <= bits0; // splitters sit on first-level bucket boundaries
+    if (P == 1) {
+        plan->send_counts[0] = plan->recv_counts[0] = n_local;
+    } else if (matrix_known) {
+        std::vector<int64_t> edge(P + 1);
+        edge[0] = 0;
+        edge[P] = width0;
+        for (int r = 1; r < P; ++r) edge[r] = (int64_t)(plan->splitters[r - 1] >> shift0);
+        for (int dst = 0; dst < P; ++dst) {
+            int64_t mine = 0, col = 0;
+            for (int src = 0; src < P; ++src) {
+                int64_t c = 0;
+                for (int64_t d = edge[dst]; d < edge[dst + 1]; ++d) c += H[(size_t)src * width0 + d];
+                if (src == me) mine = c;
+                if (dst == me) plan->recv_counts[src] = c;
+                col += c;
+            }
+            plan->send_counts[dst] = mine;
+            if (col < 1) return IBVH_ERR_DOMAIN; // a rank would receive nothing: EVERY rank stops here, together
+        }
+    }
+    // stable partition of the local leaves by destination (always inside the library); unknown matrix: it counts as well
+    if (P > 1 && n_local > 0) {
+        IBVH_TRY(ibvh_dist_partition(kb, base + L.keys, n_local, plan->splitters, P, base + L.perm, matrix_known ? nullptr : base + L.cnt,
+                                     base + L.part, L.part_bytes, stream));
+    } else if (P > 1 && !matrix_known) {
+        DIST_HIP_CHECK(hipMemsetAsync(base + L.cnt, 0, (size_t)P * 8, st));
+    }
+    if (P > 1 && !matrix_known) {
+        // exchange the counts (8 bytes per peer), then make sure no rank is left empty
+        std::vector<int64_t> eight(P, 8);
+        IBVH_TRY(comm->all_to_all_v(comm->ctx, base + L.cnt, eight.data(), base + L.cnt + (size_t)P * 8, eight.data(), stream));
+        IBVH_TRY(d2h(plan->send_counts, base + L.cnt, (size_t)P * 8, st));
+        IBVH_TRY(d2h(plan->recv_counts, base + L.cnt + (size_t)P * 8, (size_t)P * 8, st));
+        DIST_HIP_CHECK(hipStreamSynchronize(st));
+        int64_t got = 0;
+        for (int r = 0; r < P; ++r) got += plan->recv_counts[r];
+        DIST_HIP_CHECK(hipMemcpyAsync(base + L.cnt + (size_t)2 * P * 8, &got, 8, hipMemcpyHostToDevice, st));
+        IBVH_TRY(comm->all_reduce(comm->ctx, base + L.cnt + (size_t)2 * P * 8, 1, IBVH_COMM_I64, IBVH_COMM_MIN, stream));
+        int64_t min_recv = 0;
+        IBVH_TRY(d2h(&min_recv, base + L.cnt + (size_t)2 * P * 8, 8, st));
+        DIST_HIP_CHECK(hipStreamSynchronize(st));
+        if (min_recv < 1) return IBVH_ERR_DOMAIN;
+    }
+    int64_t n_slice = 0;
+    for (int r = 0; r < P; ++r) n_slice += plan->recv_counts[r];
+    plan->n_slice = n_slice;
+    if (n_slice < 1) return IBVH_ERR_DOMAIN;
+    return IBVH_OK;
+}
+
+ibvh_status ibvh_dist_exchange(const ibvh_types *types, const ibvh_comm *comm, const void *volumes, const ibvh_dist_plan_t *plan,
+                               void *scratch, size_t scratch_bytes, void *records_out, void *stream) {
+    if (!types || !comm || !plan || !records_out) return IBVH_ERR_INVALID_ARG;
+    const int P = comm->size;
+    if (P != plan->size || P < 1 || P > MAX_RANKS) return IBVH_ERR_INVALID_ARG;
+    ibvh_layout lay;
+    if (!layout_of(*types, lay)) return IBVH_ERR_UNSUPPORTED;
+    const int64_t n_local = plan->n_local;
+    if (n_local > 0 && !volumes) return IBVH_ERR_INVALID_ARG;
+    const Layout L = make_layout(*types, n_local, P);
+    if (!scratch || scratch_bytes < L.total) return IBVH_ERR_SCRATCH;
+    hipStream_t st = (hipStream_t)stream;
+    char *base = (char *)scratch;
+    const int64_t rb = lay.leaf_bytes;
+    if (P == 1) { // records straight into the caller's array
+        if (n_local > 0) IBVH_TRY(ibvh_pack_records(types, volumes, base + L.keys, nullptr, plan->base, n_local, records_out, stream));
+        return IBVH_OK;
+    }
+    if (n_local > 0) IBVH_TRY(ibvh_pack_records(types, volumes, base + L.keys, base + L.perm, plan->base, n_local, base + L.records, stream));
+    int64_t sb[MAX_RANKS], rbts[MAX_RANKS];
+    for (int r = 0; r < P; ++r) {
+        sb[r] = plan->send_counts[r] * rb;
+        rbts[r] = plan->recv_counts[r] * rb;
+    }
+    IBVH_TRY(comm->all_to_all_v(comm->ctx, base + L.records, sb, records_out, rbts, stream));
+    (void)st;
+    return IBVH_OK;
+#undef IBVH_TRY
+}
+
+} // extern "C"

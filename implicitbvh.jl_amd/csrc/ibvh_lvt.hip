@@ -552,9 +552,17 @@ constexpr int QUEUE_WAVES = IBVH_QUEUE_WAVES; // waves per workgroup (they share
 #endif
 constexpr int QUEUE_MINWAVES = IBVH_QUEUE_MINWAVES; // waves per SIMD the register allocator has to leave room for (8: 64 VGPRs)
 
+// Waves per SIMD a given instantiation can actually reach: Float64 volumes and 64-bit queue entries need more registers than
+// the bench types, and asking for 7 waves there only makes the allocator spill and warn (-Wpass-failed, 48 times in round 3).
+template <class L, class N, class I, bool WIDE> constexpr int queue_min_waves() {
+    if (sizeof(typename N::elt) == 8) return 4;
+    if (sizeof(typename L::elt) == 8) return 5;
+    if (WIDE && sizeof(I) == 8) return 6;
+    return QUEUE_MINWAVES;
+}
 // WIDE: 64-bit queue entries for trees of 29 .. 31 levels (leaf-parent indices beyond 2^26), see launch().
 template <class L, class N, class I, int MODE, bool WRITE, bool NARROW, bool WIDE, bool COUNT = false>
-__global__ __launch_bounds__(64 * QUEUE_WAVES, QUEUE_MINWAVES) void lvt_queue_kernel(Args<L, N, I> a, PairCache<I> cache, int cut_level) {
+__global__ __launch_bounds__(64 * QUEUE_WAVES, (queue_min_waves<L, N, I, WIDE>())) void lvt_queue_kernel(Args<L, N, I> a, PairCache<I> cache, int cut_level) {
     using TN = typename N::elt;
     Work<COUNT> work; // (COUNT: one lane-level box / sphere test = one count; lane 0 carries the wave-uniform parts)
     using Q = Query<L, N, I, MODE, WRITE, NARROW>;
@@ -1439,8 +1447,11 @@ template <int STEP> IBVH_D void group_reduce_step_dpp(float (&mn)[6], float (&mx
 }
 #undef IBVH_DPP12
 
+template <class L, class N> constexpr int dual_min_waves() { // (Float64 volumes cannot reach the bench types' occupancy)
+    return sizeof(typename N::elt) == 8 ? 4 : (sizeof(typename L::elt) == 8 ? 5 : DUAL_MINWAVES);
+}
 template <class L, class N, class I, int MODE, bool WRITE, bool NARROW, bool WIDE, bool COUNT = false>
-__global__ __launch_bounds__(64, DUAL_MINWAVES) void lvt_dual_kernel(Args<L, N, I> a, PairCache<I> cache, DualPlan plan) {
+__global__ __launch_bounds__(64, (dual_min_waves<L, N>())) void lvt_dual_kernel(Args<L, N, I> a, PairCache<I> cache, DualPlan plan) {
     using TN = typename N::elt;
     Work<COUNT> work;
     using Q = Query<L, N, I, MODE, WRITE, NARROW>;

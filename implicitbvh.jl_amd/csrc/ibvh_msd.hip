@@ -793,6 +793,9 @@ struct FinishArgs {
     // slow path only: (key, position) arrays of n entries each
     void *kalt, *kpri;
     uint32_t *valt, *vpri;
+    // resident path (32-bit keys): 8-byte words of LDS behind the sort's arrays that hold a range's RECORDS (0: off), and
+    // where they start (bytes from the base of the dynamic LDS)
+    uint32_t resident_words, resident_off;
 };
 
 template <class K, int TPB, int IPT> struct FinishLds {
@@ -804,11 +807,13 @@ template <class K, int TPB, int IPT> struct FinishLds {
     uint32_t *gbase;      // R
     uint32_t *wave_tot;   // 16
     uint16_t *whist;      // W * R
-    IBVH_D explicit FinishLds(unsigned char *p) {
+    // resident_off != 0 (the resident kernel): the 16-bit positions of the plain path — which then only serves the ranges too
+    // large to be resident — live in the record area, so that the record area is as large as possible
+    IBVH_D explicit FinishLds(unsigned char *p, uint32_t resident_off = 0) {
         s_keys = (K *)p;
-        s_idx = (uint16_t *)(s_keys + CAP);
+        s_idx = resident_off ? (uint16_t *)(p + resident_off) : (uint16_t *)(s_keys + CAP);
         s_vals32 = (uint32_t *)(s_keys + CAP / 2);
-        local_base = (uint32_t *)(s_idx + CAP);
+        local_base = resident_off ? (uint32_t *)(s_keys + CAP) : (uint32_t *)(s_idx + CAP);
         gbase = local_base + R;
         wave_tot = gbase + R;
         whist = (uint16_t *)(wave_tot + 16);
@@ -816,7 +821,7 @@ template <class K, int TPB, int IPT> struct FinishLds {
 };
 
 // records [start, start + m) of `part`, whose keys are key_base + (an nbits-bit number): sorted into out[start ...)
-template <class K, int TPB, int IPT>
+template <class K, int TPB, int IPT, bool RES>
 IBVH_D void finish_range(const FinishArgs &fa, const FinishLds<K, TPB, IPT> &l, const char *part, int64_t start, int64_t m, K key_base,
                          int nbits) {
     constexpr int W = TPB / 64;
@@ -828,6 +833,85 @@ IBVH_D void finish_range(const FinishArgs &fa, const FinishLds<K, TPB, IPT> &l, 
     const char *bucket = part + start * stride;
     const int passes = (nbits + RB - 1) / RB;
     IBVH_STAMP(1, 1);
+    // ---- resident path (round 4): the range's RECORDS live in LDS.  The fast path below reads every record twice from
+    // memory — the strided key loads pull the range's lines through L2, the gather by sorted position fetches them again
+    // (and with 512 cells of ~117 KB in flight the second read often misses: FETCH_SIZE showed the records read ~2.8 x) —
+    // here each record is read from memory exactly ONCE, coalesced, into LDS; the keys are taken from the LDS copy, sorted
+    // as one 32-bit word (key - base) << IDXB | position (a stable LSD on the key bits only: the position rides along), and
+    // the output is gathered out of LDS.  32-bit keys whose varying bits + IDXB fit 32 bits only.
+    if constexpr (RES && sizeof(K) == 4) {
+        constexpr int IDXB = 32 - __builtin_clz((unsigned)(CAP - 1)); // bits of a position inside the range
+        if (m <= CAP && nbits + IDXB <= 32 && (uint32_t)m * fa.words <= fa.resident_words) {
+            uint64_t *s_rec = (uint64_t *)((unsigned char *)l.s_keys + fa.resident_off);
+            const uint64_t *__restrict__ src = (const uint64_t *)bucket;
+            const uint32_t total = (uint32_t)m * fa.words;
+            constexpr int U = 8;
+            for (uint32_t g0 = threadIdx.x; g0 < total; g0 += TPB * U) {
+                uint64_t v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t g = g0 + u * TPB;
+                    v[u] = src[g < total ? g : 0u];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t g = g0 + u * TPB;
+                    if (g < total) s_rec[g] = v[u];
+                }
+            }
+            __syncthreads();
+            const int chunk = (int)((m + W * 64 - 1) / (W * 64)) * 64;
+            const int jmax = chunk / 64; // <= IPT
+            const uint32_t mw = (uint32_t)fa.lay.morton_off >> 3, msh = ((uint32_t)fa.lay.morton_off & 7u) * 8u;
+            const uint32_t mmask = fa.lay.morton_bytes == 2 ? 0xffffu : 0xffffffffu;
+            K key[IPT];
+            const rsort::NoVal none[IPT] = {};
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) {
+                const int idx = w * chunk + j * 64 + lane;
+                const bool ok = j < jmax && idx < m;
+                const uint32_t k = (uint32_t)(s_rec[(uint32_t)(ok ? idx : 0) * fa.words + mw] >> msh) & mmask;
+                key[j] = ok ? (K)(((k - (uint32_t)key_base) << IDXB) | (uint32_t)idx) : (K) ~(K)0; // sentinels sort last
+            }
+            if (passes == 0) {
+#pragma unroll
+                for (int j = 0; j < IPT; ++j) {
+                    const int idx = w * chunk + j * 64 + lane;
+                    if (j < jmax) l.s_keys[idx] = key[j];
+                }
+                __syncthreads();
+            }
+            int done = 0;
+            for (int p = 0; p < passes; ++p) {
+                const int bits = (nbits - done + (passes - p) - 1) / (passes - p);
+                lds_radix_pass<K, rsort::NoVal, TPB, IPT, RB>(key, none, IDXB + done, bits, jmax, l.s_keys, (rsort::NoVal *)nullptr, l.local_base,
+                                                              l.wave_tot, l.whist);
+                done += bits;
+                if (p + 1 < passes) {
+#pragma unroll
+                    for (int j = 0; j < IPT; ++j) {
+                        const int idx = w * chunk + j * 64 + lane;
+                        if (j < jmax) key[j] = l.s_keys[idx];
+                    }
+                    __syncthreads();
+                }
+            }
+            uint64_t *__restrict__ dst = (uint64_t *)(fa.out + start * stride);
+            for (uint32_t g0 = threadIdx.x; g0 < total; g0 += TPB * U) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t g = g0 + u * TPB;
+                    if (g < total) {
+                        const uint32_t r = __umulhi(g, fa.inv_words);
+                        const uint32_t part_w = g - r * fa.words;
+                        dst[g] = s_rec[((uint32_t)l.s_keys[r] & ((1u << IDXB) - 1u)) * fa.words + part_w];
+                    }
+                }
+            }
+            __syncthreads(); // (the LDS arrays are reused by the workgroup's next range)
+            return;
+        }
+    }
     if (m <= CAP) {
         // ---- fast path: the range's keys live in LDS -------------------------------------------------------
         // the m keys are dealt to the waves in equal contiguous shares of `chunk` (a multiple of 64): a range of
@@ -978,17 +1062,17 @@ IBVH_D uint64_t uni(uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 
 // tiles of every extra level: tile t of segment k finishes the window of sub-cells that START inside records
 // [t * tile, (t + 1) * tile) of the segment (consecutive sub-cells: one LDS sort with the sub-cell number as the top
 // bits); a window that does not fit is finished sub-cell by sub-cell, skipping those the next level took
-template <class K, int TPB, int IPT>
+template <class K, int TPB, int IPT, bool RES = false>
 __global__ __launch_bounds__(TPB) void finish_kernel(Tables tb, int radix, FinishArgs fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
-    const FinishLds<K, TPB, IPT> l(bsm);
+    const FinishLds<K, TPB, IPT> l(bsm, RES ? fa.resident_off : 0u);
     IBVH_STAMP(1, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0 && fa.skew_flag) *fa.skew_flag = (int32_t)(tb.needed[0] | (tb.needed[1] << 8));
     if ((int)blockIdx.x < radix) {
         const uint32_t d = blockIdx.x;
         const uint32_t start = uni(tb.cell_start[d]), m = uni(tb.cell_start[d + 1]) - start;
         if (m == 0 || (m > fa.cap && fa.levels > 0)) return; // (crowded cells are finished window by window below)
-        finish_range<K, TPB, IPT>(fa, l, fa.buf[0], (int64_t)start, (int64_t)m, (K)((K)d << fa.shift1), fa.shift1);
+        finish_range<K, TPB, IPT, RES>(fa, l, fa.buf[0], (int64_t)start, (int64_t)m, (K)((K)d << fa.shift1), fa.shift1);
         return;
     }
     constexpr int C = 1 << L2_BITS;
@@ -1053,7 +1137,7 @@ __global__ __launch_bounds__(TPB) void finish_kernel(Tables tb, int radix, Finis
                 }
                 const uint32_t m = ss(f) - s0;
                 if (m != 0 && !(crowded && handed_down))
-                    finish_range<K, TPB, IPT>(fa, l, buf, seg0 + s0, (int64_t)m, (K)(prefix + ((K)e << dg.shift)),
+                    finish_range<K, TPB, IPT, RES>(fa, l, buf, seg0 + s0, (int64_t)m, (K)(prefix + ((K)e << dg.shift)),
                                               dg.shift + bit_length(f - e - 1));
                 e = f;
             }
@@ -1130,7 +1214,7 @@ Plan make_plan(int64_t n, int key_bits, int key_bytes, int leaf_bytes, void *sor
     int tile = (n >= (int64_t(1) << 22) && leaf_bytes <= 32) ? 4096 : 2048;
     if (f_tile) tile = f_tile;
     while (tile > 1024 && (size_t)tile * leaf_bytes + ((size_t)8 << bits) + 128 > 160 * 1024) tile >>= 1;
-    if (tile > cap / 2) tile = cap / 2 < 1024 ? 1024 : cap / 2; // a window of sub-cells (< tile + one sub-cell) should fit the LDS sort
+    while (!f_tile && tile > 1024 && tile > cap / 2) tile >>= 1; // a window of sub-cells (< tile + one sub-cell) should fit the LDS sort
     switch (tile) {
     case 1024: p.ptpb = 256, p.pipt = 4; break;
     case 2048: p.ptpb = 256, p.pipt = 8; break;
@@ -1207,10 +1291,34 @@ static int launch_partitions(const Plan &p, const K *keys, int64_t n, const Reco
     return IBVH_OK;
 }
 template <class K, int FT, int FI>
-static int launch_finish(const Plan &p, const FinishArgs &fa, hipStream_t st) {
-    constexpr size_t smem = finish_smem<K, FT, FI>();
-    IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)finish_kernel<K, FT, FI>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+static int launch_finish(const Plan &p, const FinishArgs &fa_in, hipStream_t st) {
+    FinishArgs fa = fa_in;
+    size_t smem = finish_smem<K, FT, FI>();
+    // resident path: room for a full range of records behind the sort's arrays, as long as the workgroup stays within the
+    // LDS budget (tuning msd_resident_kb; 0 = off: the records are then gathered from memory as in rounds 2 and 3)
+    if (sizeof(K) == 4 && g_tuning.msd_resident_kb > 0) {
+        const size_t cap = (size_t)FT * FI;
+        const size_t off = (size_t)align_up((int64_t)(smem - cap * 2), 16); // (no 16-bit positions in front of the record area)
+        const size_t budget = (size_t)g_tuning.msd_resident_kb * 1024 < (size_t)kMaxLds ? (size_t)g_tuning.msd_resident_kb * 1024 : (size_t)kMaxLds;
+        size_t rec = cap * (size_t)fa.lay.stride;  // a full range, or what the budget leaves (larger ranges take the plain path)
+        if (off + rec > budget) rec = budget > off ? ((budget - off) / 8) * 8 : 0;
+        if (rec >= cap * 2 && rec >= 1024 * (size_t)fa.lay.stride) {
+            fa.resident_off = (uint32_t)off;
+            fa.resident_words = (uint32_t)(rec / 8);
+            smem = off + rec;
+        }
+    }
+    // (development knob: ask for more LDS than needed, i.e. fewer workgroups per CU — a smaller footprint in flight per L2)
+    if ((size_t)g_tuning.msd_finish_pad_kb * 1024 > smem && g_tuning.msd_finish_pad_kb <= 160) smem = (size_t)g_tuning.msd_finish_pad_kb * 1024;
     const int f2 = fa.levels <= 0 ? 0 : (p.max_tiles2 < 1024 ? p.max_tiles2 : 1024); // workgroups that stride over the extra levels' windows
+    if constexpr (sizeof(K) == 4) {
+        if (fa.resident_words) { // (a kernel of its own: the resident branch must not cost the plain one registers)
+            IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)finish_kernel<K, FT, FI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+            IBVH_LAUNCH((finish_kernel<K, FT, FI, true>), dim3((1u << p.bits) + f2), dim3(FT), smem, st, p.tb, 1 << p.bits, fa);
+            return IBVH_OK;
+        }
+    }
+    IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)finish_kernel<K, FT, FI>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
     IBVH_LAUNCH((finish_kernel<K, FT, FI>), dim3((1u << p.bits) + f2), dim3(FT), smem, st, p.tb, 1 << p.bits, fa);
     return IBVH_OK;
 }
@@ -1267,8 +1375,11 @@ int sort_records(const Plan &p, int key_bytes, const void *keys, int64_t n, cons
 #define IBVH_FIN(K, T, I) \
     if (p.ftpb == T && p.fipt == I) rc = launch_finish<K, T, I>(p, fa, st);
     if (key_bytes == 4) {
+        IBVH_FIN(uint32_t, 256, 6) IBVH_FIN(uint32_t, 256, 10) IBVH_FIN(uint32_t, 256, 11) IBVH_FIN(uint32_t, 256, 12)
         IBVH_FIN(uint32_t, 256, 8) IBVH_FIN(uint32_t, 256, 16) IBVH_FIN(uint32_t, 256, 32) IBVH_FIN(uint32_t, 512, 8)
         IBVH_FIN(uint32_t, 512, 16) IBVH_FIN(uint32_t, 512, 32) IBVH_FIN(uint32_t, 1024, 8) IBVH_FIN(uint32_t, 1024, 16)
+        IBVH_FIN(uint32_t, 1024, 3) IBVH_FIN(uint32_t, 1024, 4) IBVH_FIN(uint32_t, 512, 6) IBVH_FIN(uint32_t, 1024, 6) IBVH_FIN(uint32_t, 512, 11)
+        IBVH_FIN(uint32_t, 512, 12) IBVH_FIN(uint32_t, 512, 5) IBVH_FIN(uint32_t, 512, 7)
     } else {
         IBVH_FIN(uint64_t, 256, 8) IBVH_FIN(uint64_t, 256, 16) IBVH_FIN(uint64_t, 256, 32) IBVH_FIN(uint64_t, 512, 8)
         IBVH_FIN(uint64_t, 512, 16) IBVH_FIN(uint64_t, 1024, 8)

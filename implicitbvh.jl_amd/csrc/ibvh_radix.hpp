@@ -5,6 +5,7 @@
 // order — the single-task Base.sort! behaviour the oracle restates for AK.sort! (reference src/build.jl:248-253;
 // tie order is unpinned there).
 #pragma once
+#include <type_traits>
 #include "ibvh_common.hpp"
 
 #ifndef IBVH_PASS_STAMP
@@ -206,6 +207,7 @@ IBVH_D void write_record(const RecordArgs &rec, uint32_t p, uint64_t dest, uint6
 // One stable pass over the keys a workgroup holds in registers (wave-striped: (w, j, lane) order == sequence
 // order) on the digit (key >> shift) & (2^bits - 1), bits <= RBITS: afterwards s_keys / s_vals hold the sequence
 // in the new order.  whist: W * 2^RBITS 16-bit counters, local_base: 2^RBITS words, wave_tot: TPB/64 words.
+struct NoVal {}; // VT of a pass that moves keys only (the payload is packed into the key's low bits)
 template <class K, class VT, int TPB, int IPT, int RBITS>
 IBVH_D void lds_radix_pass(const K (&key)[IPT], const VT (&val)[IPT], int shift, int bits, int jmax, K *s_keys, VT *s_vals,
                            uint32_t *local_base, uint32_t *wave_tot, uint16_t *whist, uint32_t *tot_d_out = nullptr) {
@@ -248,7 +250,7 @@ IBVH_D void lds_radix_pass(const K (&key)[IPT], const VT (&val)[IPT], int shift,
         const uint32_t d = (uint32_t)(key[j] >> shift) & mask;
         const uint32_t pos = local_base[d] + my_hist[d] + rank[j];
         s_keys[pos] = key[j];
-        s_vals[pos] = val[j];
+        if constexpr (!std::is_same<VT, NoVal>::value) s_vals[pos] = val[j];
     }
     __syncthreads();
     IBVH_PASS_STAMP(9);

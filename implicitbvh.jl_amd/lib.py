@@ -59,6 +59,12 @@ SIGNATURES = {
     "ibvh_dist_partition": [_i32, _vp, _i64, _P(C.c_uint64), _i32, _vp, _vp, _vp, _sz, _vp],
     "ibvh_key_histogram": [_i32, _vp, _i64, _i32, _i32, _i32, _P(C.c_uint64), _i32, _vp, _vp],
     "ibvh_pack_records": [_P(abi.Types), _vp, _vp, _vp, _i64, _i64, _vp, _vp],
+    "ibvh_comm_from_rccl": [_vp, _i32, _i32, _P(abi.Comm)],
+    "ibvh_splitter_search_init": [_P(abi.SplitterSearch), _i32, _i32, _i64, C.c_double],
+    "ibvh_splitter_search_step": [_P(abi.SplitterSearch), _P(_i64)],
+    "ibvh_dist_scratch_bytes": [_P(abi.Types), _i64, _i32, _P(_sz)],
+    "ibvh_dist_plan": [_P(abi.Types), _P(abi.Comm), _vp, _i64, C.c_double, _vp, _sz, _P(abi.DistPlan), _vp],
+    "ibvh_dist_exchange": [_P(abi.Types), _P(abi.Comm), _vp, _P(abi.DistPlan), _vp, _sz, _vp, _vp],
     "ibvh_volumes_from_triangles": [_i32, _i32, _vp, _i64, _vp, _vp],
     "ibvh_generate_spheres_f32": [_i64, C.c_uint64, _i64, _P(C.c_float), _P(C.c_float), C.c_float, _vp, _vp],
     "ibvh_profile_enable": [_i32],
@@ -104,8 +110,13 @@ def load():
 
 
 def set_tuning(name, value):
-    """ibvh_set_tuning: a process-wide development knob (include/ibvh.h)."""
+    """ibvh_set_tuning: a process-wide development knob (include/ibvh.h).  Sizes the mirror has memoised (scratch bytes
+    depend on the sort's geometry) are forgotten."""
     call("ibvh_set_tuning", name.encode(), int(value))
+    import sys
+    api = sys.modules.get(__package__ + ".api")
+    if api is not None:
+        api._shape_memo.clear()
 
 
 def call(name, *args):

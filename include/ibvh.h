@@ -38,7 +38,7 @@ extern "C" {
  * library and refuses a mismatch: a stale caller would otherwise hand the GPU garbage pointers.
  *   1: round 1   2: ibvh_build_desc.sort_levels / skew_flag, ibvh_bfs_result.resume_*, *_enqueue(total_dev)
  *   3: *_enqueue(total_host), ibvh_set_tuning, ibvh_lvt_work_counters, ray `narrow`, contact positions */
-#define IBVH_ABI_VERSION 3
+#define IBVH_ABI_VERSION 4
 int32_t ibvh_abi_version(void);
 
 /* ----------------------------------------------------------------------------------- */
@@ -407,6 +407,87 @@ ibvh_status ibvh_key_histogram(int32_t key_bytes, const void *keys, int64_t n, i
 ibvh_status ibvh_pack_records(const ibvh_types *types, const void *volumes, const void *keys,
                               const void *perm, int64_t index_base, int64_t n, void *records_out,
                               void *stream);
+
+/* ----------------------------------------------------------------------------------- */
+/* multi-GPU build: the driver (round 4).  No reference counterpart: ImplicitBVH.jl is    */
+/* single-device; BASELINE.json's north star shards the BUILD over the GPUs of one node   */
+/* ("RCCL allreduce over xGMI for the global AABB and a distributed radix-sort exchange") */
+/* and keeps the host in Julia behind "a thin C-ABI (ccall) shim" — this is that shim.    */
+/* ----------------------------------------------------------------------------------- */
+#define IBVH_DIST_MAX_RANKS 256
+enum { IBVH_COMM_F64 = 0, IBVH_COMM_I64 = 1, IBVH_COMM_I32 = 2 };  /* element type of an all-reduce */
+enum { IBVH_COMM_MAX = 0, IBVH_COMM_SUM = 1, IBVH_COMM_MIN = 2 };  /* its operation                 */
+
+/* Collectives the driver needs, as a vtable: every rank calls the same sequence.  Buffers are DEVICE pointers; a call is
+ * ordered behind earlier work on `stream` and later work on `stream` sees its result (RCCL semantics).  Return 0 on
+ * success.  all_to_all_v: `send` is partitioned contiguously by destination (send_bytes[p] bytes for rank p), `recv`
+ * contiguously by source (recv_bytes[p]); both count arrays are HOST arrays of `size` entries. */
+typedef struct ibvh_comm {
+    void *ctx;
+    int32_t rank, size;
+    int32_t (*all_reduce)(void *ctx, void *buf, int64_t count, int32_t dtype, int32_t op, void *stream); /* in place */
+    int32_t (*all_gather)(void *ctx, const void *send, void *recv, int64_t bytes_per_rank, void *stream);
+    int32_t (*all_to_all_v)(void *ctx, const void *send, const int64_t *send_bytes, void *recv, const int64_t *recv_bytes,
+                            void *stream);
+} ibvh_comm;
+
+/* The vtable over RCCL for an ncclComm_t the caller created (ncclCommInitRank), collectives issued on the stream each
+ * call is handed.  librccl.so is resolved with dlopen on first use (libibvh.so does not link it): IBVH_ERR_UNSUPPORTED
+ * when it cannot be found.  all_to_all_v = grouped ncclSend / ncclRecv: xGMI is point-to-point. */
+ibvh_status ibvh_comm_from_rccl(void *nccl_comm, int32_t rank, int32_t size, ibvh_comm *out);
+
+/* Splitter search of the distributed radix sort — HOST arithmetic only (no GPU), identical on every rank: keys
+ * k_1 <= ... <= k_{P-1}, rank r receives the keys in [k_r, k_{r+1}).  Protocol: init; then, until all_done: make the GLOBAL
+ * histogram of the digit (key >> next_shift) & (2^next_bits - 1) — one row over all keys at level 0, later one row per
+ * prefix rows[j] (keys with key >> (next_shift + next_bits) == rows[j]), num_rows rows — and hand it to _step.  A splitter
+ * stops refining once the bucket it landed in holds at most tolerance * n_global / size keys (0: full key resolution). */
+typedef struct ibvh_splitter_search {
+    int32_t size, key_bits, decided /* key bits decided so far */, all_done;
+    int32_t next_bits, next_shift, num_rows, reserved_;
+    int64_t n_global;
+    double tolerance;
+    uint64_t rows[IBVH_DIST_MAX_RANKS];      /* prefixes the next histogram needs, ascending */
+    uint64_t prefix[IBVH_DIST_MAX_RANKS];    /* per splitter: the bits decided so far        */
+    uint64_t splitters[IBVH_DIST_MAX_RANKS]; /* per splitter: the final key, once done       */
+    int64_t below[IBVH_DIST_MAX_RANKS];      /* per splitter: global number of keys strictly below its decided prefix range */
+    int32_t row_of[IBVH_DIST_MAX_RANKS];     /* per splitter: its row of the next histogram  */
+    uint8_t done[IBVH_DIST_MAX_RANKS];
+} ibvh_splitter_search;
+ibvh_status ibvh_splitter_search_init(ibvh_splitter_search *s, int32_t size, int32_t key_bits, int64_t n_global, double tolerance);
+ibvh_status ibvh_splitter_search_step(ibvh_splitter_search *s, const int64_t *hist);
+
+/* What ibvh_dist_plan found out (HOST memory). */
+typedef struct ibvh_dist_plan_t {
+    int32_t size, levels_used /* key bits the splitter search decided */;
+    int64_t n_local, n_global;
+    int64_t base;             /* global 0-based number of this rank's first local leaf (records carry base + p + 1)   */
+    int64_t n_slice;          /* records this rank receives = leaves of its slice of the globally sorted sequence    */
+    int64_t record_bytes;
+    double extrema[6];        /* global centre extrema, epsilon-expanded: mins / maxs for the local ibvh_build        */
+    uint64_t splitters[IBVH_DIST_MAX_RANKS];
+    int64_t send_counts[IBVH_DIST_MAX_RANKS], recv_counts[IBVH_DIST_MAX_RANKS]; /* records per peer */
+} ibvh_dist_plan_t;
+
+/* Scratch for ibvh_dist_plan + ibvh_dist_exchange (the same buffer must be passed to both, untouched in between: the plan
+ * leaves the keys and the partition's permutation there). */
+ibvh_status ibvh_dist_scratch_bytes(const ibvh_types *types, int64_t n_local, int32_t size, size_t *bytes_out);
+
+/* Everything up to the exchange (see csrc/ibvh_distdrv.hip): global AABB (one all-reduce(MAX) that also carries every
+ * rank's leaf count), Morton keys, splitters (one all-gather; further all-reduce(SUM) levels only while a splitter's bucket
+ * is heavier than `tolerance` of a shard — 0.005 is the Python mirror's default), stable partition by destination.  BLOCKS
+ * on `stream` once (twice when the send matrix does not follow from the first histogram): the record counts must reach the
+ * host before RCCL can be told the transfer sizes — the reference's own "count, then size, then write" shape.
+ * IBVH_ERR_DOMAIN (on EVERY rank, so that none is left waiting in a collective) when there are fewer leaves than ranks or a
+ * rank would receive none. */
+ibvh_status ibvh_dist_plan(const ibvh_types *types, const ibvh_comm *comm, const void *volumes, int64_t n_local, double tolerance,
+                           void *scratch, size_t scratch_bytes, ibvh_dist_plan_t *plan_out, void *stream);
+
+/* Pack the local leaves into BoundingVolume records with GLOBAL 1-based indices and exchange them: ONE all-to-all.
+ * records_out: DEVICE, plan->n_slice records, grouped by source rank in source order — so the stable local sort of
+ * ibvh_build (already_wrapped = 1, compute_extrema = 0, mins / maxs = plan->extrema) keeps global input order among equal
+ * keys, and rank r ends with the r-th slice of the single-device sorted sequence, bit for bit.  Asynchronous on `stream`. */
+ibvh_status ibvh_dist_exchange(const ibvh_types *types, const ibvh_comm *comm, const void *volumes, const ibvh_dist_plan_t *plan,
+                               void *scratch, size_t scratch_bytes, void *records_out, void *stream);
 
 /* ----------------------------------------------------------------------------------- */
 /* input preparation adjacent to the path                                               */

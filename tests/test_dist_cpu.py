@@ -1,6 +1,8 @@
-"""Multi-rank build logic on CPU: world_size-2 gloo processes (and in-process virtual ranks) drive
-implicitbvh_amd.dist.DistributedBuilder with an oracle-backed engine standing in for the HIP kernels, so
-the splitter search, partition, exchange and global numbering are exercised without a GPU.  Property:
+"""Multi-rank build logic on CPU: world_size-2 gloo processes (and in-process virtual ranks) drive the CPU stand-in of the
+distributed build's driver (tests/dist_cpu_driver.py: the same collectives, the PRODUCT's host-only splitter arithmetic
+ibvh_splitter_search_* of libibvh, an oracle-backed engine standing in for the HIP kernels), so the splitter search, send
+matrix, exchange and global numbering are exercised without a GPU; the device driver itself (csrc/ibvh_distdrv.hip) is
+covered on the GPU with virtual ranks and with RCCL at world size 1 (tests/test_gpu_parity.py, tests/test_gpu_dist.py).  Property:
 concatenating the ranks' sorted leaves reproduces the single-device sorted leaf array bit for bit."""
 import os
 import tempfile
@@ -15,6 +17,10 @@ import oracle_lib as orc
 import implicitbvh_amd as ibvh
 from implicitbvh_amd import abi
 from implicitbvh_amd import dist as ibd
+from dist_cpu_driver import CpuDistributedBuilder
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+from virtual_ranks import run_virtual_ranks  # noqa: E402
 
 
 class OracleEngine:
@@ -147,7 +153,7 @@ def _worker(rank, world, path, n, seed, kind, flt, morton, init_file):
         local = torch.from_numpy(vols[b[rank]:b[rank + 1]].copy())
         types = abi.make_types(kind, flt, abi.BBOX, abi.F32, abi.I32, morton)
         opts = ibvh.BVHOptions(morton=ibvh.DefaultMortonAlgorithm(abi.MORTON_DTYPES[morton]))
-        builder = ibd.DistributedBuilder(ibd.TorchComm(), engine=OracleEngine())
+        builder = CpuDistributedBuilder(ibd.TorchComm(), OracleEngine())
         bvh = builder.build(local, ibvh.api._VolumeType(abi.BBOX, abi.F32), options=opts)
         np.save(os.path.join(path, f"leaves_{rank}.npy"), bvh.leaves)
         np.save(os.path.join(path, f"ext_{rank}.npy"), builder.last["extrema"])
@@ -191,7 +197,7 @@ def _worker_ragged(rank, world, path, n, seed, bounds, init_file):
     try:
         vols = ragged_clustered_cloud(n, seed)
         local = torch.from_numpy(vols[bounds[rank]:bounds[rank + 1]].copy())
-        builder = ibd.DistributedBuilder(ibd.TorchComm(), engine=OracleEngine())
+        builder = CpuDistributedBuilder(ibd.TorchComm(), OracleEngine())
         bvh = builder.build(local)
         np.save(os.path.join(path, f"leaves_{rank}.npy"), bvh.leaves)
         np.save(os.path.join(path, f"send_{rank}.npy"), np.asarray(builder.last["send_counts"]))
@@ -229,10 +235,10 @@ def test_virtual_ranks_cpu(world):
     b = shard_bounds(n, world)
 
     def fn(comm):
-        builder = ibd.DistributedBuilder(comm, engine=OracleEngine())
+        builder = CpuDistributedBuilder(comm, OracleEngine())
         bvh = builder.build(torch.from_numpy(vols[b[comm.rank]:b[comm.rank + 1]].copy()))
         return bvh.leaves, builder.last
-    out = ibd.run_virtual_ranks(world, fn)
+    out = run_virtual_ranks(world, fn)
     check_against_single_build(vols, types, [o[0] for o in out])
     sizes = [len(o[0]) for o in out]
     assert max(sizes) - min(sizes) <= max(8, n // (50 * world))
@@ -252,12 +258,12 @@ def test_cross_shard_completion_cpu(world):
     b = shard_bounds(n, world)
 
     def fn(comm):
-        builder = ibd.DistributedBuilder(comm, engine=OracleEngine())
+        builder = CpuDistributedBuilder(comm, OracleEngine())
         bvh = builder.build(torch.from_numpy(vols[b[comm.rank]:b[comm.rank + 1]].copy()))
         own = orc.traverse_lvt(bvh)[0]
         cross = builder.cross_contacts(bvh).numpy()
         return set(zip(own["a"].tolist(), own["b"].tolist())), {(min(x, y), max(x, y)) for x, y in cross.tolist()}
-    out = ibd.run_virtual_ranks(world, fn)
+    out = run_virtual_ranks(world, fn)
     got = set()
     total = 0
     for own, cross in out:
@@ -272,9 +278,9 @@ def test_exact_splitters_with_zero_tolerance():
     b = shard_bounds(n, world)
 
     def fn(comm):
-        builder = ibd.DistributedBuilder(comm, engine=OracleEngine(), tolerance=0.0)
+        builder = CpuDistributedBuilder(comm, OracleEngine(), tolerance=0.0)
         return builder.build(torch.from_numpy(vols[b[comm.rank]:b[comm.rank + 1]].copy())).leaves
-    out = ibd.run_virtual_ranks(world, fn)
+    out = run_virtual_ranks(world, fn)
     check_against_single_build(vols, abi.make_types(), out)
     sizes = [len(o) for o in out]
     assert max(sizes) - min(sizes) <= 4  # exact up to the multiplicity of one key
@@ -290,9 +296,9 @@ def test_heavy_duplicates_and_uneven_shards():
     bounds = [0, 17, 5000, n]
 
     def fn(comm):
-        builder = ibd.DistributedBuilder(comm, engine=OracleEngine())
+        builder = CpuDistributedBuilder(comm, OracleEngine())
         return builder.build(torch.from_numpy(vols[bounds[comm.rank]:bounds[comm.rank + 1]].copy())).leaves
-    out = ibd.run_virtual_ranks(3, fn)
+    out = run_virtual_ranks(3, fn)
     check_against_single_build(vols, abi.make_types(), out)
 
 
@@ -304,12 +310,12 @@ def test_starved_rank_raises_on_every_rank():
     seen = []
 
     def fn(comm):
-        builder = ibd.DistributedBuilder(comm, engine=OracleEngine())
+        builder = CpuDistributedBuilder(comm, OracleEngine())
         try:
             builder.build(torch.from_numpy(vols[comm.rank * 200:(comm.rank + 1) * 200].copy()))
         except abi.DomainError:
             seen.append(comm.rank)
             return "raised"
         return "built"
-    out = ibd.run_virtual_ranks(3, fn)
+    out = run_virtual_ranks(3, fn)
     assert out == ["raised"] * 3 and sorted(seen) == [0, 1, 2]

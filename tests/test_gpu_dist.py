@@ -36,6 +36,16 @@ def test_distributed_builder_over_nccl_config5_share_of_one_rank():
     _run("props", 12_500_000)
 
 
+def test_c_abi_collective_vtable_over_rccl_and_dist_build_through_it():
+    """include/ibvh.h "multi-GPU build: the driver": ibvh_comm_from_rccl on an ncclComm_t made with RCCL's own C API (no
+    torch.distributed), its three collectives called directly, then ibvh_dist_plan + ibvh_dist_exchange + ibvh_build through
+    it == the single-device build (world size 1: the one GPU of the box)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "dist_rccl_vtable_world1.py"), "300000"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
 def test_bench_self_launches_its_ranks():
     """`python bench.py --gpus 1 --force-dist`: the distributed path of the bench on one rank, and the self-launcher's
     plumbing (a parent that never touches the GPU) via --gpus 2 on a box with one GPU is NOT attempted here: only that the
@@ -48,3 +58,61 @@ def test_bench_self_launches_its_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["leaves_total"] == 200000 and line["value"] > 0
+
+
+def test_config5_at_its_stated_size_with_eight_virtual_ranks():
+    """BASELINE.json configs[4] — 1e8 BSphere{Float32} leaves over 8 GPUs — AT FULL SIZE on the one GPU of the box: 8 virtual
+    ranks (threads; tools/virtual_ranks.py) x 1.25e7 leaves run the library's distributed driver (ibvh_dist_plan /
+    ibvh_dist_exchange, same kernels and the same sequence of collectives as on a node; EMULATED: no xGMI, no RCCL peers).
+    The concatenation of the ranks' slices must be the single-device 1e8-leaf build, byte for byte, ON DEVICE; slices are
+    balanced within the splitter tolerance; every slice's tree is spot-checked; per-slice self contacts + cross-shard
+    contacts add up to the single-device contact count."""
+    import math
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import implicitbvh_amd as ibvh
+    from implicitbvh_amd import dist as ibd
+    from virtual_ranks import run_virtual_ranks
+    P, n_rank = 8, 12_500_000
+    n = P * n_rank
+    r0 = 0.5 * (3 * 8 / (4 * math.pi * n)) ** (1 / 3)
+    single = ibvh.BVH(ibvh.generate_spheres(n, 46, r0=r0))
+    total_single = ibvh.traverse(single).num_contacts
+    ref_leaves = single.leaves.buf
+    ref_ext = single.extrema.clone()
+    del single
+    torch.cuda.empty_cache()
+
+    def fn(comm):
+        vols = ibvh.generate_spheres(n_rank, 46, first_index=comm.rank * n_rank, r0=r0)
+        builder = ibd.DistributedBuilder(comm)
+        bvh = builder.build(vols)
+        own = ibvh.traverse(bvh).num_contacts
+        cross = int(builder.cross_contacts(bvh).shape[0])
+        torch.cuda.synchronize()
+        return bvh, builder.last, own, cross
+    out = run_virtual_ranks(P, fn)
+    sizes = [len(b.leaves) for b, _, _, _ in out]
+    assert sum(sizes) == n
+    # balance: a splitter may stop refining once its bucket holds <= 0.5 % of a shard
+    assert max(abs(s - n_rank) for s in sizes) <= 0.02 * n_rank, sizes
+    off = 0
+    for (bvh, last, _, _) in out:
+        nb = bvh.leaves.buf.numel()
+        assert torch.equal(bvh.leaves.buf, ref_leaves[off:off + nb]), "a slice differs from the single-device sorted sequence"
+        off += nb
+        assert last["extrema"].tolist() == ref_ext.cpu().numpy().tolist()
+        # spot checks of the slice's tree: the level above the leaf parents is the exact min / max of its children
+        t = bvh.tree
+        lp, up = t.levels - 1, t.levels - 2
+        nodes = bvh.nodes
+        first = lambda lvl: int(ibvh.api.memory_index(t, 2 ** (lvl - 1))) - 1  # noqa: E731
+        cnt_up = 2 ** (up - 1) - (t.virtual_leaves >> (t.levels - up))
+        cnt_lp = 2 ** (lp - 1) - (t.virtual_leaves >> (t.levels - lp))
+        sel = torch.randint(0, min(cnt_up, cnt_lp // 2), (200000,), device="cuda")
+        par = nodes[first(up) + sel]
+        c0, c1 = nodes[first(lp) + 2 * sel], nodes[first(lp) + 2 * sel + 1]
+        assert torch.equal(par[:, :3], torch.minimum(c0[:, :3], c1[:, :3])) and torch.equal(par[:, 3:], torch.maximum(c0[:, 3:], c1[:, 3:]))
+    assert off == ref_leaves.numel()
+    own_total, cross_total = sum(o for _, _, o, _ in out), sum(c for _, _, _, c in out)
+    assert cross_total > 0 and own_total + cross_total == total_single, (own_total, cross_total, total_single)

@@ -1124,8 +1124,16 @@ def test_bfs_resumes_at_the_level_that_overflowed(monkeypatch):
 
 
 # ---------------------------------------------------------------------------------------------
-# multi-GPU build, emulated with virtual ranks on this one GPU (HipEngine + in-process collectives)
+# multi-GPU build, emulated with virtual ranks on this one GPU (the library's driver + in-process collectives)
 # ---------------------------------------------------------------------------------------------
+def _virtual_ranks():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import virtual_ranks
+    return virtual_ranks
+
+
+
 @pytest.mark.parametrize("world", [1, 2, 4, 8])
 def test_distributed_build_virtual_ranks_gpu(world):
     from implicitbvh_amd import dist as ibd
@@ -1142,7 +1150,7 @@ def test_distributed_build_virtual_ranks_gpu(world):
         trav = ibvh.traverse(bvh)
         torch.cuda.synchronize()
         return bvh.leaves.to_numpy(), bvh.nodes.cpu().numpy(), contacts_np(trav), builder.last
-    out = ibd.run_virtual_ranks(world, fn)
+    out = _virtual_ranks().run_virtual_ranks(world, fn)
     cat = np.concatenate([o[0] for o in out])
     assert cat.tobytes() == single.leaves.tobytes()  # global stable-sorted sequence, global 1-based indices
     for leaves, nodes, contacts, last in out:
@@ -1185,7 +1193,7 @@ def test_distributed_build_clustered_duplicates_and_ragged_shards_gpu(world, tol
         leaves = bvh.leaves.to_numpy()
         leaves["index"] = leaves["index"]                # (global numbering follows the concatenated shards)
         return leaves, builder.last
-    out = ibd.run_virtual_ranks(world, fn)
+    out = _virtual_ranks().run_virtual_ranks(world, fn)
     cat = np.concatenate([o[0] for o in out])
     for field in ("morton", "index"):
         assert cat[field].tolist() == single.leaves[field].tolist(), field
@@ -1213,7 +1221,7 @@ def test_cross_shard_completion_gives_the_global_contact_set(world):
         cross = builder.cross_contacts(bvh).cpu().numpy().astype(np.int64)
         torch.cuda.synchronize()
         return own, cross
-    out = ibd.run_virtual_ranks(world, fn)
+    out = _virtual_ranks().run_virtual_ranks(world, fn)
     got = set()
     total = 0
     for own, cross in out:
