@@ -546,6 +546,64 @@ def _attach_counters(roofline, tag, avg_s):
         break
 
 
+def emulate_config5(args):
+    """configs[4] shaped for its first real node: P virtual ranks on ONE GPU run the library's distributed driver (same kernels,
+    same sequence of collectives, collectives served in process).  Per rank: leaves sent / received, slice size, build and
+    traverse time (the ranks share the GPU and the Python interpreter: these are serialised times of one rank's work, NOT
+    a scaling measurement), contacts.  Marked emulated: nothing here says anything about xGMI."""
+    import threading
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import implicitbvh_amd as ibvh
+    from implicitbvh_amd import dist as ibd
+    from virtual_ranks import run_virtual_ranks
+    P = args.virtual_ranks
+    n = args.n or 12_500_000
+    r0 = 0.5 * (3 * 8 / (4 * math.pi * n * P)) ** (1 / 3)
+    lock = threading.Lock()
+
+    def fn(comm):
+        vols = ibvh.generate_spheres(n, args.seed, first_index=comm.rank * n, r0=r0)
+        builder = ibd.DistributedBuilder(comm)
+        bvh = builder.build(vols)
+        trav = ibvh.traverse(bvh)
+        _ = trav.num_contacts
+        torch.cuda.synchronize()
+        # the build needs the other ranks for its collectives: timed as a JOINT rebuild of all ranks; the traversal of one
+        # slice is timed alone on the GPU
+        t0 = time.perf_counter()
+        bvh = builder.build(vols, cache=bvh)
+        torch.cuda.synchronize()
+        t_build = time.perf_counter() - t0
+        with lock:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _k in range(3):
+                trav = ibvh.traverse(bvh, cache=trav)
+                _ = trav.num_contacts
+            torch.cuda.synchronize()
+            t_trav = (time.perf_counter() - t0) / 3
+        last = builder.last
+        rb = last["record_bytes"]
+        return {"rank": comm.rank, "leaves_in": n, "leaves_slice": last["n_slice"], "contacts": int(trav.num_contacts),
+                "bytes_sent_to_peers": int(sum(c for r, c in enumerate(last["send_counts"]) if r != comm.rank) * rb),
+                "bytes_received_from_peers": int(sum(c for r, c in enumerate(last["recv_counts"]) if r != comm.rank) * rb),
+                "busiest_peer_bytes": int(max(c for r, c in enumerate(last["send_counts"]) if r != comm.rank) * rb),
+                "joint_build_wall_ms": round(t_build * 1e3, 3), "traverse_alone_ms": round(t_trav * 1e3, 3),
+                "splitter_key_bits": last["levels_used"]}
+    rows = run_virtual_ranks(P, fn)
+    slices = [r["leaves_slice"] for r in rows]
+    line = {"metric": "BVH build+traverse throughput", "emulated": True, "n_gpus": 1, "virtual_ranks": P, "unit": "Mleaves/s",
+            "value": None, "note": "EMULATED, unmeasured on xGMI: P virtual ranks (threads) share ONE GPU; per-rank figures show the shape of the work "
+                                   "(exchange bytes per peer link, slice balance, traversal time of one slice alone on the GPU), not a scaling curve",
+            "config": {"workload": f"BASELINE.json configs[4] law: {n * P} BSphere{{Float32}} leaves as {P} shards of {n}, distributed Morton + "
+                                   "radix-sort exchange + global-AABB all-reduce (served in process), per-rank self-traverse"},
+            "slice_imbalance": round(max(abs(s - n) for s in slices) / n, 5),
+            "xgmi_link_time_at_153GBps_ms": round(max(r["busiest_peer_bytes"] for r in rows) / 153e9 * 1e3, 4),
+            "per_rank": rows}
+    print(json.dumps(line))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -563,9 +621,14 @@ def main():
     ap.add_argument("--extra-n", type=int, default=10_000_000,
                     help="also report the north-star size (1e7 leaves) at N=1; 0 disables")
     ap.add_argument("--cpu-n", type=int, default=0, help="leaves of the CPU baseline sample (0 = same as --n, capped)")
+    ap.add_argument("--virtual-ranks", type=int, default=0,
+                    help="EMULATE BASELINE.json configs[4] on ONE GPU: this many virtual ranks (threads) x --n leaves (default 1.25e7) run the "
+                         "distributed build + per-rank traversal; per-rank figures, no xGMI (nothing is measured about the links)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)  # (does not return)
+    if args.virtual_ranks > 1:
+        return emulate_config5(args)
 
     # the CPU baseline's OpenMP teams: one thread per core, neighbours first (read by libgomp when the oracle is loaded)
     os.environ.setdefault("OMP_PROC_BIND", "close")

@@ -64,6 +64,18 @@ mutable struct IbvhBfsResult
     num_contacts::Int64; num_checks::Int64; contacts_in::Int64; required_capacity::Int64
     resume_step::Int64; resume_num::Int64
 end
+# multi-GPU build (include/ibvh.h "multi-GPU build: the driver")
+# (IbvhComm is filled by ibvh_comm_from_rccl; its last three fields are C function pointers)
+struct IbvhComm
+    ctx::Ptr{Cvoid}; rank::Int32; size::Int32
+    all_reduce::Ptr{Cvoid}; all_gather::Ptr{Cvoid}; all_to_all_v::Ptr{Cvoid}
+end
+mutable struct IbvhDistPlan
+    size::Int32; levels_used::Int32; n_local::Int64; n_global::Int64; base::Int64; n_slice::Int64; record_bytes::Int64
+    extrema::NTuple{6, Float64}
+    splitters::NTuple{256, UInt64}; send_counts::NTuple{256, Int64}; recv_counts::NTuple{256, Int64}
+    IbvhDistPlan() = new()
+end
 
 kind(::Type{<:BSphere}) = Int32(0);  kind(::Type{<:BBox}) = Int32(1)
 fltcode(::Type{Float32}) = Int32(0); fltcode(::Type{Float64}) = Int32(1)
@@ -188,6 +200,20 @@ c_build(desc, volumes, leaves, nodes, skips, extrema_out, scratch, scratch_bytes
     ccall((:ibvh_build, libibvh), Cint,
           (Ref{IbvhBuildDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
           desc, volumes, leaves, nodes, skips, extrema_out, scratch, scratch_bytes, stream)
+c_comm_from_rccl(nccl_comm, rank, size, out) =
+    ccall((:ibvh_comm_from_rccl, libibvh), Cint,
+          (Ptr{Cvoid}, Int32, Int32, Ref{IbvhComm}), nccl_comm, rank, size, out)
+c_dist_scratch_bytes(types, n_local, size, out) =
+    ccall((:ibvh_dist_scratch_bytes, libibvh), Cint,
+          (Ref{IbvhTypes}, Int64, Int32, Ref{Csize_t}), types, n_local, size, out)
+c_dist_plan(types, comm, volumes, n_local, tolerance, scratch, sb, plan, stream) =
+    ccall((:ibvh_dist_plan, libibvh), Cint,
+          (Ref{IbvhTypes}, Ref{IbvhComm}, Ptr{Cvoid}, Int64, Float64, Ptr{Cvoid}, Csize_t, Ref{IbvhDistPlan}, Ptr{Cvoid}),
+          types, comm, volumes, n_local, tolerance, scratch, sb, plan, stream)
+c_dist_exchange(types, comm, volumes, plan, scratch, sb, records, stream) =
+    ccall((:ibvh_dist_exchange, libibvh), Cint,
+          (Ref{IbvhTypes}, Ref{IbvhComm}, Ptr{Cvoid}, Ref{IbvhDistPlan}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}, Ptr{Cvoid}),
+          types, comm, volumes, plan, scratch, sb, records, stream)
 c_lvt_scratch_bytes(types, n_items, cache_slots, out) =
     ccall((:ibvh_lvt_scratch_bytes, libibvh), Cint,
           (Ref{IbvhTypes}, Int64, Int32, Ref{Csize_t}),
@@ -316,6 +342,46 @@ function ImplicitBVH.BVH(
     check(c_build(desc, wrapped ? C_NULL : devptr(bounding_volumes), devptr(leaves), devptr(nodes), devptr(skips),
                   C_NULL, devptr(scratch), need[], stream_ptr()), "ibvh_build")
     BVH(I(built_ilevel), tree, skips, nodes, leaves)
+end
+
+# ---- multi-GPU build: one Julia process per GPU, leaves sharded over the ranks -----------------------------------
+# No reference counterpart (ImplicitBVH.jl is single-device): BASELINE.json's north star.  `nccl_comm` is the ncclComm_t of
+# this rank (RCCL's C API: ncclGetUniqueId on rank 0, broadcast it, ncclCommInitRank on every rank — e.g. through MPI.jl or
+# a file); `local_volumes` this rank's share of the leaves.  Returns this rank's slice of the globally sorted sequence as an
+# ordinary BVH (leaf .index = GLOBAL 1-based number) that traverse() takes like any other; contacts across slices are NOT
+# found by it (DistributedBuilder.cross_contacts in the Python mirror shows the completion).
+"""
+    dist_comm(nccl_comm::Ptr{Cvoid}, rank, size) -> IbvhComm
+"""
+function dist_comm(nccl_comm::Ptr{Cvoid}, rank::Integer, size::Integer)
+    out = Ref{IbvhComm}()
+    check(c_comm_from_rccl(nccl_comm, Int32(rank), Int32(size), out), "ibvh_comm_from_rccl")
+    out[]
+end
+
+"""
+    dist_BVH(comm::IbvhComm, local_volumes::ROCVector, node_type=BBox{Float32}; tolerance=0.005, cache=nothing, options=BVHOptions())
+"""
+function dist_BVH(comm::IbvhComm, local_volumes::ROCVector{V}, node_type::Type{N}=BBox{Float32};
+                  tolerance::Float64=0.005, cache::Union{Nothing, BVH}=nothing, options=BVHOptions()) where {V, N}
+    I = get_index_type(options)
+    M = eltype(options.morton)
+    types = ibvh_types(V, N, I, M)
+    n_local = length(local_volumes)
+    need = Ref{Csize_t}(0)
+    check(c_dist_scratch_bytes(types, n_local, comm.size, need), "ibvh_dist_scratch_bytes")
+    scratch = scratch!(:dist, need[])
+    plan = IbvhDistPlan()
+    # blocks once: the record counts must reach the host before RCCL can be told the transfer sizes
+    check(c_dist_plan(types, comm, devptr(local_volumes), n_local, tolerance, devptr(scratch), need[], plan, stream_ptr()), "ibvh_dist_plan")
+    n_slice = Int(plan.n_slice)
+    records = similar(local_volumes, BoundingVolume{V, I, M}, n_slice)       # sized from the plan: count, then size, then write
+    check(c_dist_exchange(types, comm, devptr(local_volumes), plan, devptr(scratch), need[], devptr(records), stream_ptr()), "ibvh_dist_exchange")
+    # the ordinary local build over the received slice: pre-wrapped records, the GLOBAL extrema fixed
+    e = plan.extrema
+    fixed = DefaultMortonAlgorithm(M, false, (e[1], e[2], e[3]), (e[4], e[5], e[6]))
+    opts = BVHOptions(index_exemplar=options.index_exemplar, morton=fixed, num_threads=options.num_threads, block_size=options.block_size)
+    ImplicitBVH.BVH(records, N; cache=cache, options=opts)
 end
 
 # ---- leaf-vs-tree: count -> (cache) -> write, or enqueue against a cached contact buffer ------------------------
