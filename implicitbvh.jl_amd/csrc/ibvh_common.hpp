@@ -517,7 +517,8 @@ struct Tuning {
     int msd_avg = 1024;     // largest average cell before another first-level bit is taken
     int msd_range = 1;      // 0 = first extra level on the next 8 bits, unmeasured
     int msd_finish_pad_kb = 0; // LDS (KiB) a finish workgroup asks for at least: limits the workgroups per CU (0 = what it needs)
-    int msd_resident_kb = 0; // LDS budget (KiB) of a finish workgroup that keeps its range's RECORDS in LDS (0 = off)
+    int msd_resident_kb = 0; // LDS budget (KiB) of a finish workgroup that keeps its range's RECORDS in LDS: 0 = the plan decides
+                             // (8,192-record geometry only), > 0 = every geometry with this budget, < 0 = never
     int bfs_wg_per_cu = 4;  // workgroups per CU of the BFS level kernels' fixed grid (ibvh_bfs.hip, level_grid)
     int rays_shadow = 0;    // 1 = ray traversals walk the quantised 8-wide shadow of the node levels when the scratch has room
                             // (ibvh_rays_scratch_bytes); measured slower than the binary walk on config 3 (4.6 vs 4.3 ms): off

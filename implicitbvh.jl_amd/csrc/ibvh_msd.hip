@@ -1228,6 +1228,15 @@ Plan make_plan(int64_t n, int key_bits, int key_bytes, int leaf_bytes, void *sor
     case 8192: p.ftpb = 512; break;
     default: p.ftpb = 512; break;
     }
+    // Round 4: cells of the 8,192-record geometry (~2.5 .. 6.5 k records of 24 bytes: 1e7-leaf builds) are finished with
+    // their RECORDS resident in LDS — read from memory once instead of ~2.8 times (finish_range, resident path) — by one
+    // 1,024-thread workgroup per CU (the memory phases of a lone workgroup need that many loads in flight); cells beyond the
+    // ~5,000 records that fit beside the sort's arrays take the plain path inside the same kernel.  Measured at 1e7 leaves:
+    // finish 212 -> 196 us, Morton+sort 463 -> 448 us (tools/ab_sort.py); smaller geometries lose (1e6: 24 -> 32 us: fewer
+    // workgroups per CU) and keep the plain kernel.
+    // (cells of ~3,000 records — 1.25e7 leaves at 12 bits — lose: 289 against 265 us; the rule asks for >= 4,096 on average)
+    p.resident = cap == 8192 && avg >= 4096 && key_bytes == 4 && leaf_bytes <= 24 && g_tuning.msd_resident_kb >= 0 && !f_ftpb;
+    if (p.resident) p.ftpb = 1024;
     if (f_ftpb) p.ftpb = f_ftpb;
     p.fipt = cap / p.ftpb;
     p.bits = bits;
@@ -1296,10 +1305,11 @@ static int launch_finish(const Plan &p, const FinishArgs &fa_in, hipStream_t st)
     size_t smem = finish_smem<K, FT, FI>();
     // resident path: room for a full range of records behind the sort's arrays, as long as the workgroup stays within the
     // LDS budget (tuning msd_resident_kb; 0 = off: the records are then gathered from memory as in rounds 2 and 3)
-    if (sizeof(K) == 4 && g_tuning.msd_resident_kb > 0) {
+    if (sizeof(K) == 4 && (g_tuning.msd_resident_kb > 0 || p.resident)) {
         const size_t cap = (size_t)FT * FI;
         const size_t off = (size_t)align_up((int64_t)(smem - cap * 2), 16); // (no 16-bit positions in front of the record area)
-        const size_t budget = (size_t)g_tuning.msd_resident_kb * 1024 < (size_t)kMaxLds ? (size_t)g_tuning.msd_resident_kb * 1024 : (size_t)kMaxLds;
+        const size_t want = g_tuning.msd_resident_kb > 0 ? (size_t)g_tuning.msd_resident_kb * 1024 : (size_t)kMaxLds;
+        const size_t budget = want < (size_t)kMaxLds ? want : (size_t)kMaxLds;
         size_t rec = cap * (size_t)fa.lay.stride;  // a full range, or what the budget leaves (larger ranges take the plain path)
         if (off + rec > budget) rec = budget > off ? ((budget - off) / 8) * 8 : 0;
         if (rec >= cap * 2 && rec >= 1024 * (size_t)fa.lay.stride) {

@@ -43,6 +43,7 @@ struct Plan {
     int ptpb, pipt;      // partition (and histogram) tile geometry
     int num_tiles;
     int ftpb, fipt;      // finish workgroup: threads, keys per thread (capacity = ftpb * fipt)
+    bool resident;       // the finish keeps a cell's records in LDS (ibvh_msd.hip, finish_range)
     int max_seg;         // S
     int max_tiles2;      // T2
     Tables tb;
