@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MORTON_SORT_KERNELS = ("extrema_partial_kernel", "extrema_final_kernel", "encode_kernel", "encode_hist_kernel", "hist_kernel",
                        "hist_wide_kernel", "scan_kernel", "bucket_start_kernel", "scatter_kernel", "scatter_wide_kernel",
                        "scatter_records_kernel", "bucket_sort_kernel", "gather_kernel", "scan_tiles_kernel", "plan_kernel",
-                       "partition_kernel", "finish_kernel", "range_kernel", "hist_level_kernel", "scan_level_kernel")
+                       "partition_kernel", "finish_kernel", "finish_resident_kernel", "range_kernel", "hist_level_kernel", "scan_level_kernel")
 TRAVERSE_PREFIXES = ("lvt_", "scan_reduce", "scan_apply", "level_kernel", "fill_")
 
 
@@ -56,6 +56,7 @@ def algorithmic_bytes(kernel, n, contacts):
         "bucket_sort_kernel": 8.0 + 16.0 + 24.0,      # read (key, pos) + source volume, write the sorted record
         "partition_kernel": 4.0 + 16.0 + 24.0,        # MSD partition of whole records: read key + source volume, write the record
         "finish_kernel": 24.0 + 24.0,                 # per-bucket in-LDS finish: read the partitioned record, write the sorted one
+        "finish_resident_kernel": 24.0 + 24.0,        # the same, records resident in LDS (cells of the 8,192-record geometry)
         "hist_kernel": 4.0,                        # read keys
         "scatter_kernel": 8.0 + 8.0,               # read + write (key, position)
         "gather_kernel": 4.0 + 4.0 + 16.0 + 24.0,  # perm + key + volume -> record

@@ -16,6 +16,6 @@ for f in implicitbvh.jl_amd/csrc/*.hip; do
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libibvh_$TAG.so $OBJ/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libibvh_$TAG.so $OBJ/*.o -ldl
 rm -rf $OBJ
 echo built variants/libibvh_$TAG.so
