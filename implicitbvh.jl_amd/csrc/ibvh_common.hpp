@@ -554,6 +554,13 @@ IBVH_D int xcd_remap(int b, int nwg) {
 // still share an L2 while a workload whose cost is concentrated in part of the index range (two partially
 // overlapping clouds) is still spread over all XCDs.  Bijective for any grid size (the ragged tail is left as is).
 IBVH_D int xcd_run_remap(int b, int nwg, int run) {
+    if ((run & (run - 1)) == 0) { // (the launch code hands out power-of-two runs: shifts instead of two integer divisions per wave)
+        const int sh = __builtin_ctz((unsigned)run);
+        const int full = (nwg >> (sh + 3)) << (sh + 3);
+        if (b >= full) return b;
+        const int xcd = b & 7, k = b >> 3;
+        return ((((k >> sh) << 3) + xcd) << sh) + (k & (run - 1));
+    }
     const int period = 8 * run;
     const int full = (nwg / period) * period;
     if (b >= full) return b;
