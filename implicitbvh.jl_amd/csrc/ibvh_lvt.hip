@@ -49,6 +49,8 @@ template <class L, class N, class I> struct Args {
     // slab test is not monotone under box inclusion for them), 2 only regular ones
     const char *shadow;
     int32_t rays_filter;
+    // RAYS: the binary walker as the stand-by of the binned path (RayBins below): it returns at once unless *gate != 0
+    const int32_t *gate;
     // ibvh_lvt_work_counters only (COUNT instantiations): [0] node tests, [1] leaf tests, [2] node records fetched,
     // [3] leaf records fetched, summed over the launch
     unsigned long long *work;
@@ -1986,6 +1988,7 @@ __global__ __launch_bounds__(64) void lvt_rays_kernel(Args<L, N, I> a, PairCache
         I meta;
     };
     __shared__ int s_fill;
+    if (a.gate != nullptr && *(const __attribute__((address_space(4))) int32_t *)(uintptr_t)a.gate == 0) return;
     const int lane = threadIdx.x;
     const int64_t first_item = (int64_t)blockIdx.x * ray_block;
     const int64_t left = a.n_items - first_item;
@@ -2508,6 +2511,538 @@ __global__ __launch_bounds__(64) void lvt_rays_wide_kernel(Args<L, N, I> a, Pair
     }
 }
 
+// ---- (3c) rays BINNED BY SUBTREE: the bottom of the tree is walked out of LDS ---------------------------------------
+// What the per-lane walk above costs on config 3 (SQ / TCC counters, round 4): 1,700 wave-steps per wave at 32 % of the lanes
+// busy, 138 VALU + 94 SALU instructions a wave-step, and every step below level ~17 misses L2 — 237 M 128-byte lines come
+// out of L2 for 48 useful bytes each (30 GB), 109 M of them out of HBM / Infinity Cache (14 GB, 31 x the algorithmic bytes).
+// The RAYS are the small side (24 bytes each), so the bottom of the tree is turned node-major:
+//   A. rays_top_kernel — the same per-lane walk, but only down to the CUT level K = levels - D (D = 9: subtrees of 512
+//      leaves).  Levels 1 .. K are a few hundred KB: every fetch is an L2 hit.  A hit at level K is not descended into, it
+//      is EMITTED as an item (ray, subtree j, ordinal of the item within its ray); items leave the wave through an LDS
+//      stage in chunks (one global atomic per ~700 items).
+//   B. the items are grouped by subtree: a counting sort whose tiles count in LDS first (rays_tilehist_kernel, rays_binscan_kernel,
+//      rays_scatter_kernel) — the buckets are far from even (config 3: 1,400 items on average, 190,000 in the busiest) and
+//      same-address global atomics serialise at ~11 ns each.  An item's rank in (ray, ordinal) order, g, is known once the
+//      per-ray item counts are scanned and travels with it.
+//   C. rays_subtree_kernel — a workgroup copies one subtree's node levels and leaves into LDS (the tree is read about once
+//      per call, coalesced), then its lanes take up to RAYSUB_CHUNK of the subtree's items (busy subtrees are shared by several
+//      workgroups) and finish the walk below the subtree's root out of LDS: the random access that remains is the item's
+//      24-byte ray.  A hit is counted for its item AND kept as a record (pair, g, rank within the item) in a list.
+//   D. hits per item in g order -> inclusive scan -> an item's hits go to [scan[g-1], scan[g]); the per-ray counts the
+//      entry points return are differences of that scan at the rays' item boundaries.  The writing pass only moves the kept
+//      records to scan[g-1] + rank (rays_place_kernel); if the record list overflowed it walks the subtrees again instead.
+// Order: a ray's walk visits subtrees left to right and emits its items in that order, so (ray, ordinal) order followed
+// by the walk's own order inside the subtree is exactly the order in which the reference's loop
+// (raytrace/leaf_vs_tree/leaf_vs_tree.jl:187-225) reports the ray's hits — the walk is the same walk, cut in two at
+// level K; no property of the ray is assumed, so irregular rays (zero / infinite / NaN components) take this path too.
+// The item list has a fixed capacity inside the caller's scratch (ibvh_rays_scratch_bytes: 16 items per ray; config 3
+// emits 10.4); a call that overflows it raises *flag and every later kernel of the path returns at once, while the
+// binary walker — launched behind it in every call, gated on that flag — serves the call instead.  No host round trip.
+struct RayBins {
+    unsigned long long *cursor; // header + 0: items emitted so far (may run past cap: that is the overflow test)
+    int32_t *flag;              // header + 8: != 0 -> the item list overflowed, the binary walker serves this call
+    int32_t *n_items;           // header + 12: min(cursor, cap), written by rays_binscan_kernel
+    int32_t *n_chunks;          // header + 16: workgroups of rays_subtree_kernel that have work (rays_binscan_kernel)
+    int32_t *reflag;            // header + 20: != 0 -> a region of the hit list overflowed, the writing pass walks the subtrees again
+    uint32_t *region_cursor;    // header + 1024: [RAY_REGIONS] records in each region of the hit list
+    int64_t *dummy_total;       // header + 64: where the helper scans put their totals
+    void *scan_scratch;         // tile sums of the helper scans (room for cap items)
+    int32_t *ray_items;         // [rays] items a ray emitted; after the scan: inclusive prefix
+    uint64_t *items;            // [cap] emission order: ray | subtree << 32 | ordinal << 48
+    uint32_t *bin_count;        // [subtrees]
+    uint32_t *bin_start;        // [subtrees + 1] exclusive prefix of bin_count
+    uint32_t *bin_cursor;       // [subtrees]
+    uint2 *bucket;              // [cap] {ray, g} grouped by subtree
+    uint2 *chunk_tab;           // [subtrees + cap / RAYSUB_CHUNK] {subtree, chunk of its bucket}: one workgroup each
+    void *hit_list;             // [RAY_REGIONS][region_cap] RayHit<I>: the hits of the counting pass
+    int32_t region_cap;
+    void *hits;                 // [cap] of I: hits of item g; after the scan: inclusive prefix
+    int32_t cap;                // 0: the path is not in use
+    int32_t cut_level;          // K
+    int32_t depth;              // D = levels - K: a subtree holds 2^D leaves
+    int32_t subtrees;           // real nodes on level K
+};
+
+constexpr int RAYTOP_STAGE = 768; // items a wave stages in LDS before it reserves room in the global list
+template <class L, class N, class I>
+__global__ __launch_bounds__(64) void rays_top_kernel(Args<L, N, I> a, RayBins rb, int ray_block) {
+    using T = typename L::elt;
+    __shared__ uint64_t s_items[RAYTOP_STAGE];
+    const int lane = threadIdx.x;
+    const int64_t first_item = (int64_t)blockIdx.x * ray_block;
+    const int64_t left = a.n_items - first_item;
+    const int items_here = (int)(left < ray_block ? left : ray_block);
+    const int levels = (int)a.tree.levels;
+    const uint32_t vl = (uint32_t)a.tree.virtual_leaves;
+    const int K = rb.cut_level;
+    const uint32_t kfirst = 1u << (K - 1);
+    const int plevel = (int)a.start_level - 1;
+    const int64_t roots = level_num_real(a.tree.levels, a.tree.virtual_leaves, a.start_level);
+    const uint32_t pfirst = plevel >= 1 ? (1u << (plevel - 1)) : 0u;
+    const uint32_t pcount = (uint32_t)((roots + 1) / 2);
+
+    T p[3] = {0, 0, 0}, d[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
+    int ray = -1;
+    uint32_t pi = 0, inode = 0, pend = 0, ord = 0;
+    int level = 0;
+    int next = 0; // wave-uniform: rays of the block handed out so far
+    int fill = 0; // wave-uniform: items staged
+
+    auto node_hit = [&](const N &n) {
+        if constexpr (N::kind == IBVH_BBOX) return isintersection_inv(n, p, inv);
+        else return isintersection(n, p, d);
+    };
+    auto flush = [&]() {
+        if (fill == 0) return;
+        __syncthreads(); // (one wave: orders the stage's writes before the reads below)
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(rb.cursor, (unsigned long long)fill);
+        base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base + (unsigned long long)fill > (unsigned long long)rb.cap) {
+            if (lane == 0) *rb.flag = 1;
+        } else {
+            for (int t = lane; t < fill; t += 64) {
+                const uint64_t it = s_items[t];
+                rb.items[base + t] = it;
+            }
+        }
+        __syncthreads();
+        fill = 0;
+    };
+
+    for (;;) {
+        const uint64_t idle = __builtin_amdgcn_ballot_w64(ray < 0);
+        if (idle != 0 && next < items_here) {
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            const int mine = next + rank;
+            if (ray < 0 && mine < items_here) {
+                const int64_t item = first_item + mine;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    p[k] = a.points[3 * item + k];
+                    d[k] = a.dirs[3 * item + k];
+                    inv[k] = T(1) / d[k];
+                }
+                ray = mine;
+                pi = 0;
+                inode = pfirst;
+                level = plevel;
+                pend = 0;
+                ord = 0;
+            }
+            const int taken = __popcll(idle);
+            next = next + taken < items_here ? next + taken : items_here;
+        }
+        if (__builtin_amdgcn_ballot_w64(ray >= 0) == 0) break; // (every lane idle after a refill: the block is used up)
+        for (;;) {
+            bool e0 = false, e1 = false;
+            uint64_t it0 = 0, it1 = 0;
+            if (ray >= 0) {
+                const int cl = level + 1;
+                const uint32_t c0 = 2u * inode, c1 = c0 + 1u;
+                const uint32_t first = 1u << (cl - 1);
+                const uint32_t nreal = first - (uint32_t)((uint64_t)vl >> (levels - cl));
+                const bool real0 = c0 != 0u, real1 = (c1 - first) < nreal; // (c0 == 0: the pseudo node above the root)
+                const uint64_t v = (uint64_t)vl >> (levels - cl + 1);
+                const uint32_t sk = (uint32_t)(2 * v) - (uint32_t)__popcll(v); // level_skips(cl)
+                const N *np = a.nodes + ((int64_t)c0 - (int64_t)sk - 1);
+                struct Two {
+                    N a, b;
+                };
+                Two ch;
+                if (real0 && real1) {
+                    __builtin_memcpy(&ch, __builtin_assume_aligned(np, 8), sizeof(Two));
+                } else {
+                    ch.a = load_vol<N>(real0 ? np : np + 1);
+                    ch.b = ch.a;
+                }
+                const bool h0 = real0 && node_hit(ch.a), h1 = real1 && node_hit(ch.b);
+                bool descended = false;
+                if (cl == K) { // the cut: hits become items, left before right
+                    const uint64_t r64 = (uint64_t)(first_item + ray);
+                    e0 = h0;
+                    it0 = r64 | ((uint64_t)(c0 - kfirst) << 32) | ((uint64_t)ord << 48);
+                    ord += h0 ? 1u : 0u;
+                    e1 = h1;
+                    it1 = r64 | ((uint64_t)(c1 - kfirst) << 32) | ((uint64_t)ord << 48);
+                    ord += h1 ? 1u : 0u;
+                } else if (h0) {
+                    if (h1) pend |= 1u << cl;
+                    inode = c0;
+                    level = cl;
+                    descended = true;
+                } else if (h1) {
+                    inode = c1;
+                    level = cl;
+                    descended = true;
+                }
+                if (!descended) {
+                    if (pend != 0) {
+                        const int pl = 31 - __builtin_clz(pend);
+                        pend &= ~(1u << pl);
+                        inode = (inode >> (level - pl)) | 1u;
+                        level = pl;
+                    } else if (++pi < pcount) {
+                        inode = pfirst + pi;
+                        level = plevel;
+                    } else {
+                        rb.ray_items[first_item + ray] = (int32_t)ord;
+                        ray = -1;
+                    }
+                }
+            }
+            const uint64_t m0 = __builtin_amdgcn_ballot_w64(e0), m1 = __builtin_amdgcn_ballot_w64(e1);
+            if ((m0 | m1) != 0) {
+                const int n0 = __popcll(m0);
+                if (e0) s_items[fill + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))] = it0;
+                if (e1) s_items[fill + n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))] = it1;
+                fill += n0 + __popcll(m1);
+                if (fill > RAYTOP_STAGE - 128) flush();
+            }
+            const uint64_t idle_now = __builtin_amdgcn_ballot_w64(ray < 0);
+            if (idle_now == ~(uint64_t)0) break;
+            if (next < items_here && __popcll(idle_now) >= 16) break;
+        }
+    }
+    flush();
+}
+
+// items per subtree.  The distribution is far from even (config 3: mean 1,400 items, the busiest subtree 190,000) and
+// same-address global atomics serialise (~11 ns each), so a tile of items is counted in LDS first and every non-empty bin
+// of the tile costs ONE global atomic.
+constexpr int RAYTILE = 4096, RAYTILE_TPB = 256;
+constexpr int RAYSUB_CHUNK = 1024; // items of one rays_subtree_kernel workgroup: busy subtrees are shared by several
+__global__ __launch_bounds__(RAYTILE_TPB) void rays_tilehist_kernel(RayBins rb) {
+    extern __shared__ uint32_t s_hist[];
+    if (*rb.flag != 0) return;
+    const unsigned long long cur = *rb.cursor;
+    const int64_t n = (int64_t)(cur < (unsigned long long)rb.cap ? cur : (unsigned long long)rb.cap);
+    const int64_t base = (int64_t)blockIdx.x * RAYTILE;
+    if (base >= n) return;
+    const int64_t end = base + RAYTILE < n ? base + RAYTILE : n;
+    for (int b = threadIdx.x; b < rb.subtrees; b += RAYTILE_TPB) s_hist[b] = 0;
+    __syncthreads();
+    for (int64_t i = base + threadIdx.x; i < end; i += RAYTILE_TPB) atomicAdd(&s_hist[(uint32_t)(rb.items[i] >> 32) & 0xffffu], 1u);
+    __syncthreads();
+    for (int b = threadIdx.x; b < rb.subtrees; b += RAYTILE_TPB) {
+        const uint32_t c = s_hist[b];
+        if (c != 0) atomicAdd(&rb.bin_count[b], c);
+    }
+}
+
+// one workgroup: bin_start = exclusive prefix of bin_count, the table of rays_subtree_kernel's workgroups (one per
+// RAYSUB_CHUNK items of a bucket), the item count clipped to the capacity
+__global__ __launch_bounds__(1024) void rays_binscan_kernel(RayBins rb) {
+    __shared__ unsigned long long s_w[16];
+    const unsigned long long cur = *rb.cursor;
+    if (threadIdx.x == 0) *rb.n_items = (int32_t)(cur < (unsigned long long)rb.cap ? cur : (unsigned long long)rb.cap);
+    if (*rb.flag != 0) {
+        if (threadIdx.x == 0) *rb.n_chunks = 0;
+        return;
+    }
+    const int per = (rb.subtrees + 1023) / 1024;
+    const int b = (int)threadIdx.x * per;
+    // items in the low word, chunks in the high word: one scan for both (items <= 2^30)
+    unsigned long long sum = 0;
+    for (int k = 0; k < per; ++k) {
+        const uint32_t c = b + k < rb.subtrees ? rb.bin_count[b + k] : 0u;
+        sum += (unsigned long long)c | ((unsigned long long)((c + RAYSUB_CHUNK - 1) / RAYSUB_CHUNK) << 32);
+    }
+    unsigned long long inc = sum;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    unsigned long long run = inc - sum;
+    for (int k = 0; k < w; ++k) run += s_w[k];
+    for (int k = 0; k < per; ++k) {
+        if (b + k < rb.subtrees) {
+            const uint32_t c = rb.bin_count[b + k];
+            const uint32_t chunks = (c + RAYSUB_CHUNK - 1) / RAYSUB_CHUNK, c0 = (uint32_t)(run >> 32);
+            rb.bin_start[b + k] = (uint32_t)run;
+            for (uint32_t q = 0; q < chunks; ++q) rb.chunk_tab[c0 + q] = make_uint2((uint32_t)(b + k), q);
+            run += (unsigned long long)c | ((unsigned long long)chunks << 32);
+            if (b + k == rb.subtrees - 1) {
+                rb.bin_start[rb.subtrees] = (uint32_t)run;
+                *rb.n_chunks = (int32_t)(run >> 32);
+            }
+        }
+    }
+}
+
+// items -> buckets by subtree; an item's rank g in (ray, ordinal) order comes from the scanned per-ray item counts.  Same
+// tiles and the same LDS counting as rays_tilehist_kernel: a tile reserves its share of a bucket with one global atomic.
+__global__ __launch_bounds__(RAYTILE_TPB) void rays_scatter_kernel(RayBins rb) {
+    extern __shared__ uint32_t s_hist[];
+    if (*rb.flag != 0) return;
+    const int64_t n = *rb.n_items;
+    const int64_t base = (int64_t)blockIdx.x * RAYTILE;
+    if (base >= n) return;
+    constexpr int IPT = RAYTILE / RAYTILE_TPB;
+    for (int b = threadIdx.x; b < rb.subtrees; b += RAYTILE_TPB) s_hist[b] = 0;
+    __syncthreads();
+    uint32_t rank[IPT];
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int64_t i = base + k * RAYTILE_TPB + threadIdx.x;
+        rank[k] = i < n ? atomicAdd(&s_hist[(uint32_t)(rb.items[i] >> 32) & 0xffffu], 1u) : 0u;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < rb.subtrees; b += RAYTILE_TPB) {
+        const uint32_t c = s_hist[b];
+        if (c != 0) s_hist[b] = rb.bin_start[b] + atomicAdd(&rb.bin_cursor[b], c);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int64_t i = base + k * RAYTILE_TPB + threadIdx.x;
+        if (i < n) {
+            const uint64_t it = rb.items[i];
+            const uint32_t ray = (uint32_t)it, j = (uint32_t)(it >> 32) & 0xffffu, ord = (uint32_t)(it >> 48);
+            const uint32_t g = (ray > 0 ? (uint32_t)rb.ray_items[ray - 1] : 0u) + ord;
+            rb.bucket[s_hist[j] + rank[k]] = make_uint2(ray, g);
+        }
+    }
+}
+
+constexpr int RAYSUB_TPB = 256;
+constexpr int RAYSUB_STAGE = 64;  // hit records a wave stages in LDS (a step adds at most 64 left and 64 right hits: two appends)
+constexpr int RAY_REGIONS = 256;  // the hit list is RAY_REGIONS lists with a cursor each: same-address atomics serialise
+// a hit of the counting pass: the pair as it will be reported, the item it belongs to and its rank within the item; the
+// writing pass puts it at scan[g - 1] + k (rays_place_kernel) instead of walking again
+template <class I> struct RayHit {
+    IndexPair<I> pair;
+    uint32_t g, k;
+};
+IBVH_HD size_t rays_subtree_lds(int depth, size_t node_bytes, size_t leaf_bytes, size_t index_bytes, size_t hit_bytes, bool write) {
+    const size_t S = (size_t)1 << depth;
+    size_t o = (S * node_bytes + 15) & ~(size_t)15;
+    o += (S * leaf_bytes + 15) & ~(size_t)15;
+    o += (S * index_bytes + 15) & ~(size_t)15;
+    if (!write) o += (size_t)(RAYSUB_TPB / 64) * RAYSUB_STAGE * hit_bytes;
+    return o;
+}
+
+template <class L, class N, class I, bool WRITE>
+__global__ __launch_bounds__(RAYSUB_TPB) void rays_subtree_kernel(Args<L, N, I> a, RayBins rb) {
+    using T = typename L::elt;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    __shared__ uint32_t s_next;
+    if (*rb.flag != 0) return;
+    if constexpr (WRITE) {
+        if (*rb.reflag == 0) return; // the counting pass kept every hit: rays_place_kernel writes them
+        if (a.guard_total != nullptr && load_total_uniform(a.guard_total) > a.guard_capacity) return;
+    }
+    if ((int32_t)blockIdx.x >= *rb.n_chunks) return;
+    const uint2 chunk = rb.chunk_tab[blockIdx.x];
+    const uint32_t j = chunk.x; // the subtree; this workgroup takes items [chunk.y * RAYSUB_CHUNK, ...) of its bucket
+    const uint32_t b0 = rb.bin_start[j] + chunk.y * RAYSUB_CHUNK;
+    const uint32_t n_here = rb.bin_start[j + 1] - b0 < (uint32_t)RAYSUB_CHUNK ? rb.bin_start[j + 1] - b0 : (uint32_t)RAYSUB_CHUNK;
+    const int levels = (int)a.tree.levels, K = rb.cut_level, D = rb.depth;
+    const uint32_t S = 1u << D;
+    const uint32_t vl = (uint32_t)a.tree.virtual_leaves;
+    const uint32_t real_leaves = (uint32_t)a.tree.real_leaves;
+    // LDS: nodes by heap index t (1 = the subtree's root, never read; children of t are 2t, 2t + 1), the leaves' volumes,
+    // what a hit reports for them (user index, or 1-based position), the waves' hit stages
+    size_t o = 0;
+    N *s_nodes = (N *)s_raw;
+    o += ((size_t)S * sizeof(N) + 15) & ~(size_t)15;
+    L *s_leaves = (L *)(s_raw + o);
+    o += ((size_t)S * sizeof(L) + 15) & ~(size_t)15;
+    I *s_index = (I *)(s_raw + o);
+    o += ((size_t)S * sizeof(I) + 15) & ~(size_t)15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    RayHit<I> *s_stage = (RayHit<I> *)(s_raw + o) + wave * RAYSUB_STAGE;
+    {
+        constexpr uint32_t WPN = sizeof(N) / 8;
+        const uint64_t *src = (const uint64_t *)a.nodes;
+        uint64_t *dst = (uint64_t *)s_nodes;
+#pragma unroll 4
+        for (uint32_t wd = 2 * WPN + tid; wd < S * WPN; wd += RAYSUB_TPB) {
+            const uint32_t h = wd / WPN, part = wd - h * WPN;
+            const int dl = 31 - __builtin_clz(h), level = K + dl;
+            const uint32_t gi = (j << dl) + (h - (1u << dl)), first = 1u << (level - 1);
+            const uint32_t nreal = first - (uint32_t)((uint64_t)vl >> (levels - level));
+            const uint64_t v = (uint64_t)vl >> (levels - level + 1);
+            const uint32_t sk = (uint32_t)(2 * v) - (uint32_t)__popcll(v);
+            if (gi < nreal) dst[wd] = src[((int64_t)first + (int64_t)gi - (int64_t)sk - 1) * WPN + part];
+        }
+        const uint32_t g0 = j << D;
+        const uint32_t cnt = g0 >= real_leaves ? 0u : (real_leaves - g0 < S ? real_leaves - g0 : S);
+        for (uint32_t t = tid; t < cnt; t += RAYSUB_TPB) {
+            const char *rec = a.leaves + (int64_t)(g0 + t) * a.lay.stride;
+            s_leaves[t] = load_vol<L>(rec);
+            s_index[t] = a.positions ? (I)(g0 + t + 1u) : load_index<I>(rec, a.lay);
+        }
+    }
+    if (tid == 0) s_next = 0;
+    __syncthreads();
+
+    const I *hits = (const I *)rb.hits;
+    const uint32_t region = blockIdx.x & (RAY_REGIONS - 1);
+    T p[3] = {0, 0, 0}, d[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
+    bool busy = false, more = true; // more: wave-uniform, the chunk may still hold items
+    uint32_t ray = 0, g = 0, tn = 1, pend = 0;
+    int dl = 0;
+    int64_t w = 0;
+    uint32_t cnt = 0;
+    int fill = 0; // wave-uniform: hit records staged
+    auto node_hit = [&](const N &n) {
+        if constexpr (N::kind == IBVH_BBOX) return isintersection_inv(n, p, inv);
+        else return isintersection(n, p, d);
+    };
+    auto flush = [&]() {
+        if (fill == 0) return;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&rb.region_cursor[region], (uint32_t)fill);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if ((uint64_t)base + (uint32_t)fill > (uint64_t)rb.region_cap) {
+            if (lane == 0) *rb.reflag = 1;
+        } else {
+            RayHit<I> *dst = (RayHit<I> *)rb.hit_list + (size_t)region * rb.region_cap + base;
+            for (int t = lane; t < fill; t += 64) dst[t] = s_stage[t];
+        }
+        fill = 0;
+    };
+    for (;;) {
+        const uint64_t idle = __builtin_amdgcn_ballot_w64(!busy);
+        if (idle != 0 && more) {
+            const int want = __popcll(idle);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_next, (uint32_t)want);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            more = base + (uint32_t)want < n_here;
+            const uint32_t mine = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            if (!busy && mine < n_here) {
+                const uint2 e = rb.bucket[b0 + mine];
+                ray = e.x;
+                g = e.y;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    p[k] = a.points[3 * (int64_t)ray + k];
+                    d[k] = a.dirs[3 * (int64_t)ray + k];
+                    inv[k] = T(1) / d[k];
+                }
+                busy = true;
+                tn = 1;
+                dl = 0;
+                pend = 0;
+                cnt = 0;
+                if constexpr (WRITE) w = g > 0 ? (int64_t)hits[g - 1] : 0;
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(busy) == 0) break;
+        for (;;) {
+            bool h0 = false, h1 = false;
+            uint32_t li = 0;
+            if (busy) {
+                const int cd = dl + 1;
+                const uint32_t c0 = 2u * tn, c1 = c0 + 1u;
+                bool descended = false;
+                if (cd == D) { // the two leaves under tn
+                    li = c0 - S;
+                    const bool real1 = (j << D) + li + 1u < real_leaves; // (a real parent's left child is real)
+                    const L la = s_leaves[li], lb = s_leaves[li + 1];
+                    h0 = isintersection(la, p, d);
+                    h1 = real1 && isintersection(lb, p, d);
+                    if (a.narrow == IBVH_NARROW_RAY_ORIGIN_OUTSIDE) { // raytrace/lvt:194: isintersection(...) && narrow(leaf, p, d)
+                        h0 = h0 && origin_outside(la, p);
+                        h1 = h1 && origin_outside(lb, p);
+                    }
+                    if constexpr (WRITE) {
+                        if (h0) a.contacts[w++] = IndexPair<I>{s_index[li], (I)((int64_t)ray + 1)};
+                        if (h1) a.contacts[w++] = IndexPair<I>{s_index[li + 1], (I)((int64_t)ray + 1)};
+                    }
+                } else {
+                    const int level = K + cd;
+                    const uint32_t nreal = (1u << (level - 1)) - (uint32_t)((uint64_t)vl >> (levels - level));
+                    const bool real1 = (j << cd) + (c1 - (1u << cd)) < nreal;
+                    const N na = s_nodes[c0], nb = s_nodes[c1];
+                    const bool n0 = node_hit(na), n1 = real1 && node_hit(nb);
+                    if (n0) {
+                        if (n1) pend |= 1u << cd;
+                        tn = c0;
+                        dl = cd;
+                        descended = true;
+                    } else if (n1) {
+                        tn = c1;
+                        dl = cd;
+                        descended = true;
+                    }
+                }
+                if (!descended) {
+                    if (pend != 0) {
+                        const int pl = 31 - __builtin_clz(pend);
+                        pend &= ~(1u << pl);
+                        tn = (tn >> (dl - pl)) | 1u;
+                        dl = pl;
+                    } else {
+                        if constexpr (!WRITE) ((I *)rb.hits)[g] = (I)(cnt + (h0 ? 1u : 0u) + (h1 ? 1u : 0u));
+                        busy = false;
+                    }
+                }
+            }
+            if constexpr (!WRITE) {
+                const uint64_t m0 = __builtin_amdgcn_ballot_w64(h0), m1 = __builtin_amdgcn_ballot_w64(h1);
+                if ((m0 | m1) != 0) {
+                    const int n0 = __popcll(m0), n1 = __popcll(m1);
+                    if (n0 != 0) {
+                        if (fill + n0 > RAYSUB_STAGE) flush();
+                        if (h0) {
+                            const int s0 = fill + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
+                            s_stage[s0] = RayHit<I>{IndexPair<I>{s_index[li], (I)((int64_t)ray + 1)}, g, cnt};
+                        }
+                        fill += n0;
+                    }
+                    if (n1 != 0) {
+                        if (fill + n1 > RAYSUB_STAGE) flush();
+                        if (h1) {
+                            const int s1 = fill + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+                            s_stage[s1] = RayHit<I>{IndexPair<I>{s_index[li + 1], (I)((int64_t)ray + 1)}, g, cnt + (h0 ? 1u : 0u)};
+                        }
+                        fill += n1;
+                    }
+                    cnt += (h0 ? 1u : 0u) + (h1 ? 1u : 0u);
+                }
+            }
+            const uint64_t idle_now = __builtin_amdgcn_ballot_w64(!busy);
+            if (idle_now == ~(uint64_t)0) break;
+            if (more && __popcll(idle_now) >= 16) break;
+        }
+    }
+    if constexpr (!WRITE) flush();
+}
+
+// the writing pass when the counting pass kept every hit: records -> their places in the contact list
+template <class I> __global__ __launch_bounds__(256) void rays_place_kernel(RayBins rb, IndexPair<I> *contacts, const int64_t *guard_total, int64_t guard_capacity) {
+    if (*rb.flag != 0 || *rb.reflag != 0) return;
+    if (guard_total != nullptr && load_total_uniform(guard_total) > guard_capacity) return;
+    const uint32_t region = blockIdx.y;
+    const uint32_t n = rb.region_cursor[region] < (uint32_t)rb.region_cap ? rb.region_cursor[region] : (uint32_t)rb.region_cap;
+    const RayHit<I> *src = (const RayHit<I> *)rb.hit_list + (size_t)region * rb.region_cap;
+    const I *h = (const I *)rb.hits;
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
+        const RayHit<I> r = src[t];
+        const int64_t at = (r.g > 0 ? (int64_t)h[r.g - 1] : 0) + (int64_t)r.k;
+        contacts[at] = r.pair;
+    }
+}
+
+// per-ray hit counts from the scanned per-item hits: the difference of the scan at the ray's item boundaries
+template <class I> __global__ __launch_bounds__(256) void rays_counts_kernel(RayBins rb, I *counts, int64_t n_rays) {
+    if (*rb.flag != 0) return;
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rays) return;
+    const I *h = (const I *)rb.hits;
+    const int32_t e1 = rb.ray_items[r], e0 = r > 0 ? rb.ray_items[r - 1] : 0;
+    const int64_t s1 = e1 > 0 ? (int64_t)h[e1 - 1] : 0, s0 = e0 > 0 ? (int64_t)h[e0 - 1] : 0;
+    counts[r] = (I)(s1 - s0);
+}
+
 // ---- inclusive scan of the per-item counts (AK.accumulate!, traverse_single.jl:57) ---------------
 constexpr int SCAN_TPB = 256, SCAN_IPT = 16, SCAN_TILE = SCAN_TPB * SCAN_IPT;
 
@@ -2523,8 +3058,10 @@ IBVH_D int64_t block_sum(int64_t v, int64_t *s_w) {
     return t;
 }
 
-template <class I> __global__ __launch_bounds__(SCAN_TPB) void scan_reduce_kernel(const I *c, int64_t n, int64_t *partials) {
+// (limit != nullptr: the array's length is min(n, *limit), known only on the device)
+template <class I> __global__ __launch_bounds__(SCAN_TPB) void scan_reduce_kernel(const I *c, int64_t n, int64_t *partials, const int32_t *limit) {
     __shared__ int64_t s_w[SCAN_TPB / 64];
+    if (limit != nullptr) n = (int64_t)*limit < n ? (int64_t)*limit : n;
     int64_t base = (int64_t)blockIdx.x * SCAN_TILE, v = 0;
 #pragma unroll
     for (int j = 0; j < SCAN_IPT; ++j) {
@@ -2539,8 +3076,9 @@ template <class I> __global__ __launch_bounds__(SCAN_TPB) void scan_reduce_kerne
 // values) instead of waiting for a single-workgroup scan launch in between; the last tile also publishes the total.
 template <class I>
 __global__ __launch_bounds__(SCAN_TPB) void scan_apply_kernel(I *c, int64_t n, const int64_t *partials, int64_t *totals,
-                                                              int64_t *total_host) {
+                                                              int64_t *total_host, const int32_t *limit) {
     __shared__ int64_t s_w[SCAN_TPB / 64], s_p[SCAN_TPB / 64];
+    if (limit != nullptr) n = (int64_t)*limit < n ? (int64_t)*limit : n;
     int64_t before = 0;
     for (int64_t j = threadIdx.x; j < (int64_t)blockIdx.x; j += SCAN_TPB) before += partials[j];
     const int64_t tile_offset = block_sum(before, s_p);
@@ -2629,12 +3167,12 @@ inline int cache_slots_for(size_t scratch_bytes, int64_t n_items, int64_t pair_b
 // inclusive scan in place + (total_out != nullptr) blocking read of the total (the reference's @allowscalar, :60)
 template <class I>
 int scan_counts(I *counts, int64_t n, int64_t *total_out, void *scratch, hipStream_t st, int64_t *total_dev = nullptr,
-                int64_t *total_host = nullptr) {
+                int64_t *total_host = nullptr, const int32_t *limit = nullptr) {
     int64_t nparts = ceil_div(n, SCAN_TILE);
     int64_t *totals = total_dev ? total_dev : (int64_t *)scratch; // where the device-side total goes
     int64_t *partials = (int64_t *)scratch + 8;
-    IBVH_LAUNCH((scan_reduce_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, partials);
-    IBVH_LAUNCH((scan_apply_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, partials, totals, total_host);
+    IBVH_LAUNCH((scan_reduce_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, partials, limit);
+    IBVH_LAUNCH((scan_apply_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, partials, totals, total_host, limit);
     IBVH_LAUNCH_CHECK();
     if (!total_out) return IBVH_OK; // *_enqueue: the total stays in the scratch header, nobody waits
     int64_t total = 0;
@@ -2660,8 +3198,101 @@ inline bool same_types(const ibvh_types &x, const ibvh_types &y) {
 template <class L, class N, class I> constexpr bool kWorkTypes =
     std::is_same<L, BSphere<float>>::value && std::is_same<N, BBox<float>>::value && std::is_same<I, int32_t>::value;
 
+// Geometry of the binned ray path (kernels (3c)) for a tree and a batch of rays; depth == 0: the binary walker serves it.
+// The region lives at the END of the caller's scratch (ibvh_rays_scratch_bytes adds its size), offsets below are inside it.
+struct RayBinPlan {
+    int depth = 0, cut_level = 0, subtrees = 0;
+    int64_t cap = 0;
+    size_t bytes = 0, off_scan = 0, off_ray_items = 0, off_bin_count = 0, off_bin_start = 0, off_bin_cursor = 0, off_items = 0,
+           off_bucket = 0, off_hits = 0, off_chunks = 0, off_hit_list = 0;
+    int64_t region_cap = 0;
+};
+inline RayBinPlan rays_bin_plan(const ibvh_bvh &bvh, int64_t num_rays) {
+    RayBinPlan p;
+    const int mode = g_tuning.rays_binned; // 1 = where it pays, 2 = wherever the tree allows it (tests), 0 = never
+    if (mode == 0 || num_rays <= 0 || num_rays >= (int64_t)1 << 30) return p;
+    if (bvh.types.leaf_float != IBVH_F32 || bvh.types.node_float != IBVH_F32) return p;
+    const int levels = (int)bvh.tree.levels;
+    if (levels < 3 || levels > 32) return p;
+    // 512-leaf subtrees: 26 KB of LDS a workgroup, six workgroups a CU (config 3: 1.47 ms for the subtree pass; 1,024 leaves, three
+    // workgroups a CU: 2.50 ms; 256 leaves: 1.49 ms with a longer top walk)
+    int D = g_tuning.rays_subtree_depth > 0 ? g_tuning.rays_subtree_depth : 9;
+    if (D > 11) D = 11; // 2^11 leaves: 112 KB of LDS with the widest records
+    if (mode == 1) {
+        // enough subtrees to fill the chip (>= ~1,000: the cut at level 11 or below) holding >= 64 leaves each, and enough
+        // rays for one pass over the whole tree per launch to pay
+        if (D > levels - 11) D = levels - 11;
+        if (D < 6) return p;
+    } else if (D > levels - 2) {
+        D = levels - 2;
+    }
+    int K = levels - D;
+    if (K < (int)bvh.built_level) { // the nodes above built_level do not exist
+        K = (int)bvh.built_level;
+        D = levels - K;
+        if (D < 1) return p;
+    }
+    int64_t subtrees = level_num_real(bvh.tree.levels, bvh.tree.virtual_leaves, K);
+    while (subtrees > 16384 && D < 11 && K - 1 >= (int)bvh.built_level) { // (one LDS counter per subtree in the binning kernels)
+        ++D;
+        --K;
+        subtrees = level_num_real(bvh.tree.levels, bvh.tree.virtual_leaves, K);
+    }
+    if (subtrees > 16384) return p;
+    if (mode == 1 && num_rays < 16 * subtrees) return p;
+    const int per_ray = g_tuning.rays_items_per_ray > 0 ? g_tuning.rays_items_per_ray : 16;
+    int64_t cap = num_rays * per_ray;
+    if (cap > ((int64_t)1 << 30)) cap = (int64_t)1 << 30;
+    p.depth = D;
+    p.cut_level = K;
+    p.subtrees = (int)subtrees;
+    p.cap = cap;
+    size_t o = 2048; // header
+    p.off_scan = o, o += scan_scratch_bytes(cap > num_rays ? cap : num_rays);
+    p.off_ray_items = o, o += (size_t)align_up(4 * num_rays, 256);
+    p.off_bin_count = o, o += (size_t)align_up(4 * (subtrees + 1), 256);
+    p.off_bin_start = o, o += (size_t)align_up(4 * (subtrees + 1), 256);
+    p.off_bin_cursor = o, o += (size_t)align_up(4 * (subtrees + 1), 256);
+    p.off_items = o, o += (size_t)cap * 8;
+    p.off_bucket = o, o += (size_t)cap * 8;
+    p.off_hits = o, o += (size_t)cap * 8;
+    p.off_chunks = o, o += (size_t)align_up(8 * (subtrees + cap / RAYSUB_CHUNK + 1), 256);
+    p.region_cap = (cap + 255) / 256; // (RAY_REGIONS lists, as many records as items all together)
+    p.off_hit_list = o, o += (size_t)p.region_cap * 256 * (bvh.types.index_type == IBVH_I64 ? 24 : 16);
+    p.bytes = o;
+    return p;
+}
+inline RayBins rays_bins_at(const RayBinPlan &p, char *base) {
+    RayBins rb{};
+    rb.cursor = (unsigned long long *)base;
+    rb.flag = (int32_t *)(base + 8);
+    rb.n_items = (int32_t *)(base + 12);
+    rb.n_chunks = (int32_t *)(base + 16);
+    rb.reflag = (int32_t *)(base + 20);
+    rb.region_cursor = (uint32_t *)(base + 1024);
+    rb.dummy_total = (int64_t *)(base + 64);
+    rb.scan_scratch = base + p.off_scan;
+    rb.ray_items = (int32_t *)(base + p.off_ray_items);
+    rb.bin_count = (uint32_t *)(base + p.off_bin_count);
+    rb.bin_start = (uint32_t *)(base + p.off_bin_start);
+    rb.bin_cursor = (uint32_t *)(base + p.off_bin_cursor);
+    rb.items = (uint64_t *)(base + p.off_items);
+    rb.bucket = (uint2 *)(base + p.off_bucket);
+    rb.hits = base + p.off_hits;
+    rb.chunk_tab = (uint2 *)(base + p.off_chunks);
+    rb.hit_list = base + p.off_hit_list;
+    rb.region_cap = (int32_t)p.region_cap;
+    rb.cap = (int32_t)p.cap;
+    rb.cut_level = p.cut_level;
+    rb.depth = p.depth;
+    rb.subtrees = p.subtrees;
+    return rb;
+}
+// the type combinations the binned path is compiled for (one float type throughout; everything else: the binary walker)
+template <class L, class N> constexpr bool kRayBinTypes = std::is_same<typename L::elt, float>::value && std::is_same<typename N::elt, float>::value;
+
 template <class L, class N, class I, int MODE>
-int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStream_t st) {
+int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStream_t st, const RayBins &rb = RayBins{}) {
     if (a.n_items == 0) return IBVH_OK;
     const bool count_work = a.work != nullptr; // (the counting pass of the COUNT instantiation; nothing else is launched)
     if (count_work && (!kWorkTypes<L, N, I> || write)) return IBVH_ERR_UNSUPPORTED;
@@ -2680,6 +3311,44 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
         const int forced_block = g_tuning.ray_block;
         if (forced_block >= 64 && forced_block <= RAY_BLOCK_MAX && (forced_block & (forced_block - 1)) == 0) ray_block = forced_block;
         const unsigned rblocks = (unsigned)ceil_div(a.n_items, (int64_t)ray_block);
+        if constexpr (kRayBinTypes<L, N>) {
+            if (rb.cap > 0 && !count_work) {
+                // the binned path (3c); the binary walker stands by behind it, gated on the overflow flag
+                static_assert(RAY_REGIONS == 256, "rays_bin_plan sizes the hit list for 256 regions");
+                const size_t lds = rays_subtree_lds(rb.depth, sizeof(N), sizeof(L), sizeof(I), sizeof(RayHit<I>), write);
+                Args<L, N, I> standby = a;
+                standby.gate = rb.flag;
+                standby.shadow = nullptr;
+                const PairCache<I> none{nullptr, 0};
+                if (!write) {
+                    IBVH_HIP_CHECK(hipMemsetAsync(rb.cursor, 0, 2048, st));
+                    IBVH_HIP_CHECK(hipMemsetAsync(rb.bin_count, 0, (size_t)((char *)rb.items - (char *)rb.bin_count), st)); // counts, starts, cursors
+                    IBVH_LAUNCH((rays_top_kernel<L, N, I>), dim3(rblocks), dim3(64), 0, st, a, rb, ray_block);
+                    if (int e = scan_counts<int32_t>(rb.ray_items, a.n_items, nullptr, rb.scan_scratch, st, rb.dummy_total)) return e;
+                    const unsigned tiles = (unsigned)ceil_div((int64_t)rb.cap, RAYTILE);
+                    const size_t hist_lds = (size_t)rb.subtrees * 4;
+                    const unsigned chunks = (unsigned)(rb.subtrees + rb.cap / RAYSUB_CHUNK);
+                    IBVH_LAUNCH((rays_tilehist_kernel), dim3(tiles), dim3(RAYTILE_TPB), hist_lds, st, rb);
+                    IBVH_LAUNCH((rays_binscan_kernel), dim3(1), dim3(1024), 0, st, rb);
+                    IBVH_LAUNCH((rays_scatter_kernel), dim3(tiles), dim3(RAYTILE_TPB), hist_lds, st, rb);
+                    if (lds > 64 * 1024)
+                        IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)rays_subtree_kernel<L, N, I, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    IBVH_LAUNCH((rays_subtree_kernel<L, N, I, false>), dim3(chunks), dim3(RAYSUB_TPB), lds, st, a, rb);
+                    if (int e = scan_counts<I>((I *)rb.hits, (int64_t)rb.cap, nullptr, rb.scan_scratch, st, rb.dummy_total, nullptr, rb.n_items)) return e;
+                    IBVH_LAUNCH((rays_counts_kernel<I>), dim3((unsigned)ceil_div(a.n_items, 256)), dim3(256), 0, st, rb, a.counts, a.n_items);
+                    IBVH_LAUNCH((lvt_rays_kernel<L, N, I, false>), dim3(rblocks), dim3(64), 0, st, standby, none, ray_block);
+                } else {
+                    IBVH_LAUNCH((rays_place_kernel<I>), dim3((unsigned)ceil_div((int64_t)rb.region_cap, 1024), RAY_REGIONS), dim3(256), 0, st, rb, a.contacts,
+                                a.guard_total, a.guard_capacity);
+                    if (lds > 64 * 1024)
+                        IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)rays_subtree_kernel<L, N, I, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    IBVH_LAUNCH((rays_subtree_kernel<L, N, I, true>), dim3((unsigned)(rb.subtrees + rb.cap / RAYSUB_CHUNK)), dim3(RAYSUB_TPB), lds, st, a, rb);
+                    IBVH_LAUNCH((lvt_rays_kernel<L, N, I, true>), dim3(rblocks), dim3(64), 0, st, standby, none, ray_block);
+                }
+                IBVH_LAUNCH_CHECK();
+                return IBVH_OK;
+            }
+        }
         if constexpr (std::is_same<typename L::elt, float>::value && std::is_same<N, BBox<float>>::value) {
             if (a.shadow != nullptr && !count_work) {
                 // regular rays over the 8-wide shadow; the irregular ones (if any) by the binary walker behind it, without
@@ -2830,12 +3499,18 @@ int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const voi
     // RAYS: the quantised shadow of the node levels lives at the END of the scratch when the caller sized it with
     // ibvh_rays_scratch_bytes (and the walk qualifies: rays_shadow_bytes); the contact cache gets what lies in between
     size_t shadow_bytes = 0;
+    RayBinPlan bin_plan; // RAYS: the binned path's region, same place, when the tree and the batch qualify (it goes before the shadow)
     if (MODE == MODE_RAYS && !work) {
-        shadow_bytes = rays_shadow_bytes(*walk, n_items);
+        bin_plan = rays_bin_plan(*walk, n_items);
+        if (bin_plan.cut_level < start_level || scratch_bytes < scan_scratch_bytes(n_items) + bin_plan.bytes + 256) bin_plan = RayBinPlan{};
+        if (bin_plan.depth == 0) shadow_bytes = rays_shadow_bytes(*walk, n_items);
         if (scratch_bytes < scan_scratch_bytes(n_items) + shadow_bytes + 256) shadow_bytes = 0;
     }
-    const size_t cache_room = scratch_bytes - (shadow_bytes ? shadow_bytes + 256 : 0);
-    char *shadow_ptr = shadow_bytes ? (char *)scratch + ((scratch_bytes - shadow_bytes) & ~(size_t)255) : nullptr;
+    const size_t tail_bytes = bin_plan.depth ? bin_plan.bytes : shadow_bytes;
+    const size_t cache_room = scratch_bytes - (tail_bytes ? tail_bytes + 256 : 0);
+    char *tail_ptr = tail_bytes ? (char *)scratch + ((scratch_bytes - tail_bytes) & ~(size_t)255) : nullptr;
+    char *shadow_ptr = shadow_bytes ? tail_ptr : nullptr;
+    const RayBins bins = bin_plan.depth ? rays_bins_at(bin_plan, tail_ptr) : RayBins{};
     const int K = work ? 0 : cache_slots_for(cache_room, n_items, lay.pair_bytes);
     return dispatch_leaf_node(walk->types, [&](auto lt, auto nt) -> int {
         using L = typename decltype(lt)::type;
@@ -2869,6 +3544,7 @@ int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const voi
                 a.work = work;
                 a.shadow = shadow_ptr;
                 a.rays_filter = 0;
+                a.gate = nullptr;
                 if constexpr (MODE == MODE_RAYS && std::is_same<N, BBox<float>>::value && std::is_same<typename L::elt, float>::value) {
                     if (shadow_ptr && !write) { // (the writing pass of a _count / _write pair finds the shadow where the count left it)
                         const RayShadow sh = make_ray_shadow(walk->tree);
@@ -2877,14 +3553,14 @@ int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const voi
                     }
                 }
                 PairCache<I> cache{K ? (IndexPair<I> *)((char *)scratch + scan_scratch_bytes(n_items)) : nullptr, K};
-                if (int e = launch<L, N, I, MODE>(a, cache, write, st)) return e;
+                if (int e = launch<L, N, I, MODE>(a, cache, write, st, bins)) return e;
                 if (write || work) return (int)IBVH_OK;
                 if (int e = scan_counts<I>((I *)counts, n_items, enqueue ? nullptr : total_out, scratch, st, enqueue ? total_dev : nullptr,
                                            enqueue ? total_host : nullptr)) return e;
                 if (enqueue && capacity > 0) {
                     a.guard_total = total_dev ? (const int64_t *)total_dev : (const int64_t *)scratch; // the total contacts
                     a.guard_capacity = sizeof(I) == 4 && capacity > (int64_t)INT32_MAX ? (int64_t)INT32_MAX : capacity;
-                    return launch<L, N, I, MODE>(a, cache, true, st);
+                    return launch<L, N, I, MODE>(a, cache, true, st, bins);
                 }
                 return (int)IBVH_OK;
             });
@@ -2918,6 +3594,12 @@ ibvh_status ibvh_rays_scratch_bytes(const ibvh_bvh *bvh, int64_t num_rays, int32
     if (!bvh || !bytes_out || num_rays < 0) return IBVH_ERR_INVALID_ARG;
     size_t base = 0;
     if (ibvh_status e = ibvh_lvt_scratch_bytes(&bvh->types, num_rays, cache_slots, &base)) return e;
+    const RayBinPlan bp = rays_bin_plan(*bvh, num_rays);
+    if (bp.depth) { // the binned path keeps no contact cache: its writing pass walks the subtrees out of LDS again
+        if (ibvh_status e = ibvh_lvt_scratch_bytes(&bvh->types, num_rays, 0, &base)) return e;
+        *bytes_out = (size_t)align_up((int64_t)base, 256) + bp.bytes + 512;
+        return IBVH_OK;
+    }
     const size_t sh = rays_shadow_bytes(*bvh, num_rays);
     *bytes_out = sh ? (size_t)align_up((int64_t)base, 256) + sh + 512 : base;
     return IBVH_OK;

@@ -1,0 +1,130 @@
+"""The binned ray path (csrc/ibvh_lvt.hip "(3c)": the walk of raytrace/leaf_vs_tree/leaf_vs_tree.jl:170-228 cut at a
+level, the bottom finished subtree by subtree out of LDS) against the oracle's walk: the SAME list in the SAME order.
+The knob "rays_binned" = 2 forces the path onto trees far smaller than the ones it is chosen for, so that the oracle can
+walk them: every F32 leaf / node kind, subtrees of 2 .. 1,024 leaves, ragged last levels, start levels up to the cut and
+past it, irregular rays (zero / infinite / NaN components), the cached (enqueue) path, the ray narrow, positions, Int64
+indices, and an item list that overflows (the stand-by binary walker must then serve the call)."""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+import implicitbvh_amd as ibvh  # noqa: E402
+from implicitbvh_amd import abi, api, lib  # noqa: E402
+
+from test_gpu_parity import _positions, _rays_positions, build_both, contacts_np, cuda, oracle_pairs, random_volumes  # noqa: E402
+
+
+class knobs:
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            lib.set_tuning(k, v)
+        api._shape_memo.clear()
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            lib.set_tuning(k, {"rays_binned": 1}.get(k, 0))
+        api._shape_memo.clear()
+
+
+def _rays(rng, nr, extent):
+    p = (rng.random((nr, 3)) * (extent + 3) - 1).astype(np.float32)
+    d = (rng.random((nr, 3)) - 0.5).astype(np.float32)
+    d[::5, rng.integers(0, 3)] = 0
+    d[7::41] = 0
+    d[3::53, 1] = np.inf
+    d[11::67, 2] = 1e-45
+    p[13::71, 0] = np.nan
+    p[17::73, 1] = np.inf
+    d[19::79] *= 1e30
+    return p, d
+
+
+COMBOS = [(abi.BSPHERE, abi.F32, abi.BBOX, abi.F32), (abi.BBOX, abi.F32, abi.BBOX, abi.F32),
+          (abi.BSPHERE, abi.F32, abi.BSPHERE, abi.F32)]
+
+
+@pytest.mark.parametrize("combo", COMBOS, ids=str)
+@pytest.mark.parametrize("depth", [1, 3, 6, 10])
+def test_binned_rays_identical_order(combo, depth):
+    rng = np.random.default_rng(100 + depth)
+    types = abi.make_types(*combo)
+    with knobs(rays_binned=2, rays_subtree_depth=depth):
+        for n in (5, 129, 1000, 4097, 40_001):
+            vols = random_volumes(rng, n, combo[0], combo[1], scale=20.0 if n > 2000 else 8.0)
+            o, g = build_both(vols, types)
+            nr = 2500
+            p, d = _rays(rng, nr, 20 if n > 2000 else 8)
+            P_, D_ = cuda(p).t(), cuda(d).t()
+            for sl in sorted({1, 2, max(1, o.tree.levels - depth), o.tree.levels}):
+                if sl > o.tree.levels:
+                    continue
+                with np.errstate(all="ignore"):
+                    exp = oracle_pairs(orc.traverse_rays_lvt(o, p, d, sl)[0]).reshape(-1, 2)
+                t1 = ibvh.traverse_rays(g, P_, D_, start_level=sl)
+                assert t1.num_contacts == len(exp), (n, sl)
+                assert (contacts_np(t1).reshape(-1, 2) == exp).all(), (n, sl)
+                t2 = ibvh.traverse_rays(g, P_, D_, start_level=sl, cache=t1)  # enqueue path into the cached buffer
+                assert (contacts_np(t2).reshape(-1, 2) == exp).all(), (n, sl)
+            with np.errstate(all="ignore"):
+                exp = oracle_pairs(orc.traverse_rays_lvt(o, p, d)[0]).reshape(-1, 2)
+            # the ray narrow on the menu, and positions
+            with np.errstate(all="ignore"):
+                en = oracle_pairs(orc.traverse_rays_lvt(o, p, d)[0]).reshape(-1, 2)
+            tn = ibvh.traverse_rays(g, P_, D_, narrow=ibvh.NARROW_RAY_ORIGIN_OUTSIDE)
+            got = contacts_np(tn).reshape(-1, 2)
+            assert set(map(tuple, got.tolist())) <= set(map(tuple, en.tolist()))
+            lib.set_tuning("rays_binned", 0)
+            api._shape_memo.clear()
+            ref = contacts_np(ibvh.traverse_rays(g, P_, D_, narrow=ibvh.NARROW_RAY_ORIGIN_OUTSIDE)).reshape(-1, 2)
+            lib.set_tuning("rays_binned", 2)
+            api._shape_memo.clear()
+            assert got.shape == ref.shape and (got == ref).all()  # (the binary walker's narrowed list is pinned to the oracle elsewhere)
+            pos = _positions(o.leaves)
+            raw = contacts_np(_rays_positions(g, P_, D_)).reshape(-1, 2)
+            assert (raw[:, 0] == pos[exp[:, 0]]).all() and (raw[:, 1] == exp[:, 1]).all()
+
+
+def test_binned_rays_overflowing_item_list_falls_back_to_the_walker():
+    rng = np.random.default_rng(7)
+    types = abi.make_types()
+    vols = random_volumes(rng, 30_000, abi.BSPHERE, abi.F32, scale=10.0)
+    o, g = build_both(vols, types)
+    p, d = _rays(rng, 4000, 10)
+    with np.errstate(all="ignore"):
+        exp = oracle_pairs(orc.traverse_rays_lvt(o, p, d)[0]).reshape(-1, 2)
+    P_, D_ = cuda(p).t(), cuda(d).t()
+    with knobs(rays_binned=2, rays_subtree_depth=4, rays_items_per_ray=1):  # far fewer slots than items: overflow
+        t1 = ibvh.traverse_rays(g, P_, D_)
+        assert (contacts_np(t1).reshape(-1, 2) == exp).all()
+        t2 = ibvh.traverse_rays(g, P_, D_, cache=t1)
+        assert (contacts_np(t2).reshape(-1, 2) == exp).all()
+    with knobs(rays_binned=2, rays_subtree_depth=4, rays_items_per_ray=64):  # and with room: the binned path itself
+        t3 = ibvh.traverse_rays(g, P_, D_)
+        assert (contacts_np(t3).reshape(-1, 2) == exp).all()
+
+
+def test_binned_rays_int64_indices_and_the_default_rule():
+    """Int64 contacts through the binned path, and the shipped rule (knob = 1): a tree of 17+ levels with enough rays takes
+    it, a small batch does not — same list either way."""
+    rng = np.random.default_rng(9)
+    types = abi.make_types(abi.BSPHERE, abi.F32, abi.BBOX, abi.F32, index_type=abi.I64)
+    vols = random_volumes(rng, 70_000, abi.BSPHERE, abi.F32, scale=30.0)
+    o, g = build_both(vols, types)
+    assert o.tree.levels >= 17
+    p, d = _rays(rng, 20_000, 30)
+    with np.errstate(all="ignore"):
+        exp = oracle_pairs(orc.traverse_rays_lvt(o, p, d)[0]).reshape(-1, 2)
+    P_, D_ = cuda(p).t(), cuda(d).t()
+    for mode in (2, 1, 0):
+        with knobs(rays_binned=mode):
+            t = ibvh.traverse_rays(g, P_, D_)
+            assert t.contacts.dtype == torch.int64
+            assert (contacts_np(t).reshape(-1, 2) == exp).all(), mode
+            few = ibvh.traverse_rays(g, P_[:, :100].contiguous(), D_[:, :100].contiguous())
+            assert (contacts_np(few).reshape(-1, 2) == exp[exp[:, 1] <= 100]).all()
