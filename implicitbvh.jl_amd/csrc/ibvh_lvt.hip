@@ -2538,12 +2538,44 @@ __global__ __launch_bounds__(64) void lvt_rays_wide_kernel(Args<L, N, I> a, Pair
 // The item list has a fixed capacity inside the caller's scratch (ibvh_rays_scratch_bytes: 16 items per ray; config 3
 // emits 10.4); a call that overflows it raises *flag and every later kernel of the path returns at once, while the
 // binary walker — launched behind it in every call, gated on that flag — serves the call instead.  No host round trip.
+// The slab test of isintersection.jl:1-33 for a ray and a box that cannot produce a NaN: the ray is REGULAR (finite origin,
+// finite non-zero direction with finite non-zero reciprocal: ray_is_regular) and the box holds no NaN — then every
+// (bound - p) * inv is a number (possibly infinite), and on numbers the reference's `a < b ? a : b` / `a > b ? a : b` and
+// the hardware's v_min_f32 / v_max_f32 differ at most in the sign of a zero, which no later min, max or comparison can
+// tell apart: the same boolean, for half the instructions (packed subtract / multiply on the six bounds as they lie in
+// memory, v_min3 / v_max3).  Rays and boxes that do not qualify take isintersection_inv.  Used by rays_top_kernel
+// (0.72 -> 0.65 ms on config 3).
+#ifdef IBVH_RAYS_NO_FAST_SLAB // (development builds: the walks without the second code path, tools/build_variant.sh)
+constexpr bool kRaysFastSlab = false;
+#else
+constexpr bool kRaysFastSlab = true;
+#endif
+typedef float ray_f2 __attribute__((ext_vector_type(2)));
+struct RayPk {
+    ray_f2 p01, p20, p12, i01, i20, i12; // origin and reciprocals paired like a BBox{Float32}'s six floats: lo0 lo1 | lo2 up0 | up1 up2
+};
+IBVH_D RayPk ray_pk(const float *p, const float *inv) {
+    return RayPk{ray_f2{p[0], p[1]}, ray_f2{p[2], p[0]}, ray_f2{p[1], p[2]}, ray_f2{inv[0], inv[1]}, ray_f2{inv[2], inv[0]}, ray_f2{inv[1], inv[2]}};
+}
+IBVH_D bool slab_fast(const BBox<float> &b, const RayPk &r) {
+    const ray_f2 a = (ray_f2{b.lo[0], b.lo[1]} - r.p01) * r.i01; // t(lo0), t(lo1)
+    const ray_f2 c = (ray_f2{b.lo[2], b.up[0]} - r.p20) * r.i20; // t(lo2), t(up0)
+    const ray_f2 e = (ray_f2{b.up[1], b.up[2]} - r.p12) * r.i12; // t(up1), t(up2)
+    const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a.x, c.y), __builtin_fminf(a.y, e.x)), __builtin_fminf(c.x, e.y));
+    const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a.x, c.y), __builtin_fmaxf(a.y, e.x)), __builtin_fmaxf(c.x, e.y));
+    return (tmin <= tmax) && (tmax >= 0.f);
+}
+IBVH_D bool word_has_nan(uint64_t w) { // either float of an 8-byte word
+    return ((uint32_t)w & 0x7fffffffu) > 0x7f800000u || ((uint32_t)(w >> 32) & 0x7fffffffu) > 0x7f800000u;
+}
+
 struct RayBins {
     unsigned long long *cursor; // header + 0: items emitted so far (may run past cap: that is the overflow test)
     int32_t *flag;              // header + 8: != 0 -> the item list overflowed, the binary walker serves this call
     int32_t *n_items;           // header + 12: min(cursor, cap), written by rays_binscan_kernel
     int32_t *n_chunks;          // header + 16: workgroups of rays_subtree_kernel that have work (rays_binscan_kernel)
     int32_t *reflag;            // header + 20: != 0 -> a region of the hit list overflowed, the writing pass walks the subtrees again
+    int32_t *top_nan;           // header + 24: != 0 -> a node of levels 1 .. K holds a NaN (rays_topcheck_kernel): no fast slab test up there
     uint32_t *region_cursor;    // header + 1024: [RAY_REGIONS] records in each region of the hit list
     int64_t *dummy_total;       // header + 64: where the helper scans put their totals
     void *scan_scratch;         // tile sums of the helper scans (room for cap items)
@@ -2562,6 +2594,15 @@ struct RayBins {
     int32_t depth;              // D = levels - K: a subtree holds 2^D leaves
     int32_t subtrees;           // real nodes on level K
 };
+
+// any NaN in the node levels 1 .. K?  (a few hundred KB; decides whether rays_top_kernel may use slab_fast)
+template <class N> __global__ __launch_bounds__(256) void rays_topcheck_kernel(const N *nodes, int64_t count, RayBins rb) {
+    const uint64_t *w = (const uint64_t *)nodes;
+    const int64_t words = count * (int64_t)(sizeof(N) / 8);
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (int64_t)gridDim.x * 256) bad |= word_has_nan(w[i]);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) *rb.top_nan = 1;
+}
 
 constexpr int RAYTOP_STAGE = 768; // items a wave stages in LDS before it reserves room in the global list
 template <class L, class N, class I>
@@ -2582,6 +2623,9 @@ __global__ __launch_bounds__(64) void rays_top_kernel(Args<L, N, I> a, RayBins r
     const uint32_t pcount = (uint32_t)((roots + 1) / 2);
 
     T p[3] = {0, 0, 0}, d[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
+    RayPk pk{};
+    bool regular = true; // (idle lanes count as regular)
+    const bool top_clean = kRaysFastSlab && N::kind == IBVH_BBOX && *rb.top_nan == 0; // (the knob rays_fast_slab = 0 stores -1 there)
     int ray = -1;
     uint32_t pi = 0, inode = 0, pend = 0, ord = 0;
     int level = 0;
@@ -2623,6 +2667,10 @@ __global__ __launch_bounds__(64) void rays_top_kernel(Args<L, N, I> a, RayBins r
                     d[k] = a.dirs[3 * item + k];
                     inv[k] = T(1) / d[k];
                 }
+                if constexpr (N::kind == IBVH_BBOX) {
+                    regular = ray_is_regular(p, d, inv);
+                    pk = ray_pk(p, inv);
+                }
                 ray = mine;
                 pi = 0;
                 inode = pfirst;
@@ -2634,6 +2682,8 @@ __global__ __launch_bounds__(64) void rays_top_kernel(Args<L, N, I> a, RayBins r
             next = next + taken < items_here ? next + taken : items_here;
         }
         if (__builtin_amdgcn_ballot_w64(ray >= 0) == 0) break; // (every lane idle after a refill: the block is used up)
+        // (wave-uniform, fixed between refills: slab_fast serves the wave while all its rays are regular)
+        const bool fast = top_clean && __builtin_amdgcn_ballot_w64(ray >= 0 && !regular) == 0;
         for (;;) {
             bool e0 = false, e1 = false;
             uint64_t it0 = 0, it1 = 0;
@@ -2656,7 +2706,19 @@ __global__ __launch_bounds__(64) void rays_top_kernel(Args<L, N, I> a, RayBins r
                     ch.a = load_vol<N>(real0 ? np : np + 1);
                     ch.b = ch.a;
                 }
-                const bool h0 = real0 && node_hit(ch.a), h1 = real1 && node_hit(ch.b);
+                bool h0, h1;
+                if constexpr (N::kind == IBVH_BBOX) {
+                    if (fast) {
+                        h0 = real0 && slab_fast(ch.a, pk);
+                        h1 = real1 && slab_fast(ch.b, pk);
+                    } else {
+                        h0 = real0 && node_hit(ch.a);
+                        h1 = real1 && node_hit(ch.b);
+                    }
+                } else {
+                    h0 = real0 && node_hit(ch.a);
+                    h1 = real1 && node_hit(ch.b);
+                }
                 bool descended = false;
                 if (cl == K) { // the cut: hits become items, left before right
                     const uint64_t r64 = (uint64_t)(first_item + ray);
@@ -2688,6 +2750,7 @@ __global__ __launch_bounds__(64) void rays_top_kernel(Args<L, N, I> a, RayBins r
                     } else {
                         rb.ray_items[first_item + ray] = (int32_t)ord;
                         ray = -1;
+                        regular = true;
                     }
                 }
             }
@@ -2711,7 +2774,7 @@ __global__ __launch_bounds__(64) void rays_top_kernel(Args<L, N, I> a, RayBins r
 // same-address global atomics serialise (~11 ns each), so a tile of items is counted in LDS first and every non-empty bin
 // of the tile costs ONE global atomic.
 constexpr int RAYTILE = 4096, RAYTILE_TPB = 256;
-constexpr int RAYSUB_CHUNK = 1024; // items of one rays_subtree_kernel workgroup: busy subtrees are shared by several
+constexpr int RAYSUB_CHUNK = 4096; // items of one rays_subtree_kernel workgroup: busy subtrees are shared by several (1,024: 2 % slower on config 3)
 __global__ __launch_bounds__(RAYTILE_TPB) void rays_tilehist_kernel(RayBins rb) {
     extern __shared__ uint32_t s_hist[];
     if (*rb.flag != 0) return;
@@ -2810,6 +2873,11 @@ __global__ __launch_bounds__(RAYTILE_TPB) void rays_scatter_kernel(RayBins rb) {
 }
 
 constexpr int RAYSUB_TPB = 256;
+// waves of a workgroup that WALK (all of them load).  A wave lives as long as its longest item (config 3: 12 steps on
+// average, ~150 for the longest of a bucket), so four walkers with 256 items each keep only ~20 % of their lanes busy — but
+// fewer walkers lose more to latency than they gain in lane use (config 3, subtree pass: 1.47 ms with four, 2.09 ms with one
+// per 512 items, 2.47 ms with one)
+constexpr int RAYSUB_WALKERS = 4;
 constexpr int RAYSUB_STAGE = 64;  // hit records a wave stages in LDS (a step adds at most 64 left and 64 right hits: two appends)
 constexpr int RAY_REGIONS = 256;  // the hit list is RAY_REGIONS lists with a cursor each: same-address atomics serialise
 // a hit of the counting pass: the pair as it will be reported, the item it belongs to and its rank within the item; the
@@ -2823,7 +2891,7 @@ IBVH_HD size_t rays_subtree_lds(int depth, size_t node_bytes, size_t leaf_bytes,
     size_t o = (S * node_bytes + 15) & ~(size_t)15;
     o += (S * leaf_bytes + 15) & ~(size_t)15;
     o += (S * index_bytes + 15) & ~(size_t)15;
-    if (!write) o += (size_t)(RAYSUB_TPB / 64) * RAYSUB_STAGE * hit_bytes;
+    if (!write) o += (size_t)RAYSUB_WALKERS * RAYSUB_STAGE * hit_bytes;
     return o;
 }
 
@@ -2881,6 +2949,7 @@ __global__ __launch_bounds__(RAYSUB_TPB) void rays_subtree_kernel(Args<L, N, I> 
     }
     if (tid == 0) s_next = 0;
     __syncthreads();
+    if (wave >= RAYSUB_WALKERS) return;
 
     const I *hits = (const I *)rb.hits;
     const uint32_t region = blockIdx.x & (RAY_REGIONS - 1);
@@ -2962,6 +3031,7 @@ __global__ __launch_bounds__(RAYSUB_TPB) void rays_subtree_kernel(Args<L, N, I> 
                     const uint32_t nreal = (1u << (level - 1)) - (uint32_t)((uint64_t)vl >> (levels - level));
                     const bool real1 = (j << cd) + (c1 - (1u << cd)) < nreal;
                     const N na = s_nodes[c0], nb = s_nodes[c1];
+                    // (the packed slab test of rays_top_kernel as a second code path in this loop made it slower: 1.65 against 1.55 ms)
                     const bool n0 = node_hit(na), n1 = real1 && node_hit(nb);
                     if (n0) {
                         if (n1) pend |= 1u << cd;
@@ -3269,6 +3339,7 @@ inline RayBins rays_bins_at(const RayBinPlan &p, char *base) {
     rb.n_items = (int32_t *)(base + 12);
     rb.n_chunks = (int32_t *)(base + 16);
     rb.reflag = (int32_t *)(base + 20);
+    rb.top_nan = (int32_t *)(base + 24);
     rb.region_cursor = (uint32_t *)(base + 1024);
     rb.dummy_total = (int64_t *)(base + 64);
     rb.scan_scratch = base + p.off_scan;
@@ -3323,6 +3394,13 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
                 if (!write) {
                     IBVH_HIP_CHECK(hipMemsetAsync(rb.cursor, 0, 2048, st));
                     IBVH_HIP_CHECK(hipMemsetAsync(rb.bin_count, 0, (size_t)((char *)rb.items - (char *)rb.bin_count), st)); // counts, starts, cursors
+                    if (!g_tuning.rays_fast_slab) IBVH_HIP_CHECK(hipMemsetAsync(rb.top_nan, 0xff, 4, st)); // (-1: no fast slab test anywhere)
+                    if constexpr (N::kind == IBVH_BBOX) {
+                        const int64_t top_first = level_start(a.tree.levels, a.tree.virtual_leaves, a.built_level) - 1; // (memory index of the first node that exists)
+                        const int64_t top_count = level_start(a.tree.levels, a.tree.virtual_leaves, rb.cut_level + 1) - 1 - top_first;
+                        IBVH_LAUNCH((rays_topcheck_kernel<N>), dim3((unsigned)(ceil_div(top_count * 3, 256) < 256 ? ceil_div(top_count * 3, 256) : 256)), dim3(256), 0,
+                                    st, a.nodes + top_first, top_count, rb);
+                    }
                     IBVH_LAUNCH((rays_top_kernel<L, N, I>), dim3(rblocks), dim3(64), 0, st, a, rb, ray_block);
                     if (int e = scan_counts<int32_t>(rb.ray_items, a.n_items, nullptr, rb.scan_scratch, st, rb.dummy_total)) return e;
                     const unsigned tiles = (unsigned)ceil_div((int64_t)rb.cap, RAYTILE);

@@ -23,6 +23,10 @@ first = None
 for v in variants:
     mode, depth = (int(x) for x in v.split(":")[:2])
     per_ray = int(v.split(":")[2]) if v.count(":") >= 2 else 0
+    try:
+        lib.set_tuning("rays_fast_slab", int(v.split(":")[3]) if v.count(":") >= 3 else 1)
+    except Exception:  # noqa: BLE001  (a development build without the knob)
+        pass
     lib.set_tuning("rays_binned", mode)
     lib.set_tuning("rays_subtree_depth", depth)
     lib.set_tuning("rays_items_per_ray", per_ray)
