@@ -2021,7 +2021,7 @@ __global__ __launch_bounds__(64) void lvt_rays_kernel(Args<L, N, I> a, PairCache
     const uint32_t pcount = (uint32_t)((roots + 1) / 2); // pseudo-parents of the start-level roots
     // one fetch path for nodes and leaves when both are 24-byte records whose volume comes first
     constexpr bool SAME = sizeof(N) == 24 && sizeof(L) == 16;
-    const bool unified = SAME && a.lay.stride == 24;
+    const bool unified = SAME && sizeof(I) == 4 && a.lay.stride == 24 && a.lay.index_off == 16;
 
     // per-lane ray state
     T p[3] = {0, 0, 0}, d[3] = {0, 0, 0}, inv[3] = {0, 0, 0}; // inv = 1 / d, once per ray (isintersection.jl:2-4)
@@ -2135,11 +2135,12 @@ __global__ __launch_bounds__(64) void lvt_rays_kernel(Args<L, N, I> a, PairCache
                                 h1 = h1 && origin_outside(lb, p);
                             }
                             // .index sits right behind the 16-byte volume (4 or 8 bytes)
-                            I ia, ib;
-                            __builtin_memcpy(&ia, (const char *)&raw.w[0] + a.lay.index_off, sizeof(I) <= 8 ? sizeof(I) : 8);
-                            __builtin_memcpy(&ib, (const char *)&raw.w[6] + a.lay.index_off, sizeof(I) <= 8 ? sizeof(I) : 8);
-                            idx0 = ia;
-                            idx1 = ib;
+                            // (a 24-byte record with a 16-byte volume: the index is the 4 bytes behind it — a CONSTANT offset; the
+                            // run-time a.lay.index_off made the compiler keep `raw` in LDS: 18 LDS instructions a step, SQ counters)
+                            if constexpr (sizeof(I) == 4) {
+                                idx0 = (I)raw.w[4];
+                                idx1 = (I)raw.w[10];
+                            }
                         } else {
                             N na, nb;
                             __builtin_memcpy(&na, &raw.w[0], 24);
