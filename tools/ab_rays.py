@@ -12,9 +12,11 @@ from implicitbvh_amd.synthetic import random_rays, torus_mesh
 
 nr = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 variants = sys.argv[2].split(",") if len(sys.argv) > 2 else ["0:0", "1:10", "1:9", "1:11", "1:8"]
-tris = torch.from_numpy(torus_mesh()).cuda()
+uv = os.environ.get("AB_MESH_UV", "")  # e.g. "353,354": the 249,924-triangle surrogate of the reference's published case
+tris = torch.from_numpy(torus_mesh(*[int(x) for x in uv.split(",")]) if uv else torus_mesh()).cuda()
 vols = ibvh.bounding_volumes_from_triangles(tris)
 bvh = ibvh.BVH(vols)
+print("leaves", int(vols.shape[0]), "levels", bvh.tree.levels, "rays", nr)
 hv = vols[:, :3]
 lo, hi = hv.min(0).values.cpu().numpy(), hv.max(0).values.cpu().numpy()
 ph, dh = random_rays(nr, lo, hi, seed=43)
