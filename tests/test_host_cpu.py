@@ -103,6 +103,47 @@ def test_scratch_queries():
     assert need.value >= 8 * 22
 
 
+def _ray_scratch(n_leaves, n_rays, types=None, built_level=1):
+    b = abi.Bvh()
+    b.types = types or abi.make_types()
+    lib.call("ibvh_tree_shape", int(n_leaves), C.byref(b.tree))
+    b.built_level = built_level
+    need, base = C.c_size_t(), C.c_size_t()
+    lib.call("ibvh_rays_scratch_bytes", C.byref(b), int(n_rays), 8, C.byref(need))
+    lib.call("ibvh_lvt_scratch_bytes", C.byref(b.types), int(n_rays), 8, C.byref(base))
+    return need.value, base.value
+
+
+def test_ray_scratch_follows_the_binned_path_rule():
+    """ibvh_rays_scratch_bytes (host arithmetic only) makes room for the binned ray path exactly where the launch code takes it
+    (csrc/ibvh_lvt.hip rays_bin_plan): single-precision trees of >= 17 levels under >= 4,096 rays — 40 bytes x 16 items per
+    ray plus tables; everything else gets the leaf-query scratch; the knobs move the rule."""
+    need, base = _ray_scratch(7_201_012, 1_000_000)
+    assert 16 * 40 * 10**6 <= need <= 16 * 40 * 10**6 + 64 * 2**20
+    need, base = _ray_scratch(7_201_012, 30_000)          # few rays: still binned (subtrees nobody reaches are never loaded)
+    assert need >= 16 * 40 * 30_000
+    need, base = _ray_scratch(7_201_012, 1000)            # a handful of rays: the per-lane walker
+    assert need == base
+    need, base = _ray_scratch(30_000, 1_000_000)          # 16 levels: too few subtrees to fill the chip
+    assert need == base
+    f64 = abi.make_types(abi.BSPHERE, abi.F64, abi.BBOX, abi.F64)
+    need, base = _ray_scratch(7_201_012, 1_000_000, f64)  # compiled for single precision only
+    assert need == base
+    try:
+        lib.set_tuning("rays_binned", 0)
+        need, base = _ray_scratch(7_201_012, 1_000_000)
+        assert need == base
+        lib.set_tuning("rays_binned", 2)                  # wherever the tree allows it: a 1,000-leaf tree too
+        need, base = _ray_scratch(1000, 5000)
+        assert need > base
+        lib.set_tuning("rays_items_per_ray", 4)
+        small, _ = _ray_scratch(7_201_012, 1_000_000)
+        assert 4 * 40 * 10**6 <= small < 16 * 40 * 10**6
+    finally:
+        lib.set_tuning("rays_binned", 1)
+        lib.set_tuning("rays_items_per_ray", 0)
+
+
 def test_options_validation_like_argcheck():
     ibvh.BVHOptions()
     for bad in ({"num_threads": 0}, {"block_size": 0}, {"min_sorts_per_thread": -1}):

@@ -26,8 +26,12 @@ for variant in ("binned", "walker"):
             k = k.split("(")[0].split("<")[0][-40:] + ("<W>" if ", true" in r["Kernel_Name"].split("(")[0] else "")
             c = acc[k][r["Counter_Name"]]; c[0] += float(r["Counter_Value"]); c[1] += 1
     print("==", variant)
+    summary = {}
     for k, v in acc.items():
         print(k)
+        summary[k] = {n: round(c[0] / c[1], 1) for n, c in sorted(v.items())}
         for n, c in sorted(v.items()):
             print(f"    {n:34s} {c[0] / c[1]:16.1f}  (x{c[1]})")
+    import json
+    json.dump(summary, open(sys.argv[1] + f"/summary_{variant}.json", "w"), indent=1)
 PY
