@@ -2528,7 +2528,9 @@ __global__ __launch_bounds__(64) void lvt_rays_wide_kernel(Args<L, N, I> a, Pair
 //   C. rays_subtree_kernel — a workgroup copies one subtree's node levels and leaves into LDS (the tree is read about once
 //      per call, coalesced), then its lanes take up to RAYSUB_CHUNK of the subtree's items (busy subtrees are shared by several
 //      workgroups) and finish the walk below the subtree's root out of LDS: the random access that remains is the item's
-//      24-byte ray.  A hit is counted for its item AND kept as a record (pair, g, rank within the item) in a list.
+//      24-byte ray (bucket entries that carry the ray — one coalesced 32-byte read — cost the scatter more than they save
+//      here: 0.18 -> 0.35 ms against 1.46 -> 1.44).  A hit is counted for its item AND kept as a record (pair, g, rank
+//      within the item) in a list.
 //   D. hits per item in g order -> inclusive scan -> an item's hits go to [scan[g-1], scan[g]); the per-ray counts the
 //      entry points return are differences of that scan at the rays' item boundaries.  The writing pass only moves the kept
 //      records to scan[g-1] + rank (rays_place_kernel); if the record list overflowed it walks the subtrees again instead.
@@ -3285,7 +3287,8 @@ struct RayBinPlan {
 inline RayBinPlan rays_bin_plan(const ibvh_bvh &bvh, int64_t num_rays) {
     RayBinPlan p;
     const int mode = g_tuning.rays_binned; // 1 = where it pays, 2 = wherever the tree allows it (tests), 0 = never
-    if (mode == 0 || num_rays <= 0 || num_rays >= (int64_t)1 << 30) return p;
+    // (the tables take 40 bytes x 16 items per ray: batches beyond 8 M rays — 5.4 GB — are left to the per-lane walker)
+    if (mode == 0 || num_rays <= 0 || num_rays > (int64_t)1 << 23) return p;
     if (bvh.types.leaf_float != IBVH_F32 || bvh.types.node_float != IBVH_F32) return p;
     const int levels = (int)bvh.tree.levels;
     if (levels < 3 || levels > 32) return p;

@@ -269,7 +269,7 @@ ibvh_status ibvh_traverse_pair_lvt_write(const ibvh_bvh *bvh1, const ibvh_bvh *b
  * Scratch: ibvh_rays_scratch_bytes().  For single-precision trees of >= 17 levels and >= 4,096 rays it holds the tables
  * of the BINNED path (csrc/ibvh_lvt.hip "(3c)": the walk is cut at a level, the hits at that level are grouped by subtree
  * and the walks are finished subtree by subtree out of LDS — the reference's walk cut in two, the same hit list in the same
- * order): 40 bytes x 16 items per ray.  A call that needs more raises a flag on the device and is served by the binary
+ * order): 40 bytes x 16 items per ray (batches of up to 8 M rays).  A call that needs more raises a flag on the device and is served by the binary
  * walker in the same launch sequence; a caller that passes a smaller buffer (ibvh_lvt_scratch_bytes) gets the binary
  * walker from the start.  Otherwise it is ibvh_lvt_scratch_bytes(num_rays work items) — plus, ONLY while the development
  * knob "rays_shadow" is set (off by default: measured slower than the binary walk), room for a quantised

@@ -110,6 +110,15 @@ def test_binned_rays_overflowing_item_list_falls_back_to_the_walker():
     with knobs(rays_binned=2, rays_subtree_depth=4, rays_items_per_ray=64):  # and with room: the binned path itself
         t3 = ibvh.traverse_rays(g, P_, D_)
         assert (contacts_np(t3).reshape(-1, 2) == exp).all()
+    with knobs(rays_binned=2, rays_subtree_depth=11):  # 2,048-leaf subtrees: more than 64 KB of LDS a workgroup
+        t4 = ibvh.traverse_rays(g, P_, D_)
+        assert (contacts_np(t4).reshape(-1, 2) == exp).all()
+        bt = abi.make_types(abi.BBOX, abi.F32, abi.BBOX, abi.F32, index_type=abi.I64)
+        bv = random_volumes(rng, 30_000, abi.BBOX, abi.F32, scale=10.0)
+        ob, gb = build_both(bv, bt)
+        with np.errstate(all="ignore"):
+            eb = oracle_pairs(orc.traverse_rays_lvt(ob, p, d)[0]).reshape(-1, 2)
+        assert (contacts_np(ibvh.traverse_rays(gb, P_, D_)).reshape(-1, 2) == eb).all()
 
 
 def test_binned_rays_int64_indices_and_the_default_rule():
@@ -131,3 +140,47 @@ def test_binned_rays_int64_indices_and_the_default_rule():
             assert (contacts_np(t).reshape(-1, 2) == exp).all(), mode
             few = ibvh.traverse_rays(g, P_[:, :100].contiguous(), D_[:, :100].contiguous())
             assert (contacts_np(few).reshape(-1, 2) == exp[exp[:, 1] <= 100]).all()
+
+
+def test_binned_rays_partially_built_trees():
+    """built_level > 1 (the node levels above it do not exist): the cut level never lies above it, the walk starts at or below it."""
+    rng = np.random.default_rng(31)
+    types = abi.make_types()
+    vols = random_volumes(rng, 20_000, abi.BSPHERE, abi.F32, scale=12.0)
+    p, d = _rays(rng, 3000, 12)
+    P_, D_ = cuda(p).t(), cuda(d).t()
+    for built_level, depth in ((3, 6), (9, 10), (12, 2), (15, 10)):
+        o, g = build_both(vols, types, built_level=built_level)
+        with knobs(rays_binned=2, rays_subtree_depth=depth):
+            for sl in sorted({built_level, min(o.tree.levels, built_level + 2), o.tree.levels}):
+                with np.errstate(all="ignore"):
+                    exp = oracle_pairs(orc.traverse_rays_lvt(o, p, d, sl)[0]).reshape(-1, 2)
+                t = ibvh.traverse_rays(g, P_, D_, start_level=sl)
+                assert (contacts_np(t).reshape(-1, 2) == exp).all(), (built_level, depth, sl)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_binned_rays_seeds_under_the_shipped_rule(seed):
+    """Random sizes on both sides of the shipped rule (17 levels = 65,537 leaves; 4,096 rays), random extents and ray
+    mixes, default knobs: whichever path the rule picks, the oracle's list in the oracle's order."""
+    rng = np.random.default_rng(1000 + seed)
+    kind = (abi.BSPHERE, abi.BBOX)[seed % 2]
+    types = abi.make_types(kind, abi.F32, abi.BBOX, abi.F32)
+    n = int(rng.integers(40_000, 400_000))
+    nr = int(rng.integers(2_000, 30_000))
+    scale = float(rng.uniform(5.0, 60.0))
+    vols = random_volumes(rng, n, kind, abi.F32, scale=scale, size=float(rng.uniform(0.2, 1.5)))
+    o, g = build_both(vols, types)
+    p, d = _rays(rng, nr, scale)
+    if seed % 3 == 0:  # a batch of ordinary rays only: every wave takes the packed slab test
+        p = (rng.random((nr, 3)) * scale).astype(np.float32)
+        d = (rng.random((nr, 3)) - 0.5).astype(np.float32)
+        d[d == 0] = 0.25
+    with np.errstate(all="ignore"):
+        exp = oracle_pairs(orc.traverse_rays_lvt(o, p, d)[0]).reshape(-1, 2)
+    P_, D_ = cuda(p).t(), cuda(d).t()
+    t1 = ibvh.traverse_rays(g, P_, D_)
+    assert t1.num_contacts == len(exp)
+    assert (contacts_np(t1).reshape(-1, 2) == exp).all()
+    t2 = ibvh.traverse_rays(g, P_, D_, cache=t1)
+    assert (contacts_np(t2).reshape(-1, 2) == exp).all()

@@ -124,6 +124,8 @@ def test_ray_scratch_follows_the_binned_path_rule():
     assert need >= 16 * 40 * 30_000
     need, base = _ray_scratch(7_201_012, 1000)            # a handful of rays: the per-lane walker
     assert need == base
+    need, base = _ray_scratch(7_201_012, 10_000_000)      # more than 8 M rays: the tables would take > 5 GB
+    assert need == base
     need, base = _ray_scratch(30_000, 1_000_000)          # 16 levels: too few subtrees to fill the chip
     assert need == base
     f64 = abi.make_types(abi.BSPHERE, abi.F64, abi.BBOX, abi.F64)
