@@ -523,7 +523,8 @@ struct Tuning {
     int rays_shadow = 0;    // 1 = ray traversals walk the quantised 8-wide shadow of the node levels when the scratch has room
                             // (ibvh_rays_scratch_bytes); measured slower than the binary walk on config 3 (4.6 vs 4.3 ms): off
     int rays_binned = 1;    // ray traversals (F32 trees) cut the walk at a level and finish it subtree by subtree out of LDS:
-                            // 1 = where it pays (>= 17 levels, >= 4,096 rays), 2 = wherever the tree allows it, 0 = never
+                            // 1 = where it pays (rays_bin_plan: >= 17 levels, or >= 13 under <= 8,192 rays; not a small tree under many
+                            // rays), 2 = wherever the tree allows it, 0 = never
     int rays_subtree_depth = 0; // levels of such a subtree below its root (0 = 9: 512 leaves; at most 11)
     int rays_fast_slab = 1;     // 0 = the binned path tests every box with isintersection_inv (A/B of the packed / v_min3 slab test)
     int rays_items_per_ray = 0; // capacity of the (ray, subtree) item list per ray (0 = 16); a call that overflows it is served by the binary walker

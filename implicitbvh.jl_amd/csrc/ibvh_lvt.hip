@@ -3296,10 +3296,17 @@ inline RayBinPlan rays_bin_plan(const ibvh_bvh &bvh, int64_t num_rays) {
     // workgroups a CU: 2.50 ms; 256 leaves: 1.49 ms with a longer top walk)
     int D = g_tuning.rays_subtree_depth > 0 ? g_tuning.rays_subtree_depth : 9;
     if (D > 11) D = 11; // 2^11 leaves: 112 KB of LDS with the widest records
+    const bool small_batch = num_rays <= 8192;
     if (mode == 1) {
-        // enough subtrees to fill the chip (>= ~1,000: the cut at level 11 or below) holding >= 64 leaves each
-        if (D > levels - 11) D = levels - 11;
+        // subtrees of >= 64 leaves; enough of them to fill the chip (>= ~1,000: the cut at level 11 or below) unless the batch
+        // is small anyway (then the walk is a chain of dependent fetches and cutting it pays on any tree: 1,000 rays on 3,200 /
+        // 20,000 / 45,000 / 7.2 M leaves: 0.29 -> 0.18, 0.42 -> 0.20, 0.49 -> 0.22, 1.49 -> 0.51 ms; 64 rays on 7.2 M: 0.86 -> 0.35)
+        const int k_min = small_batch ? 7 : 11;
+        if (D > levels - k_min) D = levels - k_min;
         if (D < 6) return p;
+        // a SMALL tree under MANY rays stays with the per-lane walker: it lives in L2 and the binning is pure overhead
+        // (45 k leaves, 1e6 rays: 1.62 ms against 2.17 binned; 250 k leaves, 1e6 rays: 2.42 / 2.61; but 250 k, 1e5: 1.04 / 0.71)
+        if (!small_batch && bvh.tree.real_leaves < ((int64_t)1 << 20) && num_rays > 2 * bvh.tree.real_leaves) return p;
     } else if (D > levels - 2) {
         D = levels - 2;
     }
@@ -3317,9 +3324,7 @@ inline RayBinPlan rays_bin_plan(const ibvh_bvh &bvh, int64_t num_rays) {
     }
     if (subtrees > 16384) return p;
     // (few rays are no reason to stay away: a subtree nobody reaches is never loaded — 7.2 M-leaf mesh, 3e4 rays: 0.78 ms
-    // against 1.89 ms for the binary walker, 1e5 rays: 1.01 / 2.29, 3e5: 1.52 / 2.52; 250 k-leaf mesh, 1e5 rays: 0.71 / 1.04;
-    // the one measured loss is a SMALL tree under MANY rays — 250 k leaves, 1e6 rays: 2.61 / 2.42)
-    if (mode == 1 && num_rays < 4096) return p;
+    // against 1.89 ms for the binary walker, 1e5 rays: 1.01 / 2.29, 3e5: 1.52 / 2.52)
     const int per_ray = g_tuning.rays_items_per_ray > 0 ? g_tuning.rays_items_per_ray : 16;
     int64_t cap = num_rays * per_ray;
     if (cap > ((int64_t)1 << 30)) cap = (int64_t)1 << 30;

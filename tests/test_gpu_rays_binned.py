@@ -161,7 +161,7 @@ def test_binned_rays_partially_built_trees():
 
 @pytest.mark.parametrize("seed", range(8))
 def test_binned_rays_seeds_under_the_shipped_rule(seed):
-    """Random sizes on both sides of the shipped rule (17 levels = 65,537 leaves; 4,096 rays), random extents and ray
+    """Random sizes on both sides of the shipped rule (17 levels = 65,537 leaves; 8,192 rays; two rays per leaf), random extents and ray
     mixes, default knobs: whichever path the rule picks, the oracle's list in the oracle's order."""
     rng = np.random.default_rng(1000 + seed)
     kind = (abi.BSPHERE, abi.BBOX)[seed % 2]

@@ -116,17 +116,27 @@ def _ray_scratch(n_leaves, n_rays, types=None, built_level=1):
 
 def test_ray_scratch_follows_the_binned_path_rule():
     """ibvh_rays_scratch_bytes (host arithmetic only) makes room for the binned ray path exactly where the launch code takes it
-    (csrc/ibvh_lvt.hip rays_bin_plan): single-precision trees of >= 17 levels under >= 4,096 rays — 40 bytes x 16 items per
+    (csrc/ibvh_lvt.hip rays_bin_plan): single-precision trees of >= 17 levels, or >= 13 under small batches — 40 bytes x 16 items per
     ray plus tables; everything else gets the leaf-query scratch; the knobs move the rule."""
     need, base = _ray_scratch(7_201_012, 1_000_000)
     assert 16 * 40 * 10**6 <= need <= 16 * 40 * 10**6 + 64 * 2**20
     need, base = _ray_scratch(7_201_012, 30_000)          # few rays: still binned (subtrees nobody reaches are never loaded)
     assert need >= 16 * 40 * 30_000
-    need, base = _ray_scratch(7_201_012, 1000)            # a handful of rays: the per-lane walker
-    assert need == base
+    need, base = _ray_scratch(7_201_012, 64)              # a handful of rays: the walk is a dependent chain, cutting it pays most
+    assert need > base
     need, base = _ray_scratch(7_201_012, 10_000_000)      # more than 8 M rays: the tables would take > 5 GB
     assert need == base
-    need, base = _ray_scratch(30_000, 1_000_000)          # 16 levels: too few subtrees to fill the chip
+    need, base = _ray_scratch(30_000, 1_000_000)          # 16 levels, a big batch: too few subtrees to fill the chip
+    assert need == base
+    need, base = _ray_scratch(3_200, 1_000)               # ... a small batch on a small tree: binned again
+    assert need > base
+    need, base = _ray_scratch(3_200, 100_000)
+    assert need == base
+    need, base = _ray_scratch(250_000, 100_000)           # a medium tree: binned unless the rays outnumber its leaves 2 : 1
+    assert need > base
+    need, base = _ray_scratch(250_000, 1_000_000)
+    assert need == base
+    need, base = _ray_scratch(2_000, 500)                 # 12 levels: subtrees would hold fewer than 64 leaves
     assert need == base
     f64 = abi.make_types(abi.BSPHERE, abi.F64, abi.BBOX, abi.F64)
     need, base = _ray_scratch(7_201_012, 1_000_000, f64)  # compiled for single precision only
