@@ -556,15 +556,17 @@ constexpr int QUEUE_MINWAVES = IBVH_QUEUE_MINWAVES; // waves per SIMD the regist
 
 // Waves per SIMD a given instantiation can actually reach: Float64 volumes and 64-bit queue entries need more registers than
 // the bench types, and asking for 7 waves there only makes the allocator spill and warn (-Wpass-failed, 48 times in round 3).
-template <class L, class N, class I, bool WIDE> constexpr int queue_min_waves() {
+template <class L, class N, class I, bool WIDE, bool WRITE = false> constexpr int queue_min_waves() {
     if (sizeof(typename N::elt) == 8) return 4;
     if (sizeof(typename L::elt) == 8) return 5;
     if (WIDE && sizeof(I) == 8) return 6;
-    return QUEUE_MINWAVES;
+    // (the writing pass puts pairs together from 8-byte cache entries: a few registers more, one wave per SIMD fewer — it
+    // is a streaming pass of 0.013 ms at 1e6 leaves)
+    return WRITE ? QUEUE_MINWAVES - 1 : QUEUE_MINWAVES;
 }
 // WIDE: 64-bit queue entries for trees of 29 .. 31 levels (leaf-parent indices beyond 2^26), see launch().
 template <class L, class N, class I, int MODE, bool WRITE, bool NARROW, bool WIDE, bool COUNT = false>
-__global__ __launch_bounds__(64 * QUEUE_WAVES, (queue_min_waves<L, N, I, WIDE>())) void lvt_queue_kernel(Args<L, N, I> a, PairCache<I> cache, int cut_level) {
+__global__ __launch_bounds__(64 * QUEUE_WAVES, (queue_min_waves<L, N, I, WIDE, WRITE>())) void lvt_queue_kernel(Args<L, N, I> a, PairCache<I> cache, int cut_level) {
     using TN = typename N::elt;
     Work<COUNT> work; // (COUNT: one lane-level box / sphere test = one count; lane 0 carries the wave-uniform parts)
     using Q = Query<L, N, I, MODE, WRITE, NARROW>;
@@ -573,6 +575,7 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, (queue_min_waves<L, N, I, WIDE>()
     using QE = typename std::conditional<WIDE, uint64_t, uint32_t>::type; // queue entry: query lane | leaf-parent index << 6
     __shared__ QE s_queue[QUEUE_WAVES][QUEUE_CAP];
     __shared__ Cnt s_cnt[QUEUE_WAVES][64];
+    __shared__ I s_qside[QUEUE_WAVES][64]; // writing pass from the cache: the query's half of a pair, by query lane
 #if IBVH_LVT_QTABLE
     // The wave's 64 query leaves (volume, index) in LDS: the leaf-test step fetches its candidate's query with one or two
     // ds_read instead of five ds_bpermute out of registers, and the volume / index need not stay in VGPRs through the loops.
@@ -591,13 +594,16 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, (queue_min_waves<L, N, I, WIDE>()
 #endif
     // Wave-dense contact cache.  The wave owns the scratch bytes its 64 items own in the slot-major layout of the
     // other walkers ([item0 * K, (item0 + 64) * K) pairs) but fills them densely, in discovery order, with
-    // (pair, query lane | position within that query's list << 6) entries behind a 16-byte header {fill}: the
+    // (partner, query lane | position within that query's list << 6) entries behind a 16-byte header {fill}: the
     // counting pass writes them with coalesced stores instead of one scattered 8-byte store per contact, and the
-    // writing pass reads ~14 B per contact instead of touching K sparse slot arrays (measured at 1e7 leaves:
+    // writing pass reads ~10 B per contact instead of touching K sparse slot arrays (measured at 1e7 leaves:
     // 0.72 GB fetched by the writing pass with the slot-major cache).  fill < 0: the wave found more contacts than
     // fit (or fell back to the exact walk) and walks again in the writing pass.
+    // Round 4: an entry is 8 bytes, not 12 — the QUERY's half of the pair is a function of the query lane, which the
+    // writing pass has anyway (it loads its 64 items), so only the partner's half (its index, or its 1-based position
+    // with IBVH_OUTPUT_POSITIONS) is kept and the pair is put together when it is written out.
     struct Entry {
-        IndexPair<I> pair;
+        I other;
         I meta;
     };
     const int64_t first_item = q.item - lane;
@@ -613,11 +619,18 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, (queue_min_waves<L, N, I, WIDE>()
         if (fill >= 0) {
             // serve the whole wave from its cache: entry t goes to (prefix of its query) + (its position in the list)
             s_cnt[wv][lane] = q.w;
+            s_qside[wv][lane] = a.positions ? (I)(q.item + 1) : q.q_index;
             __builtin_amdgcn_wave_barrier();
             for (int t = lane; t < fill; t += 64) {
                 const Entry e = entries[t];
-                const int64_t dest = (int64_t)s_cnt[wv][(int)(e.meta & 63)] + (int64_t)(e.meta >> 6);
-                a.contacts[dest] = e.pair;
+                const int qi = (int)(e.meta & 63);
+                const int64_t dest = (int64_t)s_cnt[wv][qi] + (int64_t)(e.meta >> 6);
+                const I qv = s_qside[wv][qi];
+                IndexPair<I> c2; // (the same rules as put() below)
+                if (a.positions) c2 = (MODE == MODE_PAIR && a.flip) ? IndexPair<I>{e.other, qv} : IndexPair<I>{qv, e.other};
+                else if constexpr (MODE == MODE_SELF) c2 = qv > e.other ? IndexPair<I>{e.other, qv} : IndexPair<I>{qv, e.other};
+                else c2 = a.flip ? IndexPair<I>{e.other, qv} : IndexPair<I>{qv, e.other};
+                a.contacts[dest] = c2;
             }
             return;
         }
@@ -876,16 +889,16 @@ __global__ __launch_bounds__(64 * QUEUE_WAVES, (queue_min_waves<L, N, I, WIDE>()
         // WRITE: straight to the output; counting pass: appended to the wave's dense cache (slot = running fill +
         // number of hitting lanes below this one, a-hits of the step before its b-hits)
         auto put = [&](Cnt at, I lidx, int slot, uint32_t lpos) {
-            IndexPair<I> c2;
-            if (a.positions) { // 1-based positions, query / bvh1 first (include/ibvh.h, IBVH_OUTPUT_POSITIONS)
-                const I qp = (I)(item_q + 1u), lp = (I)(lpos + 1u);
-                c2 = (MODE == MODE_PAIR && a.flip) ? IndexPair<I>{lp, qp} : IndexPair<I>{qp, lp};
-            } else if constexpr (MODE == MODE_SELF) c2 = qidx > lidx ? IndexPair<I>{lidx, qidx} : IndexPair<I>{qidx, lidx};
-            else c2 = a.flip ? IndexPair<I>{lidx, qidx} : IndexPair<I>{qidx, lidx};
             if constexpr (WRITE) {
+                IndexPair<I> c2;
+                if (a.positions) { // 1-based positions, query / bvh1 first (include/ibvh.h, IBVH_OUTPUT_POSITIONS)
+                    const I qp = (I)(item_q + 1u), lp = (I)(lpos + 1u);
+                    c2 = (MODE == MODE_PAIR && a.flip) ? IndexPair<I>{lp, qp} : IndexPair<I>{qp, lp};
+                } else if constexpr (MODE == MODE_SELF) c2 = qidx > lidx ? IndexPair<I>{lidx, qidx} : IndexPair<I>{qidx, lidx};
+                else c2 = a.flip ? IndexPair<I>{lidx, qidx} : IndexPair<I>{qidx, lidx};
                 a.contacts[(int64_t)at] = c2;
             } else {
-                if (slot < entry_cap) entries[slot] = Entry{c2, (I)((I)qi | ((I)(at - 0) << 6))};
+                if (slot < entry_cap) entries[slot] = Entry{a.positions ? (I)(lpos + 1u) : lidx, (I)((I)qi | ((I)(at - 0) << 6))};
             }
         };
         const Cnt at = base + (Cnt)rank;
@@ -1983,8 +1996,8 @@ template <class L, class N, class I, bool WRITE, bool COUNT = false>
 __global__ __launch_bounds__(64) void lvt_rays_kernel(Args<L, N, I> a, PairCache<I> cache, int ray_block) {
     using T = typename L::elt;
     Work<COUNT> work;
-    struct Entry {
-        IndexPair<I> pair;
+    struct Entry { // 8 bytes: the ray's half of the pair follows from the meta field (ray-in-block | position << RAY_BITS)
+        I leaf;
         I meta;
     };
     __shared__ int s_fill;
@@ -2006,7 +2019,7 @@ __global__ __launch_bounds__(64) void lvt_rays_kernel(Args<L, N, I> a, PairCache
                 const Entry e = entries[t];
                 const int64_t ray = first_item + (int64_t)(e.meta & (RAY_BLOCK_MAX - 1));
                 const int64_t w0 = ray > 0 ? (int64_t)a.counts[ray - 1] : 0;
-                a.contacts[w0 + (int64_t)(e.meta >> RAY_BITS)] = e.pair;
+                a.contacts[w0 + (int64_t)(e.meta >> RAY_BITS)] = IndexPair<I>{e.leaf, (I)(ray + 1)};
             }
             return;
         }
@@ -2049,7 +2062,7 @@ __global__ __launch_bounds__(64) void lvt_rays_kernel(Args<L, N, I> a, PairCache
             if (region) {
                 const int slot = atomicAdd(&s_fill, 1);
                 if (cnt >= ((int64_t)1 << (sizeof(I) * 8 - 1 - RAY_BITS))) meta_bad = true;
-                if (slot < entry_cap) entries[slot] = Entry{c2, (I)((I)ray | ((I)cnt << RAY_BITS))};
+                if (slot < entry_cap) entries[slot] = Entry{c2.a, (I)((I)ray | ((I)cnt << RAY_BITS))};
             }
             ++cnt;
         }
