@@ -145,10 +145,8 @@ def make_types(leaf_kind=BSPHERE, leaf_float=F32, node_kind=BBOX, node_float=F32
 
 
 def combo_supported(t):
-    """NodeType(leaf) must exist in the reference (merge.jl) and the node float is never wider."""
+    """NodeType(leaf) must exist in the reference (merge.jl); any node float type (build.jl:198-205)."""
     if t.node_kind == BSPHERE and t.leaf_kind != BSPHERE:
-        return False
-    if t.node_float == F64 and t.leaf_float != F64:
         return False
     return True
 

@@ -155,8 +155,8 @@ template <class T> IBVH_HD void center(const BBox<T> &b, T c[3]) {
 }
 
 // ------------------------------------------------------------------------------------------
-// conversions / merges — merge.jl:2-85.  Arithmetic in the leaf float type TL (never narrower
-// than the node's TN), one rounding into TN at the end, as Julia's constructors do.
+// conversions / merges — merge.jl:2-85.  Arithmetic in Julia's promoted type — the leaf float type TL unless the node's
+// TN is wider and a T-typed constant enters the expression (sphere merge) — and one conversion into TN at the end.
 // ------------------------------------------------------------------------------------------
 template <class TN, class TL> IBVH_HD BSphere<TN> convert_to(const BSphere<TL> &a, BSphere<TN> *) {
     return {{TN(a.x[0]), TN(a.x[1]), TN(a.x[2])}, TN(a.r)};
@@ -173,11 +173,12 @@ IBVH_HD BSphere<TN> merge_to(const BSphere<TL> &a, const BSphere<TL> &b, BSphere
     TL length = dist3(a.x, b.x);
     if (length + a.r <= b.r) return convert_to(b, (BSphere<TN> *)nullptr);
     if (length + b.r <= a.r) return convert_to(a, (BSphere<TN> *)nullptr);
-    TL frac = TL(0.5) * ((b.r - a.r) / length + TL(1));
-    TL c0 = a.x[0] + frac * (b.x[0] - a.x[0]);
-    TL c1 = a.x[1] + frac * (b.x[1] - a.x[1]);
-    TL c2 = a.x[2] + frac * (b.x[2] - a.x[2]);
-    TL radius = TL(0.5) * (length + a.r + b.r);
+    using TP = decltype(TL() + TN()); // promote_type(TL, TN): TL for every combination but Float32 leaves under Float64 nodes
+    TP frac = TP(0.5) * ((b.r - a.r) / length + TP(1));
+    TP c0 = a.x[0] + frac * (b.x[0] - a.x[0]);
+    TP c1 = a.x[1] + frac * (b.x[1] - a.x[1]);
+    TP c2 = a.x[2] + frac * (b.x[2] - a.x[2]);
+    TP radius = TP(0.5) * (length + a.r + b.r);
     return {{TN(c0), TN(c1), TN(c2)}, TN(radius)};
 }
 template <class TN, class TL> IBVH_HD BBox<TN> merge_to(const BBox<TL> &a, const BBox<TL> &b, BBox<TN> *) { // :30-40
@@ -430,8 +431,7 @@ inline bool combo_ok(const ibvh_types &t) {
     if (t.leaf_float < 0 || t.leaf_float > 1 || t.node_float < 0 || t.node_float > 1) return false;
     if (t.index_type < 0 || t.index_type > 1 || t.morton_type < 0 || t.morton_type > 2) return false;
     if (t.node_kind == IBVH_BSPHERE && t.leaf_kind != IBVH_BSPHERE) return false; // no BSphere(BBox) ctor
-    if (t.node_float == IBVH_F64 && t.leaf_float != IBVH_F64) return false;
-    return true;
+    return true; // (any node float type: narrower, equal or wider than the leaves', build.jl:198-205)
 }
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 inline bool layout_of(const ibvh_types &t, ibvh_layout &out, LeafLayout *dev = nullptr) {
@@ -472,8 +472,7 @@ template <class F> int dispatch_leaf_node(const ibvh_types &t, F &&f) {
         using L = typename decltype(lt)::type;
         return dispatch_volume(t.node_kind, t.node_float, [&](auto nt) -> int {
             using N = typename decltype(nt)::type;
-            constexpr bool ok = !(N::kind == IBVH_BSPHERE && L::kind != IBVH_BSPHERE) &&
-                                !(sizeof(typename N::elt) > sizeof(typename L::elt));
+            constexpr bool ok = !(N::kind == IBVH_BSPHERE && L::kind != IBVH_BSPHERE);
             if constexpr (ok) return f(lt, nt);
             else return (int)IBVH_ERR_UNSUPPORTED;
         });

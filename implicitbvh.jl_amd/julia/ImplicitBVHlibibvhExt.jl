@@ -323,7 +323,7 @@ function ImplicitBVH.BVH(
     types = ibvh_types(V, N, I, M)
     need = Ref{Csize_t}(0)
     st = c_build_scratch_bytes(types, numbv, need)
-    if st == IBVH_ERR_UNSUPPORTED   # e.g. Float16 volumes, F32 leaves under F64 nodes: the reference's own path
+    if st == IBVH_ERR_UNSUPPORTED   # e.g. Float16 volumes: the reference's own path
         return invoke(ImplicitBVH.BVH, Tuple{AbstractVector, Type}, bounding_volumes, node_type;
                       built_level=built_level, cache=cache, options=options)
     end

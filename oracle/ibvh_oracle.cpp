@@ -44,11 +44,11 @@ template <class F> int dispatch_volume(int kind, int flt, F &&f) {
     return IBVH_ERR_UNSUPPORTED;
 }
 // leaf/node combinations that exist in the reference AND are instantiated here:
-// NodeType(leaf) must exist (merge.jl): sphere->sphere, sphere->box, box->box; and the node float
-// type is never wider than the leaf's.
+// NodeType(leaf) must exist (merge.jl): sphere->sphere, sphere->box, box->box; any node float type (build.jl:198-205
+// builds whatever node_type it is given: narrower, equal or WIDER than the leaves' — the constructors of merge.jl compute in
+// Julia's promoted type and convert once).
 inline bool combo_ok(const ibvh_types &t) {
     if (t.node_kind == IBVH_BSPHERE && t.leaf_kind != IBVH_BSPHERE) return false;
-    if (t.node_float == IBVH_F64 && t.leaf_float != IBVH_F64) return false;
     return true;
 }
 template <class F> int dispatch_leaf_node(const ibvh_types &t, F &&f) {
@@ -57,8 +57,7 @@ template <class F> int dispatch_leaf_node(const ibvh_types &t, F &&f) {
         using L = typename decltype(lt)::type;
         return dispatch_volume(t.node_kind, t.node_float, [&](auto nt) -> int {
             using N = typename decltype(nt)::type;
-            constexpr bool ok = !(N::kind == IBVH_BSPHERE && L::kind != IBVH_BSPHERE) &&
-                                !(sizeof(typename N::elt) > sizeof(typename L::elt));
+            constexpr bool ok = !(N::kind == IBVH_BSPHERE && L::kind != IBVH_BSPHERE);
             if constexpr (ok) return f(lt, nt);
             else return IBVH_ERR_UNSUPPORTED;
         });

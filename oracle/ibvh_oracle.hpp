@@ -225,12 +225,15 @@ inline BSphere<TN> merge_to(const BSphere<TL> &a, const BSphere<TL> &b, BSphere<
     TL length = dist3(a.x, b.x);
     if (length + a.r <= b.r) return convert_to(b, (BSphere<TN> *)nullptr); // :6
     if (length + b.r <= a.r) return convert_to(a, (BSphere<TN> *)nullptr); // :10
-    // T(0.5), T(1) are exact in every float type, so with TL at least as wide as TN the
-    // promoted arithmetic is TL arithmetic (:15-19)
-    TL frac = TL(0.5) * ((b.r - a.r) / length + TL(1));
-    TL centre[3] = {a.x[0] + frac * (b.x[0] - a.x[0]), a.x[1] + frac * (b.x[1] - a.x[1]),
+    // :15-19 in Julia's promoted type TP = promote_type(TL, TN): T(0.5) and T(1) are exact in every float type, so with TL
+    // at least as wide as TN all of it is TL arithmetic; with a WIDER node type the leaf-typed sub-expressions
+    // ((b.r - a.r) / length, b.x - a.x, length + a.r + b.r) are still evaluated in TL and only their combination with a
+    // T-typed value is promoted — which is exactly what C++'s usual arithmetic conversions do with these expressions
+    using TP = decltype(TL() + TN());
+    TP frac = TP(0.5) * ((b.r - a.r) / length + TP(1));
+    TP centre[3] = {a.x[0] + frac * (b.x[0] - a.x[0]), a.x[1] + frac * (b.x[1] - a.x[1]),
                     a.x[2] + frac * (b.x[2] - a.x[2])};
-    TL radius = TL(0.5) * (length + a.r + b.r);
+    TP radius = TP(0.5) * (length + a.r + b.r);
     return {{TN(centre[0]), TN(centre[1]), TN(centre[2])}, TN(radius)};
 }
 // BBox{T}(a::BBox, b::BBox) — merge.jl:30-40

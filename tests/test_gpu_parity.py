@@ -75,6 +75,8 @@ ALL_COMBOS = [
     (abi.BSPHERE, abi.F64, abi.BBOX, abi.F64), (abi.BSPHERE, abi.F64, abi.BSPHERE, abi.F64),
     (abi.BSPHERE, abi.F64, abi.BSPHERE, abi.F32), (abi.BBOX, abi.F64, abi.BBOX, abi.F64),
     (abi.BBOX, abi.F64, abi.BBOX, abi.F32),
+    # node float types WIDER than the leaves' (build.jl:198-205 builds any node_type; merge.jl computes in the promoted type)
+    (abi.BSPHERE, abi.F32, abi.BBOX, abi.F64), (abi.BSPHERE, abi.F32, abi.BSPHERE, abi.F64), (abi.BBOX, abi.F32, abi.BBOX, abi.F64),
 ]
 
 

@@ -209,3 +209,51 @@ def test_layouts_match_julia_struct_layout():
                     dt = abi.leaf_dtype(t)
                     assert dt.itemsize == lay.leaf_bytes
                     assert dt.fields["index"][1] == lay.index_off and dt.fields["morton"][1] == lay.morton_off
+
+
+def test_merges_into_a_wider_node_type_follow_julias_promotion():
+    """build.jl:198-205 builds any node_type, also one WIDER than the leaves' float type; the constructors of merge.jl then
+    compute in Julia's promoted type: `BSphere{Float64}(a::BSphere{Float32}, b)` evaluates (b.r - a.r) / length, b.x - a.x
+    and length + a.r + b.r in Float32 and everything that meets a T(0.5) / T(1) in Float64 (merge.jl:15-19); the box
+    constructors compute min / max / x -+ r in Float32 and convert (merge.jl:30-40, :47-51, :58-81).  The oracle against an
+    independent numpy restatement of those rules."""
+    rng = np.random.default_rng(5)
+    f32, f64 = np.float32, np.float64
+    ts = abi.make_types(abi.BSPHERE, abi.F32, abi.BSPHERE, abi.F64)
+    tb = abi.make_types(abi.BSPHERE, abi.F32, abi.BBOX, abi.F64)
+    tbb = abi.make_types(abi.BBOX, abi.F32, abi.BBOX, abi.F64)
+    for k in range(200):
+        a = rng.random(4).astype(f32)
+        b = rng.random(4).astype(f32)
+        if k % 5 == 0:
+            b[3] = f32(5.0)  # a inside b
+        if k % 7 == 0:
+            a[3] = f32(6.0)  # b inside a
+        dx = [f32(a[i] - b[i]) for i in range(3)]
+        length = f32(np.sqrt(f32(f32(f32(dx[0] * dx[0]) + f32(dx[1] * dx[1])) + f32(dx[2] * dx[2]))))
+        got = orc.merge(ts, a, b)
+        if f32(length + a[3]) <= b[3]:
+            exp_x, exp_r = [f64(v) for v in b[:3]], f64(b[3])
+        elif f32(length + b[3]) <= a[3]:
+            exp_x, exp_r = [f64(v) for v in a[:3]], f64(a[3])
+        else:
+            frac = f64(0.5) * (f64(f32(f32(b[3] - a[3]) / length)) + f64(1))
+            exp_x = [f64(a[i]) + frac * f64(f32(b[i] - a[i])) for i in range(3)]
+            exp_r = f64(0.5) * f64(f32(f32(length + a[3]) + b[3]))
+        assert got["x"].dtype == np.float64
+        assert got["x"].tolist() == exp_x and float(got["r"]) == exp_r
+        gb = orc.merge(tb, a, b)
+        if f32(length + a[3]) <= b[3]:
+            lo, up = [f64(f32(b[i] - b[3])) for i in range(3)], [f64(f32(b[i] + b[3])) for i in range(3)]
+        elif f32(length + b[3]) <= a[3]:
+            lo, up = [f64(f32(a[i] - a[3])) for i in range(3)], [f64(f32(a[i] + a[3])) for i in range(3)]
+        else:
+            lo = [f64(min(f32(a[i] - a[3]), f32(b[i] - b[3]))) for i in range(3)]
+            up = [f64(max(f32(a[i] + a[3]), f32(b[i] + b[3]))) for i in range(3)]
+        assert gb["lo"].tolist() == lo and gb["up"].tolist() == up
+        ba = np.concatenate([np.minimum(a[:3], b[:3]), np.maximum(a[:3], b[:3]) + f32(0.1)]).astype(f32)
+        bb = rng.random(6).astype(f32)
+        bb[3:] += bb[:3]
+        gbb = orc.merge(tbb, ba, bb)
+        assert gbb["lo"].tolist() == [f64(min(ba[i], bb[i])) for i in range(3)]
+        assert gbb["up"].tolist() == [f64(max(ba[3 + i], bb[3 + i])) for i in range(3)]
