@@ -2641,7 +2641,8 @@ __global__ __launch_bounds__(64) void rays_top_kernel(Args<L, N, I> a, RayBins r
     T p[3] = {0, 0, 0}, d[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
     RayPk pk{};
     bool regular = true; // (idle lanes count as regular)
-    const bool top_clean = kRaysFastSlab && N::kind == IBVH_BBOX && *rb.top_nan == 0; // (the knob rays_fast_slab = 0 stores -1 there)
+    constexpr bool kPacked = N::kind == IBVH_BBOX && std::is_same<T, float>::value; // (slab_fast is single precision)
+    const bool top_clean = kRaysFastSlab && kPacked && *rb.top_nan == 0; // (the knob rays_fast_slab = 0 stores -1 there)
     int ray = -1;
     uint32_t pi = 0, inode = 0, pend = 0, ord = 0;
     int level = 0;
@@ -2683,7 +2684,7 @@ __global__ __launch_bounds__(64) void rays_top_kernel(Args<L, N, I> a, RayBins r
                     d[k] = a.dirs[3 * item + k];
                     inv[k] = T(1) / d[k];
                 }
-                if constexpr (N::kind == IBVH_BBOX) {
+                if constexpr (kPacked) {
                     regular = ray_is_regular(p, d, inv);
                     pk = ray_pk(p, inv);
                 }
@@ -2723,7 +2724,7 @@ __global__ __launch_bounds__(64) void rays_top_kernel(Args<L, N, I> a, RayBins r
                     ch.b = ch.a;
                 }
                 bool h0, h1;
-                if constexpr (N::kind == IBVH_BBOX) {
+                if constexpr (kPacked) {
                     if (fast) {
                         h0 = real0 && slab_fast(ch.a, pk);
                         h1 = real1 && slab_fast(ch.b, pk);
@@ -3302,13 +3303,17 @@ inline RayBinPlan rays_bin_plan(const ibvh_bvh &bvh, int64_t num_rays) {
     const int mode = g_tuning.rays_binned; // 1 = where it pays, 2 = wherever the tree allows it (tests), 0 = never
     // (the tables take 40 bytes x 16 items per ray: batches beyond 8 M rays — 5.4 GB — are left to the per-lane walker)
     if (mode == 0 || num_rays <= 0 || num_rays > (int64_t)1 << 23) return p;
-    if (bvh.types.leaf_float != IBVH_F32 || bvh.types.node_float != IBVH_F32) return p;
+    if (bvh.types.leaf_float != bvh.types.node_float) return p; // (isintersection needs one float type: the entry points refuse the rest)
+    ibvh_layout lay;
+    if (!layout_of(bvh.types, lay)) return p;
     const int levels = (int)bvh.tree.levels;
     if (levels < 3 || levels > 32) return p;
     // 512-leaf subtrees: 26 KB of LDS a workgroup, six workgroups a CU (config 3: 1.47 ms for the subtree pass; 1,024 leaves, three
-    // workgroups a CU: 2.50 ms; 256 leaves: 1.49 ms with a longer top walk)
-    int D = g_tuning.rays_subtree_depth > 0 ? g_tuning.rays_subtree_depth : 9;
-    if (D > 11) D = 11; // 2^11 leaves: 112 KB of LDS with the widest records
+    // workgroups a CU: 2.50 ms; 256 leaves: 1.49 ms with a longer top walk); Float64 records are twice as wide: 256 leaves
+    int D = g_tuning.rays_subtree_depth > 0 ? g_tuning.rays_subtree_depth : (bvh.types.leaf_float == IBVH_F64 ? 8 : 9);
+    if (D > 11) D = 11;
+    const size_t index_bytes = bvh.types.index_type == IBVH_I64 ? 8 : 4;
+    while (D > 1 && rays_subtree_lds(D, (size_t)lay.node_bytes, (size_t)lay.volume_bytes, index_bytes, index_bytes * 2 + 8, false) > 144 * 1024) --D; // (the CU's LDS)
     const bool small_batch = num_rays <= 8192;
     if (mode == 1) {
         // subtrees of >= 64 leaves; enough of them to fill the chip (>= ~1,000: the cut at level 11 or below) unless the batch
@@ -3388,7 +3393,7 @@ inline RayBins rays_bins_at(const RayBinPlan &p, char *base) {
     return rb;
 }
 // the type combinations the binned path is compiled for (one float type throughout; everything else: the binary walker)
-template <class L, class N> constexpr bool kRayBinTypes = std::is_same<typename L::elt, float>::value && std::is_same<typename N::elt, float>::value;
+template <class L, class N> constexpr bool kRayBinTypes = std::is_same<typename L::elt, typename N::elt>::value; // (what ray traversal asks for anyway)
 
 template <class L, class N, class I, int MODE>
 int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStream_t st, const RayBins &rb = RayBins{}) {
@@ -3423,7 +3428,7 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
                     IBVH_HIP_CHECK(hipMemsetAsync(rb.cursor, 0, 2048, st));
                     IBVH_HIP_CHECK(hipMemsetAsync(rb.bin_count, 0, (size_t)((char *)rb.items - (char *)rb.bin_count), st)); // counts, starts, cursors
                     if (!g_tuning.rays_fast_slab) IBVH_HIP_CHECK(hipMemsetAsync(rb.top_nan, 0xff, 4, st)); // (-1: no fast slab test anywhere)
-                    if constexpr (N::kind == IBVH_BBOX) {
+                    if constexpr (N::kind == IBVH_BBOX && std::is_same<typename N::elt, float>::value) {
                         const int64_t top_first = level_start(a.tree.levels, a.tree.virtual_leaves, a.built_level) - 1; // (memory index of the first node that exists)
                         const int64_t top_count = level_start(a.tree.levels, a.tree.virtual_leaves, rb.cut_level + 1) - 1 - top_first;
                         IBVH_LAUNCH((rays_topcheck_kernel<N>), dim3((unsigned)(ceil_div(top_count * 3, 256) < 256 ? ceil_div(top_count * 3, 256) : 256)), dim3(256), 0,

@@ -266,7 +266,7 @@ ibvh_status ibvh_traverse_pair_lvt_write(const ibvh_bvh *bvh1, const ibvh_bvh *b
 /* traverse_rays(bvh, points, directions, LVTTraversal()) — raytrace/leaf_vs_tree/
  * leaf_vs_tree.jl:1-228.  points/directions: (3, num_rays) column-major arrays of the leaf
  * float type; contacts are (leaf.index, iray); `narrow`: IBVH_NARROW_NONE / _RAY_ORIGIN_OUTSIDE (| IBVH_OUTPUT_POSITIONS).
- * Scratch: ibvh_rays_scratch_bytes().  For single-precision trees of >= 17 levels (>= 13 under batches of <= 8,192 rays; not for a tree of
+ * Scratch: ibvh_rays_scratch_bytes().  For trees of >= 17 levels (>= 13 under batches of <= 8,192 rays; not for a tree of
  * < 2^20 leaves under more than two rays per leaf) it holds the tables
  * of the BINNED path (csrc/ibvh_lvt.hip "(3c)": the walk is cut at a level, the hits at that level are grouped by subtree
  * and the walks are finished subtree by subtree out of LDS — the reference's walk cut in two, the same hit list in the same

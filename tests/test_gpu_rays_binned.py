@@ -46,7 +46,9 @@ def _rays(rng, nr, extent):
 
 
 COMBOS = [(abi.BSPHERE, abi.F32, abi.BBOX, abi.F32), (abi.BBOX, abi.F32, abi.BBOX, abi.F32),
-          (abi.BSPHERE, abi.F32, abi.BSPHERE, abi.F32)]
+          (abi.BSPHERE, abi.F32, abi.BSPHERE, abi.F32),
+          (abi.BSPHERE, abi.F64, abi.BBOX, abi.F64), (abi.BBOX, abi.F64, abi.BBOX, abi.F64), (abi.BSPHERE, abi.F64, abi.BSPHERE, abi.F64)]
+NP_F = {abi.F32: np.float32, abi.F64: np.float64}
 
 
 @pytest.mark.parametrize("combo", COMBOS, ids=str)
@@ -63,6 +65,7 @@ def test_binned_rays_identical_order(combo, depth):
             o, g = build_both(vols, types)
             nr = 2500
             p, d = _rays(rng, nr, 20 if n > 2000 else 8)
+            p, d = p.astype(NP_F[combo[1]]), d.astype(NP_F[combo[1]])  # (rays in the leaf float type, raytrace/lvt:116-125)
             P_, D_ = cuda(p).t(), cuda(d).t()
             for sl in sorted({1, 2, max(1, o.tree.levels - depth), o.tree.levels}):
                 if sl > o.tree.levels:

@@ -116,7 +116,7 @@ def _ray_scratch(n_leaves, n_rays, types=None, built_level=1):
 
 def test_ray_scratch_follows_the_binned_path_rule():
     """ibvh_rays_scratch_bytes (host arithmetic only) makes room for the binned ray path exactly where the launch code takes it
-    (csrc/ibvh_lvt.hip rays_bin_plan): single-precision trees of >= 17 levels, or >= 13 under small batches — 40 bytes x 16 items per
+    (csrc/ibvh_lvt.hip rays_bin_plan): trees (one float type throughout) of >= 17 levels, or >= 13 under small batches — 40 bytes x 16 items per
     ray plus tables; everything else gets the leaf-query scratch; the knobs move the rule."""
     need, base = _ray_scratch(7_201_012, 1_000_000)
     assert 16 * 40 * 10**6 <= need <= 16 * 40 * 10**6 + 64 * 2**20
@@ -139,7 +139,10 @@ def test_ray_scratch_follows_the_binned_path_rule():
     need, base = _ray_scratch(2_000, 500)                 # 12 levels: subtrees would hold fewer than 64 leaves
     assert need == base
     f64 = abi.make_types(abi.BSPHERE, abi.F64, abi.BBOX, abi.F64)
-    need, base = _ray_scratch(7_201_012, 1_000_000, f64)  # compiled for single precision only
+    need, base = _ray_scratch(7_201_012, 1_000_000, f64)  # Float64 throughout: binned as well (256-leaf subtrees)
+    assert need > base
+    mixed = abi.make_types(abi.BSPHERE, abi.F64, abi.BBOX, abi.F32)
+    need, base = _ray_scratch(7_201_012, 1_000_000, mixed)  # two float types: ray traversal refuses those trees anyway
     assert need == base
     try:
         lib.set_tuning("rays_binned", 0)

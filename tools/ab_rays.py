@@ -15,12 +15,15 @@ variants = sys.argv[2].split(",") if len(sys.argv) > 2 else ["0:0", "1:10", "1:9
 uv = os.environ.get("AB_MESH_UV", "")  # e.g. "353,354": the 249,924-triangle surrogate of the reference's published case
 tris = torch.from_numpy(torus_mesh(*[int(x) for x in uv.split(",")]) if uv else torus_mesh()).cuda()
 vols = ibvh.bounding_volumes_from_triangles(tris)
-bvh = ibvh.BVH(vols)
+f64 = os.environ.get("AB_F64", "") == "1"  # the same mesh and rays in double precision (BBox{Float64} nodes)
+bvh = ibvh.BVH(vols.double(), ibvh.BBox(torch.float64)) if f64 else ibvh.BVH(vols)
 print("leaves", int(vols.shape[0]), "levels", bvh.tree.levels, "rays", nr)
 hv = vols[:, :3]
 lo, hi = hv.min(0).values.cpu().numpy(), hv.max(0).values.cpu().numpy()
 ph, dh = random_rays(nr, lo, hi, seed=43)
 p, d = torch.from_numpy(ph).cuda().t(), torch.from_numpy(dh).cuda().t()
+if f64:
+    p, d = p.double(), d.double()
 first = None
 for v in variants:
     mode, depth = (int(x) for x in v.split(":")[:2])
