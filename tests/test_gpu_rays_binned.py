@@ -187,3 +187,48 @@ def test_binned_rays_seeds_under_the_shipped_rule(seed):
     assert (contacts_np(t1).reshape(-1, 2) == exp).all()
     t2 = ibvh.traverse_rays(g, P_, D_, cache=t1)
     assert (contacts_np(t2).reshape(-1, 2) == exp).all()
+
+
+def _kernels_of(fn):
+    """names of the library kernels one call of fn launches (the library's own launch profiler)"""
+    import ctypes as C
+    lib.call("ibvh_profile_enable", 1)
+    try:
+        fn()
+        torch.cuda.synchronize()
+        cnt = C.c_int64()
+        lib.call("ibvh_profile_count", C.byref(cnt))
+        names = set()
+        for i in range(cnt.value):
+            name, ms = C.c_char_p(), C.c_float()
+            lib.call("ibvh_profile_get", i, C.byref(name), C.byref(ms))
+            names.add(name.value.decode().strip("() ").split("<")[0].split("::")[-1].strip())
+        return names
+    finally:
+        lib.call("ibvh_profile_enable", 0)
+
+
+def test_the_shipped_rule_really_takes_the_path_it_names():
+    """A regression in the scratch sizing or in the rule would be SILENT (the per-lane walker gives the same list): look at
+    the kernels a call launches.  70,000 leaves (18 levels): 5,000 rays -> binned; 1e6 rays (more than two per leaf of a
+    tree below 2^20 leaves) -> the per-lane walker; Float64 throughout -> binned; knob 0 -> the per-lane walker."""
+    rng = np.random.default_rng(17)
+    vols = random_volumes(rng, 70_000, abi.BSPHERE, abi.F32, scale=30.0)
+    g = ibvh.BVH(cuda(vols))
+    g64 = ibvh.BVH(cuda(vols.astype(np.float64)), ibvh.BBox(torch.float64))
+    def rays(nr, dt):
+        p = (rng.random((nr, 3)) * 30).astype(dt)
+        d = (rng.random((nr, 3)) - 0.5).astype(dt)
+        return cuda(p).t(), cuda(d).t()
+    P, D = rays(5000, np.float32)
+    k = _kernels_of(lambda: ibvh.traverse_rays(g, P, D))
+    assert {"rays_top_kernel", "rays_subtree_kernel", "rays_place_kernel"} <= k
+    Pm, Dm = rays(300_000, np.float32)
+    k = _kernels_of(lambda: ibvh.traverse_rays(g, Pm, Dm))
+    assert "rays_top_kernel" not in k and "lvt_rays_kernel" in k
+    P6, D6 = rays(5000, np.float64)
+    k = _kernels_of(lambda: ibvh.traverse_rays(g64, P6, D6))
+    assert {"rays_top_kernel", "rays_subtree_kernel"} <= k
+    with knobs(rays_binned=0):
+        k = _kernels_of(lambda: ibvh.traverse_rays(g, P, D))
+        assert "rays_top_kernel" not in k and "lvt_rays_kernel" in k
