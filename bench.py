@@ -468,25 +468,120 @@ def run_timestep(n, ibvh, lib, torch, cpu, steps=40, cells=1.0):
            "ms_per_step": round(ms, 4), "mleaves_per_s": round(n / ms / 1e3, 1), "contacts": contacts,
            "move_ms_per_step_subtracted": round(t_move / steps * 1e3, 4),
            "input_descents_fraction": round(descents, 4), "kernels_ms": ks,
-           "morton_sort_phase": {"ms": round(ms_sort, 4), "frac": round(152.0 * n / (ms_sort * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_sort else None},
+           # priced at the chain's OWN input: pre-wrapped 24-byte records instead of 16-byte volumes cost extrema and encode 8 B/leaf
+           # more each (SURVEY.md §8d's 152 B/leaf is for raw volumes): 168 B/leaf; frac_at_152 is the raw-volume pricing
+           "morton_sort_phase": {"ms": round(ms_sort, 4), "bytes_per_leaf": 168,
+                                 "frac": round(168.0 * n / (ms_sort * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_sort else None,
+                                 "frac_at_152": round(152.0 * n / (ms_sort * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_sort else None},
            "roofline": _roof("whole step (build + LVT self-traverse)", ms, bytes_step,
                              "build 216 B/leaf + traverse 60 B/leaf + 8 per contact (SURVEY.md §8d)")}
     if n <= 2_000_000:
         res["roofline"]["cache_residency"] = "infinity-cache-resident: the step's working set (~130 MB) fits the 256 MB Infinity Cache"
     if orc is not None:
-        hv = st["b"].leaves.volume.contiguous().cpu().numpy()  # the chain's current state, in Morton order
-        hv[:, :3] += ((np.random.default_rng(3).random((n, 3)) * 2 - 1) * step).astype(np.float32)
+        # the SAME step on both sides: move the chain once more, hand the moved volumes (the build's input, in the chain's nearly
+        # sorted order) to the oracle, then let the GPU take that very step and compare the contact counts
+        move()
+        hv = st["b"].leaves.volume.contiguous().cpu().numpy()
+        st["b"] = ibvh.BVH(st["b"].leaves, cache=st["b"])
+        st["t"] = ibvh.traverse(st["b"], cache=st["t"])
+        gpu_contacts = int(st["t"].num_contacts)
         _, cc, tb, tt = orc.bench_build_traverse_f32(hv, threads, native)
         res["cpu_baseline"] = {"value": round(n / (tb + tt) / 1e6, 3), "unit": "Mleaves/s", "cores": threads, "threads_used": threads,
                                "kind": "port", "build_ms": round(tb * 1e3, 2), "traverse_ms": round(tt * 1e3, 2),
-                               "sample": f"the same {n} leaves in the chain's (nearly sorted) order, one step: oracle build + two-pass LVT, "
-                                         f"{len(cc)} contacts, one run (the oracle wraps anew: same work, indices 1..n)"}
+                               "contacts_match_gpu": len(cc) == gpu_contacts,
+                               "sample": f"the {n} leaves of ONE step of the chain (the moved volumes the GPU then builds from, nearly sorted order): "
+                                         f"oracle build + two-pass LVT, {len(cc)} contacts (GPU, same step: {gpu_contacts}), one run "
+                                         "(the oracle wraps anew: same work, indices 1..n)"}
         res["gpu_over_cpu"] = round((n / ms / 1e3) / res["cpu_baseline"]["value"], 1)
     del st, bv
     torch.cuda.empty_cache()
     return res
 
-PROFILE_ROUND = "r04"
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _compact_roof(r):
+    if not isinstance(r, dict):
+        return None
+    out = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms"))
+    out["traffic"] = r.get("traffic")
+    if "kernel" in out and len(out["kernel"]) > 40:
+        out["kernel"] = out["kernel"][:37] + "..."
+    if isinstance(r.get("cache_residency"), str):
+        out["cache"] = "infinity-cache" if r["cache_residency"].startswith("infinity") else "hbm"
+    if isinstance(r.get("morton_sort_phase"), dict):
+        out["morton_sort_phase"] = _pick(r["morton_sort_phase"], ("ms", "frac", "bytes_per_leaf"))
+    if isinstance(r.get("issue"), dict):
+        out["issue"] = _pick(r["issue"], ("wave_instructions_per_launch", "valu_busy_frac", "salu_busy_frac"))
+    return out
+
+
+def _compact_node(d):
+    """One config entry -> {ms, roofline.frac, ...}; dicts without a time of their own are walked."""
+    if not isinstance(d, dict):
+        return None
+    ms = d.get("ms", d.get("ms_per_step"))
+    if ms is not None:
+        out = {"ms": ms}
+        if isinstance(d.get("roofline"), dict):
+            out["frac"] = d["roofline"].get("frac")
+        if isinstance(d.get("morton_sort_phase"), dict):
+            out["morton_sort_frac"] = d["morton_sort_phase"].get("frac")
+            out["morton_sort_ms"] = d["morton_sort_phase"].get("ms")
+        cb = d.get("cpu_baseline")
+        if isinstance(cb, dict):
+            out["cpu"] = cb.get("value")
+            if "contacts_match_gpu" in cb:
+                out["cpu_contacts_match"] = cb["contacts_match_gpu"]
+        if d.get("gpu_over_cpu") is not None:
+            out["gpu_over_cpu"] = d["gpu_over_cpu"]
+        elif isinstance(cb, dict) and cb.get("gpu_over_cpu") is not None:
+            out["gpu_over_cpu"] = cb["gpu_over_cpu"]
+        return out
+    out = {}
+    for k, v in d.items():
+        c = _compact_node(v)
+        if c:
+            out[k] = c
+    return out or None
+
+
+def compact_line(line, detail_path):
+    """The ONE line the driver records (<= 4 KB): the contract's fields, the north-star size and one {ms, frac} per config;
+    everything else is in `detail_path` (a 17 KB line lost its head in the driver's tail)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "value_enqueue_only", "ms_per_step_enqueue_only", "mcontacts_per_s", "profiled_ms_per_step")
+    out = {k: line[k] for k in keep if k in line}
+    cfg = line.get("config") or {}
+    out["config"] = _pick(cfg, ("workload", "leaves_per_gpu", "leaves_total", "contacts_total", "parallelism"))
+    out["roofline"] = _compact_roof(line.get("roofline"))
+    cb = line.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = _pick(cb, ("value", "unit", "cores", "kind", "host_cores", "contacts_match_gpu", "gpu_over_cpu", "build_ms", "traverse_ms"))
+        c["sample"] = (cb.get("sample") or "")[:160]
+        out["cpu_baseline"] = c
+    else:
+        out["cpu_baseline"] = None
+    ns = line.get("north_star_1e7")
+    if isinstance(ns, dict):
+        o = _pick(ns, ("leaves", "ms_per_step", "value", "unit", "contacts", "build_ms", "gpu_over_cpu"))
+        o["roofline"] = _compact_roof(ns.get("roofline"))
+        o["morton_sort_phase"] = _pick(ns.get("morton_sort_phase") or {}, ("ms", "frac", "bytes_per_leaf"))
+        if isinstance(ns.get("cpu_baseline"), dict):
+            o["cpu_baseline"] = _pick(ns["cpu_baseline"], ("value", "unit", "cores", "kind"))
+        out["north_star_1e7"] = o
+    if line.get("configs"):
+        out["configs"] = _compact_node(line["configs"])
+    if isinstance(line.get("exchange"), dict):
+        out["exchange"] = _pick(line["exchange"], ("max_exchange_ms", "bytes_sent_max", "xgmi_frac_per_link"))
+    if isinstance(line.get("work"), dict):
+        out["work"] = _pick(line["work"], ("tests_hip_over_reference",))
+    out["detail"] = detail_path
+    return out
+
+PROFILE_ROUND = "r05"
 
 
 def _host_cpu():
@@ -516,7 +611,7 @@ def _attach_counters(roofline, tag, avg_s):
     """roofline.traffic / roofline.issue from the committed counter profiles of the dominant kernel — only while the kernel
     sources still hash to the state the profile was taken at."""
     sha = csrc_sha()
-    for rnd in (PROFILE_ROUND, "r03"):
+    for rnd in (PROFILE_ROUND, "r04", "r03"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_fetch_write_{tag}.json")
         if not os.path.exists(path):
             continue
@@ -535,7 +630,7 @@ def _attach_counters(roofline, tag, avg_s):
         break
     else:
         roofline["traffic_note"] = "no counter profile for this state of the kernels"
-    for rnd in (PROFILE_ROUND, "r03"):
+    for rnd in (PROFILE_ROUND, "r04", "r03"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_sq_counters_{tag}.json")
         if not os.path.exists(path):
             continue
@@ -630,6 +725,7 @@ def main():
     ap.add_argument("--extra-n", type=int, default=10_000_000,
                     help="also report the north-star size (1e7 leaves) at N=1; 0 disables")
     ap.add_argument("--cpu-n", type=int, default=0, help="leaves of the CPU baseline sample (0 = same as --n, capped)")
+    ap.add_argument("--detail", default="bench_detail.json", help="where the full (long) record goes; stdout carries the compact line")
     ap.add_argument("--virtual-ranks", type=int, default=0,
                     help="EMULATE BASELINE.json configs[4] on ONE GPU: this many virtual ranks (threads) x --n leaves (default 1.25e7) run the "
                          "distributed build + per-rank traversal; per-rank figures, no xGMI (nothing is measured about the links)")
@@ -944,7 +1040,20 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline, "work": work, "north_star_1e7": north_star, "configs": configs,
             "exchange": exchange, "kernels": kernels, "profiled_ms_per_step": round(tp / prof_steps * 1e3, 4),
         }
-        print(json.dumps(line))
+        # full detail beside the script (gitignored; tools/profile_round.sh copies it under profiles/), ONE compact line on stdout
+        detail_path = args.detail
+        try:
+            with open(os.path.join(ROOT, detail_path) if not os.path.isabs(detail_path) else detail_path, "w") as f:
+                json.dump(line, f, indent=1)
+        except OSError as e:
+            print(f"bench.py: could not write {detail_path}: {e}", file=sys.stderr)
+            detail_path = None
+        short = compact_line(line, detail_path)
+        text = json.dumps(short, separators=(",", ":"))
+        if len(text) > 4096:  # (never: the compact line has a fixed shape; if it ever grows, drop the per-config block first)
+            short.pop("configs", None)
+            text = json.dumps(short, separators=(",", ":"))
+        print(text)
     if dist is not None:
         dist.destroy_process_group()
 
