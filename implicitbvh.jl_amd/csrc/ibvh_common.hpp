@@ -505,7 +505,7 @@ IBVH_HD int64_t ceil_div_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
 struct Tuning {
     int ray_block = 0;      // rays per wave of lvt_rays_kernel (0 = chosen from the batch size; a power of two, 64 .. 1024)
     int lvt_wide = 0;       // 1 = 64-bit queue entries for every tree (otherwise only for 29 .. 31 levels)
-    int lvt_dual = 0;       // 1 = BBox-node leaf queries take the dual descent (lvt_dual_kernel: fewer box tests, no overflow path; measured 7 - 25 % slower than lvt_queue_kernel in round 4), 0 = lvt_queue_kernel
+    int lvt_dual = 0;       // -DIBVH_VARIANTS builds only (variants/lvt_dual.inc): 1 = BBox-node leaf queries take the dual descent (7 - 25 % slower than lvt_queue_kernel, round 4)
     int lvt_xcd = 64;       // LVT item placement: 0 = round robin, 1 = one range per XCD, n = runs of n workgroups
     int sort_tile = 0;      // LSD path: keys per tile (0 = by size; 2048, 4096, 8192, 16384)
     int sort_lsd = 0;       // 1 = ibvh_sort_pairs always takes the plain LSD passes
@@ -519,7 +519,7 @@ struct Tuning {
     int msd_resident_kb = 0; // LDS budget (KiB) of a finish workgroup that keeps its range's RECORDS in LDS: 0 = the plan decides
                              // (8,192-record geometry only), > 0 = every geometry with this budget, < 0 = never
     int bfs_wg_per_cu = 4;  // workgroups per CU of the BFS level kernels' fixed grid (ibvh_bfs.hip, level_grid)
-    int rays_shadow = 0;    // 1 = ray traversals walk the quantised 8-wide shadow of the node levels when the scratch has room
+    int rays_shadow = 0;    // -DIBVH_VARIANTS builds only (variants/rays_shadow.inc): 1 = ray traversals walk the quantised 8-wide shadow of the node levels when the scratch has room
                             // (ibvh_rays_scratch_bytes); measured slower than the binary walk on config 3 (4.6 vs 4.3 ms): off
     int rays_binned = 1;    // ray traversals (F32 trees) cut the walk at a level and finish it subtree by subtree out of LDS:
                             // 1 = where it pays (rays_bin_plan: >= 17 levels, or >= 13 under <= 8,192 rays; not a small tree under many

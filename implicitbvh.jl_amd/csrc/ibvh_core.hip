@@ -68,7 +68,11 @@ const Knob kKnobs[] = {
     {"bucket_tpb", &Tuning::bucket_tpb}, {"msd", &Tuning::msd},               {"msd_bits", &Tuning::msd_bits},
     {"msd_cap", &Tuning::msd_cap},       {"msd_tile", &Tuning::msd_tile},     {"msd_ftpb", &Tuning::msd_ftpb},
     {"msd_avg", &Tuning::msd_avg},       {"msd_range", &Tuning::msd_range},   {"bfs_wg_per_cu", &Tuning::bfs_wg_per_cu},
-    {"rays_shadow", &Tuning::rays_shadow}, {"rays_binned", &Tuning::rays_binned}, {"rays_fast_slab", &Tuning::rays_fast_slab}, {"rays_subtree_depth", &Tuning::rays_subtree_depth}, {"rays_items_per_ray", &Tuning::rays_items_per_ray}, {"lvt_dual", &Tuning::lvt_dual}, {"msd_resident_kb", &Tuning::msd_resident_kb}, {"msd_finish_pad_kb", &Tuning::msd_finish_pad_kb},
+    {"rays_binned", &Tuning::rays_binned}, {"rays_fast_slab", &Tuning::rays_fast_slab}, {"rays_subtree_depth", &Tuning::rays_subtree_depth},
+    {"rays_items_per_ray", &Tuning::rays_items_per_ray}, {"msd_resident_kb", &Tuning::msd_resident_kb}, {"msd_finish_pad_kb", &Tuning::msd_finish_pad_kb},
+#ifdef IBVH_VARIANTS // (development builds only: the kernels behind these knobs are not in libibvh.so, variants/*.inc)
+    {"rays_shadow", &Tuning::rays_shadow}, {"lvt_dual", &Tuning::lvt_dual},
+#endif
 };
 inline int64_t ilog2_down(int64_t n) { return 63 - __builtin_clzll((unsigned long long)n); }
 } // namespace
