@@ -67,7 +67,14 @@ int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const voi
         if (bin_plan.depth == 0) shadow_bytes = rays_shadow_bytes(*walk, n_items);
         if (scratch_bytes < scan_scratch_bytes(n_items) + shadow_bytes + 256) shadow_bytes = 0;
     }
-    const size_t tail_bytes = bin_plan.depth ? bin_plan.bytes : shadow_bytes;
+    // SELF / PAIR under BBox nodes: the rows of the shared descent (ibvh_lvt.hpp "BlockRows") live at the END of the scratch when
+    // the caller sized it with ibvh_lvt_scratch_bytes; a smaller scratch simply has none (every wave descends on its own)
+    size_t rows_bytes = 0;
+    if (MODE != MODE_RAYS && !work && walk->types.node_kind == IBVH_BBOX) {
+        rows_bytes = blk_rows_bytes(n_items, BLK_SHIFT_MIN);
+        if (scratch_bytes < scan_scratch_bytes(n_items) + rows_bytes + 256) rows_bytes = 0;
+    }
+    const size_t tail_bytes = bin_plan.depth ? bin_plan.bytes : (shadow_bytes ? shadow_bytes : rows_bytes);
     const size_t cache_room = scratch_bytes - (tail_bytes ? tail_bytes + 256 : 0);
     char *tail_ptr = tail_bytes ? (char *)scratch + ((scratch_bytes - tail_bytes) & ~(size_t)255) : nullptr;
     char *shadow_ptr = shadow_bytes ? tail_ptr : nullptr;
@@ -106,6 +113,12 @@ int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const voi
                 a.shadow = shadow_ptr;
                 a.rays_filter = 0;
                 a.gate = nullptr;
+                a.blk_rows = rows_bytes ? (uint32_t *)tail_ptr : nullptr;
+                a.blk_shift = 0;
+                const ibvh_bvh *qside = drv ? drv : walk;
+                a.q_nodes = (const N *)qside->nodes;
+                a.q_tree = TreeDev{qside->tree.levels, qside->tree.real_leaves, qside->tree.virtual_leaves};
+                a.q_built_level = qside->built_level;
                 PairCache<I> cache{K ? (IndexPair<I> *)((char *)scratch + scan_scratch_bytes(n_items)) : nullptr, K};
                 if (int e = launch<L, N, I, MODE>(a, cache, write, st, bins)) return e;
                 if (write || work) return (int)IBVH_OK;
@@ -139,6 +152,8 @@ ibvh_status ibvh_lvt_scratch_bytes(const ibvh_types *types, int64_t n_items, int
     if (!layout_of(*types, lay)) return IBVH_ERR_UNSUPPORTED;
     if (cache_slots > MAX_CACHE_SLOTS) cache_slots = MAX_CACHE_SLOTS;
     *bytes_out = scan_scratch_bytes(n_items) + (size_t)cache_slots * (size_t)n_items * (size_t)lay.pair_bytes;
+    if (types->node_kind == IBVH_BBOX) // room for the rows of the shared descent (2 bytes per work item), behind the contact cache
+        *bytes_out = (size_t)align_up((int64_t)*bytes_out, 256) + blk_rows_bytes(n_items, BLK_SHIFT_MIN) + 512;
     return IBVH_OK;
 }
 

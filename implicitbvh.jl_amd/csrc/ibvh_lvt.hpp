@@ -57,7 +57,34 @@ template <class L, class N, class I> struct Args {
     // ibvh_lvt_work_counters only (COUNT instantiations): [0] node tests, [1] leaf tests, [2] node records fetched,
     // [3] leaf records fetched, summed over the launch
     unsigned long long *work;
+    // SELF / PAIR, walker 2: the shared part of the descent (BlockRows below).  blk_rows != nullptr: one row per block of
+    // 2^blk_shift consecutive work items, written by lvt_block_frontier_kernel in front of the counting pass
+    uint32_t *blk_rows;
+    int32_t blk_shift;
+    const N *q_nodes;    // the nodes of the tree the work items are the leaves of (SELF: == nodes)
+    TreeDev q_tree;
+    int64_t q_built_level;
 };
+
+// ---- walker 2, the shared part of the descent ---------------------------------------------------------------------------
+// Round 5.  The descent from the start level to the cut level is per-wave fixed cost that the ~16 neighbouring waves of a
+// Morton-sorted range repeat almost identically (30 - 36 % of the counting pass, profiles/r04_lvt_sections.json).  So it is
+// done ONCE per block of 2^shift consecutive sorted leaves: the block IS a node of the implicit tree the leaves belong to
+// (shift levels above them), its box is that node's box, and lvt_block_frontier_kernel — one wave per block, in front of the
+// counting pass — descends the walked tree with that one box and leaves the cut-level nodes it touches, in ascending order,
+// in the block's row.  A wave of the counting pass then starts at the cut level: it filters its block's row with its own two
+// boxes (the existing per-subtree test) instead of descending.  The row is a superset of what the wave's own descent finds
+// PROVIDED the block's box contains the wave's queries — true whenever the merges below the block node were exact minima /
+// maxima; a NaN anywhere below can be dropped or propagated by merge.jl's `a < b ? a : b`, so every wave CHECKS the
+// containment of its valid queries (six compares per lane) and descends on its own when it fails, when the block's list
+// overflowed its row, or when there are no rows (small trees, the writing pass, the work-counter instantiation).  Any
+// conservative enumeration is exact here (ibvh_lvt.hpp header: box tests are monotone along a root-to-leaf path).
+constexpr int BLK_ROW = 512;   // 32-bit words per row: [0] count (-1: no list), [2 .. 2 + sizeof(N) / 4) the block's box, [BLK_HEAD ..) nodes
+constexpr int BLK_HEAD = 16;
+constexpr int BLK_CAP = BLK_ROW - BLK_HEAD;
+constexpr int BLK_FCAP = 512;  // frontier entries of a block's descent per level (LDS)
+inline size_t blk_rows_bytes(int64_t n_items, int shift) { return (size_t)ceil_div(n_items > 0 ? n_items : 1, (int64_t)1 << shift) * BLK_ROW * 4; }
+constexpr int BLK_SHIFT_MIN = 9; // (the scratch is sized for the smallest block the launch code may choose)
 
 // per-lane work counters of the COUNT instantiations (nothing at all otherwise)
 template <bool COUNT> struct Work {
