@@ -507,7 +507,7 @@ struct Tuning {
     int lvt_wide = 0;       // 1 = 64-bit queue entries for every tree (otherwise only for 29 .. 31 levels)
     int lvt_dual = 0;       // -DIBVH_VARIANTS builds only (variants/lvt_dual.inc): 1 = BBox-node leaf queries take the dual descent (7 - 25 % slower than lvt_queue_kernel, round 4)
     int lvt_blocks = 1;     // walker 2: 1 = the descent is shared per block of leaves (lvt_block_frontier_kernel), 0 = every wave descends on its own
-    int lvt_block_shift = 0; // log2 of the leaves per block (0 = 10; 9 .. 12)
+    int lvt_block_shift = 0; // log2 of the leaves per block (0 = 11; 9 .. 12)
     int lvt_blocks_paired_below = -1; // block grids smaller than this take two levels per trip (-1 = 4096)
     int lvt_blocks_min_items = 0; // fewest work items for the shared descent (0 = 2^17)
     int lvt_xcd = 64;       // LVT item placement: 0 = round robin, 1 = one range per XCD, n = runs of n workgroups

@@ -379,8 +379,12 @@ function dist_BVH(comm::IbvhComm, local_volumes::ROCVector{V}, node_type::Type{N
     check(c_dist_exchange(types, comm, devptr(local_volumes), plan, devptr(scratch), need[], devptr(records), stream_ptr()), "ibvh_dist_exchange")
     # the ordinary local build over the received slice: pre-wrapped records, the GLOBAL extrema fixed
     e = plan.extrema
-    fixed = DefaultMortonAlgorithm(M, false, (e[1], e[2], e[3]), (e[4], e[5], e[6]))
-    opts = BVHOptions(index_exemplar=options.index_exemplar, morton=fixed, num_threads=options.num_threads, block_size=options.block_size)
+    # (morton/default.jl:30-40: the keyword method takes the code type or an exemplar; utils.jl:54-71: the keyword is `index`)
+    fixed = DefaultMortonAlgorithm(zero(M); compute_extrema=false, mins=(e[1], e[2], e[3]), maxs=(e[4], e[5], e[6]))
+    opts = BVHOptions(index=options.index_exemplar, morton=fixed, num_threads=options.num_threads,
+                      min_mortons_per_thread=options.min_mortons_per_thread, min_sorts_per_thread=options.min_sorts_per_thread,
+                      min_boundings_per_thread=options.min_boundings_per_thread,
+                      min_traversals_per_thread=options.min_traversals_per_thread, block_size=options.block_size)
     ImplicitBVH.BVH(records, N; cache=cache, options=opts)
 end
 

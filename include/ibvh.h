@@ -235,7 +235,17 @@ ibvh_status ibvh_aggregate(const ibvh_types *types, const ibvh_tree *tree, int64
  *   _write : pass 2, contact k of work item i lands at counts[i-1] + k (1-based), which makes
  *            the contact list order deterministic and identical to the reference's.
  * counts : one I per work item (cache2 of BVHTraversal on the GPU path, :31-32).
- * scratch: ibvh_lvt_scratch_bytes() bytes of device memory: scan tile sums + the contact cache.
+ * scratch: ibvh_lvt_scratch_bytes() bytes of device memory: scan tile sums + the contact cache + (BBox nodes) the rows of
+ *          the shared descent: one list of cut-level nodes per block of 2,048 consecutive leaves, made by one small kernel
+ *          in front of the counting pass and read by both passes (csrc/ibvh_lvt.hpp "BlockRows"); a scratch without room
+ *          for them is served without them.
+ * NaN: with BBox nodes the walkers rely on parents being the exact minima / maxima of their children (merge.jl:30-40): a
+ *      contact is decided by the leaf parent's box and the leaf test, the levels above only prune.  On volumes whose boxes
+ *      hold no NaN that is the reference's list, element for element.  A NaN leaf box (a NaN radius; Inf - Inf in the
+ *      sphere -> box conversion) can make merge.jl's `a < b ? a : b` produce a NaN NODE box above NaN-free leaves; the
+ *      reference's walk then prunes those leaves at that node, while this library tests the node levels from level 7 down to
+ *      the level of the 128-leaf subtrees and then the leaf parents: on such trees its list is a superset of the
+ *      reference's (tests/test_gpu_lvt_blocks.py::test_nan_and_infinite_radii pins the relation).  Infinite boxes are exact.
  */
 /* cache_slots: contacts per work item (on average) the counting pass keeps for the writing pass (0 = none: the
  * writing pass walks the tree again; 8 suits ~2 contacts per leaf).  The BBox-node and ray walkers pool the slots of

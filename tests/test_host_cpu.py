@@ -251,3 +251,40 @@ def test_julia_extension_never_drops_narrow():
     assert "narrow_code(narrow) = Int32(0)" not in src
     assert src.count("isnothing(code)") >= 4 and src.count("invoke(ImplicitBVH.traverse") >= 4
     assert src.count("invoke(ImplicitBVH.traverse_rays") == 2
+
+
+def _julia_calls(src, name):
+    """argument text of every call `name(...)` in the extension (balanced parentheses, comments stripped)"""
+    import re
+    code = "\n".join(line.split("#")[0] for line in src.splitlines())
+    out = []
+    for m in re.finditer(r"(?<![\w.!])" + re.escape(name) + r"\(", code):
+        depth, i = 1, m.end()
+        while depth and i < len(code):
+            depth += {"(": 1, ")": -1}.get(code[i], 0)
+            i += 1
+        out.append(code[m.end():i - 1])
+    return out
+
+
+def test_julia_constructor_calls_use_the_reference_signatures():
+    """dist_BVH called constructors that do not exist.  Julia is not in the image, so the check is static:
+    every `BVHOptions(...)` the extension builds passes only the reference's keywords (utils.jl:73-87: index, morton,
+    num_threads, min_*_per_thread, block_size — there is no `index_exemplar` keyword, that is the FIELD), and every
+    `DefaultMortonAlgorithm(...)` it builds is the one-positional keyword method (morton/default.jl:30-40: exemplar or type,
+    then compute_extrema / mins / maxs by keyword; the four-positional inner constructor wants an exemplar VALUE)."""
+    import re
+    src = _julia_ext()
+    ref_kw = {"index", "morton", "num_threads", "min_mortons_per_thread", "min_sorts_per_thread", "min_boundings_per_thread",
+              "min_traversals_per_thread", "block_size"}
+    calls = [c for c in _julia_calls(src, "BVHOptions") if c.strip()]
+    assert calls, "dist_BVH builds its options"
+    for c in calls:
+        kws = set(re.findall(r"(?:^|[,;(\s])([a-z_]+)\s*=(?!=)", c))
+        assert kws and kws <= ref_kw, (c, kws - ref_kw)
+    morton = [c for c in _julia_calls(src, "DefaultMortonAlgorithm") if c.strip()]
+    assert morton
+    for c in morton:
+        head, _, tail = c.partition(";")
+        assert "," not in head, f"one positional argument, the rest by keyword: {c}"
+        assert set(re.findall(r"([a-z_]+)\s*=(?!=)", tail)) <= {"compute_extrema", "mins", "maxs"}, c

@@ -7,5 +7,5 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd); C=$R/implicitbvh.jl_amd/csrc
 mkdir -p "$R/variants"
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt \
-  -DIBVH_PHASE_STAMPS -shared -Wl,--no-undefined -w -o "$R/variants/libibvh_stamps.so" $C/ibvh_core.hip $C/ibvh_sort.hip $C/ibvh_msd.hip $C/ibvh_build.hip $C/ibvh_lvt.hip $C/ibvh_bfs.hip $C/ibvh_misc.hip $C/ibvh_dist.hip $C/ibvh_distdrv.hip -ldl
+  -DIBVH_PHASE_STAMPS -shared -Wl,--no-undefined -w -o "$R/variants/libibvh_stamps.so" $C/*.hip -ldl
 echo built
