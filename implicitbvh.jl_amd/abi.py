@@ -108,6 +108,15 @@ class DistPlan(C.Structure):
                 ("recv_counts", C.c_int64 * DIST_MAX_RANKS)]
 
 
+class DistCrossPlan(C.Structure):
+    """ibvh_dist_cross_plan_t (include/ibvh.h)"""
+    _fields_ = [("size", C.c_int32), ("rank", C.c_int32), ("n_recv", C.c_int32), ("cache_slots", C.c_int32),
+                ("import_bytes", C.c_int64), ("scratch_bytes", C.c_int64),
+                ("recv_rank", C.c_int32 * DIST_MAX_RANKS), ("recv_leaves", C.c_int64 * DIST_MAX_RANKS),
+                ("recv_offset", C.c_int64 * DIST_MAX_RANKS), ("scratch_offset", C.c_int64 * DIST_MAX_RANKS),
+                ("slice_leaves", C.c_int64 * DIST_MAX_RANKS), ("touches", C.c_int32 * DIST_MAX_RANKS)]
+
+
 def volume_dtype(kind, flt):
     t = FLOAT_DTYPES[flt]
     if kind == BSPHERE:

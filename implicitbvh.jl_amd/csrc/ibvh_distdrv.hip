@@ -89,11 +89,18 @@ Rccl &rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (r.lib) break;
+        // The library that CREATED the caller's ncclComm_t must serve it: a librccl already loaded into the process (torch
+        // bundles its own copy) is found through the global scope first; dlopen by name is the fallback for hosts that
+        // have not loaded one yet (a communicator must not cross two copies of the library).
+        if (dlsym(RTLD_DEFAULT, "ncclAllReduce") != nullptr) {
+            r.lib = RTLD_DEFAULT;
+        } else {
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+                r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (r.lib) break;
+            }
+            if (!r.lib) return;
         }
-        if (!r.lib) return;
         r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
         r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
         r.Send = (decltype(r.Send))dlsym(r.lib, "ncclSend");
@@ -153,13 +160,20 @@ extern "C" {
 ibvh_status ibvh_comm_from_rccl(void *nccl_comm, int32_t rank, int32_t size, ibvh_comm *out) {
     if (!nccl_comm || !out || size < 1 || rank < 0 || rank >= size) return IBVH_ERR_INVALID_ARG;
     if (!rccl().ok) return IBVH_ERR_UNSUPPORTED; // librccl.so not found
-    RcclCtx *c = new RcclCtx{nccl_comm, rank, size}; // (a few bytes per communicator, lives as long as the process: no destroy call needed)
+    RcclCtx *c = new RcclCtx{nccl_comm, rank, size}; // (released by ibvh_comm_release)
     out->ctx = c;
     out->rank = rank;
     out->size = size;
     out->all_reduce = rccl_all_reduce;
     out->all_gather = rccl_all_gather;
     out->all_to_all_v = rccl_all_to_all_v;
+    return IBVH_OK;
+}
+
+ibvh_status ibvh_comm_release(ibvh_comm *comm) {
+    if (!comm) return IBVH_ERR_INVALID_ARG;
+    if (comm->all_reduce == rccl_all_reduce && comm->ctx) delete (RcclCtx *)comm->ctx; // (a caller's own vtable owns its own context)
+    std::memset(comm, 0, sizeof(*comm));
     return IBVH_OK;
 }
 
@@ -322,17 +336,21 @@ ibvh_status ibvh_dist_plan(const ibvh_types *types, const ibvh_comm *comm, const
         std::vector<int64_t> rows_host;
         while (!ss.all_done) { // (rare: a splitter landed in a bucket heavier than the tolerance allows)
             const int nr = ss.num_rows, width = 1 << ss.next_bits;
-            if (nr > 15) return IBVH_ERR_UNSUPPORTED; // (more than 15 distinct undecided prefixes: > 16 ranks in one bucket chain)
-            if (n_local > 0)
-                IBVH_TRY(ibvh_key_histogram(kb, base + L.keys, n_local, ss.next_shift, ss.next_bits, ss.next_shift + ss.next_bits, ss.rows, nr,
-                                            base + L.hist, stream));
-            else DIST_HIP_CHECK(hipMemsetAsync(base + L.hist, 0, (size_t)nr * width * 4, st));
-            const int64_t cnt = (int64_t)nr * width;
-            widen_u32_i64_kernel<<<dim3((unsigned)ceil_div(cnt, 256)), dim3(256), 0, st>>>((const uint32_t *)(base + L.hist), (long long *)(base + L.hist64), cnt);
-            IBVH_TRY(comm->all_reduce(comm->ctx, base + L.hist64, cnt, IBVH_COMM_I64, IBVH_COMM_SUM, stream));
-            rows_host.resize((size_t)cnt);
-            IBVH_TRY(d2h(rows_host.data(), base + L.hist64, (size_t)cnt * 8, st));
-            DIST_HIP_CHECK(hipStreamSynchronize(st));
+            rows_host.resize((size_t)nr * width);
+            // (the histogram tables hold 16 rows: more undecided prefixes than that — many ranks under tolerance 0, or a tightly
+            // clustered cloud — go through them 15 rows at a time, one all-reduce per batch)
+            for (int r0 = 0; r0 < nr; r0 += 15) {
+                const int nb = nr - r0 < 15 ? nr - r0 : 15;
+                if (n_local > 0)
+                    IBVH_TRY(ibvh_key_histogram(kb, base + L.keys, n_local, ss.next_shift, ss.next_bits, ss.next_shift + ss.next_bits, ss.rows + r0, nb,
+                                                base + L.hist, stream));
+                else DIST_HIP_CHECK(hipMemsetAsync(base + L.hist, 0, (size_t)nb * width * 4, st));
+                const int64_t cnt = (int64_t)nb * width;
+                widen_u32_i64_kernel<<<dim3((unsigned)ceil_div(cnt, 256)), dim3(256), 0, st>>>((const uint32_t *)(base + L.hist), (long long *)(base + L.hist64), cnt);
+                IBVH_TRY(comm->all_reduce(comm->ctx, base + L.hist64, cnt, IBVH_COMM_I64, IBVH_COMM_SUM, stream));
+                IBVH_TRY(d2h(rows_host.data() + (size_t)r0 * width, base + L.hist64, (size_t)cnt * 8, st));
+                DIST_HIP_CHECK(hipStreamSynchronize(st));
+            }
             IBVH_TRY(ibvh_splitter_search_step(&ss, rows_host.data()));
         }
     }
@@ -418,6 +436,212 @@ ibvh_status ibvh_dist_exchange(const ibvh_types *types, const ibvh_comm *comm, c
     (void)st;
     return IBVH_OK;
 #undef IBVH_TRY
+}
+
+} // extern "C"
+
+// ---- cross-shard contact completion behind the boundary ---------------------------------------------------
+// Per-slice trees do not see contacts between leaves of different slices.  Every rank publishes its slice's root box and leaf
+// count (ONE all-gather of 64 bytes a rank); for every pair of slices r < s whose boxes touch, rank s sends its sorted leaves and
+// its nodes to rank r — round d of P - 1 rounds moves the trees of the pairs (s - d, s), every round one all_to_all_v for the
+// leaves and one for the nodes, straight out of the BVH's own arrays into the receiver's import buffer — and rank r runs the
+// ordinary pair traversal (ibvh_traverse_pair_lvt_*) of its own tree against each imported one.  Per-slice self contacts and
+// these pairs together are the contact set of the whole cloud, every pair exactly once (tests/test_gpu_dist_procs.py,
+// test_gpu_parity.py).  The protocol is the reference's count -> size -> write: _plan (one host synchronisation) tells the
+// caller how large the import buffer and the traversal scratch are, _count how many pairs there are, _write writes them.
+namespace {
+void root_box_of(const ibvh_types &t, const unsigned char *raw, bool is_leaf, double out[6]) {
+    const int kind = is_leaf ? t.leaf_kind : t.node_kind, flt = is_leaf ? t.leaf_float : t.node_float;
+    double v[6];
+    const int w = kind == IBVH_BSPHERE ? 4 : 6;
+    for (int k = 0; k < w; ++k) v[k] = flt == IBVH_F64 ? ((const double *)raw)[k] : (double)((const float *)raw)[k];
+    if (kind == IBVH_BSPHERE) { // the sphere's box (in double precision: never smaller than the box any node type would hold)
+        for (int k = 0; k < 3; ++k) {
+            out[k] = v[k] - v[3];
+            out[3 + k] = v[k] + v[3];
+        }
+    } else {
+        for (int k = 0; k < 6; ++k) out[k] = v[k];
+    }
+}
+struct CrossSizes {
+    int64_t leaf_bytes, node_bytes, nodes, tree_bytes; // one imported tree: leaves | nodes, each padded to 256 bytes
+    size_t counts_bytes, lvt_bytes;                     // its share of the traversal scratch
+};
+bool cross_sizes(const ibvh_types &t, int64_t n_other, int64_t n_mine, int32_t cache_slots, CrossSizes &z) {
+    ibvh_layout lay;
+    if (!layout_of(t, lay)) return false;
+    ibvh_tree tree;
+    if (ibvh_tree_shape(n_other, &tree) != IBVH_OK) return false;
+    z.leaf_bytes = n_other * lay.leaf_bytes;
+    z.nodes = tree.real_nodes - tree.real_leaves;
+    z.node_bytes = z.nodes * lay.node_bytes;
+    z.tree_bytes = align_up(z.leaf_bytes, 256) + align_up(z.node_bytes, 256);
+    const int64_t items = n_other > n_mine ? n_other : n_mine; // the BVH with more leaves supplies the work items (traverse_pair.jl:15-36)
+    z.counts_bytes = (size_t)align_up(items * (t.index_type == IBVH_I64 ? 8 : 4), 256);
+    if (ibvh_lvt_scratch_bytes(&t, items, cache_slots, &z.lvt_bytes) != IBVH_OK) return false;
+    z.lvt_bytes = (size_t)align_up((int64_t)z.lvt_bytes, 256);
+    return true;
+}
+ibvh_bvh imported_tree(const ibvh_bvh &mine, const ibvh_dist_cross_plan_t &plan, int k, const void *import_buf) {
+    ibvh_bvh o{};
+    o.types = mine.types;
+    ibvh_tree_shape(plan.recv_leaves[k], &o.tree);
+    o.built_level = 1;
+    ibvh_layout lay;
+    layout_of(mine.types, lay);
+    const char *at = (const char *)import_buf + plan.recv_offset[k];
+    o.leaves = at;
+    o.nodes = at + align_up(plan.recv_leaves[k] * lay.leaf_bytes, 256);
+    o.skips = nullptr; // (the leaf-vs-tree walkers derive everything from the tree's shape)
+    return o;
+}
+} // namespace
+
+extern "C" {
+
+ibvh_status ibvh_dist_cross_plan(const ibvh_comm *comm, const ibvh_bvh *bvh, int32_t cache_slots, void *scratch, size_t scratch_bytes,
+                                 ibvh_dist_cross_plan_t *plan, void *stream) {
+    if (!comm || !bvh || !plan || cache_slots < 0) return IBVH_ERR_INVALID_ARG;
+    const int P = comm->size, me = comm->rank;
+    if (P < 1 || P > MAX_RANKS || me < 0 || me >= P) return IBVH_ERR_INVALID_ARG;
+    if (P > 1 && (!comm->all_gather || !comm->all_to_all_v)) return IBVH_ERR_INVALID_ARG;
+    if (bvh->built_level > 1 && bvh->tree.real_nodes > bvh->tree.real_leaves) return IBVH_ERR_UNSUPPORTED; // (the root must exist)
+    ibvh_layout lay;
+    if (!layout_of(bvh->types, lay)) return IBVH_ERR_UNSUPPORTED;
+    if (!scratch || scratch_bytes < (size_t)64 * (P + 1)) return IBVH_ERR_SCRATCH;
+    hipStream_t st = (hipStream_t)stream;
+    std::memset(plan, 0, sizeof(*plan));
+    plan->size = P;
+    plan->rank = me;
+    plan->cache_slots = cache_slots;
+    const int64_t n_mine = bvh->tree.real_leaves;
+    // this rank's record: root box (the root node, or the only leaf's volume) + leaf count
+    unsigned char raw[48];
+    const bool from_leaf = bvh->tree.real_nodes <= bvh->tree.real_leaves;
+    DIST_HIP_CHECK(hipMemcpyAsync(raw, from_leaf ? bvh->leaves : bvh->nodes, (size_t)(from_leaf ? lay.volume_bytes : lay.node_bytes),
+                                  hipMemcpyDeviceToHost, st));
+    DIST_HIP_CHECK(hipStreamSynchronize(st));
+    struct Rec {
+        double box[6];
+        int64_t leaves, pad;
+    } mine_rec{};
+    root_box_of(bvh->types, raw, from_leaf, mine_rec.box);
+    mine_rec.leaves = n_mine;
+    std::vector<Rec> all(P);
+    all[me] = mine_rec;
+    if (P > 1) {
+        char *base = (char *)scratch;
+        DIST_HIP_CHECK(hipMemcpyAsync(base, &mine_rec, sizeof(Rec), hipMemcpyHostToDevice, st));
+        if (int e = comm->all_gather(comm->ctx, base, base + 64, (int64_t)sizeof(Rec), stream)) return (ibvh_status)e;
+        DIST_HIP_CHECK(hipMemcpyAsync(all.data(), base + 64, sizeof(Rec) * (size_t)P, hipMemcpyDeviceToHost, st));
+        DIST_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    auto touch = [&](int a, int b) { // iscontact of two boxes (iscontact.jl:20-28); a NaN box touches nothing
+        for (int k = 0; k < 3; ++k)
+            if (!(all[a].box[3 + k] >= all[b].box[k] && all[a].box[k] <= all[b].box[3 + k])) return false;
+        return true;
+    };
+    int64_t off = 0, scr = 0;
+    for (int r = 0; r < P; ++r) {
+        plan->slice_leaves[r] = all[r].leaves;
+        plan->touches[r] = (r != me && touch(me < r ? me : r, me < r ? r : me)) ? 1 : 0;
+    }
+    for (int r = me + 1; r < P; ++r) { // trees this rank imports, by ascending rank
+        if (!plan->touches[r]) continue;
+        CrossSizes z;
+        if (!cross_sizes(bvh->types, all[r].leaves, n_mine, cache_slots, z)) return IBVH_ERR_UNSUPPORTED;
+        const int k = plan->n_recv++;
+        plan->recv_rank[k] = r;
+        plan->recv_leaves[k] = all[r].leaves;
+        plan->recv_offset[k] = off;
+        plan->scratch_offset[k] = scr;
+        off += z.tree_bytes;
+        scr += (int64_t)(z.counts_bytes + z.lvt_bytes);
+    }
+    plan->import_bytes = off;
+    plan->scratch_bytes = scr;
+    return IBVH_OK;
+}
+
+ibvh_status ibvh_dist_cross_exchange(const ibvh_comm *comm, const ibvh_bvh *bvh, const ibvh_dist_cross_plan_t *plan, void *import_buf,
+                                     void *stream) {
+    if (!comm || !bvh || !plan) return IBVH_ERR_INVALID_ARG;
+    const int P = comm->size, me = comm->rank;
+    if (P != plan->size || me != plan->rank || P < 1 || P > MAX_RANKS) return IBVH_ERR_INVALID_ARG;
+    if (plan->import_bytes > 0 && !import_buf) return IBVH_ERR_INVALID_ARG;
+    ibvh_layout lay;
+    if (!layout_of(bvh->types, lay)) return IBVH_ERR_UNSUPPORTED;
+    const int64_t my_leaf_bytes = bvh->tree.real_leaves * lay.leaf_bytes;
+    const int64_t my_node_bytes = (bvh->tree.real_nodes - bvh->tree.real_leaves) * lay.node_bytes;
+    int k_of[MAX_RANKS];
+    for (int r = 0; r < P; ++r) k_of[r] = -1;
+    for (int k = 0; k < plan->n_recv; ++k) k_of[plan->recv_rank[k]] = k;
+    int64_t sb[MAX_RANKS], rbts[MAX_RANKS];
+    for (int d = 1; d < P; ++d) { // round d: rank s sends its tree to rank s - d when their boxes touch — EVERY rank takes part in every round
+        const int dst = me - d, src = me + d;
+        const bool sending = dst >= 0 && plan->touches[dst], receiving = src < P && plan->touches[src];
+        char *at = receiving ? (char *)import_buf + plan->recv_offset[k_of[src]] : (char *)import_buf;
+        for (int part = 0; part < 2; ++part) { // the leaves, then the nodes: straight out of the BVH's own arrays
+            for (int r = 0; r < P; ++r) sb[r] = rbts[r] = 0;
+            if (sending) sb[dst] = part == 0 ? my_leaf_bytes : my_node_bytes;
+            if (receiving) {
+                const int k = k_of[src];
+                ibvh_tree t;
+                ibvh_tree_shape(plan->recv_leaves[k], &t);
+                rbts[src] = part == 0 ? plan->recv_leaves[k] * lay.leaf_bytes : (t.real_nodes - t.real_leaves) * lay.node_bytes;
+            }
+            const void *send = part == 0 ? bvh->leaves : bvh->nodes;
+            void *recv = receiving ? (void *)(at + (part == 0 ? 0 : align_up(plan->recv_leaves[k_of[src]] * lay.leaf_bytes, 256))) : (void *)at;
+            if (int e = comm->all_to_all_v(comm->ctx, send, sb, recv, rbts, stream)) return (ibvh_status)e;
+        }
+    }
+    return IBVH_OK;
+}
+
+ibvh_status ibvh_dist_cross_count(const ibvh_bvh *bvh, const ibvh_dist_cross_plan_t *plan, const void *import_buf, void *scratch,
+                                  size_t scratch_bytes, int64_t *totals_out, int64_t *total_out, void *stream) {
+    if (!bvh || !plan || !total_out) return IBVH_ERR_INVALID_ARG;
+    *total_out = 0;
+    if (plan->n_recv == 0) return IBVH_OK;
+    if (!import_buf || !scratch || scratch_bytes < (size_t)plan->scratch_bytes) return IBVH_ERR_SCRATCH;
+    for (int k = 0; k < plan->n_recv; ++k) {
+        CrossSizes z;
+        if (!cross_sizes(bvh->types, plan->recv_leaves[k], bvh->tree.real_leaves, plan->cache_slots, z)) return IBVH_ERR_UNSUPPORTED;
+        const ibvh_bvh other = imported_tree(*bvh, *plan, k, import_buf);
+        char *counts = (char *)scratch + plan->scratch_offset[k];
+        int64_t total = 0;
+        // (own slice first: the pairs come out as (index in this slice, index in the other slice), both GLOBAL 1-based numbers)
+        const ibvh_status e = ibvh_traverse_pair_lvt_count(bvh, &other, bvh->built_level > 1 ? bvh->built_level : 1, 1, IBVH_NARROW_NONE, counts, &total,
+                                                           counts + z.counts_bytes, z.lvt_bytes, stream);
+        if (e != IBVH_OK) return e;
+        if (totals_out) totals_out[k] = total;
+        *total_out += total;
+    }
+    return IBVH_OK;
+}
+
+ibvh_status ibvh_dist_cross_write(const ibvh_bvh *bvh, const ibvh_dist_cross_plan_t *plan, const void *import_buf, void *scratch,
+                                  size_t scratch_bytes, const int64_t *totals, void *contacts_out, void *stream) {
+    if (!bvh || !plan) return IBVH_ERR_INVALID_ARG;
+    if (plan->n_recv == 0) return IBVH_OK;
+    if (!import_buf || !scratch || scratch_bytes < (size_t)plan->scratch_bytes || !totals || !contacts_out) return IBVH_ERR_INVALID_ARG;
+    ibvh_layout lay;
+    if (!layout_of(bvh->types, lay)) return IBVH_ERR_UNSUPPORTED;
+    int64_t at = 0;
+    for (int k = 0; k < plan->n_recv; ++k) {
+        CrossSizes z;
+        if (!cross_sizes(bvh->types, plan->recv_leaves[k], bvh->tree.real_leaves, plan->cache_slots, z)) return IBVH_ERR_UNSUPPORTED;
+        const ibvh_bvh other = imported_tree(*bvh, *plan, k, import_buf);
+        char *counts = (char *)scratch + plan->scratch_offset[k];
+        if (totals[k] > 0) {
+            const ibvh_status e = ibvh_traverse_pair_lvt_write(bvh, &other, bvh->built_level > 1 ? bvh->built_level : 1, 1, IBVH_NARROW_NONE, counts,
+                                                               (char *)contacts_out + at * lay.pair_bytes, counts + z.counts_bytes, z.lvt_bytes, stream);
+            if (e != IBVH_OK) return e;
+        }
+        at += totals[k];
+    }
+    return IBVH_OK;
 }
 
 } // extern "C"

@@ -25,8 +25,9 @@ Round 4: the driver itself lives BEHIND the C ABI (include/ibvh.h "multi-GPU bui
 ibvh_dist_exchange, ibvh_splitter_search_*, ibvh_comm / ibvh_comm_from_rccl; csrc/ibvh_distdrv.hip), so that a Julia host
 can run it with nothing but ccall.  This module is the binding: it hands the library a collective vtable whose entries call
 back into a small `comm` object (torch.distributed: RCCL on GPUs; in-process virtual ranks in tests), sizes the record
-array from the plan and runs the ordinary local build.  The cross-shard contact completion stays here (it is a loop of
-all-to-all rounds around the ordinary pair traversal).
+array from the plan and runs the ordinary local build.  Round 5: the cross-shard contact completion is behind the boundary
+as well (ibvh_dist_cross_plan / _exchange / _count / _write over the same vtable); `cross_contacts` below sizes two buffers
+from the plan and calls them.  Nothing in this module is an algorithm any more.
 """
 import ctypes as C
 
@@ -144,104 +145,6 @@ class CommVtable:
 
 
 # ---------------------------------------------------------------------------------------------
-# per-rank device work of the cross-shard completion (tests inject an oracle-backed CPU engine there)
-# ---------------------------------------------------------------------------------------------
-class HipEngine:
-    """libibvh on the current GPU."""
-
-    def __init__(self):
-        self.torch = api._require_gpu()
-        self.device = "cuda"
-
-    def tensor(self, data, dtype):
-        return self.torch.tensor(data, dtype=dtype, device=self.device)
-
-    def to_host(self, t):
-        return t.cpu().numpy()
-
-    def root_box(self, bvh):
-        """(lo, up) of the slice as 6 float64: the root node, or the single leaf's box."""
-        torch = self.torch
-        if bvh.nodes.shape[0] > 0:
-            v = bvh.nodes[0].to(torch.float64)
-        else:
-            v = bvh.leaves.volume[0].to(torch.float64)
-        if v.numel() == 4:  # sphere -> its box (conservative in float64)
-            v = torch.cat([v[:3] - v[3], v[:3] + v[3]])
-        return v
-
-    def export(self, bvh):
-        """leaves ‖ nodes as one byte tensor for the peer copy."""
-        torch = self.torch
-        return torch.cat([bvh.leaves.buf.view(torch.uint8), bvh.nodes.contiguous().view(torch.uint8).reshape(-1)])
-
-    def import_(self, types, n, buf):
-        lay = abi.Layout()
-        lib.call("ibvh_layout_of", C.byref(types), C.byref(lay))
-        lb = n * lay.leaf_bytes
-        tree = api.ImplicitTree(n)
-        nn = tree.real_nodes - tree.real_leaves
-        leaves = buf[:lb].clone()
-        ndt = api._torch_float(types.node_float)
-        nodes = buf[lb:lb + nn * lay.node_bytes].clone().view(ndt).reshape(nn, abi.volume_width(types.node_kind))
-        return api.BVH.from_buffers(types, n, leaves, nodes)
-
-    def export_bytes(self, types, n):
-        lay = abi.Layout()
-        lib.call("ibvh_layout_of", C.byref(types), C.byref(lay))
-        tree = api.ImplicitTree(n)
-        return n * lay.leaf_bytes + (tree.real_nodes - tree.real_leaves) * lay.node_bytes
-
-    def pair_contacts(self, bvh_a, bvh_b):
-        return api.traverse(bvh_a, bvh_b).contacts
-
-    def empty_contacts(self, types):
-        return self.torch.empty((0, 2), dtype=api._torch_index(types.index_type), device=self.device)
-
-    def cat(self, ts):
-        return self.torch.cat(ts)
-
-
-def cross_contacts(comm, eng, types, n_slice, bvh):
-    """Cross-shard contact completion: contacts between leaves of DIFFERENT slices.
-
-    Root boxes of all slices are all-gathered; for every pair of slices (r < s) whose root boxes touch, rank s
-    copies its sorted leaves + nodes to rank r over xGMI and rank r runs the ordinary pair traversal
-    (ibvh_traverse_pair_lvt_*) of its tree against the received one.  Returns this rank's share as an (m, 2)
-    tensor of GLOBAL 1-based indices (index in own slice, index in the other slice).  The union over ranks of
-    the per-slice self contacts and these pairs is the contact set of the whole cloud."""
-    torch = api._torch()
-    P, me = comm.size, comm.rank
-    boxes = eng.tensor([[0.0] * 6] * P, torch.float64)
-    boxes[me] = eng.root_box(bvh)
-    comm.all_reduce(boxes, "sum")
-    sizes = eng.tensor([0] * P, torch.int64)
-    sizes[me] = n_slice
-    comm.all_reduce(sizes, "sum")
-    bx, sz = eng.to_host(boxes), eng.to_host(sizes).tolist()
-
-    def touch(a, b):
-        return bool(np.all(bx[a][3:] >= bx[b][:3]) and np.all(bx[a][:3] <= bx[b][3:]))
-    out = []
-    payload = None
-    for d in range(1, P):  # round d: rank s sends to rank s - d (if their boxes touch)
-        dst, src = me - d, me + d
-        send_counts, recv_counts = [0] * P, [0] * P
-        if dst >= 0 and touch(dst, me):
-            if payload is None:
-                payload = eng.export(bvh)
-            send_counts[dst] = payload.numel()
-        if src < P and touch(me, src):
-            recv_counts[src] = eng.export_bytes(types, sz[src])
-        send = payload if sum(send_counts) else eng.tensor([], torch.uint8)
-        recv = comm.all_to_all(send, send_counts, recv_counts)
-        if sum(recv_counts):
-            other = eng.import_(types, sz[src], recv)
-            out.append(eng.pair_contacts(bvh, other))
-    return eng.cat(out) if out else eng.empty_contacts(types)
-
-
-# ---------------------------------------------------------------------------------------------
 # the binding
 # ---------------------------------------------------------------------------------------------
 class DistributedBuilder:
@@ -255,7 +158,6 @@ class DistributedBuilder:
         if comm is None or not hasattr(comm, "all_reduce"):
             comm = TorchComm(comm)
         self.comm = comm
-        self.engine = HipEngine()
         self.vtable = CommVtable(comm)
         self.tolerance = tolerance  # allowed imbalance per splitter, as a fraction of N/P (0 = exact)
         self.last = {}
@@ -330,5 +232,31 @@ class DistributedBuilder:
         return {"rank": me, "exchange_ms": round(sum(ms) / len(ms), 4) if ms else None, "bytes_sent": int(sent),
                 "bytes_received": int(received), "peers": self.comm.size - 1}
 
-    def cross_contacts(self, bvh):
-        return cross_contacts(self.comm, self.engine, self.last["types"], self.last["n_slice"], bvh)
+    def cross_contacts(self, bvh, cache_slots=None):
+        """Cross-shard contact completion (include/ibvh.h "Cross-shard contact completion"): this rank's
+        share of the contacts between leaves of DIFFERENT slices as an (m, 2) tensor of GLOBAL 1-based indices (index in own
+        slice, index in the other slice).  The union over ranks of the per-slice self contacts and these pairs is the contact
+        set of the whole cloud.  Collective: every rank calls it."""
+        torch = api._torch()
+        vt, comm = self.vtable, self.comm
+        L = lib.load()
+        s = bvh.struct()
+        k = api.LVT_CACHE_SLOTS if cache_slots is None else int(cache_slots)
+        small = torch.empty(64 * (comm.size + 1), dtype=torch.uint8, device="cuda")
+        plan = abi.DistCrossPlan()
+        vt.begin()
+        vt.check("ibvh_dist_cross_plan", L.ibvh_dist_cross_plan(C.byref(vt.struct), C.byref(s), k, api._ptr(small), small.numel(), C.byref(plan),
+                                                                api._stream()))
+        imp = torch.empty(max(int(plan.import_bytes), 1), dtype=torch.uint8, device="cuda")
+        vt.check("ibvh_dist_cross_exchange", L.ibvh_dist_cross_exchange(C.byref(vt.struct), C.byref(s), C.byref(plan), api._ptr(imp), api._stream()))
+        scratch = torch.empty(max(int(plan.scratch_bytes), 1), dtype=torch.uint8, device="cuda")
+        totals = (C.c_int64 * abi.DIST_MAX_RANKS)()
+        total = C.c_int64()
+        vt.check("ibvh_dist_cross_count", L.ibvh_dist_cross_count(C.byref(s), C.byref(plan), api._ptr(imp), api._ptr(scratch), scratch.numel(), totals,
+                                                                  C.byref(total), api._stream()))
+        out = torch.empty((int(total.value), 2), dtype=api._torch_index(bvh.types.index_type), device="cuda")
+        vt.check("ibvh_dist_cross_write", L.ibvh_dist_cross_write(C.byref(s), C.byref(plan), api._ptr(imp), api._ptr(scratch), scratch.numel(), totals,
+                                                                  api._ptr(out) if out.numel() else None, api._stream()))
+        self.last_cross = {"partners": [int(plan.recv_rank[i]) for i in range(plan.n_recv)], "import_bytes": int(plan.import_bytes),
+                           "pairs": [int(totals[i]) for i in range(plan.n_recv)]}
+        return out

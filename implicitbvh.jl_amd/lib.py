@@ -65,6 +65,11 @@ SIGNATURES = {
     "ibvh_dist_scratch_bytes": [_P(abi.Types), _i64, _i32, _P(_sz)],
     "ibvh_dist_plan": [_P(abi.Types), _P(abi.Comm), _vp, _i64, C.c_double, _vp, _sz, _P(abi.DistPlan), _vp],
     "ibvh_dist_exchange": [_P(abi.Types), _P(abi.Comm), _vp, _P(abi.DistPlan), _vp, _sz, _vp, _vp],
+    "ibvh_dist_cross_plan": [_P(abi.Comm), _P(abi.Bvh), _i32, _vp, _sz, _P(abi.DistCrossPlan), _vp],
+    "ibvh_dist_cross_exchange": [_P(abi.Comm), _P(abi.Bvh), _P(abi.DistCrossPlan), _vp, _vp],
+    "ibvh_dist_cross_count": [_P(abi.Bvh), _P(abi.DistCrossPlan), _vp, _vp, _sz, _P(_i64), _P(_i64), _vp],
+    "ibvh_dist_cross_write": [_P(abi.Bvh), _P(abi.DistCrossPlan), _vp, _vp, _sz, _P(_i64), _vp, _vp],
+    "ibvh_comm_release": [_P(abi.Comm)],
     "ibvh_volumes_from_triangles": [_i32, _i32, _vp, _i64, _vp, _vp],
     "ibvh_generate_spheres_f32": [_i64, C.c_uint64, _i64, _P(C.c_float), _P(C.c_float), C.c_float, _vp, _vp],
     "ibvh_profile_enable": [_i32],

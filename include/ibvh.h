@@ -505,6 +505,43 @@ ibvh_status ibvh_dist_plan(const ibvh_types *types, const ibvh_comm *comm, const
 ibvh_status ibvh_dist_exchange(const ibvh_types *types, const ibvh_comm *comm, const void *volumes, const ibvh_dist_plan_t *plan,
                                void *scratch, size_t scratch_bytes, void *records_out, void *stream);
 
+/* Cross-shard contact completion: the contacts between leaves of DIFFERENT slices, which the
+ * per-slice self-traversals cannot see.  Root boxes and leaf counts of all slices are all-gathered; for every pair of slices
+ * r < s whose boxes touch, rank s sends its sorted leaves and its nodes to rank r (P - 1 rounds of all_to_all_v over the same
+ * vtable, straight out of the BVH's arrays into the receiver's import buffer) and rank r runs the ordinary pair traversal
+ * (traverse(bvh_r, bvh_s), lvt/traverse_pair.jl) against each tree it received.  Per-slice self contacts + these pairs = the
+ * contact set of the whole cloud, every pair once.  Count -> size -> write like everything else:
+ *   _plan     collective; ONE host synchronisation; fills the plan: which trees this rank imports, import_bytes (the buffer
+ *             the caller hands to _exchange), scratch_bytes (the traversal scratch for _count / _write, cache_slots as in
+ *             ibvh_lvt_scratch_bytes).  `scratch` here: 64 * (size + 1) bytes of device memory for the all-gather.
+ *   _exchange collective (every rank calls it, also one that neither sends nor receives); asynchronous on `stream`.
+ *   _count    pair-traversal counting passes against every imported tree; totals_out[k] (may be NULL) and *total_out: pairs.
+ *   _write    contacts_out: *total_out IndexPair{I}, the pairs against imported tree 0 first: (index in THIS slice, index in
+ *             the other slice), both GLOBAL 1-based leaf numbers (the records carry them).  `totals`: what _count returned.
+ * The BVH must be fully built (built_level = 1).  Errors inside a collective sequence: the caller must abort the communicator
+ * (a rank that returns early leaves its peers waiting). */
+typedef struct ibvh_dist_cross_plan_t {
+    int32_t size, rank, n_recv /* trees this rank imports */, cache_slots;
+    int64_t import_bytes, scratch_bytes;
+    int32_t recv_rank[IBVH_DIST_MAX_RANKS];      /* [n_recv] ascending: the ranks whose trees are imported                  */
+    int64_t recv_leaves[IBVH_DIST_MAX_RANKS];    /* [n_recv] leaves of that slice                                            */
+    int64_t recv_offset[IBVH_DIST_MAX_RANKS];    /* [n_recv] byte offset of that tree in the import buffer (leaves | nodes)  */
+    int64_t scratch_offset[IBVH_DIST_MAX_RANKS]; /* [n_recv] byte offset of its counts + traversal scratch                   */
+    int64_t slice_leaves[IBVH_DIST_MAX_RANKS];   /* [size] leaves of every rank's slice                                      */
+    int32_t touches[IBVH_DIST_MAX_RANKS];        /* [size] 1: this rank's root box touches rank r's (r != rank)              */
+} ibvh_dist_cross_plan_t;
+ibvh_status ibvh_dist_cross_plan(const ibvh_comm *comm, const ibvh_bvh *bvh, int32_t cache_slots, void *scratch, size_t scratch_bytes,
+                                 ibvh_dist_cross_plan_t *plan_out, void *stream);
+ibvh_status ibvh_dist_cross_exchange(const ibvh_comm *comm, const ibvh_bvh *bvh, const ibvh_dist_cross_plan_t *plan, void *import_buf,
+                                     void *stream);
+ibvh_status ibvh_dist_cross_count(const ibvh_bvh *bvh, const ibvh_dist_cross_plan_t *plan, const void *import_buf, void *scratch,
+                                  size_t scratch_bytes, int64_t *totals_out, int64_t *total_out, void *stream);
+ibvh_status ibvh_dist_cross_write(const ibvh_bvh *bvh, const ibvh_dist_cross_plan_t *plan, const void *import_buf, void *scratch,
+                                  size_t scratch_bytes, const int64_t *totals, void *contacts_out, void *stream);
+
+/* Release what ibvh_comm_from_rccl allocated for `comm` (the ncclComm_t itself stays the caller's). */
+ibvh_status ibvh_comm_release(ibvh_comm *comm);
+
 /* ----------------------------------------------------------------------------------- */
 /* input preparation adjacent to the path                                               */
 /* ----------------------------------------------------------------------------------- */

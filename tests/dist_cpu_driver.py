@@ -2,7 +2,9 @@
 and the PRODUCT's splitter arithmetic (ibvh_splitter_search_* of libibvh, host-only code) around an engine that does the
 per-rank data work on CPU (tests/test_dist_cpu.py: the oracle).  Test infrastructure: lets gloo processes and virtual
 ranks exercise the N > 1 logic — splitters, send matrix, count exchange, global numbering, the "every rank stops together"
-rule, cross-shard completion — without a GPU."""
+rule, cross-shard completion — without a GPU.  It is NOT the product's driver: that one needs a GPU and is run in real OS
+processes by tests/test_gpu_dist_procs.py (gloo staged through host memory) and with virtual ranks by tests/test_gpu_parity.py;
+what these CPU tests pin is the protocol and the library's host-side splitter arithmetic."""
 import ctypes as C
 
 import numpy as np
@@ -29,6 +31,45 @@ def find_splitters(engine, comm, keys, key_bits, n_global, tolerance, first_hist
         h = np.ascontiguousarray(engine.to_host(hist), dtype=np.int64)
         abi.check(L.ibvh_splitter_search_step(C.byref(s), h.ctypes.data_as(C.POINTER(C.c_int64))), "ibvh_splitter_search_step")
     return [int(s.splitters[k]) for k in range(comm.size - 1)], int(s.decided)
+
+
+# (the CPU restatement of ibvh_dist_cross_* — csrc/ibvh_distdrv.hip — for engines without a GPU)
+def cross_contacts(comm, eng, types, n_slice, bvh):
+    """Cross-shard contact completion: contacts between leaves of DIFFERENT slices.
+
+    Root boxes of all slices are all-gathered; for every pair of slices (r < s) whose root boxes touch, rank s
+    copies its sorted leaves + nodes to rank r over xGMI and rank r runs the ordinary pair traversal
+    (ibvh_traverse_pair_lvt_*) of its tree against the received one.  Returns this rank's share as an (m, 2)
+    tensor of GLOBAL 1-based indices (index in own slice, index in the other slice).  The union over ranks of
+    the per-slice self contacts and these pairs is the contact set of the whole cloud."""
+    P, me = comm.size, comm.rank
+    boxes = eng.tensor([[0.0] * 6] * P, torch.float64)
+    boxes[me] = eng.root_box(bvh)
+    comm.all_reduce(boxes, "sum")
+    sizes = eng.tensor([0] * P, torch.int64)
+    sizes[me] = n_slice
+    comm.all_reduce(sizes, "sum")
+    bx, sz = eng.to_host(boxes), eng.to_host(sizes).tolist()
+
+    def touch(a, b):
+        return bool(np.all(bx[a][3:] >= bx[b][:3]) and np.all(bx[a][:3] <= bx[b][3:]))
+    out = []
+    payload = None
+    for d in range(1, P):  # round d: rank s sends to rank s - d (if their boxes touch)
+        dst, src = me - d, me + d
+        send_counts, recv_counts = [0] * P, [0] * P
+        if dst >= 0 and touch(dst, me):
+            if payload is None:
+                payload = eng.export(bvh)
+            send_counts[dst] = payload.numel()
+        if src < P and touch(me, src):
+            recv_counts[src] = eng.export_bytes(types, sz[src])
+        send = payload if sum(send_counts) else eng.tensor([], torch.uint8)
+        recv = comm.all_to_all(send, send_counts, recv_counts)
+        if sum(recv_counts):
+            other = eng.import_(types, sz[src], recv)
+            out.append(eng.pair_contacts(bvh, other))
+    return eng.cat(out) if out else eng.empty_contacts(types)
 
 
 class CpuDistributedBuilder:
@@ -103,4 +144,4 @@ class CpuDistributedBuilder:
         return eng.build_local(types, recv, n_recv, ext_host, node_type, options, cache)
 
     def cross_contacts(self, bvh):
-        return ibd.cross_contacts(self.comm, self.engine, self.last["types"], self.last["n_slice"], bvh)
+        return cross_contacts(self.comm, self.engine, self.last["types"], self.last["n_slice"], bvh)
