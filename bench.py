@@ -689,11 +689,20 @@ def emulate_config5(args):
             t_trav = (time.perf_counter() - t0) / 3
         last = builder.last
         rb = last["record_bytes"]
+        # cross-shard completion (ibvh_dist_cross_*: trees of touching slices exchanged, pair traversals): a JOINT call of all
+        # ranks (collectives served in process), wall time of this rank's call
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cross = builder.cross_contacts(bvh)
+        torch.cuda.synchronize()
+        t_cross = time.perf_counter() - t0
         return {"rank": comm.rank, "leaves_in": n, "leaves_slice": last["n_slice"], "contacts": int(trav.num_contacts),
                 "bytes_sent_to_peers": int(sum(c for r, c in enumerate(last["send_counts"]) if r != comm.rank) * rb),
                 "bytes_received_from_peers": int(sum(c for r, c in enumerate(last["recv_counts"]) if r != comm.rank) * rb),
                 "busiest_peer_bytes": int(max(c for r, c in enumerate(last["send_counts"]) if r != comm.rank) * rb),
                 "joint_build_wall_ms": round(t_build * 1e3, 3), "traverse_alone_ms": round(t_trav * 1e3, 3),
+                "cross_contacts": int(cross.shape[0]), "cross_partners": builder.last_cross["partners"],
+                "cross_import_bytes": builder.last_cross["import_bytes"], "joint_cross_wall_ms": round(t_cross * 1e3, 3),
                 "splitter_key_bits": last["levels_used"]}
     rows = run_virtual_ranks(P, fn)
     slices = [r["leaves_slice"] for r in rows]

@@ -76,6 +76,13 @@ mutable struct IbvhDistPlan
     splitters::NTuple{256, UInt64}; send_counts::NTuple{256, Int64}; recv_counts::NTuple{256, Int64}
     IbvhDistPlan() = new()
 end
+mutable struct IbvhDistCrossPlan
+    size::Int32; rank::Int32; n_recv::Int32; cache_slots::Int32
+    import_bytes::Int64; scratch_bytes::Int64
+    recv_rank::NTuple{256, Int32}; recv_leaves::NTuple{256, Int64}; recv_offset::NTuple{256, Int64}; scratch_offset::NTuple{256, Int64}
+    slice_leaves::NTuple{256, Int64}; touches::NTuple{256, Int32}
+    IbvhDistCrossPlan() = new()
+end
 
 kind(::Type{<:BSphere}) = Int32(0);  kind(::Type{<:BBox}) = Int32(1)
 fltcode(::Type{Float32}) = Int32(0); fltcode(::Type{Float64}) = Int32(1)
@@ -214,6 +221,22 @@ c_dist_exchange(types, comm, volumes, plan, scratch, sb, records, stream) =
     ccall((:ibvh_dist_exchange, libibvh), Cint,
           (Ref{IbvhTypes}, Ref{IbvhComm}, Ptr{Cvoid}, Ref{IbvhDistPlan}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}, Ptr{Cvoid}),
           types, comm, volumes, plan, scratch, sb, records, stream)
+c_dist_cross_plan(comm, bvh, cache_slots, scratch, sb, plan, stream) =
+    ccall((:ibvh_dist_cross_plan, libibvh), Cint,
+          (Ref{IbvhComm}, Ref{IbvhBvh}, Int32, Ptr{Cvoid}, Csize_t, Ref{IbvhDistCrossPlan}, Ptr{Cvoid}),
+          comm, bvh, cache_slots, scratch, sb, plan, stream)
+c_dist_cross_exchange(comm, bvh, plan, import_buf, stream) =
+    ccall((:ibvh_dist_cross_exchange, libibvh), Cint,
+          (Ref{IbvhComm}, Ref{IbvhBvh}, Ref{IbvhDistCrossPlan}, Ptr{Cvoid}, Ptr{Cvoid}),
+          comm, bvh, plan, import_buf, stream)
+c_dist_cross_count(bvh, plan, import_buf, scratch, sb, totals, total, stream) =
+    ccall((:ibvh_dist_cross_count, libibvh), Cint,
+          (Ref{IbvhBvh}, Ref{IbvhDistCrossPlan}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ref{Int64}, Ref{Int64}, Ptr{Cvoid}),
+          bvh, plan, import_buf, scratch, sb, totals, total, stream)
+c_dist_cross_write(bvh, plan, import_buf, scratch, sb, totals, contacts, stream) =
+    ccall((:ibvh_dist_cross_write, libibvh), Cint,
+          (Ref{IbvhBvh}, Ref{IbvhDistCrossPlan}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ref{Int64}, Ptr{Cvoid}, Ptr{Cvoid}),
+          bvh, plan, import_buf, scratch, sb, totals, contacts, stream)
 c_lvt_scratch_bytes(types, n_items, cache_slots, out) =
     ccall((:ibvh_lvt_scratch_bytes, libibvh), Cint,
           (Ref{IbvhTypes}, Int64, Int32, Ref{Csize_t}),
@@ -349,7 +372,7 @@ end
 # this rank (RCCL's C API: ncclGetUniqueId on rank 0, broadcast it, ncclCommInitRank on every rank — e.g. through MPI.jl or
 # a file); `local_volumes` this rank's share of the leaves.  Returns this rank's slice of the globally sorted sequence as an
 # ordinary BVH (leaf .index = GLOBAL 1-based number) that traverse() takes like any other; contacts across slices are NOT
-# found by it (DistributedBuilder.cross_contacts in the Python mirror shows the completion).
+# found by it: dist_cross_contacts below completes them (the trees of touching slices travel over the same communicator).
 """
     dist_comm(nccl_comm::Ptr{Cvoid}, rank, size) -> IbvhComm
 """
@@ -386,6 +409,32 @@ function dist_BVH(comm::IbvhComm, local_volumes::ROCVector{V}, node_type::Type{N
                       min_boundings_per_thread=options.min_boundings_per_thread,
                       min_traversals_per_thread=options.min_traversals_per_thread, block_size=options.block_size)
     ImplicitBVH.BVH(records, N; cache=cache, options=opts)
+end
+
+"""
+    dist_cross_contacts(comm::IbvhComm, bvh::BVH) -> ROCVector{IndexPair{I}}
+
+The contacts between the leaves of THIS rank's slice (`bvh`, from `dist_BVH`) and the leaves of the other ranks' slices that
+this rank is responsible for (pairs of slices r < s are handled by rank r): `(index in this slice, index in the other slice)`,
+both global 1-based leaf numbers.  Collective — every rank calls it.  `traverse(bvh)` on every rank plus these pairs is the
+contact set of the whole cloud, every pair once (include/ibvh.h "Cross-shard contact completion").
+"""
+function dist_cross_contacts(comm::IbvhComm, bvh::RocBVH{I}; cache_slots::Integer=LVT_CACHE_SLOTS) where {I}
+    desc = bvh_desc(bvh)
+    small = scratch!(:dist_cross_plan, 64 * (Int(comm.size) + 1))
+    plan = IbvhDistCrossPlan()
+    # blocks once: root boxes and leaf counts of all slices must reach the host before the transfers can be sized
+    check(c_dist_cross_plan(comm, desc, Int32(cache_slots), devptr(small), 64 * (Int(comm.size) + 1), plan, stream_ptr()), "ibvh_dist_cross_plan")
+    import_buf = similar(bvh.leaves, UInt8, max(Int(plan.import_bytes), 1))
+    check(c_dist_cross_exchange(comm, desc, plan, devptr(import_buf), stream_ptr()), "ibvh_dist_cross_exchange")
+    scratch = scratch!(:dist_cross, max(Int(plan.scratch_bytes), 1))
+    totals = zeros(Int64, 256)
+    total = Ref{Int64}(0)
+    check(c_dist_cross_count(desc, plan, devptr(import_buf), devptr(scratch), Int(plan.scratch_bytes), totals, total, stream_ptr()), "ibvh_dist_cross_count")
+    contacts = similar(bvh.leaves, IndexPair{I}, Int(total[]))          # count, then size, then write
+    total[] > 0 && check(c_dist_cross_write(desc, plan, devptr(import_buf), devptr(scratch), Int(plan.scratch_bytes), totals, devptr(contacts),
+                                            stream_ptr()), "ibvh_dist_cross_write")
+    contacts
 end
 
 # ---- leaf-vs-tree: count -> (cache) -> write, or enqueue against a cached contact buffer ------------------------

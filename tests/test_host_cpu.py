@@ -211,7 +211,8 @@ def test_julia_ccall_signatures_match_the_ctypes_binding():
           "Ref{Int64}": C.POINTER(C.c_int64), "Ref{Int32}": C.POINTER(C.c_int32), "Ref{Csize_t}": C.POINTER(C.c_size_t),
           "Ref{IbvhTypes}": C.POINTER(abi.Types), "Ref{IbvhTree}": C.POINTER(abi.Tree), "Ref{IbvhBvh}": C.POINTER(abi.Bvh),
           "Ref{IbvhBuildDesc}": C.POINTER(abi.BuildDesc), "Ref{IbvhBfsResult}": C.POINTER(abi.BfsResult),
-          "Ref{IbvhComm}": C.POINTER(abi.Comm), "Ref{IbvhDistPlan}": C.POINTER(abi.DistPlan)}
+          "Ref{IbvhComm}": C.POINTER(abi.Comm), "Ref{IbvhDistPlan}": C.POINTER(abi.DistPlan),
+          "Ref{IbvhDistCrossPlan}": C.POINTER(abi.DistCrossPlan)}
     seen = set()
     for name, ret, args in calls:
         assert ret == ("Int32" if name == "ibvh_abi_version" else "Cint"), name
@@ -226,6 +227,8 @@ def test_julia_ccall_signatures_match_the_ctypes_binding():
         want |= {f"ibvh_traverse{shape}_bfs", f"ibvh_bfs{shape}_initial_capacity"}
     # ... and the distributed build (round 4: the driver is reachable from Julia with nothing but ccall)
     want |= {"ibvh_comm_from_rccl", "ibvh_dist_scratch_bytes", "ibvh_dist_plan", "ibvh_dist_exchange"}
+    # ... and the cross-shard contact completion (round 5)
+    want |= {f"ibvh_dist_cross_{k}" for k in ("plan", "exchange", "count", "write")}
     assert want <= seen, want - seen
 
 
@@ -236,9 +239,9 @@ def test_julia_pod_structs_match_the_header_mirror():
     from implicitbvh_amd import abi
     src = _julia_ext()
     width = {"Int32": 4, "Int64": 8, "Ptr{Cvoid}": 8, "NTuple{3, Float64}": 24, "IbvhTypes": C.sizeof(abi.Types), "IbvhTree": C.sizeof(abi.Tree),
-             "NTuple{6, Float64}": 48, "NTuple{256, UInt64}": 2048, "NTuple{256, Int64}": 2048}
+             "NTuple{6, Float64}": 48, "NTuple{256, UInt64}": 2048, "NTuple{256, Int64}": 2048, "NTuple{256, Int32}": 1024}
     for jname, ctype in (("IbvhTypes", abi.Types), ("IbvhTree", abi.Tree), ("IbvhBvh", abi.Bvh), ("IbvhBuildDesc", abi.BuildDesc),
-                         ("IbvhBfsResult", abi.BfsResult), ("IbvhComm", abi.Comm), ("IbvhDistPlan", abi.DistPlan)):
+                         ("IbvhBfsResult", abi.BfsResult), ("IbvhComm", abi.Comm), ("IbvhDistPlan", abi.DistPlan), ("IbvhDistCrossPlan", abi.DistCrossPlan)):
         body = re.search(r"struct " + jname + r"\n(.*?)\nend", src, re.S).group(1)
         fields = [(m.group(1), m.group(2).strip()) for m in re.finditer(r"(\w+)::([^;\n]+)", body)]
         assert [f for f, _ in fields] == [f for f, _ in ctype._fields_], jname
