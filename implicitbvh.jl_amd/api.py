@@ -380,9 +380,14 @@ class _HostWords:
                 self.next = (self.next + 1) % self.SLOTS
                 if self.next == 0:
                     # the ring wraps: a scan kernel of the previous lap that is STILL queued would overwrite the new
-                    # owner's PENDING word with its own total.  One device synchronisation per SLOTS
-                    # traversals retires every such kernel before its slot is handed out again.
-                    _torch().cuda.synchronize()
+                    # owner's PENDING word with its own total.  One synchronisation per SLOTS traversals retires
+                    # every such kernel before its slot is handed out again — of EVERY device this process drives (ADVICE
+                    # r4: a traversal queued on another device is otherwise not retired), and under the lock on purpose:
+                    # a thread that took a slot of the new lap meanwhile could launch behind a stale kernel of the old lap
+                    # on its own stream and read that kernel's total as its own.  Cost: one device drain per 8,192 traversals.
+                    torch = _torch()
+                    for d in range(torch.cuda.device_count()):
+                        torch.cuda.synchronize(d)
             self.generation[slot] += 1
             gen = self.generation[slot]
         self.words[slot] = initial
