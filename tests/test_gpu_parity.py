@@ -702,6 +702,15 @@ def test_lvt_pair_identical_order():
                 assert (contacts_np(got) == exp).all(), (n1, n2, sl1, sl2)
         brute = sorted(map(tuple, orc.brute_force_pair(abi.BSPHERE, abi.F32, a, b).tolist()))
         assert sorted(map(tuple, contacts_np(ibvh.traverse(g1, g2)).tolist())) == brute
+    # the contract for BVHs of different leaf / node types: the status, never a wrong list
+    _, gb = build_both(random_volumes(rng, 100, abi.BBOX, abi.F32), abi.make_types(abi.BBOX, abi.F32, abi.BBOX, abi.F32))
+    s1, s2 = g1.struct(), gb.struct()
+    counts = torch.zeros(1000, dtype=torch.int32, device="cuda")
+    scratch = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    total = C.c_int64()
+    rc = lib.load().ibvh_traverse_pair_lvt_count(C.byref(s1), C.byref(s2), 1, 1, 0, counts.data_ptr(), C.byref(total), scratch.data_ptr(),
+                                                 scratch.numel(), None)
+    assert rc == abi.ERR_UNSUPPORTED
 
 
 @pytest.mark.parametrize("slots", [8, 0])

@@ -291,3 +291,18 @@ def test_julia_constructor_calls_use_the_reference_signatures():
         head, _, tail = c.partition(";")
         assert "," not in head, f"one positional argument, the rest by keyword: {c}"
         assert set(re.findall(r"([a-z_]+)\s*=(?!=)", tail)) <= {"compute_extrema", "mins", "maxs"}, c
+
+
+def test_julia_pair_methods_fall_back_for_mixed_types():
+    """INTEGRATION.md §4 "Pair traversal of two BVHs of DIFFERENT leaf / node types": both pair methods of the extension (LVT and
+    BFS) test `d1.types != d2.types` and hand such pairs to the reference's generic method with every keyword carried over."""
+    import re
+    src = _julia_ext()
+    for alg in ("LVTTraversal", "BFSTraversal"):
+        m = re.search(r"function ImplicitBVH\.traverse\(\s*bvh1::RocBVH\{I\}, bvh2::RocBVH, alg::" + alg + r";(.*?)\nend\n", src, re.S)
+        assert m, alg
+        body = m.group(1)
+        assert "d1.types != d2.types" in body
+        call = re.search(r"invoke\(ImplicitBVH\.traverse, Tuple\{BVH, BVH, " + alg + r"\}, bvh1, bvh2, alg;(.*?)\)\n", body, re.S).group(1)
+        for kw in ("start_level1", "start_level2", "narrow", "cache", "options"):
+            assert f"{kw}={kw}" in call, (alg, kw)
