@@ -345,6 +345,10 @@ template <int RAYTILE_TPB> __global__ __launch_bounds__(RAYTILE_TPB) void rays_s
     }
 }
 
+#ifdef IBVH_RAYSUB_HIST // (diagnostic build, tools/dbg_raysub_hist.py: wave-steps of the counting pass by number of busy lanes; [8], [9]: steps
+                        // after the wave's chunk ran dry with < 8 / >= 8 lanes busy)
+__device__ unsigned long long g_raysub_hist[16];
+#endif
 template <class L, class N, class I, bool WRITE>
 __global__ __launch_bounds__(RAYSUB_TPB) void rays_subtree_kernel(Args<L, N, I> a, RayBins rb) {
     using T = typename L::elt;
@@ -530,6 +534,15 @@ __global__ __launch_bounds__(RAYSUB_TPB) void rays_subtree_kernel(Args<L, N, I> 
                 }
             }
             const uint64_t idle_now = __builtin_amdgcn_ballot_w64(!busy);
+#ifdef IBVH_RAYSUB_HIST
+            if constexpr (!WRITE) {
+                if (lane == 0) {
+                    const int nb = 64 - __popcll(idle_now);
+                    atomicAdd(&g_raysub_hist[nb >= 64 ? 7 : nb / 8], 1ull);
+                    if (!more) atomicAdd(&g_raysub_hist[8 + (nb >= 8 ? 1 : 0)], 1ull);
+                }
+            }
+#endif
             if (idle_now == ~(uint64_t)0) break;
             if (more && __popcll(idle_now) >= 16) break;
         }
@@ -617,3 +630,13 @@ IBVH_FOR_SAME_FLOAT_COMBOS(IBVH_INSTANTIATE_RAYBINS, 0)
 
 } // namespace lvt
 } // namespace ibvh
+
+#ifdef IBVH_RAYSUB_HIST
+extern "C" int ibvh_debug_raysub_hist(unsigned long long *out /* 16 */, int reset) {
+    if (reset) {
+        unsigned long long z[16] = {};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(ibvh::lvt::g_raysub_hist), z, sizeof(z));
+    }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ibvh::lvt::g_raysub_hist), sizeof(unsigned long long) * 16);
+}
+#endif
