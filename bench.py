@@ -199,6 +199,16 @@ def _roof(kernel, avg_ms, bytes_per_launch, note):
             "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes": note}
 
 
+def _with_block_kernel(roofline, ms_by_kernel, algorithmic_bytes_):
+    """Round 5: the counting pass's descent is shared per block of leaves and runs as a small kernel in FRONT of it
+    (lvt_block_frontier_kernel).  `frac` stays the dominant kernel's own; frac_with_block_kernel prices the same algorithmic
+    bytes against both kernels' time — the like-for-like figure against round 4's single kernel."""
+    if roofline and roofline.get("kernel") == "lvt_queue_kernel_count" and ms_by_kernel.get("lvt_block_frontier_kernel"):
+        both = roofline["avg_launch_ms"] + ms_by_kernel["lvt_block_frontier_kernel"]
+        roofline["block_kernel_ms"] = round(ms_by_kernel["lvt_block_frontier_kernel"], 5)
+        roofline["frac_with_block_kernel"] = round(algorithmic_bytes_ / (both * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+
+
 def _work(ibvh, orc, gpu_args, ref_args, items, threads, native):
     """tests per work item of the HIP walk and of the reference's walk (instrumented oracle) on the same input"""
     g = ibvh.lvt_work_counters(*gpu_args[0], **gpu_args[1])
@@ -505,7 +515,7 @@ def _pick(d, keys):
 def _compact_roof(r):
     if not isinstance(r, dict):
         return None
-    out = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms"))
+    out = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "block_kernel_ms", "frac_with_block_kernel"))
     out["traffic"] = r.get("traffic")
     if "kernel" in out and len(out["kernel"]) > 40:
         out["kernel"] = out["kernel"][:37] + "..."
@@ -829,6 +839,7 @@ def main():
         ab2 = algorithmic_bytes(dom2, n2, st2[1].num_contacts)
         roof2 = _roof(dom2, avg2, ab2, "dominant kernel of the step at the north-star size (DESIGN.md §3 tables)") if ab2 else None
         if roof2 is not None:
+            _with_block_kernel(roof2, {k: v[0] / 3 for k, v in prof2.items()}, ab2)
             roof2["cache_residency"] = "HBM: the step's working set (~1.3 GB) is 5x the 256 MB Infinity Cache"
             _attach_counters(roof2, "n1e7", avg2 * 1e-3)
         north_star = {"leaves": n2, "value": round(n2 * reps / el2 / 1e6, 3), "unit": "Mleaves/s", "roofline": roof2,
@@ -914,6 +925,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                     "algorithmic_bytes_per_launch": int(ab), "avg_launch_ms": round(avg_s * 1e3, 5)}
+        _with_block_kernel(roofline, {k: v["ms_per_step"] for k, v in kernels.items()}, ab)
         # Morton+sort phase (north star: >= 40 % of the HBM roofline on 152 B/leaf)
         ms_phase = sum(v["ms_per_step"] for k, v in kernels.items() if k in MORTON_SORT_KERNELS)
         if ms_phase > 0:
