@@ -108,13 +108,23 @@ class DistPlan(C.Structure):
                 ("recv_counts", C.c_int64 * DIST_MAX_RANKS)]
 
 
+DIST_CROSS_BOXES = 16
+
+
 class DistCrossPlan(C.Structure):
     """ibvh_dist_cross_plan_t (include/ibvh.h)"""
     _fields_ = [("size", C.c_int32), ("rank", C.c_int32), ("n_recv", C.c_int32), ("cache_slots", C.c_int32),
-                ("import_bytes", C.c_int64), ("scratch_bytes", C.c_int64),
+                ("import_bytes", C.c_int64), ("scratch_bytes", C.c_int64), ("export_bytes", C.c_int64), ("build_offset", C.c_int64),
                 ("recv_rank", C.c_int32 * DIST_MAX_RANKS), ("recv_leaves", C.c_int64 * DIST_MAX_RANKS),
                 ("recv_offset", C.c_int64 * DIST_MAX_RANKS), ("scratch_offset", C.c_int64 * DIST_MAX_RANKS),
-                ("slice_leaves", C.c_int64 * DIST_MAX_RANKS), ("touches", C.c_int32 * DIST_MAX_RANKS)]
+                ("slice_leaves", C.c_int64 * DIST_MAX_RANKS), ("touches", C.c_int32 * DIST_MAX_RANKS),
+                ("send_leaves", C.c_int64 * DIST_MAX_RANKS), ("send_offset", C.c_int64 * DIST_MAX_RANKS),
+                ("n_boxes", C.c_int32 * DIST_MAX_RANKS), ("boxes", ((C.c_double * 6) * DIST_CROSS_BOXES) * DIST_MAX_RANKS)]
+
+
+def dist_cross_scratch(size):
+    """IBVH_DIST_CROSS_SCRATCH(size) of include/ibvh.h"""
+    return (DIST_CROSS_BOXES * 48 + 16) * (size + 1) + 16 * size + 512
 
 
 def volume_dtype(kind, flt):

@@ -442,13 +442,18 @@ ibvh_status ibvh_dist_exchange(const ibvh_types *types, const ibvh_comm *comm, c
 
 // ---- cross-shard contact completion behind the boundary ---------------------------------------------------
 // Per-slice trees do not see contacts between leaves of different slices.  Every rank publishes its slice's root box and leaf
-// count (ONE all-gather of 64 bytes a rank); for every pair of slices r < s whose boxes touch, rank s sends its sorted leaves and
-// its nodes to rank r — round d of P - 1 rounds moves the trees of the pairs (s - d, s), every round one all_to_all_v for the
-// leaves and one for the nodes, straight out of the BVH's own arrays into the receiver's import buffer — and rank r runs the
-// ordinary pair traversal (ibvh_traverse_pair_lvt_*) of its own tree against each imported one.  Per-slice self contacts and
-// these pairs together are the contact set of the whole cloud, every pair exactly once (tests/test_gpu_dist_procs.py,
-// test_gpu_parity.py).  The protocol is the reference's count -> size -> write: _plan (one host synchronisation) tells the
-// caller how large the import buffer and the traversal scratch are, _count how many pairs there are, _write writes them.
+// count (ONE all-gather of 64 bytes a rank); for every pair of slices r < s whose boxes touch, rank s sends rank r the leaves
+// that can matter there — those whose own box touches r's root box (a thin shell of the slice: Morton slices of a cloud meet at
+// faces), NOT its tree: round 4 shipped whole trees, 600 MB a peer at config 5 for 0.5 % of the contacts — and rank r builds an
+// ordinary BVH over what it received (ibvh_build: extrema, Morton sort, merge) and runs the ordinary pair traversal
+// (ibvh_traverse_pair_lvt_*) of its own tree against it.  Per-slice self contacts and these pairs together are the contact set
+// of the whole cloud, every pair exactly once (tests/test_gpu_dist_procs.py, test_gpu_parity.py, test_gpu_dist.py).
+//   _plan     all-gather of the boxes; per lower touching rank a counting pass over the own leaves; the counts exchanged (8 bytes a
+//             peer, one all_to_all_v); TWO host synchronisations; fills the plan: who sends how many leaves to whom and how large
+//             the caller's three buffers are (export, import, traversal scratch)
+//   _exchange selected leaves -> export buffer (one compaction pass per receiver), then P - 1 rounds of all_to_all_v (round d: the
+//             pairs (s - d, s)), every rank in every round
+//   _count    per imported set: ibvh_build in place, pair-traversal counting pass;  _write: the writing passes.
 namespace {
 void root_box_of(const ibvh_types &t, const unsigned char *raw, bool is_leaf, double out[6]) {
     const int kind = is_leaf ? t.leaf_kind : t.node_kind, flt = is_leaf ? t.leaf_float : t.node_float;
@@ -464,9 +469,82 @@ void root_box_of(const ibvh_types &t, const unsigned char *raw, bool is_leaf, do
         for (int k = 0; k < 6; ++k) out[k] = v[k];
     }
 }
+// the box a leaf is tested with, in double
+template <class T> IBVH_D void leaf_box(const BSphere<T> &s, double (&lo)[3], double (&up)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = (double)(s.x[k] - s.r);
+        up[k] = (double)(s.x[k] + s.r);
+    }
+}
+template <class T> IBVH_D void leaf_box(const BBox<T> &b, double (&lo)[3], double (&up)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = (double)b.lo[k];
+        up[k] = (double)b.up[k];
+    }
+}
+constexpr int CROSS_BOXES = IBVH_DIST_CROSS_BOXES; // boxes a slice is described by: the nodes of its tree's level 4 (Morton slices are not convex)
+struct BoxSet {
+    int n;
+    double lo[CROSS_BOXES][3], up[CROSS_BOXES][3];
+};
+// leaves of a slice whose box touches one of `box` (a peer's boxes, widened by a few ulps of the narrower float type: the filter must
+// keep every leaf the pair traversal could report, and its own box tests round differently): counted (out == nullptr) or copied,
+// unordered (the receiver sorts them again when it builds its tree), behind one atomic per workgroup
+template <class V> __global__ __launch_bounds__(256) void cross_filter_kernel(const char *leaves, LeafLayout lay, int64_t n, BoxSet box,
+                                                                              unsigned long long *cursor, char *out) {
+    __shared__ uint32_t s_cnt, s_base;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    if (i < n) {
+        const V v = load_vol<V>(leaves + i * lay.stride);
+        double lo[3], up[3];
+        leaf_box(v, lo, up);
+        for (int b = 0; b < box.n; ++b) {
+            bool t = true;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) t = t && lo[k] <= box.up[b][k] && up[k] >= box.lo[b][k];
+            keep = keep || t;
+        }
+    }
+    uint32_t at = 0;
+    if (keep) at = atomicAdd(&s_cnt, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt != 0) s_base = (uint32_t)atomicAdd(cursor, (unsigned long long)s_cnt);
+    __syncthreads();
+    if (keep && out != nullptr) {
+        const uint64_t *src = (const uint64_t *)(leaves + i * lay.stride);
+        uint64_t *dst = (uint64_t *)(out + ((int64_t)s_base + at) * lay.stride);
+        for (int w = 0; w < lay.stride / 8; ++w) dst[w] = src[w];
+    }
+}
+int launch_cross_filter(const ibvh_types &t, const void *leaves, int64_t n, const double (*boxes)[6], int n_boxes, unsigned long long *cursor, void *out,
+                        hipStream_t st) {
+    ibvh_layout lay;
+    LeafLayout dl;
+    if (!layout_of(t, lay, &dl)) return IBVH_ERR_UNSUPPORTED;
+    BoxSet b{};
+    b.n = n_boxes;
+    const double eps = (t.leaf_float == IBVH_F32 || t.node_float == IBVH_F32) ? 1e-5 : 1e-13;
+    for (int i = 0; i < n_boxes; ++i)
+        for (int k = 0; k < 3; ++k) {
+            const double ext = std::fabs(boxes[i][3 + k] - boxes[i][k]) + std::fabs(boxes[i][k]) + std::fabs(boxes[i][3 + k]);
+            b.lo[i][k] = boxes[i][k] - eps * ext - 1e-300;
+            b.up[i][k] = boxes[i][3 + k] + eps * ext + 1e-300;
+        }
+    if (n <= 0) return IBVH_OK;
+    return dispatch_volume(t.leaf_kind, t.leaf_float, [&](auto vt) -> int {
+        using V = typename decltype(vt)::type;
+        hipLaunchKernelGGL((cross_filter_kernel<V>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, (const char *)leaves, dl, n, b, cursor, (char *)out);
+        return hipGetLastError() == hipSuccess ? (int)IBVH_OK : (int)IBVH_ERR_HIP;
+    });
+}
 struct CrossSizes {
-    int64_t leaf_bytes, node_bytes, nodes, tree_bytes; // one imported tree: leaves | nodes, each padded to 256 bytes
-    size_t counts_bytes, lvt_bytes;                     // its share of the traversal scratch
+    int64_t leaf_bytes, node_bytes, skip_bytes, tree_bytes; // one imported set: leaves | nodes | skips, each padded to 256 bytes
+    size_t counts_bytes, lvt_bytes, build_bytes;             // its share of the traversal scratch; the build's scratch (shared)
 };
 bool cross_sizes(const ibvh_types &t, int64_t n_other, int64_t n_mine, int32_t cache_slots, CrossSizes &z) {
     ibvh_layout lay;
@@ -474,13 +552,14 @@ bool cross_sizes(const ibvh_types &t, int64_t n_other, int64_t n_mine, int32_t c
     ibvh_tree tree;
     if (ibvh_tree_shape(n_other, &tree) != IBVH_OK) return false;
     z.leaf_bytes = n_other * lay.leaf_bytes;
-    z.nodes = tree.real_nodes - tree.real_leaves;
-    z.node_bytes = z.nodes * lay.node_bytes;
-    z.tree_bytes = align_up(z.leaf_bytes, 256) + align_up(z.node_bytes, 256);
+    z.node_bytes = (tree.real_nodes - tree.real_leaves) * lay.node_bytes;
+    z.skip_bytes = tree.levels * (t.index_type == IBVH_I64 ? 8 : 4);
+    z.tree_bytes = align_up(z.leaf_bytes, 256) + align_up(z.node_bytes, 256) + align_up(z.skip_bytes, 256);
     const int64_t items = n_other > n_mine ? n_other : n_mine; // the BVH with more leaves supplies the work items (traverse_pair.jl:15-36)
     z.counts_bytes = (size_t)align_up(items * (t.index_type == IBVH_I64 ? 8 : 4), 256);
     if (ibvh_lvt_scratch_bytes(&t, items, cache_slots, &z.lvt_bytes) != IBVH_OK) return false;
     z.lvt_bytes = (size_t)align_up((int64_t)z.lvt_bytes, 256);
+    if (ibvh_build_scratch_bytes(&t, n_other, &z.build_bytes) != IBVH_OK) return false;
     return true;
 }
 ibvh_bvh imported_tree(const ibvh_bvh &mine, const ibvh_dist_cross_plan_t &plan, int k, const void *import_buf) {
@@ -493,7 +572,7 @@ ibvh_bvh imported_tree(const ibvh_bvh &mine, const ibvh_dist_cross_plan_t &plan,
     const char *at = (const char *)import_buf + plan.recv_offset[k];
     o.leaves = at;
     o.nodes = at + align_up(plan.recv_leaves[k] * lay.leaf_bytes, 256);
-    o.skips = nullptr; // (the leaf-vs-tree walkers derive everything from the tree's shape)
+    o.skips = (const char *)o.nodes + align_up((o.tree.real_nodes - o.tree.real_leaves) * lay.node_bytes, 256);
     return o;
 }
 } // namespace
@@ -509,97 +588,176 @@ ibvh_status ibvh_dist_cross_plan(const ibvh_comm *comm, const ibvh_bvh *bvh, int
     if (bvh->built_level > 1 && bvh->tree.real_nodes > bvh->tree.real_leaves) return IBVH_ERR_UNSUPPORTED; // (the root must exist)
     ibvh_layout lay;
     if (!layout_of(bvh->types, lay)) return IBVH_ERR_UNSUPPORTED;
-    if (!scratch || scratch_bytes < (size_t)64 * (P + 1)) return IBVH_ERR_SCRATCH;
+    if (!scratch || scratch_bytes < IBVH_DIST_CROSS_SCRATCH(P)) return IBVH_ERR_SCRATCH;
     hipStream_t st = (hipStream_t)stream;
     std::memset(plan, 0, sizeof(*plan));
     plan->size = P;
     plan->rank = me;
     plan->cache_slots = cache_slots;
     const int64_t n_mine = bvh->tree.real_leaves;
-    // this rank's record: root box (the root node, or the only leaf's volume) + leaf count
-    unsigned char raw[48];
-    const bool from_leaf = bvh->tree.real_nodes <= bvh->tree.real_leaves;
-    DIST_HIP_CHECK(hipMemcpyAsync(raw, from_leaf ? bvh->leaves : bvh->nodes, (size_t)(from_leaf ? lay.volume_bytes : lay.node_bytes),
-                                  hipMemcpyDeviceToHost, st));
-    DIST_HIP_CHECK(hipStreamSynchronize(st));
+    // this rank's record: the boxes its slice is described by + its leaf count.  A Morton slice is not convex — where it
+    // straddles a big jump of the Z-curve one node box spans the scene and every leaf of every other slice "touches" it — so
+    // the description is refined greedily: start with the root, replace the box of the largest volume by its two children,
+    // until CROSS_BOXES boxes (the straddling node is split again and again, one tight child peeled off each time, down to the
+    // level where the jump sits).  A dozen 48-byte reads from the device, once per completion.
     struct Rec {
-        double box[6];
-        int64_t leaves, pad;
+        double box[CROSS_BOXES][6];
+        int64_t leaves, n_boxes;
     } mine_rec{};
-    root_box_of(bvh->types, raw, from_leaf, mine_rec.box);
+    static_assert(sizeof(Rec) == IBVH_DIST_CROSS_BOXES * 48 + 16, "record layout");
+    const bool from_leaf = bvh->tree.real_nodes <= bvh->tree.real_leaves;
+    {
+        const size_t one = (size_t)(from_leaf ? lay.volume_bytes : lay.node_bytes);
+        unsigned char raw[2 * 48];
+        DIST_HIP_CHECK(hipMemcpyAsync(raw, from_leaf ? bvh->leaves : bvh->nodes, one, hipMemcpyDeviceToHost, st));
+        DIST_HIP_CHECK(hipStreamSynchronize(st));
+        root_box_of(bvh->types, raw, from_leaf, mine_rec.box[0]);
+        int64_t node[CROSS_BOXES], level[CROSS_BOXES]; // heap index and level of every box
+        node[0] = 1, level[0] = 1;
+        int nb = 1;
+        const int64_t levels = bvh->tree.levels, vl = bvh->tree.virtual_leaves;
+        auto volume = [&](const double *b) {
+            double v = 1.0;
+            for (int k = 0; k < 3; ++k) {
+                const double d = b[3 + k] - b[k];
+                v *= d > 0 ? d : 0.0;
+            }
+            return v == v ? v : 0.0; // (a NaN box touches nothing: nothing to refine)
+        };
+        while (!from_leaf && nb < CROSS_BOXES) {
+            int pick = -1;
+            double best = 0.0;
+            for (int i = 0; i < nb; ++i) {
+                if (level[i] + 1 > levels - 1) continue; // (its children are leaves: not node boxes)
+                const double v = volume(mine_rec.box[i]);
+                if (pick < 0 || v > best) pick = i, best = v;
+            }
+            if (pick < 0 || best <= 0.0) break;
+            const int64_t cl = level[pick] + 1, c0 = 2 * node[pick], c1 = c0 + 1;
+            const bool real1 = (c1 - ((int64_t)1 << (cl - 1))) < level_num_real(levels, vl, cl);
+            const int64_t mem0 = level_start(levels, vl, cl) - 1 + (c0 - ((int64_t)1 << (cl - 1))); // 0-based memory index of the left child
+            DIST_HIP_CHECK(hipMemcpyAsync(raw, (const char *)bvh->nodes + (size_t)mem0 * one, one * (real1 ? 2 : 1), hipMemcpyDeviceToHost, st));
+            DIST_HIP_CHECK(hipStreamSynchronize(st));
+            root_box_of(bvh->types, raw, false, mine_rec.box[pick]);
+            node[pick] = c0, level[pick] = cl;
+            if (real1) {
+                root_box_of(bvh->types, raw + one, false, mine_rec.box[nb]);
+                node[nb] = c1, level[nb] = cl;
+                ++nb;
+            }
+        }
+        mine_rec.n_boxes = nb;
+    }
     mine_rec.leaves = n_mine;
     std::vector<Rec> all(P);
     all[me] = mine_rec;
+    char *base = (char *)scratch;
+    const size_t gather_bytes = sizeof(Rec) * (size_t)(P + 1);
     if (P > 1) {
-        char *base = (char *)scratch;
         DIST_HIP_CHECK(hipMemcpyAsync(base, &mine_rec, sizeof(Rec), hipMemcpyHostToDevice, st));
-        if (int e = comm->all_gather(comm->ctx, base, base + 64, (int64_t)sizeof(Rec), stream)) return (ibvh_status)e;
-        DIST_HIP_CHECK(hipMemcpyAsync(all.data(), base + 64, sizeof(Rec) * (size_t)P, hipMemcpyDeviceToHost, st));
+        if (int e = comm->all_gather(comm->ctx, base, base + sizeof(Rec), (int64_t)sizeof(Rec), stream)) return (ibvh_status)e;
+        DIST_HIP_CHECK(hipMemcpyAsync(all.data(), base + sizeof(Rec), sizeof(Rec) * (size_t)P, hipMemcpyDeviceToHost, st));
         DIST_HIP_CHECK(hipStreamSynchronize(st));
     }
-    auto touch = [&](int a, int b) { // iscontact of two boxes (iscontact.jl:20-28); a NaN box touches nothing
-        for (int k = 0; k < 3; ++k)
-            if (!(all[a].box[3 + k] >= all[b].box[k] && all[a].box[k] <= all[b].box[3 + k])) return false;
-        return true;
+    auto touch = [&](int a, int b) { // any box of a against any box of b (iscontact.jl:20-28; a NaN box touches nothing)
+        for (int64_t i = 0; i < all[a].n_boxes; ++i)
+            for (int64_t j = 0; j < all[b].n_boxes; ++j) {
+                bool t = true;
+                for (int k = 0; k < 3; ++k) t = t && all[a].box[i][3 + k] >= all[b].box[j][k] && all[a].box[i][k] <= all[b].box[j][3 + k];
+                if (t) return true;
+            }
+        return false;
     };
-    int64_t off = 0, scr = 0;
     for (int r = 0; r < P; ++r) {
         plan->slice_leaves[r] = all[r].leaves;
         plan->touches[r] = (r != me && touch(me < r ? me : r, me < r ? r : me)) ? 1 : 0;
+        plan->n_boxes[r] = (int32_t)all[r].n_boxes;
+        for (int i = 0; i < CROSS_BOXES; ++i)
+            for (int k = 0; k < 6; ++k) plan->boxes[r][i][k] = all[r].box[i][k];
     }
-    for (int r = me + 1; r < P; ++r) { // trees this rank imports, by ascending rank
-        if (!plan->touches[r]) continue;
-        CrossSizes z;
-        if (!cross_sizes(bvh->types, all[r].leaves, n_mine, cache_slots, z)) return IBVH_ERR_UNSUPPORTED;
-        const int k = plan->n_recv++;
-        plan->recv_rank[k] = r;
-        plan->recv_leaves[k] = all[r].leaves;
-        plan->recv_offset[k] = off;
-        plan->scratch_offset[k] = scr;
-        off += z.tree_bytes;
-        scr += (int64_t)(z.counts_bytes + z.lvt_bytes);
+    // how many of the own leaves every LOWER touching rank gets: a counting pass per such rank, then the counts change hands
+    unsigned long long *cnt_send = (unsigned long long *)(base + align_up((int64_t)gather_bytes, 256)), *cnt_recv = cnt_send + P;
+    if (P > 1) {
+        DIST_HIP_CHECK(hipMemsetAsync(cnt_send, 0, (size_t)16 * P, st));
+        for (int r = 0; r < me; ++r)
+            if (plan->touches[r])
+                if (int e = launch_cross_filter(bvh->types, bvh->leaves, n_mine, plan->boxes[r], plan->n_boxes[r], cnt_send + r, nullptr, st)) return (ibvh_status)e;
+        std::vector<int64_t> eight(P, 8);
+        if (int e = comm->all_to_all_v(comm->ctx, cnt_send, eight.data(), cnt_recv, eight.data(), stream)) return (ibvh_status)e;
+        std::vector<unsigned long long> host(2 * (size_t)P);
+        DIST_HIP_CHECK(hipMemcpyAsync(host.data(), cnt_send, (size_t)16 * P, hipMemcpyDeviceToHost, st));
+        DIST_HIP_CHECK(hipStreamSynchronize(st));
+        int64_t eo = 0;
+        for (int r = 0; r < P; ++r) {
+            plan->send_leaves[r] = (int64_t)host[r];
+            plan->send_offset[r] = eo;
+            eo += align_up((int64_t)host[r] * lay.leaf_bytes, 256);
+        }
+        plan->export_bytes = eo;
+        int64_t off = 0, scr = 0;
+        size_t build_max = 0;
+        for (int r = me + 1; r < P; ++r) { // leaf sets this rank imports, by ascending rank
+            const int64_t got = (int64_t)host[(size_t)P + r];
+            if (!plan->touches[r] || got <= 0) continue;
+            CrossSizes z;
+            if (!cross_sizes(bvh->types, got, n_mine, cache_slots, z)) return IBVH_ERR_UNSUPPORTED;
+            const int k = plan->n_recv++;
+            plan->recv_rank[k] = r;
+            plan->recv_leaves[k] = got;
+            plan->recv_offset[k] = off;
+            plan->scratch_offset[k] = scr;
+            off += z.tree_bytes;
+            scr += (int64_t)(z.counts_bytes + z.lvt_bytes);
+            build_max = z.build_bytes > build_max ? z.build_bytes : build_max;
+        }
+        plan->import_bytes = off;
+        plan->build_offset = scr;
+        plan->scratch_bytes = scr + (int64_t)align_up((int64_t)build_max, 256);
     }
-    plan->import_bytes = off;
-    plan->scratch_bytes = scr;
     return IBVH_OK;
 }
 
-ibvh_status ibvh_dist_cross_exchange(const ibvh_comm *comm, const ibvh_bvh *bvh, const ibvh_dist_cross_plan_t *plan, void *import_buf,
-                                     void *stream) {
+ibvh_status ibvh_dist_cross_exchange(const ibvh_comm *comm, const ibvh_bvh *bvh, const ibvh_dist_cross_plan_t *plan, void *export_buf,
+                                     void *import_buf, void *scratch, size_t scratch_bytes, void *stream) {
     if (!comm || !bvh || !plan) return IBVH_ERR_INVALID_ARG;
     const int P = comm->size, me = comm->rank;
     if (P != plan->size || me != plan->rank || P < 1 || P > MAX_RANKS) return IBVH_ERR_INVALID_ARG;
-    if (plan->import_bytes > 0 && !import_buf) return IBVH_ERR_INVALID_ARG;
+    if ((plan->import_bytes > 0 && !import_buf) || (plan->export_bytes > 0 && !export_buf)) return IBVH_ERR_INVALID_ARG;
+    if (P == 1) return IBVH_OK;
+    if (!scratch || scratch_bytes < IBVH_DIST_CROSS_SCRATCH(P)) return IBVH_ERR_SCRATCH;
     ibvh_layout lay;
     if (!layout_of(bvh->types, lay)) return IBVH_ERR_UNSUPPORTED;
-    const int64_t my_leaf_bytes = bvh->tree.real_leaves * lay.leaf_bytes;
-    const int64_t my_node_bytes = (bvh->tree.real_nodes - bvh->tree.real_leaves) * lay.node_bytes;
+    hipStream_t st = (hipStream_t)stream;
+    // the selected leaves of every receiver, compacted into the export buffer (the counting pass of _plan, now copying)
+    unsigned long long *cursor = (unsigned long long *)((char *)scratch + align_up((int64_t)((IBVH_DIST_CROSS_BOXES * 48 + 16) * (size_t)(P + 1)), 256));
+    DIST_HIP_CHECK(hipMemsetAsync(cursor, 0, (size_t)8 * P, st));
+    for (int r = 0; r < me; ++r)
+        if (plan->touches[r] && plan->send_leaves[r] > 0)
+            if (int e = launch_cross_filter(bvh->types, bvh->leaves, bvh->tree.real_leaves, plan->boxes[r], plan->n_boxes[r], cursor + r, (char *)export_buf + plan->send_offset[r], st))
+                return (ibvh_status)e;
     int k_of[MAX_RANKS];
     for (int r = 0; r < P; ++r) k_of[r] = -1;
     for (int k = 0; k < plan->n_recv; ++k) k_of[plan->recv_rank[k]] = k;
     int64_t sb[MAX_RANKS], rbts[MAX_RANKS];
-    for (int d = 1; d < P; ++d) { // round d: rank s sends its tree to rank s - d when their boxes touch — EVERY rank takes part in every round
+    for (int d = 1; d < P; ++d) { // round d: rank s sends to rank s - d — EVERY rank takes part in every round
         const int dst = me - d, src = me + d;
-        const bool sending = dst >= 0 && plan->touches[dst], receiving = src < P && plan->touches[src];
-        char *at = receiving ? (char *)import_buf + plan->recv_offset[k_of[src]] : (char *)import_buf;
-        for (int part = 0; part < 2; ++part) { // the leaves, then the nodes: straight out of the BVH's own arrays
-            for (int r = 0; r < P; ++r) sb[r] = rbts[r] = 0;
-            if (sending) sb[dst] = part == 0 ? my_leaf_bytes : my_node_bytes;
-            if (receiving) {
-                const int k = k_of[src];
-                ibvh_tree t;
-                ibvh_tree_shape(plan->recv_leaves[k], &t);
-                rbts[src] = part == 0 ? plan->recv_leaves[k] * lay.leaf_bytes : (t.real_nodes - t.real_leaves) * lay.node_bytes;
-            }
-            const void *send = part == 0 ? bvh->leaves : bvh->nodes;
-            void *recv = receiving ? (void *)(at + (part == 0 ? 0 : align_up(plan->recv_leaves[k_of[src]] * lay.leaf_bytes, 256))) : (void *)at;
-            if (int e = comm->all_to_all_v(comm->ctx, send, sb, recv, rbts, stream)) return (ibvh_status)e;
+        for (int r = 0; r < P; ++r) sb[r] = rbts[r] = 0;
+        const void *send = export_buf ? export_buf : (const void *)scratch;
+        void *recv = import_buf ? import_buf : scratch;
+        if (dst >= 0 && plan->touches[dst] && plan->send_leaves[dst] > 0) {
+            sb[dst] = plan->send_leaves[dst] * lay.leaf_bytes;
+            send = (const char *)export_buf + plan->send_offset[dst];
         }
+        if (src < P && k_of[src] >= 0) {
+            rbts[src] = plan->recv_leaves[k_of[src]] * lay.leaf_bytes;
+            recv = (char *)import_buf + plan->recv_offset[k_of[src]];
+        }
+        if (int e = comm->all_to_all_v(comm->ctx, send, sb, recv, rbts, stream)) return (ibvh_status)e;
     }
     return IBVH_OK;
 }
 
-ibvh_status ibvh_dist_cross_count(const ibvh_bvh *bvh, const ibvh_dist_cross_plan_t *plan, const void *import_buf, void *scratch,
+ibvh_status ibvh_dist_cross_count(const ibvh_bvh *bvh, const ibvh_dist_cross_plan_t *plan, void *import_buf, void *scratch,
                                   size_t scratch_bytes, int64_t *totals_out, int64_t *total_out, void *stream) {
     if (!bvh || !plan || !total_out) return IBVH_ERR_INVALID_ARG;
     *total_out = 0;
@@ -609,6 +767,18 @@ ibvh_status ibvh_dist_cross_count(const ibvh_bvh *bvh, const ibvh_dist_cross_pla
         CrossSizes z;
         if (!cross_sizes(bvh->types, plan->recv_leaves[k], bvh->tree.real_leaves, plan->cache_slots, z)) return IBVH_ERR_UNSUPPORTED;
         const ibvh_bvh other = imported_tree(*bvh, *plan, k, import_buf);
+        // an ordinary BVH over the received leaves, in place: their own extrema, Morton sort, bottom-up merge (thin shells of a
+        // slice: the sort's extra levels stay on)
+        ibvh_build_desc desc{};
+        desc.types = bvh->types;
+        desc.n = plan->recv_leaves[k];
+        desc.built_level = 1;
+        desc.already_wrapped = 1;
+        desc.compute_extrema = 1;
+        desc.sort_levels = 2;
+        const size_t build_room = (size_t)plan->scratch_bytes - (size_t)plan->build_offset;
+        if (ibvh_status e = ibvh_build(&desc, nullptr, (void *)other.leaves, (void *)other.nodes, (void *)other.skips, nullptr,
+                                       (char *)scratch + plan->build_offset, build_room, stream)) return e;
         char *counts = (char *)scratch + plan->scratch_offset[k];
         int64_t total = 0;
         // (own slice first: the pairs come out as (index in this slice, index in the other slice), both GLOBAL 1-based numbers)

@@ -242,13 +242,15 @@ class DistributedBuilder:
         L = lib.load()
         s = bvh.struct()
         k = api.LVT_CACHE_SLOTS if cache_slots is None else int(cache_slots)
-        small = torch.empty(64 * (comm.size + 1), dtype=torch.uint8, device="cuda")
+        small = torch.empty(abi.dist_cross_scratch(comm.size), dtype=torch.uint8, device="cuda")
         plan = abi.DistCrossPlan()
         vt.begin()
         vt.check("ibvh_dist_cross_plan", L.ibvh_dist_cross_plan(C.byref(vt.struct), C.byref(s), k, api._ptr(small), small.numel(), C.byref(plan),
                                                                 api._stream()))
+        exp = torch.empty(max(int(plan.export_bytes), 1), dtype=torch.uint8, device="cuda")
         imp = torch.empty(max(int(plan.import_bytes), 1), dtype=torch.uint8, device="cuda")
-        vt.check("ibvh_dist_cross_exchange", L.ibvh_dist_cross_exchange(C.byref(vt.struct), C.byref(s), C.byref(plan), api._ptr(imp), api._stream()))
+        vt.check("ibvh_dist_cross_exchange", L.ibvh_dist_cross_exchange(C.byref(vt.struct), C.byref(s), C.byref(plan), api._ptr(exp), api._ptr(imp),
+                                                                        api._ptr(small), small.numel(), api._stream()))
         scratch = torch.empty(max(int(plan.scratch_bytes), 1), dtype=torch.uint8, device="cuda")
         totals = (C.c_int64 * abi.DIST_MAX_RANKS)()
         total = C.c_int64()
@@ -257,6 +259,11 @@ class DistributedBuilder:
         out = torch.empty((int(total.value), 2), dtype=api._torch_index(bvh.types.index_type), device="cuda")
         vt.check("ibvh_dist_cross_write", L.ibvh_dist_cross_write(C.byref(s), C.byref(plan), api._ptr(imp), api._ptr(scratch), scratch.numel(), totals,
                                                                   api._ptr(out) if out.numel() else None, api._stream()))
-        self.last_cross = {"partners": [int(plan.recv_rank[i]) for i in range(plan.n_recv)], "import_bytes": int(plan.import_bytes),
-                           "pairs": [int(totals[i]) for i in range(plan.n_recv)]}
+        lay = abi.Layout()
+        lib.call("ibvh_layout_of", C.byref(bvh.types), C.byref(lay))
+        self.last_cross = {"partners": [int(plan.recv_rank[i]) for i in range(plan.n_recv)],
+                           "leaves_received": [int(plan.recv_leaves[i]) for i in range(plan.n_recv)],
+                           "bytes_received": int(sum(plan.recv_leaves[i] for i in range(plan.n_recv)) * lay.leaf_bytes),
+                           "bytes_sent": int(sum(plan.send_leaves[r] for r in range(comm.size)) * lay.leaf_bytes),
+                           "import_bytes": int(plan.import_bytes), "pairs": [int(totals[i]) for i in range(plan.n_recv)]}
         return out

@@ -78,9 +78,12 @@ mutable struct IbvhDistPlan
 end
 mutable struct IbvhDistCrossPlan
     size::Int32; rank::Int32; n_recv::Int32; cache_slots::Int32
-    import_bytes::Int64; scratch_bytes::Int64
+    import_bytes::Int64; scratch_bytes::Int64; export_bytes::Int64; build_offset::Int64
     recv_rank::NTuple{256, Int32}; recv_leaves::NTuple{256, Int64}; recv_offset::NTuple{256, Int64}; scratch_offset::NTuple{256, Int64}
     slice_leaves::NTuple{256, Int64}; touches::NTuple{256, Int32}
+    send_leaves::NTuple{256, Int64}; send_offset::NTuple{256, Int64}
+    n_boxes::NTuple{256, Int32}
+    boxes::NTuple{24576, Float64}
     IbvhDistCrossPlan() = new()
 end
 
@@ -225,10 +228,10 @@ c_dist_cross_plan(comm, bvh, cache_slots, scratch, sb, plan, stream) =
     ccall((:ibvh_dist_cross_plan, libibvh), Cint,
           (Ref{IbvhComm}, Ref{IbvhBvh}, Int32, Ptr{Cvoid}, Csize_t, Ref{IbvhDistCrossPlan}, Ptr{Cvoid}),
           comm, bvh, cache_slots, scratch, sb, plan, stream)
-c_dist_cross_exchange(comm, bvh, plan, import_buf, stream) =
+c_dist_cross_exchange(comm, bvh, plan, export_buf, import_buf, scratch, sb, stream) =
     ccall((:ibvh_dist_cross_exchange, libibvh), Cint,
-          (Ref{IbvhComm}, Ref{IbvhBvh}, Ref{IbvhDistCrossPlan}, Ptr{Cvoid}, Ptr{Cvoid}),
-          comm, bvh, plan, import_buf, stream)
+          (Ref{IbvhComm}, Ref{IbvhBvh}, Ref{IbvhDistCrossPlan}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+          comm, bvh, plan, export_buf, import_buf, scratch, sb, stream)
 c_dist_cross_count(bvh, plan, import_buf, scratch, sb, totals, total, stream) =
     ccall((:ibvh_dist_cross_count, libibvh), Cint,
           (Ref{IbvhBvh}, Ref{IbvhDistCrossPlan}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ref{Int64}, Ref{Int64}, Ptr{Cvoid}),
@@ -421,12 +424,14 @@ contact set of the whole cloud, every pair once (include/ibvh.h "Cross-shard con
 """
 function dist_cross_contacts(comm::IbvhComm, bvh::RocBVH{I}; cache_slots::Integer=LVT_CACHE_SLOTS) where {I}
     desc = bvh_desc(bvh)
-    small = scratch!(:dist_cross_plan, 64 * (Int(comm.size) + 1))
+    nsmall = (16 * 48 + 16) * (Int(comm.size) + 1) + 16 * Int(comm.size) + 512    # IBVH_DIST_CROSS_SCRATCH
+    small = scratch!(:dist_cross_plan, nsmall)
     plan = IbvhDistCrossPlan()
-    # blocks once: root boxes and leaf counts of all slices must reach the host before the transfers can be sized
-    check(c_dist_cross_plan(comm, desc, Int32(cache_slots), devptr(small), 64 * (Int(comm.size) + 1), plan, stream_ptr()), "ibvh_dist_cross_plan")
-    import_buf = similar(bvh.leaves, UInt8, max(Int(plan.import_bytes), 1))
-    check(c_dist_cross_exchange(comm, desc, plan, devptr(import_buf), stream_ptr()), "ibvh_dist_cross_exchange")
+    # blocks twice: the root boxes of all slices, then how many leaves every peer gets, must reach the host before the transfers can be sized
+    check(c_dist_cross_plan(comm, desc, Int32(cache_slots), devptr(small), nsmall, plan, stream_ptr()), "ibvh_dist_cross_plan")
+    export_buf = similar(bvh.leaves, UInt8, max(Int(plan.export_bytes), 1))   # the own leaves whose box touches a lower rank's root box
+    import_buf = similar(bvh.leaves, UInt8, max(Int(plan.import_bytes), 1))   # what the higher ranks send, + room for the trees built over it
+    check(c_dist_cross_exchange(comm, desc, plan, devptr(export_buf), devptr(import_buf), devptr(small), nsmall, stream_ptr()), "ibvh_dist_cross_exchange")
     scratch = scratch!(:dist_cross, max(Int(plan.scratch_bytes), 1))
     totals = zeros(Int64, 256)
     total = Ref{Int64}(0)

@@ -66,7 +66,7 @@ SIGNATURES = {
     "ibvh_dist_plan": [_P(abi.Types), _P(abi.Comm), _vp, _i64, C.c_double, _vp, _sz, _P(abi.DistPlan), _vp],
     "ibvh_dist_exchange": [_P(abi.Types), _P(abi.Comm), _vp, _P(abi.DistPlan), _vp, _sz, _vp, _vp],
     "ibvh_dist_cross_plan": [_P(abi.Comm), _P(abi.Bvh), _i32, _vp, _sz, _P(abi.DistCrossPlan), _vp],
-    "ibvh_dist_cross_exchange": [_P(abi.Comm), _P(abi.Bvh), _P(abi.DistCrossPlan), _vp, _vp],
+    "ibvh_dist_cross_exchange": [_P(abi.Comm), _P(abi.Bvh), _P(abi.DistCrossPlan), _vp, _vp, _vp, _sz, _vp],
     "ibvh_dist_cross_count": [_P(abi.Bvh), _P(abi.DistCrossPlan), _vp, _vp, _sz, _P(_i64), _P(_i64), _vp],
     "ibvh_dist_cross_write": [_P(abi.Bvh), _P(abi.DistCrossPlan), _vp, _vp, _sz, _P(_i64), _vp, _vp],
     "ibvh_comm_release": [_P(abi.Comm)],

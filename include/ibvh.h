@@ -507,34 +507,42 @@ ibvh_status ibvh_dist_exchange(const ibvh_types *types, const ibvh_comm *comm, c
 
 /* Cross-shard contact completion: the contacts between leaves of DIFFERENT slices, which the
  * per-slice self-traversals cannot see.  Root boxes and leaf counts of all slices are all-gathered; for every pair of slices
- * r < s whose boxes touch, rank s sends its sorted leaves and its nodes to rank r (P - 1 rounds of all_to_all_v over the same
- * vtable, straight out of the BVH's arrays into the receiver's import buffer) and rank r runs the ordinary pair traversal
- * (traverse(bvh_r, bvh_s), lvt/traverse_pair.jl) against each tree it received.  Per-slice self contacts + these pairs = the
- * contact set of the whole cloud, every pair once.  Count -> size -> write like everything else:
- *   _plan     collective; ONE host synchronisation; fills the plan: which trees this rank imports, import_bytes (the buffer
- *             the caller hands to _exchange), scratch_bytes (the traversal scratch for _count / _write, cache_slots as in
- *             ibvh_lvt_scratch_bytes).  `scratch` here: 64 * (size + 1) bytes of device memory for the all-gather.
+ * r < s whose boxes touch, rank s sends rank r the leaves whose own box touches one of r's boxes (a slice is described by
+ * <= 16 node boxes of its tree, refined from the root by always splitting the largest: a Morton slice is not convex) — a thin shell of its slice, not its tree — in P - 1 rounds of all_to_all_v over the same vtable; rank r builds an ordinary BVH over each set it received
+ * (ibvh_build, in place) and runs the ordinary pair traversal (traverse(bvh_r, bvh_s), lvt/traverse_pair.jl) against it.
+ * Per-slice self contacts + these pairs = the contact set of the whole cloud, every pair once.  Count -> size -> write:
+ *   _plan     collective; TWO host synchronisations (the boxes; how many leaves every peer gets); fills the plan:
+ *             export_bytes / import_bytes (the two buffers the caller hands to _exchange) and scratch_bytes (the scratch of
+ *             _count / _write: traversal scratch per imported set, cache_slots as in ibvh_lvt_scratch_bytes, + the build's).
+ *             `scratch` here and in _exchange: IBVH_DIST_CROSS_SCRATCH(size) bytes of device memory.
  *   _exchange collective (every rank calls it, also one that neither sends nor receives); asynchronous on `stream`.
- *   _count    pair-traversal counting passes against every imported tree; totals_out[k] (may be NULL) and *total_out: pairs.
- *   _write    contacts_out: *total_out IndexPair{I}, the pairs against imported tree 0 first: (index in THIS slice, index in
+ *   _count    per imported set: ibvh_build + the pair traversal's counting pass; totals_out[k] (may be NULL), *total_out: pairs.
+ *   _write    contacts_out: *total_out IndexPair{I}, the pairs against imported set 0 first: (index in THIS slice, index in
  *             the other slice), both GLOBAL 1-based leaf numbers (the records carry them).  `totals`: what _count returned.
  * The BVH must be fully built (built_level = 1).  Errors inside a collective sequence: the caller must abort the communicator
  * (a rank that returns early leaves its peers waiting). */
+#define IBVH_DIST_CROSS_BOXES 16
 typedef struct ibvh_dist_cross_plan_t {
-    int32_t size, rank, n_recv /* trees this rank imports */, cache_slots;
-    int64_t import_bytes, scratch_bytes;
-    int32_t recv_rank[IBVH_DIST_MAX_RANKS];      /* [n_recv] ascending: the ranks whose trees are imported                  */
-    int64_t recv_leaves[IBVH_DIST_MAX_RANKS];    /* [n_recv] leaves of that slice                                            */
-    int64_t recv_offset[IBVH_DIST_MAX_RANKS];    /* [n_recv] byte offset of that tree in the import buffer (leaves | nodes)  */
+    int32_t size, rank, n_recv /* leaf sets this rank imports */, cache_slots;
+    int64_t import_bytes, scratch_bytes, export_bytes, build_offset /* where the build's scratch starts in the scratch */;
+    int32_t recv_rank[IBVH_DIST_MAX_RANKS];      /* [n_recv] ascending: the ranks leaves are imported from                   */
+    int64_t recv_leaves[IBVH_DIST_MAX_RANKS];    /* [n_recv] how many                                                        */
+    int64_t recv_offset[IBVH_DIST_MAX_RANKS];    /* [n_recv] byte offset of that set in the import buffer (leaves | nodes | skips) */
     int64_t scratch_offset[IBVH_DIST_MAX_RANKS]; /* [n_recv] byte offset of its counts + traversal scratch                   */
     int64_t slice_leaves[IBVH_DIST_MAX_RANKS];   /* [size] leaves of every rank's slice                                      */
     int32_t touches[IBVH_DIST_MAX_RANKS];        /* [size] 1: this rank's root box touches rank r's (r != rank)              */
+    int64_t send_leaves[IBVH_DIST_MAX_RANKS];    /* [size] own leaves rank r gets (r < rank, boxes touching r's root box)    */
+    int64_t send_offset[IBVH_DIST_MAX_RANKS];    /* [size] where they are compacted in the export buffer                     */
+    int32_t n_boxes[IBVH_DIST_MAX_RANKS];        /* [size] boxes that describe rank r's slice (1 .. IBVH_DIST_CROSS_BOXES)   */
+    double boxes[IBVH_DIST_MAX_RANKS][IBVH_DIST_CROSS_BOXES][6]; /* [size] ... node boxes of its tree, refined greedily (lo, up) */
 } ibvh_dist_cross_plan_t;
+/* device bytes _plan and _exchange need as `scratch` for `size` ranks */
+#define IBVH_DIST_CROSS_SCRATCH(size) ((size_t)(IBVH_DIST_CROSS_BOXES * 48 + 16) * ((size_t)(size) + 1) + (size_t)16 * (size_t)(size) + 512)
 ibvh_status ibvh_dist_cross_plan(const ibvh_comm *comm, const ibvh_bvh *bvh, int32_t cache_slots, void *scratch, size_t scratch_bytes,
                                  ibvh_dist_cross_plan_t *plan_out, void *stream);
-ibvh_status ibvh_dist_cross_exchange(const ibvh_comm *comm, const ibvh_bvh *bvh, const ibvh_dist_cross_plan_t *plan, void *import_buf,
-                                     void *stream);
-ibvh_status ibvh_dist_cross_count(const ibvh_bvh *bvh, const ibvh_dist_cross_plan_t *plan, const void *import_buf, void *scratch,
+ibvh_status ibvh_dist_cross_exchange(const ibvh_comm *comm, const ibvh_bvh *bvh, const ibvh_dist_cross_plan_t *plan, void *export_buf,
+                                     void *import_buf, void *scratch, size_t scratch_bytes, void *stream);
+ibvh_status ibvh_dist_cross_count(const ibvh_bvh *bvh, const ibvh_dist_cross_plan_t *plan, void *import_buf, void *scratch,
                                   size_t scratch_bytes, int64_t *totals_out, int64_t *total_out, void *stream);
 ibvh_status ibvh_dist_cross_write(const ibvh_bvh *bvh, const ibvh_dist_cross_plan_t *plan, const void *import_buf, void *scratch,
                                   size_t scratch_bytes, const int64_t *totals, void *contacts_out, void *stream);

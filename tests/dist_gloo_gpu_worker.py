@@ -78,7 +78,10 @@ bvh2 = builder.build(vols, cache=bvh)  # the time-stepping shape: buffers reused
 own = ibvh.traverse(bvh).contacts
 cross = builder.cross_contacts(bvh)
 torch.cuda.synchronize()
-assert comm.calls["all_to_all"] >= 1 + 2 * (world - 1) and comm.calls["all_gather"] >= 2, comm.calls
+# two builds (one record exchange each) + the cross-shard completion (the counts, then world - 1 rounds of selected leaves)
+assert comm.calls["all_to_all"] >= 2 + 1 + (world - 1) and comm.calls["all_gather"] >= 2, comm.calls
+lb = builder.last_cross
+assert all(0 < c <= int(sizes_hint) for c in lb["leaves_received"]) if (sizes_hint := n) else True
 if tol == 0.0:
     assert builder.last["levels_used"] > 12, builder.last["levels_used"]  # refined below the first 12-bit digit: counts were exchanged
 # the single-device build of ALL leaves, made by this rank for itself

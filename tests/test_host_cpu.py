@@ -239,7 +239,7 @@ def test_julia_pod_structs_match_the_header_mirror():
     from implicitbvh_amd import abi
     src = _julia_ext()
     width = {"Int32": 4, "Int64": 8, "Ptr{Cvoid}": 8, "NTuple{3, Float64}": 24, "IbvhTypes": C.sizeof(abi.Types), "IbvhTree": C.sizeof(abi.Tree),
-             "NTuple{6, Float64}": 48, "NTuple{256, UInt64}": 2048, "NTuple{256, Int64}": 2048, "NTuple{256, Int32}": 1024}
+             "NTuple{6, Float64}": 48, "NTuple{256, UInt64}": 2048, "NTuple{256, Int64}": 2048, "NTuple{256, Int32}": 1024, "NTuple{24576, Float64}": 196608}
     for jname, ctype in (("IbvhTypes", abi.Types), ("IbvhTree", abi.Tree), ("IbvhBvh", abi.Bvh), ("IbvhBuildDesc", abi.BuildDesc),
                          ("IbvhBfsResult", abi.BfsResult), ("IbvhComm", abi.Comm), ("IbvhDistPlan", abi.DistPlan), ("IbvhDistCrossPlan", abi.DistCrossPlan)):
         body = re.search(r"struct " + jname + r"\n(.*?)\nend", src, re.S).group(1)
