@@ -33,7 +33,11 @@ def find_splitters(engine, comm, keys, key_bits, n_global, tolerance, first_hist
     return [int(s.splitters[k]) for k in range(comm.size - 1)], int(s.decided)
 
 
-# (the CPU restatement of ibvh_dist_cross_* — csrc/ibvh_distdrv.hip — for engines without a GPU)
+# The cross-shard completion in its SIMPLEST form, for engines without a GPU: whole trees of touching slices change hands and the
+# ordinary pair traversal runs against them.  The product (ibvh_dist_cross_*, csrc/ibvh_distdrv.hip) ships only the leaves whose
+# box touches the receiver's boxes and builds a tree over them on arrival — fewer bytes, the same contact SET; the GPU tests
+# (test_gpu_dist_procs.py, test_gpu_parity.py, test_gpu_dist.py) hold the product to the single-device list, this CPU version
+# pins what that list is for sharded builds.
 def cross_contacts(comm, eng, types, n_slice, bvh):
     """Cross-shard contact completion: contacts between leaves of DIFFERENT slices.
 
