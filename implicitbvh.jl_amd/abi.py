@@ -70,7 +70,7 @@ class BuildDesc(C.Structure):
     _fields_ = [("types", Types), ("n", C.c_int64), ("built_level", C.c_int64),
                 ("already_wrapped", C.c_int32), ("compute_extrema", C.c_int32),
                 ("mins", C.c_double * 3), ("maxs", C.c_double * 3),
-                ("sort_levels", C.c_int32), ("reserved_", C.c_int32), ("skew_flag", C.c_void_p)]
+                ("sort_levels", C.c_int32), ("sort_equalize", C.c_int32), ("skew_flag", C.c_void_p)]
 
 
 class BfsResult(C.Structure):

@@ -419,6 +419,18 @@ class _HintWord:
     def __setitem__(self, i, v):
         _host_words().words[self.slot] = int(v)
 
+    def equalize(self):
+        """Bit 16: the last build ran with equalised cells and the plain grid would still have had a crowded cell."""
+        return (int(_host_words().words[self.slot]) >> 16) & 1
+
+    def apply(self, d):
+        """sort_levels / sort_equalize of a rebuild from what the chain's previous build left in the word (read ONCE)."""
+        word = int(_host_words().words[self.slot])
+        used, occupancy, eq = word & 0xff, (word >> 8) & 0xff, (word >> 16) & 1
+        spare = used > 0 or occupancy >= SPARE_OCCUPANCY or d.n >= SPARE_ALWAYS_FROM
+        d.sort_levels = min(used + (1 if spare else 0), abi.MAX_SORT_LEVELS)
+        d.sort_equalize = 1 if (used > 0 or eq) and EQUALIZE else 0
+
 
 _host_words_singleton = None
 
@@ -461,9 +473,7 @@ class BVH:
             self.tree, self.built_level, self.types = cache.tree, cache.built_level, cache.types
             self.skips, self.nodes, self._scratch = cache.skips, cache.nodes, cache._scratch
             self.leaves, self.extrema, self._skew, self._fast = cache.leaves, cache.extrema, cache._skew, fast
-            used = self._skew[0]
-            spare = used > 0 or self._skew.occupancy() >= SPARE_OCCUPANCY or d.n >= SPARE_ALWAYS_FROM
-            d.sort_levels = min(used + (1 if spare else 0), abi.MAX_SORT_LEVELS)
+            self._skew.apply(d)
             lib.call("ibvh_build", C.byref(d), _ptr(bounding_volumes), _ptr(self.leaves.buf), _ptr(self.nodes), _ptr(self.skips),
                      _ptr(self.extrema), _ptr(self._scratch), self._scratch.numel(), _stream())
             return
@@ -477,9 +487,7 @@ class BVH:
             self.tree, self.built_level, self.types = cache.tree, cache.built_level, cache.types
             self.skips, self.nodes, self._scratch = cache.skips, cache.nodes, cache._scratch
             self.leaves, self.extrema, self._skew, self._fast = cache.leaves, cache.extrema, cache._skew, fast
-            used = self._skew[0]
-            spare = used > 0 or self._skew.occupancy() >= SPARE_OCCUPANCY or d.n >= SPARE_ALWAYS_FROM
-            d.sort_levels = min(used + (1 if spare else 0), abi.MAX_SORT_LEVELS)
+            self._skew.apply(d)
             lib.call("ibvh_build", C.byref(d), C.c_void_p(0), _ptr(self.leaves.buf), _ptr(self.nodes), _ptr(self.skips),
                      _ptr(self.extrema), _ptr(self._scratch), self._scratch.numel(), _stream())
             return
@@ -585,7 +593,6 @@ class BVH:
         if not alg.compute_extrema:
             d.mins[:] = [float(v) for v in alg.mins]
             d.maxs[:] = [float(v) for v in alg.maxs]
-        used = self._skew[0]
         # A SPARE extra level (four launches that find nothing to do: ~15 us per step at 1e6 leaves) whenever the chain is
         # anywhere near needing one: the previous build used extra levels, or its fullest cell was beyond SPARE_OCCUPANCY
         # of what a finish workgroup sorts — a cloud that contracts or clusters over many steps reaches that long before
@@ -594,8 +601,13 @@ class BVH:
         # tools/dbg_spike.py) and the hint it leaves fixes the next.  That path's cost grows with the cell (~0.1 s at 1e7
         # leaves) while the idle level's share of a step shrinks (1 % at 1e7), so builds of SPARE_ALWAYS_FROM leaves and
         # more always launch the spare level.  SPARE_OCCUPANCY = 0 restores "always" at every size.
-        spare = used > 0 or self._skew.occupancy() >= SPARE_OCCUPANCY or n >= SPARE_ALWAYS_FROM
-        d.sort_levels = COLD_SORT_LEVELS if cache is None else min(used + (1 if spare else 0), abi.MAX_SORT_LEVELS)
+        # EQUALISED cells (include/ibvh.h, sort_equalize) once the chain's input has shown that it does not fill the grid: the
+        # previous build needed extra levels, or — itself built with equalised cells — reported that the plain grid would still
+        # have had a crowded cell (bit 16 of the hint).  A cloud that fills its box never pays the two extra launches.
+        if cache is None:
+            d.sort_levels, d.sort_equalize = COLD_SORT_LEVELS, 0
+        else:
+            self._skew.apply(d)
         d.skew_flag = self._skew.ptr()
         lib.call("ibvh_build", C.byref(d), vol_ptr, _ptr(self.leaves.buf), _ptr(self.nodes), _ptr(self.skips),
                  _ptr(self.extrema), _ptr(self._scratch), self._scratch.numel(), _stream())
@@ -782,6 +794,7 @@ def _cache_tensor(cache_t, need_rows, cols, dtype, what):
     return cache_t
 
 
+EQUALIZE = True  # rebuilds of a chain whose input is skewed ask for equalised cells (False: the regular grid + extra levels, always)
 COLD_SORT_LEVELS = 2  # extra partition levels a build without cache= launches (include/ibvh.h, sort_levels)
 SPARE_OCCUPANCY = 96  # (of 128) fullest coarse cell from which a cached build launches a spare extra level (BVH.__init__)
 SPARE_ALWAYS_FROM = 1 << 24  # leaves from which a cached build always launches it (the slow path it avoids grows with the input,

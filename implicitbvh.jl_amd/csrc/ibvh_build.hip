@@ -686,8 +686,8 @@ ibvh_status ibvh_build(const ibvh_build_desc *desc, const void *volumes, void *l
             // index (:220-222); in-place builds read `leaves`, stage in scratch and write `leaves`: no extra copy.
             rsort::RecordArgs ra{src, sc.records, src_stride, wrapped ? 1 : 0, (int32_t)(lay.volume_bytes / 8),
                                  ty.index_type == IBVH_I32 ? 4 : 8, dlay};
-            if (int e = msd::sort_records(mp, key_bytes, sc.keys, n, ra, sc.records2, (char *)leaves, sc.keys_alt, (uint32_t *)sc.vals_alt, sc.keys,
-                                          (uint32_t *)sc.vals, desc->sort_levels, desc->skew_flag, st))
+            if (int e = msd::sort_records(mp, key_bytes, key_bits, sc.keys, n, ra, sc.records2, (char *)leaves, sc.keys_alt, (uint32_t *)sc.vals_alt, sc.keys,
+                                          (uint32_t *)sc.vals, desc->sort_levels, desc->sort_equalize != 0, desc->skew_flag, st))
                 return e;
             return aggregate<L, N>((const char *)leaves, lay.leaf_bytes, tree, desc->built_level, (N *)nodes, st);
         }

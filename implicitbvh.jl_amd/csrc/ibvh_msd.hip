@@ -131,12 +131,190 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_tiles_kernel(const uint32_t *__
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Equalised cells (round 5; the caller asks for them: ibvh_build_desc.sort_equalize).  "Cell = top bits of the key" is right
+// for a cloud that fills its bounding box; a surface mesh fills a fraction of that grid's cells and a clustered cloud a
+// handful, and every crowded cell then goes through an extra partition level — a second move of (nearly) all the records.
+// Here the cells are key RANGES of about equal population instead: one workgroup sorts a strided sample of the keys in
+// LDS and takes every (S / R)-th one as a splitter; a histogram pass finds every leaf's cell by binary search over the
+// R splitters (in LDS) and leaves it in a 2-byte side array, so that the partition ranks by a table look-up instead of a
+// shift.  Cells are still contiguous, ascending key ranges: stability and everything behind the partition (finish by key
+// range, extra levels for cells that are crowded regardless — many equal keys) stay as they are.
+// ------------------------------------------------------------------------------------------------------------
+// The sample: S = 1,024 * G keys at evenly spaced positions, dealt round-robin to G lists.  sample_sort_kernel (one small workgroup
+// per list, each on its own CU: one workgroup sorting all 16,384 took 77 us — the LDS radix passes are latency chains — G of
+// 1,024 take ~8) sorts every list in LDS; sample_rank_kernel gives every sample its rank in the union (its place in its own list +
+// a binary search in each of the others, ties broken by list number: a strict total order) and the samples whose rank is a
+// multiple of S / R become the splitter candidates.
+template <class K> struct SampleGeom {
+    static constexpr int LIST = 1024, G = sizeof(K) == 8 ? 8 : 16, S = LIST * G; // (S keys must fit the rank kernel's LDS: 64 KiB)
+    static constexpr int TPB = 256, IPT = LIST / TPB, RB = 8;
+    static constexpr size_t sort_smem = (size_t)LIST * sizeof(K) + ((size_t)4 << RB) + 32 * 4 + (size_t)(TPB / 64) * ((size_t)2 << RB);
+};
+template <class K>
+__global__ __launch_bounds__(256) void sample_sort_kernel(const K *__restrict__ keys, int64_t n, K *__restrict__ lists, int key_bits) {
+    using G = SampleGeom<K>;
+    constexpr int TPB = G::TPB, IPT = G::IPT, RB = G::RB, R = 1 << RB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
+    K *s_keys = (K *)bsm;
+    uint32_t *local_base = (uint32_t *)(s_keys + G::LIST);
+    uint32_t *wave_tot = local_base + R;
+    uint16_t *whist = (uint16_t *)(wave_tot + 32);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int chunk = 64 * IPT;
+    K key[IPT];
+    const rsort::NoVal none[IPT] = {};
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        // sample number (place in this list) * G + list: every list spans the whole input (n < S: leaves are taken more than once — harmless)
+        const uint64_t smp = (uint64_t)(w * chunk + j * 64 + lane) * (uint64_t)G::G + blockIdx.x;
+        key[j] = keys[(smp * (uint64_t)n) / (uint64_t)G::S]; // (S is a power of two: a shift)
+    }
+    const int passes = (key_bits + RB - 1) / RB;
+    int done = 0;
+    for (int p = 0; p < passes; ++p) {
+        const int b = (key_bits - done + (passes - p) - 1) / (passes - p);
+        lds_radix_pass<K, rsort::NoVal, TPB, IPT, RB>(key, none, done, b, IPT, s_keys, (rsort::NoVal *)nullptr, local_base, wave_tot, whist);
+        done += b;
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) key[j] = s_keys[w * chunk + j * 64 + lane];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) lists[(int64_t)blockIdx.x * G::LIST + w * chunk + j * 64 + lane] = key[j];
+}
+// number of keys of the sorted list L[0 .. 1,024) that are < e (OR_EQUAL: <= e)
+template <class K, bool OR_EQUAL> IBVH_D uint32_t list_count(const K *L, K e) {
+    uint32_t base = 0;
+#pragma unroll
+    for (uint32_t half = 512; half >= 1; half >>= 1) {
+        const K v = L[base + half - 1];
+        base += (OR_EQUAL ? v <= e : v < e) ? half : 0u;
+    }
+    const K v = L[base];
+    return base + ((OR_EQUAL ? v <= e : v < e) ? 1u : 0u);
+}
+template <class K>
+__global__ __launch_bounds__(1024) void sample_rank_kernel(const K *__restrict__ lists, K *__restrict__ cand, int bits) {
+    using G = SampleGeom<K>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
+    K *s = (K *)bsm;
+    for (int i = threadIdx.x; i < G::S; i += 1024) s[i] = lists[i];
+    __syncthreads();
+    const int g = blockIdx.x;
+    const K e = s[g * G::LIST + threadIdx.x];
+    uint32_t rank = threadIdx.x;
+#pragma unroll
+    for (int o = 0; o < G::G; ++o) {
+        if (o == g) continue; // (workgroup-uniform)
+        rank += o < g ? list_count<K, true>(s + o * G::LIST, e) : list_count<K, false>(s + o * G::LIST, e);
+    }
+    const uint32_t per = (uint32_t)G::S >> bits;
+    if ((rank & (per - 1u)) == 0) cand[rank / per] = e;
+}
+
+// per tile of `tile` source leaves: every leaf's cell (the last splitter <= its key) and the tile's row of the histogram.  Every
+// workgroup makes the splitters out of the candidates for itself (workgroup 0 also leaves them, and the verdict for the caller's
+// hint, for the kernels behind it): splitter d = candidate d (the sample of rank d * S / R), except that a key that fills a whole
+// cell's worth of samples — two candidates in a row are equal — gets a cell of its own, [v, v + 1): however many records carry it,
+// they need no sorting (one extra level copies them out), and they no longer share a cell and its fate with what follows them.
+template <class K>
+__global__ __launch_bounds__(512) void bucket_hist_kernel(const K *__restrict__ keys, int64_t n, Tables tb, const K *__restrict__ cand, int bits,
+                                                         int tile, int key_bits, uint32_t cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
+    const int radix = 1 << bits;
+    // The splitters as an implicit search tree in breadth-first order (node k: children 2k, 2k + 1; level L = nodes [2^L, 2^(L+1))):
+    // a binary search over the SORTED array reads addresses a large power of two apart in its first steps — all in one LDS bank,
+    // a 2^L-way conflict at step L — while here the nodes of a level are neighbours: no conflicts down to level 5, random below.
+    K *eyt = (K *)bsm; // [1, radix): node k of level L, place j in its level = splitter (2j + 1) * radix / 2^(L+1)
+    uint32_t *h = (uint32_t *)(eyt + radix);
+    for (int k = threadIdx.x; k < radix; k += 512) {
+        h[k] = 0;
+        // splitter d, for the sorted copy workgroup 0 leaves behind
+        {
+            const int d = k;
+            const K c = cand[d], prev = cand[d > 0 ? d - 1 : 0];
+            const K v = d == 0 ? (K)0 : ((d >= 2 && c == prev) ? (K)(c + 1) : c);
+            if (blockIdx.x == 0) ((K *)tb.splitters)[d] = v;
+        }
+        if (k >= 1) {
+            const int L = 31 - __builtin_clz((unsigned)k), j = k - (1 << L);
+            const int d = (2 * j + 1) * (radix >> (L + 1));
+            const K c = cand[d], prev = cand[d - 1];
+            eyt[k] = (d >= 2 && c == prev) ? (K)(c + 1) : c;
+        }
+    }
+    if (blockIdx.x == 0) {
+        // the verdict: would the plain grid (cell = top `bits` bits) have had a crowded cell?  Crowded = clearly more samples in one
+        // cell than a full finish workgroup's share (lambda + 4 sqrt(lambda), in whole candidates: a cloud that fills its box stays
+        // below).  While it would, the caller keeps asking for equalised cells; the plain route is cheaper for an input that fits.
+        constexpr int S = SampleGeom<K>::S;
+        const int shift = key_bits - bits, per = S >> bits;
+        const float lambda = (float)cap * (float)S / (float)(n > 0 ? n : 1);
+        const float kf = (lambda + 4.0f * __builtin_sqrtf(lambda)) / (float)per + 1.0f;
+        const int m = kf >= (float)radix ? radix : (int)kf;
+        int crowded = 0;
+        for (int d = threadIdx.x + 1; d + m < radix; d += 512) crowded |= (int)((cand[d] >> shift) == (cand[d + m] >> shift));
+        crowded = __syncthreads_or(crowded);
+        if (threadIdx.x == 0) {
+            tb.needed[2] = crowded ? 1u : 0u;
+            ((K *)tb.splitters)[radix] = (K) ~(K)0;
+        }
+    }
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * tile;
+    constexpr int U = 4;
+    for (int j0 = threadIdx.x; j0 < tile; j0 += 512 * U) {
+        K k[U];
+        uint32_t lo[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + j0 + u * 512;
+            k[u] = keys[i < n ? i : n - 1];
+            lo[u] = 1;
+        }
+        for (int step = 0; step < bits; ++step) { // (the cell = the number of splitters 1 .. radix - 1 that are <= the key)
+#pragma unroll
+            for (int u = 0; u < U; ++u) lo[u] = 2u * lo[u] + (eyt[lo[u]] <= k[u] ? 1u : 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) lo[u] -= (uint32_t)radix;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + j0 + u * 512;
+            const bool valid = j0 + u * 512 < tile && i < n;
+            // (input in a coherent order — a mesh — puts most of a wave's 64 consecutive leaves into ONE cell: one LDS atomic for
+            // all lanes that share the first lane's cell instead of 64 on the same address)
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo[u]);
+            const uint64_t shared = __ballot(valid && lo[u] == first);
+            if (valid) {
+                if (lo[u] != first) atomicAdd(&h[lo[u]], 1u);
+                else if ((shared & (((uint64_t)1 << (threadIdx.x & 63)) - 1)) == 0) atomicAdd(&h[first], (uint32_t)__popcll(shared));
+                tb.dig[i] = (uint16_t)lo[u];
+            }
+        }
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < radix; d += 512) tb.tile_hist[(int64_t)blockIdx.x * radix + d] = h[d];
+}
+
+// cell d of the equalised route holds the keys in [lo, lo + 2^nbits): its first splitter and the bits that may vary behind it
+template <class K> IBVH_D void cell_range(const Tables &tb, uint32_t d, int radix, int key_bits, K *lo_out, int *nbits_out) {
+    const K *spl = (const K *)tb.splitters;
+    const K lo = spl[d];
+    const K hi = (K)((d + 1 < (uint32_t)radix ? spl[d + 1] : (K)((K)1 << key_bits)) - (K)1); // (inclusive; a non-empty cell has hi >= lo)
+    const uint64_t span = (uint64_t)(K)(hi - lo);
+    *lo_out = lo;
+    *nbits_out = span == 0 ? 0 : 64 - __builtin_clzll(span);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // plan (one workgroup): cell starts (every later kernel reads them instead of re-deriving them); the crowded cells
 // (more than `cap` records) become the segments of the first extra level, with their tiles (`tile` records each)
 // ------------------------------------------------------------------------------------------------------------
 constexpr int PLAN_TPB = 1024;
 IBVH_D uint32_t segment_tiles(uint32_t count, uint32_t tile);
-__global__ __launch_bounds__(PLAN_TPB) void plan_kernel(Tables tb, int radix, uint32_t cap, uint32_t tile, int levels, int shift1) {
+__global__ __launch_bounds__(PLAN_TPB) void plan_kernel(Tables tb, int radix, uint32_t cap, uint32_t tile, int levels, int shift1, int eq_key_bytes,
+                                                        int key_bits) {
     constexpr int PER = (1 << MSD_MAX_BITS) / PLAN_TPB; // cells per thread, at most
     __shared__ uint32_t wave_tot[PLAN_TPB / 64];
     __shared__ uint32_t s_tbase[(1 << MSD_MAX_BITS) + 1]; // first tile of every segment, for the tile -> segment search
@@ -182,8 +360,28 @@ __global__ __launch_bounds__(PLAN_TPB) void plan_kernel(Tables tb, int radix, ui
                     L.seg_count[kk] = tot[k];
                     L.seg_tile[kk] = tt;
                     // (bounds; range_kernel + hist_level_kernel replace them by what the keys really span)
-                    L.seg_and[kk] = (uint64_t)d << shift1;
-                    L.seg_or[kk] = ((uint64_t)d << shift1) | (((uint64_t)1 << shift1) - 1);
+                    if (eq_key_bytes) { // equalised cells: the key range between two splitters -> its common prefix, everything below
+                        uint64_t lo;
+                        int nb;
+                        if (eq_key_bytes == 8) {
+                            uint64_t l8;
+                            cell_range<uint64_t>(tb, (uint32_t)d, radix, key_bits, &l8, &nb);
+                            lo = l8;
+                        } else {
+                            uint32_t l4;
+                            cell_range<uint32_t>(tb, (uint32_t)d, radix, key_bits, &l4, &nb);
+                            lo = l4;
+                        }
+                        const uint64_t hi = lo + (nb >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << nb) - 1)); // (>= the cell's last key)
+                        const uint64_t x = lo ^ hi;
+                        const int hb = x ? 64 - __builtin_clzll(x) : 0;
+                        const uint64_t fixed = hb >= 64 ? 0 : (lo >> hb) << hb;
+                        L.seg_and[kk] = fixed;
+                        L.seg_or[kk] = fixed | (hb >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << hb) - 1));
+                    } else {
+                        L.seg_and[kk] = (uint64_t)d << shift1;
+                        L.seg_or[kk] = ((uint64_t)d << shift1) | (((uint64_t)1 << shift1) - 1);
+                    }
                 }
                 s_tbase[kk] = tt;
                 kk += 1;
@@ -515,7 +713,8 @@ IBVH_D void stage_rows(const uint64_t *__restrict__ src, uint32_t src_words, uin
 // occupancy the LDS stage allows (24-byte records): pinned so the layout switch cannot push the VGPR count over a step
 constexpr int partition_min_waves(int tpb, int ipt) { return tpb * ipt <= 2048 ? 3 : 2; }
 
-template <class K, int TPB, int IPT, bool L2>
+// EQ (level 1 only): the digit of a leaf is its equalised cell, read from tb.dig (bucket_hist_kernel) instead of shifted out of the key
+template <class K, int TPB, int IPT, bool L2, bool EQ = false>
 __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_kernel(const K *__restrict__ keys, int64_t n, int shift, int bits,
                                                         Tables tb, int num_tiles, RecordArgs rec, uint32_t inv_words, int digit_bits,
                                                         int li, char *out, K *__restrict__ side_out) {
@@ -531,6 +730,7 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
     uint32_t *wave_tot = delta + radix;              // 32
     uint64_t *stage = (uint64_t *)(wave_tot + 32);
     uint16_t *whist = (uint16_t *)stage;             // W * radix
+    uint16_t *sdig = (uint16_t *)((unsigned char *)stage + (size_t)TILE * (size_t)rec.lay.stride); // EQ: the digit of every staged record
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int64_t tile_base, end;         // the tile's records are [tile_base, min(tile_base + TILE, end))
@@ -590,6 +790,14 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
         const int64_t ic = i < end ? i : end - 1;
         key[j] = keys[ic]; // (extra levels: the compact keys the partition before wrote; same index space as the records)
     }
+    uint32_t dk[EQ ? IPT : 1];
+    if constexpr (EQ) {
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const int64_t i = wave_base + j * 64 + lane;
+            dk[j] = i < end ? (uint32_t)tb.dig[i] : mask; // (past the end: the last digit, like the sentinel keys)
+        }
+    }
     // 16-byte fresh volumes (BSphere{Float32}, the common case) are requested now and stay in flight while the keys are
     // ranked (the barriers below do not wait for them); other layouts are fetched when they are staged
     const uint32_t src_words = (uint32_t)(rec.src_stride / 8);
@@ -616,7 +824,8 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
     IBVH_STAMP(0, 1);
     uint16_t rank[IPT];
     uint16_t *my_hist = whist + w * radix;
-    wave_rank<K, IPT>(key, shift, mask, digit_bits, my_hist, lane, rank);
+    if constexpr (EQ) wave_rank<uint32_t, IPT>(dk, 0, mask, digit_bits, my_hist, lane, rank);
+    else wave_rank<K, IPT>(key, shift, mask, digit_bits, my_hist, lane, rank);
     lds_barrier();
     IBVH_STAMP(0, 2);
     // per digit: exclusive prefix over the waves (in place), tile total
@@ -681,10 +890,17 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
     uint32_t pos[IPT];
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
-        const uint32_t d = (uint32_t)(key[j] >> shift) & mask;
+        uint32_t d;
+        if constexpr (EQ) d = dk[j];
+        else d = (uint32_t)(key[j] >> shift) & mask;
         pos[j] = local_base[d] + my_hist[d] + rank[j];
     }
     lds_barrier(); // every wave is done with whist: its bytes become the stage
+    if constexpr (EQ) {
+#pragma unroll
+        for (int j = 0; j < IPT; ++j)
+            if (wave_base + j * 64 + lane < end) sdig[pos[j]] = (uint16_t)dk[j];
+    }
     IBVH_STAMP(0, 5);
     // the records: sources are read in memory order (coalesced) and land at their sorted place in the stage
     const TailLayout tl{rec.vol_words * 8, wrapped ? -64 : rec.lay.index_off, rec.lay.morton_off, rec.index_bytes, rec.lay.morton_bytes};
@@ -741,7 +957,8 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
             const uint32_t gc = g < total ? g : 0u;
             rr[u] = __umulhi(gc, inv_words);
             v[u] = stage[gc];
-            kd[u] = (uint32_t)((K)load_morton(stage_bytes + rr[u] * (uint32_t)rec.lay.stride, rec.lay) >> shift) & mask;
+            if constexpr (EQ) kd[u] = sdig[rr[u]];
+            else kd[u] = (uint32_t)((K)load_morton(stage_bytes + rr[u] * (uint32_t)rec.lay.stride, rec.lay) >> shift) & mask;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) kd[u] = delta[kd[u]];
@@ -759,7 +976,8 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
         if (side_out != nullptr && nli < MAX_LEVELS && tb.lvl[nli < MAX_LEVELS ? nli : 0].hdr[0] != 0) {
             for (uint32_t r = threadIdx.x; r < valid; r += TPB) {
                 const K kk = (K)load_morton(stage_bytes + r * (uint32_t)rec.lay.stride, rec.lay);
-                side_out[r + delta[(uint32_t)(kk >> shift) & mask]] = kk;
+                if constexpr (EQ) side_out[r + delta[sdig[r]]] = kk;
+                else side_out[r + delta[(uint32_t)(kk >> shift) & mask]] = kk;
             }
         }
     }
@@ -770,8 +988,8 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
     }
     } // rp
 }
-template <class K, int TPB, int IPT> inline size_t partition_smem(int bits, int stride) {
-    const size_t hist = (size_t)(TPB / 64) * ((size_t)2 << bits), st = (size_t)TPB * IPT * (size_t)stride;
+template <class K, int TPB, int IPT> inline size_t partition_smem(int bits, int stride, bool eq = false) {
+    const size_t hist = (size_t)(TPB / 64) * ((size_t)2 << bits), st = (size_t)TPB * IPT * (size_t)stride + (eq ? (size_t)TPB * IPT * 2 : 0);
     return ((size_t)8 << bits) + 128 + (hist > st ? hist : st);
 }
 
@@ -789,6 +1007,7 @@ struct FinishArgs {
     uint32_t tile;      // tile of the extra levels = window of sub-cells one workgroup finishes
     int levels;         // extra levels that ran; what is still crowded after them takes the slow path
     int shift1;         // key >> shift1 = cell
+    int eq_key_bits;    // != 0: equalised cells (cell d = the keys between splitters d and d + 1); the number of key bits
     int32_t *skew_flag; // caller's hint word (may be null): receives `needed`
     // slow path only: (key, position) arrays of n entries each
     void *kalt, *kpri;
@@ -1067,11 +1286,19 @@ __global__ __launch_bounds__(TPB) void finish_kernel(Tables tb, int radix, Finis
     extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
     const FinishLds<K, TPB, IPT> l(bsm, RES ? fa.resident_off : 0u);
     IBVH_STAMP(1, 0);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && fa.skew_flag) *fa.skew_flag = (int32_t)(tb.needed[0] | (tb.needed[1] << 8));
+    if (blockIdx.x == 0 && threadIdx.x == 0 && fa.skew_flag)
+        *fa.skew_flag = (int32_t)(tb.needed[0] | (tb.needed[1] << 8) | (fa.eq_key_bits ? (tb.needed[2] & 1u) << 16 : 0u));
     if ((int)blockIdx.x < radix) {
         const uint32_t d = blockIdx.x;
         const uint32_t start = uni(tb.cell_start[d]), m = uni(tb.cell_start[d + 1]) - start;
         if (m == 0 || (m > fa.cap && fa.levels > 0)) return; // (crowded cells are finished window by window below)
+        if (fa.eq_key_bits) {
+            K lo;
+            int nb;
+            cell_range<K>(tb, d, radix, fa.eq_key_bits, &lo, &nb);
+            finish_range<K, TPB, IPT, RES>(fa, l, fa.buf[0], (int64_t)start, (int64_t)m, (K)uni(lo), __builtin_amdgcn_readfirstlane(nb));
+            return;
+        }
         finish_range<K, TPB, IPT, RES>(fa, l, fa.buf[0], (int64_t)start, (int64_t)m, (K)((K)d << fa.shift1), fa.shift1);
         return;
     }
@@ -1152,7 +1379,7 @@ template <class K, int TPB, int IPT> constexpr size_t finish_smem() {
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
-static size_t carve_tables(Tables *tb, char *base, int radix, int num_tiles, int max_seg, int max_tiles2) {
+static size_t carve_tables(Tables *tb, char *base, int radix, int num_tiles, int max_seg, int max_tiles2, int64_t n) {
     size_t off = 0;
     auto take = [&](size_t bytes) {
         uint32_t *p = base ? (uint32_t *)(base + off) : nullptr;
@@ -1169,6 +1396,8 @@ static size_t carve_tables(Tables *tb, char *base, int radix, int num_tiles, int
     t.tile_scan2 = take((size_t)max_tiles2 * 4 << L2_BITS);
     t.tile_and = (uint64_t *)take((size_t)max_tiles2 * 8);
     t.tile_or = (uint64_t *)take((size_t)max_tiles2 * 8);
+    t.splitters = take(((size_t)(radix + 1) * 2 + 16384) * 8); // splitters, candidates, the sorted sample lists
+    t.dig = (uint16_t *)take((size_t)n * 2);
     for (int l = 0; l < MAX_LEVELS; ++l) {
         Level &L = t.lvl[l];
         L.hdr = take(64);
@@ -1245,7 +1474,7 @@ Plan make_plan(int64_t n, int key_bits, int key_bytes, int leaf_bytes, void *sor
     // segments of an extra level hold more than cap records each; a segment's last tile may be partial
     p.max_seg = (int)(n / cap + 1);
     p.max_tiles2 = p.num_tiles + p.max_seg;
-    carve_tables(&p.tb, (char *)sort_scratch, 1 << bits, p.num_tiles, p.max_seg, p.max_tiles2);
+    carve_tables(&p.tb, (char *)sort_scratch, 1 << bits, p.num_tiles, p.max_seg, p.max_tiles2, n);
     return p;
 }
 
@@ -1253,15 +1482,15 @@ Plan make_plan(int64_t n, int key_bits, int key_bytes, int leaf_bytes, void *sor
 size_t scratch_bytes(int64_t n, int key_bits, int key_bytes, int leaf_bytes) {
     const Plan p = make_plan(n, key_bits, key_bytes, leaf_bytes, nullptr);
     if (!p.bits) return 0;
-    return carve_tables(nullptr, nullptr, 1 << p.bits, p.num_tiles, p.max_seg, p.max_tiles2) + 4096;
+    return carve_tables(nullptr, nullptr, 1 << p.bits, p.num_tiles, p.max_seg, p.max_tiles2, n) + 4096;
 }
 
 constexpr int kMaxLds = 160 * 1024; // LDS of a gfx950 CU
 
 template <class K, int PT, int PI>
 static int launch_partitions(const Plan &p, const K *keys, int64_t n, const RecordArgs &ra, char *part2, char *out, K *side0, K *side1, int levels,
-                             hipStream_t st) {
-    const size_t smem = partition_smem<K, PT, PI>(p.bits, ra.lay.stride);
+                             bool eq, hipStream_t st) {
+    const size_t smem = partition_smem<K, PT, PI>(p.bits, ra.lay.stride, eq);
     if (smem > 160 * 1024) return IBVH_ERR_INVALID_ARG; // (make_plan sizes the tile for the record)
     // The attribute is per function and per device, and calls may come from several host threads with different geometries:
     // always the SAME value (the whole LDS), so that the order of concurrent calls cannot matter; a launch still only
@@ -1269,6 +1498,11 @@ static int launch_partitions(const Plan &p, const K *keys, int64_t n, const Reco
     IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)partition_kernel<K, PT, PI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
     const uint32_t words = (uint32_t)ra.lay.stride / 8u;
     const uint32_t inv_words = (uint32_t)((((uint64_t)1 << 32) + words - 1) / words);
+    if (eq) {
+        IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)partition_kernel<K, PT, PI, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        IBVH_LAUNCH((partition_kernel<K, PT, PI, false, true>), dim3(p.num_tiles), dim3(PT), smem, st, keys, n, p.shift, p.bits, p.tb,
+                    p.num_tiles, ra, inv_words, p.bits, levels > 0 ? 0 : -(p.ftpb * p.fipt), out, levels > 0 ? side0 : (K *)nullptr);
+    } else
     IBVH_LAUNCH((partition_kernel<K, PT, PI, false>), dim3(p.num_tiles), dim3(PT), smem, st, keys, n, p.shift, p.bits, p.tb,
                 p.num_tiles, ra, inv_words, p.bits, levels > 0 ? 0 : -(p.ftpb * p.fipt), out, levels > 0 ? side0 : (K *)nullptr);
     if (levels <= 0) return IBVH_OK;
@@ -1338,9 +1572,31 @@ static int launch_finish(const Plan &p, const FinishArgs &fa_in, hipStream_t st)
 // extra levels ping-pong between the two); out: the sorted records.  (kalt, valt, kpri, vpri): n-entry scratch arrays:
 // kalt / kpri carry the compact key copies of the extra levels, then all four serve the slow path (kpri may alias
 // `keys`: the source keys are dead once the first partition has run).  levels: extra partition levels to launch.
-int sort_records(const Plan &p, int key_bytes, const void *keys, int64_t n, const RecordArgs &ra, char *part2, char *out, void *kalt,
-                 uint32_t *valt, void *kpri, uint32_t *vpri, int levels, void *skew_flag, hipStream_t st) {
+int sort_records(const Plan &p, int key_bytes, int key_bits, const void *keys, int64_t n, const RecordArgs &ra, char *part2, char *out, void *kalt,
+                 uint32_t *valt, void *kpri, uint32_t *vpri, int levels, bool equalize, void *skew_flag, hipStream_t st) {
     if (levels < 0 || levels > MAX_LEVELS) levels = MAX_LEVELS;
+    // equalised cells: only where the partition's LDS stage has room for the 2-byte digit of every staged record
+    const size_t tile_elems = (size_t)p.ptpb * p.pipt;
+    bool eq = equalize && g_tuning.msd_equalize >= 0 && tile_elems * ((size_t)ra.lay.stride + 2) + ((size_t)8 << p.bits) + 128 <= (size_t)160 * 1024;
+    if (g_tuning.msd_equalize > 0) eq = tile_elems * ((size_t)ra.lay.stride + 2) + ((size_t)8 << p.bits) + 128 <= (size_t)160 * 1024; // (test knob: always)
+    if (eq) {
+        // sorted sample -> splitter candidates -> every leaf's cell + the tile histogram (three launches in place of the histogram
+        // the encode kernel fused; the lists and the candidates live behind the splitters in the sort scratch)
+        const size_t hsm = ((size_t)(key_bytes + 4)) << p.bits;
+        const uint32_t cap = (uint32_t)(p.ftpb * p.fipt);
+        auto run = [&](auto kt) -> int {
+            using K = decltype(kt);
+            using SG = SampleGeom<K>;
+            K *cand = (K *)p.tb.splitters + ((size_t)1 << p.bits) + 1, *lists = cand + ((size_t)1 << p.bits) + 1;
+            IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)sample_rank_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+            IBVH_LAUNCH((sample_sort_kernel<K>), dim3(SG::G), dim3(SG::TPB), SG::sort_smem, st, (const K *)keys, n, lists, key_bits);
+            IBVH_LAUNCH((sample_rank_kernel<K>), dim3(SG::G), dim3(1024), (size_t)SG::S * sizeof(K), st, (const K *)lists, cand, p.bits);
+            IBVH_LAUNCH((bucket_hist_kernel<K>), dim3(p.num_tiles), dim3(512), hsm, st, (const K *)keys, n, p.tb, (const K *)cand, p.bits, (int)tile_elems,
+                        key_bits, cap);
+            return IBVH_OK;
+        };
+        if (int e = key_bytes == 8 ? run(uint64_t{}) : run(uint32_t{})) return e;
+    }
     {
         const int radix = 1 << p.bits, ndb = radix >> 6;
         int chunks = 512 / ndb < 1 ? 1 : 512 / ndb; // ~512 workgroups
@@ -1353,11 +1609,11 @@ int sort_records(const Plan &p, int key_bytes, const void *keys, int64_t n, cons
         // derives those from the cell totals itself — one dependent launch less)
         if (levels > 0)
             IBVH_LAUNCH((plan_kernel), dim3(1), dim3(PLAN_TPB), 0, st, p.tb, radix, (uint32_t)(p.ftpb * p.fipt), (uint32_t)(p.ptpb * p.pipt),
-                        levels, p.shift);
+                        levels, p.shift, eq ? key_bytes : 0, key_bits);
     }
     int rc = IBVH_ERR_INVALID_ARG;
 #define IBVH_PART(K, T, I) \
-    if (p.ptpb == T && p.pipt == I) rc = launch_partitions<K, T, I>(p, (const K *)keys, n, ra, part2, out, (K *)kalt, (K *)kpri, levels, st);
+    if (p.ptpb == T && p.pipt == I) rc = launch_partitions<K, T, I>(p, (const K *)keys, n, ra, part2, out, (K *)kalt, (K *)kpri, levels, eq, st);
     if (key_bytes == 4) {
         IBVH_PART(uint32_t, 256, 4) IBVH_PART(uint32_t, 256, 8) IBVH_PART(uint32_t, 512, 8)
     } else {
@@ -1376,6 +1632,7 @@ int sort_records(const Plan &p, int key_bytes, const void *keys, int64_t n, cons
     fa.tile = (uint32_t)(p.ptpb * p.pipt);
     fa.levels = levels;
     fa.shift1 = p.shift;
+    fa.eq_key_bits = eq ? key_bits : 0;
     fa.skew_flag = (int32_t *)skew_flag;
     fa.kalt = kalt;
     fa.kpri = kpri;

@@ -29,11 +29,13 @@ struct Tables {
     uint32_t *tile_scan;  // [num_tiles][R]   exclusive prefix over the tiles (scan)
     uint32_t *cell_total; // [R]
     uint32_t *cell_start; // [R + 1]          exclusive prefix of cell_total (plan)
-    uint32_t *needed;     // [1]              extra levels this input would have used (the caller's hint)
+    uint32_t *needed;     // [3]              extra levels this input would have used, fullest cell, equalised route's verdict (the caller's hint)
     uint32_t *tile_hist2; // [T2][256]        per-tile sub-cell counts of the level being run (shared by the levels)
     uint32_t *tile_scan2; // [T2][256]
     uint64_t *tile_and;   // [T2]             AND / OR of the keys of every tile of the first extra level (range_kernel)
     uint64_t *tile_or;    // [T2]
+    void *splitters;      // [R + 1] keys     equalised route: cell d holds the keys in [splitters[d], splitters[d + 1])
+    uint16_t *dig;        // [n]              equalised route: every source leaf's cell
     Level lvl[MAX_LEVELS];
 };
 
@@ -51,8 +53,8 @@ struct Plan {
 
 Plan make_plan(int64_t n, int key_bits, int key_bytes, int leaf_bytes, void *sort_scratch);
 size_t scratch_bytes(int64_t n, int key_bits, int key_bytes, int leaf_bytes);
-int sort_records(const Plan &p, int key_bytes, const void *keys, int64_t n, const rsort::RecordArgs &ra, char *part2, char *out,
-                 void *kalt, uint32_t *valt, void *kpri, uint32_t *vpri, int levels, void *skew_flag, hipStream_t st);
+int sort_records(const Plan &p, int key_bytes, int key_bits, const void *keys, int64_t n, const rsort::RecordArgs &ra, char *part2, char *out,
+                 void *kalt, uint32_t *valt, void *kpri, uint32_t *vpri, int levels, bool equalize, void *skew_flag, hipStream_t st);
 
 } // namespace msd
 } // namespace ibvh

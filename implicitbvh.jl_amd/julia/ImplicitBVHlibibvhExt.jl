@@ -58,7 +58,7 @@ end
 struct IbvhBuildDesc
     types::IbvhTypes; n::Int64; built_level::Int64; already_wrapped::Int32; compute_extrema::Int32
     mins::NTuple{3, Float64}; maxs::NTuple{3, Float64}
-    sort_levels::Int32; reserved_::Int32; skew_flag::Ptr{Cvoid}
+    sort_levels::Int32; sort_equalize::Int32; skew_flag::Ptr{Cvoid}
 end
 mutable struct IbvhBfsResult
     num_contacts::Int64; num_checks::Int64; contacts_in::Int64; required_capacity::Int64

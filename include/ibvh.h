@@ -150,7 +150,14 @@ typedef struct ibvh_build_desc {
      * the fullest cell was close to full) without ever synchronising (build.jl:109-126 reuse pattern); a cold build
      * should pass 2 or more. */
     int32_t sort_levels;
-    int32_t reserved_;
+    /* sort_equalize != 0: the cells of the first partition are key RANGES of about equal population (splitters taken from a
+     * sorted sample of the keys) instead of the cells of a regular grid: a surface mesh or a clustered cloud fills few grid
+     * cells, and every crowded one costs a second move of its records (the extra levels above); with equalised cells only
+     * runs of EQUAL keys longer than a workgroup sorts still need a level.  Costs two small launches (~15 - 25 us) that a
+     * cloud filling its box does not need; the result is byte-identical either way.  A build that ran with it stores bit 16
+     * of skew_flag = 1 while the plain grid would have had a crowded cell: a caller that rebuilds every step asks for
+     * equalised cells when the previous build reported extra levels (low byte != 0) or that bit. */
+    int32_t sort_equalize;
     void *skew_flag;
 } ibvh_build_desc;
 
@@ -590,7 +597,7 @@ ibvh_status ibvh_lvt_work_counters(const ibvh_bvh *bvh, const ibvh_bvh *bvh2, co
  * on them, only speed and which code path is taken).  One process-wide table: set a knob BEFORE the calls it should
  * affect and not concurrently with them.  The library never reads the environment.  Names: "ray_block", "lvt_wide",
  * "lvt_xcd", "sort_tile", "sort_lsd", "sort_msd_avg", "bucket_tpb", "msd", "msd_bits", "msd_cap", "msd_tile",
- * "msd_ftpb", "msd_avg", "msd_range", "msd_finish_pad_kb", "msd_resident_kb", "bfs_wg_per_cu", "lvt_dual", "rays_shadow",
+ * "msd_ftpb", "msd_avg", "msd_range", "msd_equalize", "msd_finish_pad_kb", "msd_resident_kb", "bfs_wg_per_cu", "lvt_dual", "rays_shadow",
  * "rays_binned" (1 = the binned ray path where it pays, 2 = wherever the tree allows it, 0 = never), "rays_subtree_depth",
  * "rays_items_per_ray", "rays_fast_slab" (meanings: csrc/ibvh_common.hpp, struct Tuning).  Unknown name:
  * IBVH_ERR_INVALID_ARG. */

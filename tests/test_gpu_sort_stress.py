@@ -52,9 +52,18 @@ def test_random_clouds_every_level_depth(seed):
     g = ibvh.BVH(dev, node_type, options=make_options(types))
     assert_bvh_equal(o, g)
     torch.cuda.synchronize()
-    for pretend in (0, 1, 2, 3):  # launches 0, 2, 3, 4 extra levels
-        g._skew[0] = pretend
-        g = ibvh.BVH(dev, node_type, options=make_options(types), cache=g)
-        assert_bvh_equal(o, g)
-        torch.cuda.synchronize()
-        assert 0 <= int(g._skew[0]) <= abi.MAX_SORT_LEVELS
+    # the hint word a rebuild reads: low byte = extra levels (launches 0, 2, 3, 4 of them), bit 16 = equalised cells (round 5:
+    # cells = key ranges between splitters taken from a sorted sample; a hint with extra levels asks for them as well unless
+    # api.EQUALIZE is off — both routes, every depth)
+    try:
+        for equalize in (True, False):
+            ibvh.api.EQUALIZE = equalize
+            for pretend in (0, 1, 2, 3):
+                g._skew[0] = pretend | (1 << 16 if equalize else 0)
+                g = ibvh.BVH(dev, node_type, options=make_options(types), cache=g)
+                assert_bvh_equal(o, g)
+                torch.cuda.synchronize()
+                assert 0 <= int(g._skew[0]) <= abi.MAX_SORT_LEVELS
+                assert equalize or not g._skew.equalize()
+    finally:
+        ibvh.api.EQUALIZE = True
