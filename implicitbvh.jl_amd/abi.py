@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 4  # IBVH_ABI_VERSION of the include/ibvh.h this mirror was written against
+ABI_VERSION = 5  # IBVH_ABI_VERSION of the include/ibvh.h this mirror was written against
 
 # enums ---------------------------------------------------------------------------------------
 BSPHERE, BBOX = 0, 1

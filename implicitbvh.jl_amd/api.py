@@ -427,9 +427,9 @@ class _HintWord:
         """sort_levels / sort_equalize of a rebuild from what the chain's previous build left in the word (read ONCE)."""
         word = int(_host_words().words[self.slot])
         used, occupancy, eq = word & 0xff, (word >> 8) & 0xff, (word >> 16) & 1
-        spare = used > 0 or occupancy >= SPARE_OCCUPANCY or d.n >= SPARE_ALWAYS_FROM
-        d.sort_levels = min(used + (1 if spare else 0), abi.MAX_SORT_LEVELS)
         d.sort_equalize = 1 if (used > 0 or eq) and EQUALIZE else 0
+        spare = used > 0 or occupancy >= (EQ_SPARE_OCCUPANCY if eq and d.sort_equalize else SPARE_OCCUPANCY) or d.n >= SPARE_ALWAYS_FROM
+        d.sort_levels = min(used + (1 if spare else 0), abi.MAX_SORT_LEVELS)
 
 
 _host_words_singleton = None
@@ -794,6 +794,11 @@ def _cache_tensor(cache_t, need_rows, cols, dtype, what):
     return cache_t
 
 
+# Equalised builds re-fit their cells to the input every time, so a chain's occupancy does not creep up on them: a cell overflows only
+# by sampling chance (32 samples per cell at 1e6 leaves: never, in practice) or through runs of equal keys (then `used` > 0 and the
+# levels are launched anyway), and a mildly overflowing cell without a level costs one slower finish workgroup (~15 us), what the
+# idle spare level (plan + four launches) costs EVERY step.  So they launch a spare level only when the fullest cell was about full.
+EQ_SPARE_OCCUPANCY = 120
 EQUALIZE = True  # rebuilds of a chain whose input is skewed ask for equalised cells (False: the regular grid + extra levels, always)
 COLD_SORT_LEVELS = 2  # extra partition levels a build without cache= launches (include/ibvh.h, sort_levels)
 SPARE_OCCUPANCY = 96  # (of 128) fullest coarse cell from which a cached build launches a spare extra level (BVH.__init__)

@@ -140,13 +140,14 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_tiles_kernel(const uint32_t *__
 // shift.  Cells are still contiguous, ascending key ranges: stability and everything behind the partition (finish by key
 // range, extra levels for cells that are crowded regardless — many equal keys) stay as they are.
 // ------------------------------------------------------------------------------------------------------------
-// The sample: S = 1,024 * G keys at evenly spaced positions, dealt round-robin to G lists.  sample_sort_kernel (one small workgroup
-// per list, each on its own CU: one workgroup sorting all 16,384 took 77 us — the LDS radix passes are latency chains — G of
-// 1,024 take ~8) sorts every list in LDS; sample_rank_kernel gives every sample its rank in the union (its place in its own list +
+// The sample: S = 1,024 * G keys (32,768 32-bit ones: 8 - 32 per cell, so that a cell of twice the average population — what the
+// finish workgroups are sized for — is a 5-sigma event) at evenly spaced positions, dealt round-robin to G lists.
+// sample_sort_kernel (one small workgroup per list, each on its own CU: one workgroup sorting 16,384 keys took 77 us — the LDS radix
+// passes are latency chains — G of 1,024 take ~8) sorts every list in LDS; sample_rank_kernel gives every sample its rank in the union (its place in its own list +
 // a binary search in each of the others, ties broken by list number: a strict total order) and the samples whose rank is a
 // multiple of S / R become the splitter candidates.
 template <class K> struct SampleGeom {
-    static constexpr int LIST = 1024, G = sizeof(K) == 8 ? 8 : 16, S = LIST * G; // (S keys must fit the rank kernel's LDS: 64 KiB)
+    static constexpr int LIST = 1024, G = sizeof(K) == 8 ? 16 : 32, S = LIST * G; // (S keys must fit the rank kernel's LDS: 128 KiB)
     static constexpr int TPB = 256, IPT = LIST / TPB, RB = 8;
     static constexpr size_t sort_smem = (size_t)LIST * sizeof(K) + ((size_t)4 << RB) + 32 * 4 + (size_t)(TPB / 64) * ((size_t)2 << RB);
 };
@@ -193,6 +194,9 @@ template <class K, bool OR_EQUAL> IBVH_D uint32_t list_count(const K *L, K e) {
     const K v = L[base];
     return base + ((OR_EQUAL ? v <= e : v < e) ? 1u : 0u);
 }
+// grid = G * 4 workgroups: workgroup (g, q) ranks samples [256 q, 256 (q + 1)) of list g, four threads per sample (each takes every fourth
+// of the other lists) — the kernel is bound by the LDS reads of its searches per CU, so it is spread over 4 G CUs, each holding
+// the whole sample in LDS
 template <class K>
 __global__ __launch_bounds__(1024) void sample_rank_kernel(const K *__restrict__ lists, K *__restrict__ cand, int bits) {
     using G = SampleGeom<K>;
@@ -200,16 +204,20 @@ __global__ __launch_bounds__(1024) void sample_rank_kernel(const K *__restrict__
     K *s = (K *)bsm;
     for (int i = threadIdx.x; i < G::S; i += 1024) s[i] = lists[i];
     __syncthreads();
-    const int g = blockIdx.x;
-    const K e = s[g * G::LIST + threadIdx.x];
-    uint32_t rank = threadIdx.x;
+    const int g = blockIdx.x >> 2, q = blockIdx.x & 3;
+    const uint32_t at = (uint32_t)(q * 256 + (threadIdx.x >> 2)), part = threadIdx.x & 3;
+    const K e = s[g * G::LIST + at];
+    uint32_t rank = part == 0 ? at : 0u;
 #pragma unroll
-    for (int o = 0; o < G::G; ++o) {
-        if (o == g) continue; // (workgroup-uniform)
+    for (int o4 = 0; o4 < G::G; o4 += 4) {
+        const int o = o4 + (int)part;
+        if (o == g) continue;
         rank += o < g ? list_count<K, true>(s + o * G::LIST, e) : list_count<K, false>(s + o * G::LIST, e);
     }
+    rank += __shfl_xor(rank, 1, 64);
+    rank += __shfl_xor(rank, 2, 64);
     const uint32_t per = (uint32_t)G::S >> bits;
-    if ((rank & (per - 1u)) == 0) cand[rank / per] = e;
+    if (part == 0 && (rank & (per - 1u)) == 0) cand[rank / per] = e;
 }
 
 // per tile of `tile` source leaves: every leaf's cell (the last splitter <= its key) and the tile's row of the histogram.  Every
@@ -227,21 +235,18 @@ __global__ __launch_bounds__(512) void bucket_hist_kernel(const K *__restrict__ 
     // a 2^L-way conflict at step L — while here the nodes of a level are neighbours: no conflicts down to level 5, random below.
     K *eyt = (K *)bsm; // [1, radix): node k of level L, place j in its level = splitter (2j + 1) * radix / 2^(L+1)
     uint32_t *h = (uint32_t *)(eyt + radix);
-    for (int k = threadIdx.x; k < radix; k += 512) {
-        h[k] = 0;
-        // splitter d, for the sorted copy workgroup 0 leaves behind
-        {
-            const int d = k;
-            const K c = cand[d], prev = cand[d > 0 ? d - 1 : 0];
-            const K v = d == 0 ? (K)0 : ((d >= 2 && c == prev) ? (K)(c + 1) : c);
-            if (blockIdx.x == 0) ((K *)tb.splitters)[d] = v;
-        }
-        if (k >= 1) {
-            const int L = 31 - __builtin_clz((unsigned)k), j = k - (1 << L);
-            const int d = (2 * j + 1) * (radix >> (L + 1));
-            const K c = cand[d], prev = cand[d - 1];
-            eyt[k] = (d >= 2 && c == prev) ? (K)(c + 1) : c;
-        }
+    K *spl = (K *)(h + radix); // the sorted splitters (staged: the tree is a permutation of them — gathered from LDS, not from memory)
+    for (int d = threadIdx.x; d < radix; d += 512) {
+        h[d] = 0;
+        const K c = cand[d], prev = cand[d > 0 ? d - 1 : 0];
+        const K v = d == 0 ? (K)0 : ((d >= 2 && c == prev) ? (K)(c + 1) : c);
+        spl[d] = v;
+        if (blockIdx.x == 0) ((K *)tb.splitters)[d] = v;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x + 1; k < radix; k += 512) {
+        const int L = 31 - __builtin_clz((unsigned)k), j = k - (1 << L);
+        eyt[k] = spl[(2 * j + 1) * (radix >> (L + 1))];
     }
     if (blockIdx.x == 0) {
         // the verdict: would the plain grid (cell = top `bits` bits) have had a crowded cell?  Crowded = clearly more samples in one
@@ -1396,7 +1401,7 @@ static size_t carve_tables(Tables *tb, char *base, int radix, int num_tiles, int
     t.tile_scan2 = take((size_t)max_tiles2 * 4 << L2_BITS);
     t.tile_and = (uint64_t *)take((size_t)max_tiles2 * 8);
     t.tile_or = (uint64_t *)take((size_t)max_tiles2 * 8);
-    t.splitters = take(((size_t)(radix + 1) * 2 + 16384) * 8); // splitters, candidates, the sorted sample lists
+    t.splitters = take(((size_t)(radix + 1) * 2 + 32768) * 8); // splitters, candidates, the sorted sample lists
     t.dig = (uint16_t *)take((size_t)n * 2);
     for (int l = 0; l < MAX_LEVELS; ++l) {
         Level &L = t.lvl[l];
@@ -1582,7 +1587,7 @@ int sort_records(const Plan &p, int key_bytes, int key_bits, const void *keys, i
     if (eq) {
         // sorted sample -> splitter candidates -> every leaf's cell + the tile histogram (three launches in place of the histogram
         // the encode kernel fused; the lists and the candidates live behind the splitters in the sort scratch)
-        const size_t hsm = ((size_t)(key_bytes + 4)) << p.bits;
+        const size_t hsm = ((size_t)(2 * key_bytes + 4)) << p.bits;
         const uint32_t cap = (uint32_t)(p.ftpb * p.fipt);
         auto run = [&](auto kt) -> int {
             using K = decltype(kt);
@@ -1590,7 +1595,7 @@ int sort_records(const Plan &p, int key_bytes, int key_bits, const void *keys, i
             K *cand = (K *)p.tb.splitters + ((size_t)1 << p.bits) + 1, *lists = cand + ((size_t)1 << p.bits) + 1;
             IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)sample_rank_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
             IBVH_LAUNCH((sample_sort_kernel<K>), dim3(SG::G), dim3(SG::TPB), SG::sort_smem, st, (const K *)keys, n, lists, key_bits);
-            IBVH_LAUNCH((sample_rank_kernel<K>), dim3(SG::G), dim3(1024), (size_t)SG::S * sizeof(K), st, (const K *)lists, cand, p.bits);
+            IBVH_LAUNCH((sample_rank_kernel<K>), dim3(SG::G * 4), dim3(1024), (size_t)SG::S * sizeof(K), st, (const K *)lists, cand, p.bits);
             IBVH_LAUNCH((bucket_hist_kernel<K>), dim3(p.num_tiles), dim3(512), hsm, st, (const K *)keys, n, p.tb, (const K *)cand, p.bits, (int)tile_elems,
                         key_bits, cap);
             return IBVH_OK;

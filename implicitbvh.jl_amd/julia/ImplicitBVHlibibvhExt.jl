@@ -37,7 +37,7 @@ const libibvh = get(ENV, "LIBIBVH", "libibvh.so")
 
 # The header this file was written against (include/ibvh.h, IBVH_ABI_VERSION).  A library with another struct layout or
 # argument list would make the GPU write through garbage pointers, so a mismatch is refused when the extension loads.
-const IBVH_ABI_VERSION = Int32(4)
+const IBVH_ABI_VERSION = Int32(5)
 function __init__()
     got = ccall((:ibvh_abi_version, libibvh), Int32, ())
     got == IBVH_ABI_VERSION ||

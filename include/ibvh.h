@@ -37,8 +37,10 @@ extern "C" {
  * ibvh_abi_version() == IBVH_ABI_VERSION (the header it was written against) right after loading the
  * library and refuses a mismatch: a stale caller would otherwise hand the GPU garbage pointers.
  *   1: round 1   2: ibvh_build_desc.sort_levels / skew_flag, ibvh_bfs_result.resume_*, *_enqueue(total_dev)
- *   3: *_enqueue(total_host), ibvh_set_tuning, ibvh_lvt_work_counters, ray `narrow`, contact positions */
-#define IBVH_ABI_VERSION 4
+ *   3: *_enqueue(total_host), ibvh_set_tuning, ibvh_lvt_work_counters, ray `narrow`, contact positions
+ *   4: the multi-GPU driver (ibvh_comm, ibvh_dist_*)
+ *   5: ibvh_dist_cross_* (boundary leaves), ibvh_comm_release, ibvh_build_desc.sort_equalize (was reserved_: same layout) */
+#define IBVH_ABI_VERSION 5
 int32_t ibvh_abi_version(void);
 
 /* ----------------------------------------------------------------------------------- */

@@ -274,17 +274,34 @@ def test_build_every_sort_route_at_every_partition_depth(shape):
         dev = cuda(vols.astype(NP_F[types.leaf_float]))
         # what "the previous build" left in the hint word (levels | fullest cell << 8): launches 0 extra levels (a comfortable
         # uniform cloud before), 1 (a nearly full cell before: the spare level), 2, 3, 4
-        for pretend in (0, 127 << 8, 1, 2, 3):
+        # (the PLAIN grid's levels and hint are what is pinned here: a chain whose hint shows skew would otherwise switch to
+        # equalised cells — round 5, tests/test_gpu_sort_equalize.py and test_gpu_sort_stress.py — which need no level for most of
+        # these inputs)
+        from implicitbvh_amd import api
+        try:
+            api.EQUALIZE = False
+            for pretend in (0, 127 << 8, 1, 2, 3):
+                g._skew[0] = pretend
+                g = ibvh.BVH(dev, node_type, options=make_options(types), cache=g)
+                assert_bvh_equal(o, g)
+                torch.cuda.synchronize()
+                used = int(g._skew[0])
+                assert (used > 0) == expect_skew and used <= abi.MAX_SORT_LEVELS
+                if pretend == 0 and expect_skew:
+                    assert used == 1                       # no extra level ran: all it can know is that one is needed
+                if pretend == 127 << 8 and expect_skew:
+                    assert used <= 2                       # one extra level ran: it can ask for at most one more
+        finally:
+            api.EQUALIZE = True
+        # the same chain with equalised cells: the same bytes; only runs of equal keys longer than a finish workgroup sorts
+        # still ask for a level
+        for pretend in (1, 1 << 16, 3 | 1 << 16):
             g._skew[0] = pretend
             g = ibvh.BVH(dev, node_type, options=make_options(types), cache=g)
             assert_bvh_equal(o, g)
             torch.cuda.synchronize()
-            used = int(g._skew[0])
-            assert (used > 0) == expect_skew and used <= abi.MAX_SORT_LEVELS
-            if pretend == 0 and expect_skew:
-                assert used == 1                       # no extra level ran: all it can know is that one is needed
-            if pretend == 127 << 8 and expect_skew:
-                assert used <= 2                       # one extra level ran: it can ask for at most one more
+            assert int(g._fast[1].sort_equalize) == 1 if g._fast else True
+            assert int(g._skew[0]) <= abi.MAX_SORT_LEVELS and (expect_skew or int(g._skew[0]) == 0)
         # no extra level at all (a raw C caller may pass sort_levels = 0): everything crowded takes the one-workgroup path
         from implicitbvh_amd import api
         saved = api.COLD_SORT_LEVELS

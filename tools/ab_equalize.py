@@ -13,6 +13,7 @@ from implicitbvh_amd.synthetic import sphere_radius_law, torus_mesh
 from bench import _dominant
 
 which = sys.argv[1].split(",") if len(sys.argv) > 1 else None
+api.EQ_SPARE_OCCUPANCY = int(os.environ.get("EQ_SPARE", api.EQ_SPARE_OCCUPANCY))  # (experiments: 129 = an equalised build never launches a spare level)
 def clustered(n, seed=7):
     g = torch.Generator(device="cuda").manual_seed(seed)
     c = torch.rand((8, 3), generator=g, device="cuda")
