@@ -363,7 +363,8 @@ function ImplicitBVH.BVH(
                          # few per cent of a uniform 1e6-leaf build).  A shim that rebuilds every time step can hand the
                          # library a mapped pinned host word as skew_flag and pass the level count the previous build left
                          # in its low byte, plus a spare one when that is not 0 or the second byte (fullest cell, in 1/128 of
-                         # a workgroup's capacity) is close to 128 (include/ibvh.h).
+                         # a workgroup's capacity) is close to 128 (include/ibvh.h) — and sort_equalize = 1 (cells = key ranges
+                         # of equal population: surface meshes, clustered clouds) when that low byte was not 0 or bit 16 is set.
                          Int32(2), Int32(0), Ptr{Cvoid}(C_NULL))
     check(c_build(desc, wrapped ? C_NULL : devptr(bounding_volumes), devptr(leaves), devptr(nodes), devptr(skips),
                   C_NULL, devptr(scratch), need[], stream_ptr()), "ibvh_build")
