@@ -402,6 +402,7 @@ class _HintWord:
 
     def __init__(self, initial):
         self.slot, self.gen = _host_words().take(initial, hint=True)
+        self.holdoff = 0  # rebuilds for which the chain does not ask for equalised cells (apply)
 
     def valid(self):
         return _host_words().generation[self.slot] == self.gen
@@ -427,7 +428,13 @@ class _HintWord:
         """sort_levels / sort_equalize of a rebuild from what the chain's previous build left in the word (read ONCE)."""
         word = int(_host_words().words[self.slot])
         used, occupancy, eq = word & 0xff, (word >> 8) & 0xff, (word >> 16) & 1
-        d.sort_equalize = 1 if (used > 0 or eq) and EQUALIZE else 0
+        # (bit 17: an equalised build found most of its records in crowded cells all the same — runs of equal keys — so the chain
+        # stays with the plain grid for EQ_HOLDOFF rebuilds before it tries again)
+        if (word >> 17) & 1 and self.holdoff == 0:
+            self.holdoff = EQ_HOLDOFF
+        elif self.holdoff > 0:
+            self.holdoff -= 1
+        d.sort_equalize = 1 if (used > 0 or eq) and EQUALIZE and self.holdoff == 0 else 0
         spare = used > 0 or occupancy >= (EQ_SPARE_OCCUPANCY if eq and d.sort_equalize else SPARE_OCCUPANCY) or d.n >= SPARE_ALWAYS_FROM
         d.sort_levels = min(used + (1 if spare else 0), abi.MAX_SORT_LEVELS)
 
@@ -799,6 +806,7 @@ def _cache_tensor(cache_t, need_rows, cols, dtype, what):
 # levels are launched anyway), and a mildly overflowing cell without a level costs one slower finish workgroup (~15 us), what the
 # idle spare level (plan + four launches) costs EVERY step.  So they launch a spare level only when the fullest cell was about full.
 EQ_SPARE_OCCUPANCY = 120
+EQ_HOLDOFF = 32  # rebuilds a chain stays with the plain grid after an equalised build reported that it did not help (hint bit 17)
 EQUALIZE = True  # rebuilds of a chain whose input is skewed ask for equalised cells (False: the regular grid + extra levels, always)
 COLD_SORT_LEVELS = 2  # extra partition levels a build without cache= launches (include/ibvh.h, sort_levels)
 SPARE_OCCUPANCY = 96  # (of 128) fullest coarse cell from which a cached build launches a spare extra level (BVH.__init__)

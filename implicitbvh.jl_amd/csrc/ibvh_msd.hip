@@ -326,7 +326,7 @@ __global__ __launch_bounds__(PLAN_TPB) void plan_kernel(Tables tb, int radix, ui
     __shared__ uint32_t s_nover, s_ntiles;
     const Level L = tb.lvl[0];
     const int lo = threadIdx.x * PER;
-    uint32_t tot[PER], sum = 0, nov = 0, nt = 0, biggest = 0;
+    uint32_t tot[PER], sum = 0, nov = 0, nt = 0, biggest = 0, crowded_sum = 0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int d = lo + k;
@@ -336,12 +336,15 @@ __global__ __launch_bounds__(PLAN_TPB) void plan_kernel(Tables tb, int radix, ui
         if (tot[k] > cap) {
             nov += 1;
             nt += segment_tiles(tot[k], tile);
+            crowded_sum += tot[k];
         }
     }
     uint32_t total_n = 0, total_over = 0, total_tiles = 0;
     uint32_t run = block_exclusive_scan<PLAN_TPB>(sum, wave_tot, &total_n);
     uint32_t kk = block_exclusive_scan<PLAN_TPB>(nov, wave_tot, &total_over);
     uint32_t tt = block_exclusive_scan<PLAN_TPB>(nt, wave_tot, &total_tiles);
+    uint32_t total_crowded = 0; // records in crowded cells
+    block_exclusive_scan<PLAN_TPB>(crowded_sum, wave_tot, &total_crowded);
     // the fullest cell, in 1/128 of what a finish workgroup sorts (saturating at 255): the second byte of the caller's hint
     // word — how close a so far uniform input is to needing an extra level (include/ibvh.h, skew_flag)
     __shared__ uint32_t s_biggest;
@@ -402,6 +405,9 @@ __global__ __launch_bounds__(PLAN_TPB) void plan_kernel(Tables tb, int radix, ui
         {
             const uint64_t occ = ((uint64_t)s_biggest * 128u + cap - 1) / cap;
             tb.needed[1] = (uint32_t)(occ > 255 ? 255 : occ);
+            // equalised cells that leave most records in crowded cells all the same (runs of equal keys: nothing a choice of cells
+            // can do) have cost their launches for nothing: bit 17 of the hint, the caller goes back to the plain grid for a while
+            tb.needed[3] = (eq_key_bytes && (uint64_t)total_crowded * 2 > total_n) ? 1u : 0u;
         }
         if (levels <= 0) total_over = total_tiles = 0; // the finish kernel sorts crowded cells by itself
 #pragma unroll
@@ -1292,7 +1298,8 @@ __global__ __launch_bounds__(TPB) void finish_kernel(Tables tb, int radix, Finis
     const FinishLds<K, TPB, IPT> l(bsm, RES ? fa.resident_off : 0u);
     IBVH_STAMP(1, 0);
     if (blockIdx.x == 0 && threadIdx.x == 0 && fa.skew_flag)
-        *fa.skew_flag = (int32_t)(tb.needed[0] | (tb.needed[1] << 8) | (fa.eq_key_bits ? (tb.needed[2] & 1u) << 16 : 0u));
+        *fa.skew_flag = (int32_t)(tb.needed[0] | (tb.needed[1] << 8) |
+                                  (fa.eq_key_bits ? ((tb.needed[2] & 1u) << 16) | (fa.levels > 0 ? (tb.needed[3] & 1u) << 17 : 0u) : 0u));
     if ((int)blockIdx.x < radix) {
         const uint32_t d = blockIdx.x;
         const uint32_t start = uni(tb.cell_start[d]), m = uni(tb.cell_start[d + 1]) - start;

@@ -158,7 +158,9 @@ typedef struct ibvh_build_desc {
      * runs of EQUAL keys longer than a workgroup sorts still need a level.  Costs two small launches (~15 - 25 us) that a
      * cloud filling its box does not need; the result is byte-identical either way.  A build that ran with it stores bit 16
      * of skew_flag = 1 while the plain grid would have had a crowded cell: a caller that rebuilds every step asks for
-     * equalised cells when the previous build reported extra levels (low byte != 0) or that bit. */
+     * equalised cells when the previous build reported extra levels (low byte != 0) or that bit.  Bit 17 (equalised builds
+     * with sort_levels > 0): more than half of the records sat in crowded cells all the same — runs of equal keys, which
+     * no choice of cells can split; such a chain is better off with the plain grid (the sample's launches buy nothing). */
     int32_t sort_equalize;
     void *skew_flag;
 } ibvh_build_desc;

@@ -114,3 +114,22 @@ def test_a_chain_switches_to_equalised_cells_when_its_input_is_skewed_and_back()
     # uniform steps never ask; the first clustered step is met by the plain grid (its hint then asks), the following ones are
     # equalised and stay so (bit 16 of the hint), the first uniform step after them still is, then the chain falls back
     assert asked == [0, 0, 0, 1, 1, 1, 1, 0, 0], asked
+
+
+def test_a_chain_of_duplicates_goes_back_to_the_plain_grid_for_a_while():
+    """One tight cluster and a far outlier (every leaf shares one of 1 - 8 Morton codes): no choice of cells splits a run of equal
+    keys, the equalised build reports that most records sat in crowded cells all the same (hint bit 17) and the chain stays with
+    the plain grid for api.EQ_HOLDOFF rebuilds before it tries again."""
+    from implicitbvh_amd import api
+    n = 1_000_000
+    v = torch.cat([clouds(n, 4)["one cluster + outlier"], torch.full((n, 1), 1e-4, device="cuda")], 1).contiguous()
+    ref = ibvh.BVH(v)
+    b = ibvh.BVH(v)
+    torch.cuda.synchronize()
+    asked = []
+    for step in range(api.EQ_HOLDOFF + 2):
+        b = ibvh.BVH(v, cache=b)
+        torch.cuda.synchronize()
+        asked.append(int(b._fast[1].sort_equalize))
+        assert torch.equal(b.leaves.buf, ref.leaves.buf), step
+    assert asked == [1] + [0] * api.EQ_HOLDOFF + [1], asked
