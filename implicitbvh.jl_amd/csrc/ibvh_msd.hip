@@ -1090,6 +1090,7 @@ IBVH_D void finish_range(const FinishArgs &fa, const FinishLds<K, TPB, IPT> &l, 
                 }
             }
             __syncthreads();
+            IBVH_STAMP(1, 2);
             const int chunk = (int)((m + W * 64 - 1) / (W * 64)) * 64;
             const int jmax = chunk / 64; // <= IPT
             const uint32_t mw = (uint32_t)fa.lay.morton_off >> 3, msh = ((uint32_t)fa.lay.morton_off & 7u) * 8u;
@@ -1126,6 +1127,7 @@ IBVH_D void finish_range(const FinishArgs &fa, const FinishLds<K, TPB, IPT> &l, 
                     __syncthreads();
                 }
             }
+            IBVH_STAMP(1, 3);
             uint64_t *__restrict__ dst = (uint64_t *)(fa.out + start * stride);
             for (uint32_t g0 = threadIdx.x; g0 < total; g0 += TPB * U) {
 #pragma unroll
@@ -1138,6 +1140,7 @@ IBVH_D void finish_range(const FinishArgs &fa, const FinishLds<K, TPB, IPT> &l, 
                     }
                 }
             }
+            IBVH_STAMP(1, 4);
             __syncthreads(); // (the LDS arrays are reused by the workgroup's next range)
             return;
         }

@@ -217,8 +217,10 @@ IBVH_D void lds_radix_pass(const K (&key)[IPT], const VT (&val)[IPT], int shift,
     const uint32_t mask = (1u << bits) - 1u;
     uint16_t *my_hist = whist + w * R;
     IBVH_PASS_STAMP(5);
-    for (int i = threadIdx.x; i < W * R; i += TPB) whist[i] = 0;
-    __syncthreads();
+    // (every wave zeroes ITS OWN counters — nobody else touches them before the barrier behind the ranking, and a wave's LDS
+    // operations execute in order — so no workgroup barrier, and no wait for the slowest wave, between zeroing and ranking)
+    for (int i = lane; i < R / 2; i += 64) ((uint32_t *)my_hist)[i] = 0;
+    __builtin_amdgcn_wave_barrier();
     IBVH_PASS_STAMP(6);
     uint16_t rank[IPT];
     wave_rank<K, IPT>(key, shift, mask, bits, my_hist, lane, rank, jmax);
