@@ -426,17 +426,24 @@ class _HintWord:
 
     def apply(self, d):
         """sort_levels / sort_equalize of a rebuild from what the chain's previous build left in the word (read ONCE)."""
-        word = int(_host_words().words[self.slot])
-        used, occupancy, eq = word & 0xff, (word >> 8) & 0xff, (word >> 16) & 1
-        # (bit 17: an equalised build found most of its records in crowded cells all the same — runs of equal keys — so the chain
-        # stays with the plain grid for EQ_HOLDOFF rebuilds before it tries again)
-        if (word >> 17) & 1 and self.holdoff == 0:
-            self.holdoff = EQ_HOLDOFF
-        elif self.holdoff > 0:
-            self.holdoff -= 1
-        d.sort_equalize = 1 if (used > 0 or eq) and EQUALIZE and self.holdoff == 0 else 0
-        spare = used > 0 or occupancy >= (EQ_SPARE_OCCUPANCY if eq and d.sort_equalize else SPARE_OCCUPANCY) or d.n >= SPARE_ALWAYS_FROM
-        d.sort_levels = min(used + (1 if spare else 0), abi.MAX_SORT_LEVELS)
+        d.sort_levels, d.sort_equalize, self.holdoff = sort_hint_rule(int(_host_words().words[self.slot]), d.n, self.holdoff)
+
+
+def sort_hint_rule(word, n, holdoff):
+    """(sort_levels, sort_equalize, holdoff') of a rebuild of n leaves from the hint word the previous build of its chain left
+    (include/ibvh.h, ibvh_build_desc.skew_flag: low byte = extra partition levels that build would have used, second byte =
+    its fullest cell in 1/128 of what a finish workgroup sorts, bit 16 = it ran with equalised cells and the plain grid would
+    still have been crowded, bit 17 = equalising did not help) and the chain's hold-off counter.  Pure host logic."""
+    used, occupancy, eq = word & 0xff, (word >> 8) & 0xff, (word >> 16) & 1
+    # (bit 17: an equalised build found most of its records in crowded cells all the same — runs of equal keys — so the chain
+    # stays with the plain grid for EQ_HOLDOFF rebuilds before it tries again)
+    if (word >> 17) & 1 and holdoff == 0:
+        holdoff = EQ_HOLDOFF
+    elif holdoff > 0:
+        holdoff -= 1
+    equalize = 1 if (used > 0 or eq) and EQUALIZE and holdoff == 0 else 0
+    spare = used > 0 or occupancy >= (EQ_SPARE_OCCUPANCY if eq and equalize else SPARE_OCCUPANCY) or n >= SPARE_ALWAYS_FROM
+    return min(used + (1 if spare else 0), abi.MAX_SORT_LEVELS), equalize, holdoff
 
 
 _host_words_singleton = None

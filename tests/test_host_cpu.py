@@ -306,3 +306,39 @@ def test_julia_pair_methods_fall_back_for_mixed_types():
         call = re.search(r"invoke\(ImplicitBVH\.traverse, Tuple\{BVH, BVH, " + alg + r"\}, bvh1, bvh2, alg;(.*?)\)\n", body, re.S).group(1)
         for kw in ("start_level1", "start_level2", "narrow", "cache", "options"):
             assert f"{kw}={kw}" in call, (alg, kw)
+
+
+def test_sort_hint_rule_of_a_rebuild_chain():
+    """api.sort_hint_rule: what a `cache=` rebuild asks the library for (extra partition levels, equalised cells) from the hint
+    word the previous build left (include/ibvh.h, ibvh_build_desc.sort_levels / sort_equalize / skew_flag).  Pure host logic."""
+    from implicitbvh_amd import abi, api
+    rule = api.sort_hint_rule
+    n = 1_000_000
+    # a comfortable uniform cloud: nothing; a nearly full cell: the spare level; beyond 2^24 leaves: always the spare level
+    assert rule(60 << 8, n, 0) == (0, 0, 0)
+    assert rule(api.SPARE_OCCUPANCY << 8, n, 0) == (1, 0, 0)
+    assert rule(60 << 8, api.SPARE_ALWAYS_FROM, 0) == (1, 0, 0)
+    # the previous build needed k levels: k + 1 of them and equalised cells
+    for k in (1, 2, 3):
+        assert rule(k | 200 << 8, n, 0) == (min(k + 1, abi.MAX_SORT_LEVELS), 1, 0)
+    assert rule(abi.MAX_SORT_LEVELS, n, 0)[0] == abi.MAX_SORT_LEVELS
+    # an equalised build that fitted (no level needed) while the plain grid would not have: equalised again, no idle spare level
+    # unless its fullest cell was about full
+    assert rule(1 << 16 | 100 << 8, n, 0) == (0, 1, 0)
+    assert rule(1 << 16 | api.EQ_SPARE_OCCUPANCY << 8, n, 0) == (1, 1, 0)
+    # ... and the plain grid would fit again: back to it (its own spare rule applies to the occupancy byte)
+    assert rule(50 << 8, n, 0) == (0, 0, 0)
+    # equalising did not help (bit 17): the plain grid for EQ_HOLDOFF rebuilds, whatever they report, then equalised cells again
+    lv, eq, hold = rule(2 | 1 << 16 | 1 << 17 | 255 << 8, n, 0)
+    assert (lv, eq, hold) == (3, 0, api.EQ_HOLDOFF)
+    asked = []
+    for _ in range(api.EQ_HOLDOFF):
+        lv, eq, hold = rule(1 | 255 << 8, n, hold)
+        asked.append(eq)
+    assert asked == [0] * (api.EQ_HOLDOFF - 1) + [1] and hold == 0
+    # switched off as a whole
+    try:
+        api.EQUALIZE = False
+        assert rule(2 | 1 << 16, n, 0)[1] == 0
+    finally:
+        api.EQUALIZE = True
