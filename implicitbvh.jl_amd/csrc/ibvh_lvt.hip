@@ -69,10 +69,16 @@ int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const voi
     }
     // SELF / PAIR under BBox nodes: the rows of the shared descent (ibvh_lvt.hpp "BlockRows") live at the END of the scratch when
     // the caller sized it with ibvh_lvt_scratch_bytes; a smaller scratch simply has none (every wave descends on its own)
-    size_t rows_bytes = 0;
+    // ... in front of them, every work item's .index (the counting pass writes it for the writing pass: Args::q_index_dense), when there
+    // is room for both
+    size_t rows_bytes = 0, qidx_bytes = 0;
     if (MODE != MODE_RAYS && !work && walk->types.node_kind == IBVH_BBOX) {
         rows_bytes = blk_rows_bytes(n_items, BLK_SHIFT_MIN);
+        qidx_bytes = (size_t)align_up(n_items * (int64_t)(lay.pair_bytes / 2), 256);
+        if (scratch_bytes < scan_scratch_bytes(n_items) + rows_bytes + qidx_bytes + 256) qidx_bytes = 0;
         if (scratch_bytes < scan_scratch_bytes(n_items) + rows_bytes + 256) rows_bytes = 0;
+        if (!rows_bytes) qidx_bytes = 0;
+        rows_bytes += qidx_bytes; // (one tail: [index array | rows])
     }
     const size_t tail_bytes = bin_plan.depth ? bin_plan.bytes : (shadow_bytes ? shadow_bytes : rows_bytes);
     const size_t cache_room = scratch_bytes - (tail_bytes ? tail_bytes + 256 : 0);
@@ -113,7 +119,8 @@ int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const voi
                 a.shadow = shadow_ptr;
                 a.rays_filter = 0;
                 a.gate = nullptr;
-                a.blk_rows = rows_bytes ? (uint32_t *)tail_ptr : nullptr;
+                a.blk_rows = rows_bytes ? (uint32_t *)(tail_ptr + qidx_bytes) : nullptr;
+                a.q_index_dense = qidx_bytes ? (I *)tail_ptr : nullptr;
                 a.blk_shift = 0;
                 const ibvh_bvh *qside = drv ? drv : walk;
                 a.q_nodes = (const N *)qside->nodes;
@@ -153,7 +160,8 @@ ibvh_status ibvh_lvt_scratch_bytes(const ibvh_types *types, int64_t n_items, int
     if (cache_slots > MAX_CACHE_SLOTS) cache_slots = MAX_CACHE_SLOTS;
     *bytes_out = scan_scratch_bytes(n_items) + (size_t)cache_slots * (size_t)n_items * (size_t)lay.pair_bytes;
     if (types->node_kind == IBVH_BBOX) // room for the rows of the shared descent (2 bytes per work item), behind the contact cache
-        *bytes_out = (size_t)align_up((int64_t)*bytes_out, 256) + blk_rows_bytes(n_items, BLK_SHIFT_MIN) + 512;
+        *bytes_out = (size_t)align_up((int64_t)*bytes_out, 256) + blk_rows_bytes(n_items, BLK_SHIFT_MIN) + 512 +
+                     (size_t)align_up(n_items * (int64_t)(lay.pair_bytes / 2), 256); // (+ every work item's .index, for the writing pass)
     return IBVH_OK;
 }
 

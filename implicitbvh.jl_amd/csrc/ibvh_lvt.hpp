@@ -64,6 +64,10 @@ template <class L, class N, class I> struct Args {
     const N *q_nodes;    // the nodes of the tree the work items are the leaves of (SELF: == nodes)
     TreeDev q_tree;
     int64_t q_built_level;
+    // SELF / PAIR, walker 2: every work item's .index, densely (4 / 8 bytes an item), written by the counting pass for the writing
+    // pass — which needs nothing else of a leaf to put a cached pair together, and would otherwise pull every line of the leaf
+    // records through the memory system for it (24-byte records: 240 MB at 1e7 leaves).  nullptr: read the leaf.
+    I *q_index_dense;
 };
 
 // ---- walker 2, the shared part of the descent ---------------------------------------------------------------------------
@@ -192,7 +196,9 @@ template <class L, class N, class I, int MODE, bool WRITE, bool NARROW> struct Q
     uint64_t q_morton;
     Cnt w, cnt;
 
-    IBVH_D Query(const Args<L, N, I> &a_, const PairCache<I> &c_) : a(a_), cache(c_) {
+    // defer_leaf: the leaf is not read here but by load_leaf(), if at all (the queue walker's writing pass, which serves most waves
+    // from the cache)
+    IBVH_D Query(const Args<L, N, I> &a_, const PairCache<I> &c_, bool defer_leaf = false) : a(a_), cache(c_) {
         // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2; handing an
         // XCD RUNS of 64 consecutive workgroups (16 K Morton-sorted items) keeps neighbouring waves, which read the same
         // nodes and leaves, behind one L2.  Time-neutral for this issue-bound kernel, but L2-miss traffic drops
@@ -210,6 +216,10 @@ template <class L, class N, class I, int MODE, bool WRITE, bool NARROW> struct Q
         q_morton = 0;
         w = 0;
         cnt = 0;
+        if (!defer_leaf) load_leaf();
+        lane_on = valid;
+    }
+    IBVH_D void load_leaf() {
         if (valid) {
             // (SELF: the work items ARE the walked tree's leaves — naming them through a.leaves / a.lay lets the compiler drop
             // a.items / a.items_lay, six scalar registers that would otherwise stay live through the whole kernel)
@@ -221,7 +231,6 @@ template <class L, class N, class I, int MODE, bool WRITE, bool NARROW> struct Q
             if constexpr (NARROW)
                 if (a.narrow == IBVH_NARROW_MORTON_LT) q_morton = load_morton(rec, il);
         }
-        lane_on = valid;
     }
     // WRITE pass: serve the item from the contact cache; returns false when the whole wave is done
     IBVH_D bool begin_write() {

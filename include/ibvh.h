@@ -248,8 +248,9 @@ ibvh_status ibvh_aggregate(const ibvh_types *types, const ibvh_tree *tree, int64
  * counts : one I per work item (cache2 of BVHTraversal on the GPU path, :31-32).
  * scratch: ibvh_lvt_scratch_bytes() bytes of device memory: scan tile sums + the contact cache + (BBox nodes) the rows of
  *          the shared descent: one list of cut-level nodes per block of 2,048 consecutive leaves, made by one small kernel
- *          in front of the counting pass and read by both passes (csrc/ibvh_lvt.hpp "BlockRows"); a scratch without room
- *          for them is served without them.
+ *          in front of the counting pass and read by both passes (csrc/ibvh_lvt.hpp "BlockRows"), and a dense copy of the
+ *          work items' .index (4 / 8 bytes an item) that the counting pass leaves for the writing pass, which then does not
+ *          touch the leaf records at all; a scratch without room for either is served without it.
  * NaN: with BBox nodes the walkers rely on parents being the exact minima / maxima of their children (merge.jl:30-40): a
  *      contact is decided by the leaf parent's box and the leaf test, the levels above only prune.  On volumes whose boxes
  *      hold no NaN that is the reference's list, element for element.  A NaN leaf box (a NaN radius; Inf - Inf in the

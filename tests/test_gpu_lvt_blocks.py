@@ -181,7 +181,9 @@ def test_a_scratch_without_room_for_rows_is_served_without_them(forced_rows):
     lib.call("ibvh_lvt_scratch_bytes", C.byref(g.types), n, 0, C.byref(none))
     assert full.value > none.value > 0
     rows_bytes = -(-n // 512) * 2048  # (csrc/ibvh_lvt.hpp: blk_rows_bytes at BLK_SHIFT_MIN)
-    for nbytes, rows in ((full.value, True), (none.value, True), (none.value - rows_bytes - 512, False)):
+    qidx_bytes = -(-n * 4 // 256) * 256  # (the dense copy of the work items' indices the counting pass leaves for the writing pass)
+    for nbytes, rows in ((full.value, True), (none.value, True), (none.value - qidx_bytes, True),
+                         (none.value - qidx_bytes - rows_bytes - 512, False)):
         counts = torch.zeros(n, dtype=torch.int32, device="cuda")
         scratch = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
         total = C.c_int64()
