@@ -13,7 +13,7 @@ namespace ibvh {
 namespace lvt {
 
 template <class L, class N, class I, int MODE>
-int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStream_t st, const RayBins &rb = RayBins{}) {
+int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStream_t st, const RayBins &rb = RayBins{}, bool *agg_zeroed = nullptr) {
     if (a.n_items == 0) return IBVH_OK;
     const bool count_work = a.work != nullptr; // (the counting pass of the COUNT instantiation; nothing else is launched)
     if (count_work && (!kWorkTypes<L, N, I> || write)) return IBVH_ERR_UNSUPPORTED;
@@ -25,7 +25,7 @@ int launch(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStr
         // trees deeper than 31 levels excepted: its wave-uniform arithmetic is 32-bit); everything else (BSphere nodes,
         // start_level == levels): the exact joint walk
         if constexpr (N::kind == IBVH_BBOX) {
-            if (a.start_level < a.tree.levels && a.tree.levels <= 31) return launch_queue<L, N, I, MODE>(a, cache, write, st);
+            if (a.start_level < a.tree.levels && a.tree.levels <= 31) return launch_queue<L, N, I, MODE>(a, cache, write, st, agg_zeroed);
         }
         if (count_work) return IBVH_ERR_UNSUPPORTED; // (BSphere nodes / start at the leaf level: the exact walk has no counters)
         // (the exact walk keeps the run-time narrow switch: NARROW = true covers both)
@@ -121,16 +121,21 @@ int run(const ibvh_bvh *drv, const ibvh_bvh *walk, const void *points, const voi
                 a.gate = nullptr;
                 a.blk_rows = rows_bytes ? (uint32_t *)(tail_ptr + qidx_bytes) : nullptr;
                 a.q_index_dense = qidx_bytes ? (I *)tail_ptr : nullptr;
+                // (the scan's tile sums live behind the 64-byte header of the scratch: scan_counts)
+                const bool may_fuse = !write && !work && MODE != MODE_RAYS;
+                a.scan_agg = may_fuse ? (unsigned long long *)((int64_t *)scratch + 8) : nullptr;
+                a.scan_nparts = (int32_t)ceil_div(n_items, (int64_t)SCAN_TILE);
+                bool agg_zeroed = false;
                 a.blk_shift = 0;
                 const ibvh_bvh *qside = drv ? drv : walk;
                 a.q_nodes = (const N *)qside->nodes;
                 a.q_tree = TreeDev{qside->tree.levels, qside->tree.real_leaves, qside->tree.virtual_leaves};
                 a.q_built_level = qside->built_level;
                 PairCache<I> cache{K ? (IndexPair<I> *)((char *)scratch + scan_scratch_bytes(n_items)) : nullptr, K};
-                if (int e = launch<L, N, I, MODE>(a, cache, write, st, bins)) return e;
+                if (int e = launch<L, N, I, MODE>(a, cache, write, st, bins, &agg_zeroed)) return e;
                 if (write || work) return (int)IBVH_OK;
                 if (int e = scan_counts<I>((I *)counts, n_items, enqueue ? nullptr : total_out, scratch, st, enqueue ? total_dev : nullptr,
-                                           enqueue ? total_host : nullptr)) return e;
+                                           enqueue ? total_host : nullptr, nullptr, agg_zeroed)) return e;
                 if (enqueue && capacity > 0) {
                     a.guard_total = total_dev ? (const int64_t *)total_dev : (const int64_t *)scratch; // the total contacts
                     a.guard_capacity = sizeof(I) == 4 && capacity > (int64_t)INT32_MAX ? (int64_t)INT32_MAX : capacity;

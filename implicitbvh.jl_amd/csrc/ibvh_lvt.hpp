@@ -68,6 +68,10 @@ template <class L, class N, class I> struct Args {
     // pass — which needs nothing else of a leaf to put a cached pair together, and would otherwise pull every line of the leaf
     // records through the memory system for it (24-byte records: 240 MB at 1e7 leaves).  nullptr: read the leaf.
     I *q_index_dense;
+    // walker 2, counting pass: the tile aggregates of the single-kernel scan that follows it (scan_fused_kernel) — its first
+    // scan_nparts waves zero one word each (the scratch is the caller's, uninitialised).  nullptr: nothing to zero.
+    unsigned long long *scan_agg;
+    int32_t scan_nparts;
 };
 
 // ---- walker 2, the shared part of the descent ---------------------------------------------------------------------------
@@ -541,6 +545,91 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_apply_kernel(I *c, int64_t n, c
     }
 }
 
+// The same scan in ONE kernel (round 5), for counts whose producer zeroed the tile aggregates (walker 2's counting pass): every
+// workgroup sums its tile, PUBLISHES the sum (bit 63 = "there"; one 64-bit agent-scope atomic store: value and flag travel together,
+// no fence — an agent-scope fence on this part writes back and invalidates an XCD's whole L2), adds up the aggregates of the tiles
+// before it (polling those that are not there yet: they belong to workgroups with smaller ids, which were dispatched earlier
+// and are resident or done) and scans its tile.  One launch and one dependent round trip less than reduce + apply: they are
+// launch- and latency-bound (245 workgroups at 1e6 leaves).
+template <class I>
+__global__ __launch_bounds__(SCAN_TPB) void scan_fused_kernel(I *c, int64_t n, unsigned long long *agg, int64_t *totals, int64_t *total_host) {
+    __shared__ int64_t s_w[SCAN_TPB / 64], s_p[SCAN_TPB / 64];
+    constexpr unsigned long long THERE = 1ull << 63;
+    // thread owns SCAN_IPT consecutive items so the in-thread running sum is in memory order
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_IPT;
+    int64_t v[SCAN_IPT], sum = 0;
+    constexpr int NV = SCAN_IPT * (int)sizeof(I) / 16;
+    const bool vec = base + SCAN_IPT <= n && ((uintptr_t)c & 15) == 0;
+    if (vec) {
+        I raw[SCAN_IPT];
+        const uint4 *src = (const uint4 *)(c + base);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) ((uint4 *)raw)[k] = src[k];
+#pragma unroll
+        for (int j = 0; j < SCAN_IPT; ++j) {
+            v[j] = (int64_t)raw[j];
+            sum += v[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < SCAN_IPT; ++j) {
+            const int64_t i = base + j;
+            v[j] = i < n ? (int64_t)c[i] : 0;
+            sum += v[j];
+        }
+    }
+    int64_t inc = sum;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int64_t t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    int64_t wb = 0, tile_total = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_TPB / 64; ++k) {
+        if (k < w) wb += s_w[k];
+        tile_total += s_w[k];
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(&agg[blockIdx.x], THERE | (unsigned long long)tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int64_t before = 0;
+    for (int64_t j = threadIdx.x; j < (int64_t)blockIdx.x; j += SCAN_TPB) {
+        unsigned long long a = __hip_atomic_load(&agg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (!(a & THERE)) {
+            __builtin_amdgcn_s_sleep(1);
+            a = __hip_atomic_load(&agg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        before += (int64_t)(a & ~THERE);
+    }
+    const int64_t tile_offset = block_sum(before, s_p);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        const int64_t total = tile_offset + tile_total;
+        totals[0] = total;
+        if (total_host) __hip_atomic_store(total_host, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    int64_t run = tile_offset + wb + inc - sum;
+    if (vec) {
+        I raw[SCAN_IPT];
+#pragma unroll
+        for (int j = 0; j < SCAN_IPT; ++j) {
+            run += v[j];
+            raw[j] = (I)run;
+        }
+        uint4 *dst = (uint4 *)(c + base);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) dst[k] = ((const uint4 *)raw)[k];
+    } else {
+#pragma unroll
+        for (int j = 0; j < SCAN_IPT; ++j) {
+            const int64_t i = base + j;
+            run += v[j];
+            if (i < n) c[i] = (I)run;
+        }
+    }
+}
+
 // scratch layout of the *_count / *_write calls:
 //   [0, 64)            int64 header: [0] total contacts, [1] contact-cache slots K in use
 //   [64, scan_bytes)   scan tile sums
@@ -559,12 +648,16 @@ inline int cache_slots_for(size_t scratch_bytes, int64_t n_items, int64_t pair_b
 // inclusive scan in place + (total_out != nullptr) blocking read of the total (the reference's @allowscalar, :60)
 template <class I>
 int scan_counts(I *counts, int64_t n, int64_t *total_out, void *scratch, hipStream_t st, int64_t *total_dev = nullptr,
-                int64_t *total_host = nullptr, const int32_t *limit = nullptr) {
+                int64_t *total_host = nullptr, const int32_t *limit = nullptr, bool aggregates_zeroed = false) {
     int64_t nparts = ceil_div(n, SCAN_TILE);
     int64_t *totals = total_dev ? total_dev : (int64_t *)scratch; // where the device-side total goes
     int64_t *partials = (int64_t *)scratch + 8;
-    IBVH_LAUNCH((scan_reduce_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, partials, limit);
-    IBVH_LAUNCH((scan_apply_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, partials, totals, total_host, limit);
+    if (aggregates_zeroed && limit == nullptr && g_tuning.lvt_scan_fused != 0) {
+        IBVH_LAUNCH((scan_fused_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, (unsigned long long *)partials, totals, total_host);
+    } else {
+        IBVH_LAUNCH((scan_reduce_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, partials, limit);
+        IBVH_LAUNCH((scan_apply_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, partials, totals, total_host, limit);
+    }
     IBVH_LAUNCH_CHECK();
     if (!total_out) return IBVH_OK; // *_enqueue: the total stays in the scratch header, nobody waits
     int64_t total = 0;
@@ -700,7 +793,7 @@ template <class L, class N> constexpr bool kRayBinTypes = std::is_same<typename 
 // reach: IBVH_FOR_* below) in its own translation unit ------------------------------------------------------------------
 // walker 2: a.start_level < a.tree.levels <= 31, BBox nodes (ibvh_lvt_queue_self.hip / ibvh_lvt_queue_pair.hip)
 template <class L, class N, class I, int MODE>
-int launch_queue(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStream_t st);
+int launch_queue(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStream_t st, bool *agg_zeroed = nullptr);
 // walkers 3 and 4: the whole ray traversal of one pass (ibvh_lvt_rays.hip; it hands over to launch_rays_binned when rb.cap > 0)
 template <class L, class N, class I>
 int launch_rays(const Args<L, N, I> &a, const PairCache<I> &cache, bool write, hipStream_t st, const RayBins &rb);
