@@ -1111,6 +1111,8 @@ int sort_records(const Plan &p, int key_bytes, int key_bits, const void *keys, i
             using SG = SampleGeom<K>;
             K *cand = (K *)p.tb.splitters + ((size_t)1 << p.bits) + 1, *lists = cand + ((size_t)1 << p.bits) + 1;
             IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)sample_rank_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+            // (4,096 cells of 64-bit codes: 80 KB of splitters, tree and counters; bucket_hist_kernel has a few static bytes of its own)
+            IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)bucket_hist_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds - 8192));
             IBVH_LAUNCH((sample_sort_kernel<K>), dim3(SG::G), dim3(SG::TPB), SG::sort_smem, st, (const K *)keys, n, lists, key_bits);
             IBVH_LAUNCH((sample_rank_kernel<K>), dim3(SG::G * 4), dim3(1024), (size_t)SG::S * sizeof(K), st, (const K *)lists, cand, p.bits);
             IBVH_LAUNCH((bucket_hist_kernel<K>), dim3(p.num_tiles), dim3(512), hsm, st, (const K *)keys, n, p.tb, (const K *)cand, p.bits, (int)tile_elems,

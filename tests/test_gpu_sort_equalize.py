@@ -133,3 +133,19 @@ def test_a_chain_of_duplicates_goes_back_to_the_plain_grid_for_a_while():
         asked.append(int(b._fast[1].sort_equalize))
         assert torch.equal(b.leaves.buf, ref.leaves.buf), step
     assert asked == [1] + [0] * api.EQ_HOLDOFF + [1], asked
+
+
+def test_equalised_route_with_4096_cells_of_64_bit_codes(knob):
+    """1.5e7 leaves take 4,096 first-level cells; with UInt64 codes the histogram kernel's splitters, search tree and counters are
+    80 KB of LDS (beyond the default limit of a launch): byte-identical to the plain route."""
+    n = 15_000_000
+    c = clouds(n, 11)["8 tight clusters"]
+    vols = torch.cat([c, torch.full((n, 1), 1e-4, device="cuda")], 1).contiguous()
+    del c
+    opts = ibvh.BVHOptions(morton=ibvh.DefaultMortonAlgorithm(np.uint64))
+    knob(-1)
+    plain = ibvh.BVH(vols, options=opts)
+    knob(1)
+    eq = ibvh.BVH(vols, options=opts)
+    torch.cuda.synchronize()
+    assert torch.equal(eq.leaves.buf, plain.leaves.buf) and torch.equal(eq.nodes, plain.nodes)
