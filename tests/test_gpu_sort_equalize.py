@@ -149,3 +149,30 @@ def test_equalised_route_with_4096_cells_of_64_bit_codes(knob):
     eq = ibvh.BVH(vols, options=opts)
     torch.cuda.synchronize()
     assert torch.equal(eq.leaves.buf, plain.leaves.buf) and torch.equal(eq.nodes, plain.nodes)
+
+
+@pytest.mark.parametrize("shape", ["8 tight clusters", "torus surface", "duplicates"])
+def test_equalised_route_on_other_record_layouts_at_1e6(shape, knob):
+    """BBox leaves (40-byte records), Int64 indices with UInt16 codes (30 leaves per code: every cell is runs of equal keys), and the
+    in-place rebuild of pre-wrapped records: byte-identical to the plain route."""
+    n = 1_000_000
+    c = clouds(n, 21)[shape]
+    h = torch.full((n, 3), 1e-4, device="cuda")
+    cases = [("BBox{Float32} leaves", torch.cat([c - h, c + h], 1).contiguous(), ibvh.BVHOptions()),
+             ("Int64 indices, UInt16 codes", torch.cat([c, h[:, :1]], 1).contiguous(),
+              ibvh.BVHOptions(index=np.int64, morton=ibvh.DefaultMortonAlgorithm(np.uint16)))]
+    for what, vols, opts in cases:
+        knob(-1)
+        plain = ibvh.BVH(vols, options=opts)
+        knob(1)
+        eq = ibvh.BVH(vols, options=opts)
+        torch.cuda.synchronize()
+        assert torch.equal(eq.leaves.buf, plain.leaves.buf) and torch.equal(eq.nodes, plain.nodes), (what, shape)
+        # the in-place rebuild of the records (user indices kept), both routes
+        ref = plain.leaves.buf.clone()
+        for route in (-1, 1):
+            knob(route)
+            b = ibvh.BVH(eq.leaves, options=opts, cache=eq)
+            torch.cuda.synchronize()
+            assert torch.equal(b.leaves.buf, ref) and torch.equal(b.nodes, plain.nodes), (what, shape, route)
+            eq = b
