@@ -12,6 +12,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import csrc_sha  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from captured_sha import captured_sha  # noqa: E402
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 go = os.path.join(ROOT, "gpurun_out")
@@ -19,7 +21,7 @@ for script, src in (("pmc_traffic.py", f"prof_{tag}"), ("sq_summary.py", f"prof_
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), os.path.join(go, src), tag], check=True)
 rays = os.path.join(ROOT, "profiles", f"{tag}_rays_sq_counters.json")
 doc = json.load(open(rays)) if os.path.exists(rays) else {}
-doc.update({"csrc_sha": csrc_sha(),
+doc.update({"csrc_sha": captured_sha(os.path.join(go, f"sqr_{tag}")),
             "binned": json.load(open(os.path.join(go, f"sqr_{tag}", "summary_binned.json"))),
             "walker": json.load(open(os.path.join(go, f"sqr_{tag}", "summary_walker.json")))})
 json.dump(doc, open(rays, "w"), indent=1)

@@ -15,6 +15,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import csrc_sha
+from captured_sha import captured_sha  # noqa: E402
 
 COMMENT = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no tracing) of `python3 bench.py --n {n} --steps 5 "
            "--warmup 2 --no-cpu-baseline --no-configs --extra-n 0`, per-launch averages in KiB as reported. Per MI355X_MICROARCH.md §HBM: "
@@ -56,7 +57,7 @@ def main():
                              "WRITE_SIZE_KiB_avg": round(w[0] / w[1], 2) if w[1] else None}
         # csrc_sha: the state of the kernel sources these counters belong to (run this script BEFORE touching csrc/ again);
         # bench.py quotes the figures only while the hash still matches
-        json.dump({"_comment": COMMENT.format(n=n), "csrc_sha": csrc_sha(), "kernels": kernels},
+        json.dump({"_comment": COMMENT.format(n=n), "csrc_sha": captured_sha(root), "kernels": kernels},
                   open(f"profiles/{tag}_pmc_fetch_write_{label}.json", "w"), indent=1)
         print("wrote", label, len(kernels), "kernels")
 

@@ -8,6 +8,7 @@
 tag=${1:-r03}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$tag
 mkdir -p "$O"; cd /tmp; export TMPDIR=/tmp
+(cd "$R" && python3 -c "import bench; print(bench.csrc_sha())") > "$O/csrc_sha.txt" 2>/dev/null  # the sources these counters belong to
 common="--no-cpu-baseline --no-configs --extra-n 0"
 for n in 1000000 10000000; do
   s=$([ $n = 1000000 ] && echo "" || echo "_1e7")

@@ -7,6 +7,7 @@
 tag=${1:-r03}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_sq_$tag
 mkdir -p "$O"; cd /tmp; export TMPDIR=/tmp
+(cd "$R" && python3 -c "import bench; print(bench.csrc_sha())") > "$O/csrc_sha.txt" 2>/dev/null  # the sources these counters belong to
 common="--no-cpu-baseline --no-configs --extra-n 0 --steps 3 --warmup 1"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM --output-format csv -d "$O/sq_a" -o r -- python3 "$R/bench.py" $common > "$O/sq_a.log" 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$O/sq_b" -o r -- python3 "$R/bench.py" $common > "$O/sq_b.log" 2>&1

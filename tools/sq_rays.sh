@@ -4,6 +4,7 @@
 # usage: tools/sq_rays.sh OUTTAG [extra IBVH_TUNING items]
 tag=$1; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/sqr_$tag
 mkdir -p "$O"; cd /tmp; export TMPDIR=/tmp
+(cd "$R" && python3 -c "import bench; print(bench.csrc_sha())") > "$O/csrc_sha.txt" 2>/dev/null  # the sources these counters belong to
 for variant in binned walker; do
   if [ $variant = walker ]; then export IBVH_TUNING="rays_binned=0"; else export IBVH_TUNING="$2"; fi
   i=0

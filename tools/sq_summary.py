@@ -15,6 +15,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import csrc_sha, pmc_key
+from captured_sha import captured_sha  # noqa: E402
 
 
 def main():
@@ -47,7 +48,7 @@ def main():
     os.makedirs("profiles", exist_ok=True)
     json.dump({"_comment": "rocprofv3 --pmc SQ counter passes (three separate passes, no tracing flags) of `python3 bench.py "
                            "--no-cpu-baseline --no-configs --extra-n 0 --steps 3 --warmup 1` (1e6 leaves), per-launch averages; made by "
-                           "tools/profile_sq.sh + tools/sq_summary.py", "csrc_sha": csrc_sha(), "kernels": out},
+                           "tools/profile_sq.sh + tools/sq_summary.py", "csrc_sha": captured_sha(root), "kernels": out},
               open(f"profiles/{tag}_sq_counters_n1e6.json", "w"), indent=1)
     print("wrote", len(out), "kernels")
 

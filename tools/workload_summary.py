@@ -12,6 +12,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import csrc_sha, pmc_key
+from captured_sha import captured_sha  # noqa: E402
 
 
 def counters(d, counter):
@@ -59,6 +60,6 @@ for wdir in sorted(glob.glob(os.path.join(root, "*/"))):
 json.dump({"_comment": "one rocprofv3 process per workload and pass (tools/profile_workloads.sh -> tools/profile_workload.py NAME: 2 warm-up + 5 "
                        "timed calls of that workload only); avg_us from --kernel-trace --stats, FETCH / WRITE from separate --pmc passes, "
                        "traffic = 2*FETCH_SIZE + WRITE_SIZE (L2-miss bytes; Infinity-Cache hits included); set-up kernels (generators, "
-                       "builds) appear with their own names", "csrc_sha": csrc_sha(), "workloads": out},
+                       "builds) appear with their own names", "csrc_sha": captured_sha(root), "workloads": out},
           open(f"profiles/{tag}_workload_counters.json", "w"), indent=1)
 print("wrote", len(out), "workloads")
