@@ -413,6 +413,38 @@ def run_configs(args, ibvh, lib, torch, cpu):
     del v64
     torch.cuda.empty_cache()
 
+    # ---- skewed input: the same 1e6 leaves uniform and drawn from 8 tight Gaussian clusters (sigma 0.004 of
+    # the box), build only, `cache=` chains — the chain's hint sends the clustered one through equalised sort cells
+    # (DESIGN.md §3 "Equalised cells") —, ten chained rebuilds per figure -------------------------------------------------
+    ns = 1_000_000
+    g = torch.Generator(device="cuda").manual_seed(7)
+    centres = torch.rand((8, 3), generator=g, device="cuda")
+    clustered = torch.empty((ns, 4), dtype=torch.float32, device="cuda")
+    clustered[:, :3] = centres[torch.randint(0, 8, (ns,), generator=g, device="cuda")] + 0.004 * torch.randn((ns, 3), generator=g, device="cuda")
+    clustered[:, 3] = 1e-4
+    uniform = ibvh.generate_spheres(ns, 42)
+    skew = {}
+    for name, vv in (("uniform", uniform), ("clusters8", clustered)):
+        sk = {"b": None}
+
+        def build_sk():
+            sk["b"] = ibvh.BVH(vv, cache=sk["b"])
+            return sk["b"]
+        for _ in range(4):
+            build_sk()
+            torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            build_sk()
+        torch.cuda.synchronize()
+        skew[name] = {"ms": round((time.perf_counter() - t0) / 10 * 1e3, 4), "equalised_cells": int(sk["b"]._fast[1].sort_equalize) if sk["b"]._fast else None}
+        del sk
+    skew["clusters_over_uniform"] = round(skew["clusters8"]["ms"] / skew["uniform"]["ms"], 3)
+    out["skew_1e6_build"] = skew
+    del clustered, uniform
+    torch.cuda.empty_cache()
+
     # ---- time stepping: the reference's literal loop (build.jl:109-126, README.md:84-95) on a moving cloud -----------
     out["timestep"] = {str(nn): run_timestep(nn, ibvh, lib, torch, cpu) for nn in (1_000_000, 10_000_000)}
     return out
@@ -584,6 +616,9 @@ def compact_line(line, detail_path):
         out["north_star_1e7"] = o
     if line.get("configs"):
         out["configs"] = _compact_node(line["configs"])
+        sk = line["configs"].get("skew_1e6_build")
+        if isinstance(sk, dict) and out["configs"] is not None:
+            out["configs"]["skew_1e6_build"] = {"uniform_ms": sk["uniform"]["ms"], "clusters8_ms": sk["clusters8"]["ms"], "ratio": sk["clusters_over_uniform"]}
     if isinstance(line.get("exchange"), dict):
         out["exchange"] = _pick(line["exchange"], ("max_exchange_ms", "bytes_sent_max", "xgmi_frac_per_link"))
     if isinstance(line.get("work"), dict):
