@@ -520,7 +520,6 @@ struct Tuning {
     int msd_avg = 1024;     // largest average cell before another first-level bit is taken
     int msd_range = 1;      // 0 = first extra level on the next 8 bits, unmeasured
     int lvt_scan_fused = 1; // the scan behind walker 2's counting pass in one kernel (scan_fused_kernel); 0 = reduce + apply
-    int msd_atomic_first = 1; // resident finish: first LDS pass by atomics (unique words need no stability there); 0 = ballot ranking
     int msd_equalize = 0;   // equalised cells (ibvh_msd.hip): 0 = when the build asks (ibvh_build_desc.sort_equalize), 1 = always, -1 = never
     int msd_finish_pad_kb = 0; // LDS (KiB) a finish workgroup asks for at least: limits the workgroups per CU (0 = what it needs)
     int msd_resident_kb = 0; // LDS budget (KiB) of a finish workgroup that keeps its range's RECORDS in LDS: 0 = the plan decides

@@ -1157,7 +1157,6 @@ int sort_records(const Plan &p, int key_bytes, int key_bits, const void *keys, i
     fa.levels = levels;
     fa.shift1 = p.shift;
     fa.eq_key_bits = eq ? key_bits : 0;
-    fa.atomic_first = g_tuning.msd_atomic_first;
     fa.skew_flag = (int32_t *)skew_flag;
     fa.kalt = kalt;
     fa.kpri = kpri;

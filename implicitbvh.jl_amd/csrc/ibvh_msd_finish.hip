@@ -6,7 +6,6 @@
 
 namespace ibvh {
 namespace msd {
-#define g_tuning_msd_atomic_first (fa.atomic_first != 0)
 
 template <class K, int TPB, int IPT> struct FinishLds {
     static constexpr int W = TPB / 64, CAP = TPB * IPT, RB = 8, R = 1 << RB;
@@ -95,24 +94,6 @@ IBVH_D void finish_range(const FinishArgs &fa, const FinishLds<K, TPB, IPT> &l, 
             int done = 0;
             for (int p = 0; p < passes; ++p) {
                 const int bits = (nbits - done + (passes - p) - 1) / (passes - p);
-                if (p == 0 && passes >= 2 && g_tuning_msd_atomic_first) {
-                    // The FIRST pass of an LSD sort need not be stable when the words are unique (the position is part of them):
-                    // a counting pass with LDS atomics — count, scan, take a slot — instead of the ballot ranking, whose ~6 vector
-                    // instructions per key bit and row are what a pass costs on this kernel's 16 waves.
-                    const uint32_t dmask = (1u << bits) - 1u;
-                    uint32_t *hist = l.local_base;
-                    if (threadIdx.x < R) hist[threadIdx.x] = 0;
-                    __syncthreads();
-#pragma unroll
-                    for (int j = 0; j < IPT; ++j)
-                        if (j < jmax) atomicAdd(&hist[((uint32_t)key[j] >> IDXB) & dmask], 1u);
-                    __syncthreads();
-                    rsort::lds_exclusive_scan<TPB>(hist, R, l.wave_tot);
-#pragma unroll
-                    for (int j = 0; j < IPT; ++j)
-                        if (j < jmax) l.s_keys[atomicAdd(&hist[((uint32_t)key[j] >> IDXB) & dmask], 1u)] = key[j];
-                    __syncthreads();
-                } else
                 lds_radix_pass<K, rsort::NoVal, TPB, IPT, RB>(key, none, IDXB + done, bits, jmax, l.s_keys, (rsort::NoVal *)nullptr, l.local_base,
                                                               l.wave_tot, l.whist);
                 done += bits;

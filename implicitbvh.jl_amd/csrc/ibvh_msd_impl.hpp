@@ -94,7 +94,6 @@ struct FinishArgs {
     uint32_t tile;      // tile of the extra levels = window of sub-cells one workgroup finishes
     int levels;         // extra levels that ran; what is still crowded after them takes the slow path
     int shift1;         // key >> shift1 = cell
-    int atomic_first;   // resident path: the first LDS pass counts with atomics (tuning msd_atomic_first)
     int eq_key_bits;    // != 0: equalised cells (cell d = the keys between splitters d and d + 1); the number of key bits
     int32_t *skew_flag; // caller's hint word (may be null): receives `needed`
     // slow path only: (key, position) arrays of n entries each

@@ -602,7 +602,7 @@ ibvh_status ibvh_lvt_work_counters(const ibvh_bvh *bvh, const ibvh_bvh *bvh2, co
  * on them, only speed and which code path is taken).  One process-wide table: set a knob BEFORE the calls it should
  * affect and not concurrently with them.  The library never reads the environment.  Names: "ray_block", "lvt_wide",
  * "lvt_xcd", "sort_tile", "sort_lsd", "sort_msd_avg", "bucket_tpb", "msd", "msd_bits", "msd_cap", "msd_tile",
- * "msd_ftpb", "msd_avg", "msd_range", "msd_equalize", "msd_atomic_first", "lvt_scan_fused", "msd_finish_pad_kb", "msd_resident_kb", "bfs_wg_per_cu", "lvt_dual", "rays_shadow",
+ * "msd_ftpb", "msd_avg", "msd_range", "msd_equalize", "lvt_scan_fused", "msd_finish_pad_kb", "msd_resident_kb", "bfs_wg_per_cu", "lvt_dual", "rays_shadow",
  * "rays_binned" (1 = the binned ray path where it pays, 2 = wherever the tree allows it, 0 = never), "rays_subtree_depth",
  * "rays_items_per_ray", "rays_fast_slab" (meanings: csrc/ibvh_common.hpp, struct Tuning).  Unknown name:
  * IBVH_ERR_INVALID_ARG. */
