@@ -98,15 +98,15 @@ def pmc_key(demangled):
     return base
 
 
-def csrc_sha():
-    """Hash of the kernel sources: the committed counter profiles are stamped with it, and a profile taken at another
-    state of the kernels is not quoted (measure-or-omit)."""
+def csrc_sha(root=ROOT):
+    """Hash of everything libibvh.so is compiled from (`__graft_entry__.kernel_sources`: *.hip, *.hpp, *.inc, the
+    Makefile with its flags, include/ibvh.h): the committed counter profiles are stamped with it, and a profile taken at
+    another state of the kernels is not quoted (measure-or-omit)."""
+    from __graft_entry__ import kernel_sources
     h = hashlib.sha256()
-    d = os.path.join(ROOT, "implicitbvh.jl_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in kernel_sources(root):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -612,7 +612,7 @@ class BVH:
         # of what a finish workgroup sorts — a cloud that contracts or clusters over many steps reaches that long before
         # a cell overflows.  Only an input that changes ABRUPTLY from comfortably uniform to clustered meets no extra
         # level: its crowded cells take the one-workgroup slow path on that one step (correct; 17 ms at 1e6 leaves,
-        # tools/dbg_spike.py) and the hint it leaves fixes the next.  That path's cost grows with the cell (~0.1 s at 1e7
+        # tools/attic/dbg_spike.py) and the hint it leaves fixes the next.  That path's cost grows with the cell (~0.1 s at 1e7
         # leaves) while the idle level's share of a step shrinks (1 % at 1e7), so builds of SPARE_ALWAYS_FROM leaves and
         # more always launch the spare level.  SPARE_OCCUPANCY = 0 restores "always" at every size.
         # EQUALISED cells (include/ibvh.h, sort_equalize) once the chain's input has shown that it does not fill the grid: the
@@ -1070,7 +1070,7 @@ def _bfs_run(entry, types, initial_capacity, cache, levels_hint, *args):
         if res.contacts_in == 2:
             q1, q2 = q2, q1
         global _last_bfs_counters
-        _last_bfs_counters = (counters, int(levels_hint))  # (tools/dbg_bfs_levels.py reads the per-step counts)
+        _last_bfs_counters = (counters, int(levels_hint))  # (tools/attic/dbg_bfs_levels.py reads the per-step counts)
         return res, q1, q2
 
 

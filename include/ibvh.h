@@ -600,12 +600,14 @@ ibvh_status ibvh_lvt_work_counters(const ibvh_bvh *bvh, const ibvh_bvh *bvh2, co
 
 /* Development knobs, for measurements and tests only (the defaults are the shipped behaviour; results never depend
  * on them, only speed and which code path is taken).  One process-wide table: set a knob BEFORE the calls it should
- * affect and not concurrently with them.  The library never reads the environment.  Names: "ray_block", "lvt_wide",
- * "lvt_xcd", "sort_tile", "sort_lsd", "sort_msd_avg", "bucket_tpb", "msd", "msd_bits", "msd_cap", "msd_tile",
- * "msd_ftpb", "msd_avg", "msd_range", "msd_equalize", "lvt_scan_fused", "msd_finish_pad_kb", "msd_resident_kb", "bfs_wg_per_cu", "lvt_dual", "rays_shadow",
- * "rays_binned" (1 = the binned ray path where it pays, 2 = wherever the tree allows it, 0 = never), "rays_subtree_depth",
- * "rays_items_per_ray", "rays_fast_slab" (meanings: csrc/ibvh_common.hpp, struct Tuning).  Unknown name:
- * IBVH_ERR_INVALID_ARG. */
+ * affect and not concurrently with them.  The library never reads the environment.  Names (exactly the table in
+ * csrc/ibvh_core.hip; meanings: csrc/ibvh_common.hpp, struct Tuning): "ray_block", "lvt_wide", "lvt_xcd", "sort_tile",
+ * "sort_lsd", "sort_msd_avg", "bucket_tpb", "msd", "msd_bits", "msd_cap", "msd_tile", "msd_ftpb", "msd_avg",
+ * "msd_range", "msd_equalize", "lvt_scan_fused", "bfs_wg_per_cu", "lvt_blocks", "lvt_block_shift",
+ * "lvt_blocks_min_items", "lvt_blocks_paired_below", "rays_binned" (1 = the binned ray path where it pays, 2 =
+ * wherever the tree allows it, 0 = never), "rays_fast_slab", "rays_subtree_depth", "rays_items_per_ray",
+ * "msd_resident_kb", "msd_finish_pad_kb".  Unknown name: IBVH_ERR_INVALID_ARG — that includes the names of
+ * development variants whose kernels are not in libibvh.so (variants/ builds with -DIBVH_VARIANTS add their own). */
 ibvh_status ibvh_set_tuning(const char *name, int32_t value);
 ibvh_status ibvh_get_tuning(const char *name, int32_t *value_out);
 

@@ -342,3 +342,65 @@ def test_sort_hint_rule_of_a_rebuild_chain():
         assert rule(2 | 1 << 16, n, 0)[1] == 0
     finally:
         api.EQUALIZE = True
+
+
+def test_evidence_stamp_and_staleness_see_every_compiled_file(tmp_path):
+    """`bench.csrc_sha()` (the stamp on the committed counter profiles) and `__graft_entry__.build()`'s staleness check
+    cover every file the Makefile's compile rule depends on — including the textually included kernel bodies (*.inc:
+    the dominant kernel lives in one), the Makefile's flags and include/ibvh.h. Editing a comment in the .inc alone in
+    a temp copy must change the hash and make the library stale."""
+    import shutil
+    import time
+    import bench
+    import __graft_entry__ as entry
+    root = tmp_path / "copy"
+    csrc = root / "implicitbvh.jl_amd" / "csrc"
+    csrc.mkdir(parents=True)
+    (root / "include").mkdir()
+    for f in entry.kernel_sources():
+        rel = os.path.relpath(f, ROOT)
+        shutil.copy2(f, root / rel)
+    names = {os.path.basename(f) for f in entry.kernel_sources(str(root))}
+    assert {"ibvh_lvt_queue.inc", "Makefile", "ibvh.h", "ibvh_common.hpp", "ibvh_build.hip"} <= names
+    # the Makefile's own rule names the same dependencies
+    mk = (csrc / "Makefile").read_text()
+    rule = [l for l in mk.splitlines() if l.startswith("%.o:")][0]
+    for dep in ("$(wildcard *.hpp)", "$(wildcard *.inc)", "../../include/ibvh.h", "Makefile"):
+        assert dep in rule, rule
+    so = root / "implicitbvh.jl_amd" / "libibvh.so"
+    so.write_bytes(b"built")
+    now = time.time()
+    os.utime(so, (now, now))
+    for f in entry.kernel_sources(str(root)):
+        os.utime(f, (now - 100, now - 100))
+    assert not entry.library_is_stale(str(root))
+    assert bench.csrc_sha(str(root)) == bench.csrc_sha()
+    for name, where in (("ibvh_lvt_queue.inc", csrc), ("Makefile", csrc), ("ibvh.h", root / "include")):
+        before = bench.csrc_sha(str(root))
+        p = where / name
+        old = p.read_bytes()
+        p.write_bytes(old + (b"\n# edited\n" if name == "Makefile" else b"\n// edited\n"))
+        os.utime(p, (now + 100, now + 100))
+        assert bench.csrc_sha(str(root)) != before, name
+        assert entry.library_is_stale(str(root)), name
+        p.write_bytes(old)
+        os.utime(p, (now - 100, now - 100))
+        assert bench.csrc_sha(str(root)) == before and not entry.library_is_stale(str(root))
+
+
+def test_header_lists_exactly_the_knobs_the_library_has():
+    """include/ibvh.h names the tuning knobs; the list must be the product table (csrc/ibvh_core.hip, outside the
+    IBVH_VARIANTS block), and each name must be accepted — a variant-only name is refused."""
+    hdr = open(os.path.join(ROOT, "include", "ibvh.h")).read()
+    doc = hdr[hdr.index("Development knobs"):hdr.index("ibvh_status ibvh_set_tuning")]
+    listed = set(re.findall(r'"([a-z0-9_]+)"', doc))
+    core = open(os.path.join(ROOT, "implicitbvh.jl_amd", "csrc", "ibvh_core.hip")).read()
+    table = core[core.index("const Knob kKnobs[]"):core.index("inline int64_t ilog2_down")]
+    product = set(re.findall(r'\{"([a-z0-9_]+)"', re.sub(r"#ifdef IBVH_VARIANTS.*?#endif", "", table, flags=re.S)))
+    assert listed == product, (listed ^ product)
+    L = lib.load()
+    v = C.c_int32()
+    for name in sorted(product):
+        assert L.ibvh_get_tuning(name.encode(), C.byref(v)) == 0, name
+    for name in ("lvt_dual", "rays_shadow", "nope"):
+        assert L.ibvh_get_tuning(name.encode(), C.byref(v)) != 0
