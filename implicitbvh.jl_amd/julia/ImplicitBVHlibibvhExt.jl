@@ -87,13 +87,26 @@ mutable struct IbvhDistCrossPlan
     IbvhDistCrossPlan() = new()
 end
 
-kind(::Type{<:BSphere}) = Int32(0);  kind(::Type{<:BBox}) = Int32(1)
-fltcode(::Type{Float32}) = Int32(0); fltcode(::Type{Float64}) = Int32(1)
-idxcode(::Type{Int32}) = Int32(0);   idxcode(::Type{Int64}) = Int32(1)
-morcode(::Type{UInt16}) = Int32(0);  morcode(::Type{UInt32}) = Int32(1); morcode(::Type{UInt64}) = Int32(2)
+# Type codes of include/ibvh.h.  Every table ends in a CATCH-ALL returning -1: a volume, float, index or Morton type the
+# library has no instantiation for (BSphere{Float16}, index=UInt32, a user-defined volume, ...) is not an error here — the
+# methods below are MORE SPECIFIC than the reference's, so they must hand every input they cannot serve to the reference's
+# own generic method (`invoke`), never throw a MethodError for something that works without the extension
+# (test/runtests.jl:480,510-538 builds Float16 volumes; utils.jl:54-71 takes any Integer exemplar).
+kind(::Type{<:BSphere}) = Int32(0);  kind(::Type{<:BBox}) = Int32(1);  kind(::Type) = Int32(-1)
+fltcode(::Type{Float32}) = Int32(0); fltcode(::Type{Float64}) = Int32(1); fltcode(::Type) = Int32(-1)
+idxcode(::Type{Int32}) = Int32(0);   idxcode(::Type{Int64}) = Int32(1);   idxcode(::Type) = Int32(-1)
+morcode(::Type{UInt16}) = Int32(0);  morcode(::Type{UInt32}) = Int32(1); morcode(::Type{UInt64}) = Int32(2); morcode(::Type) = Int32(-1)
+# eltype of a volume TYPE (bsphere.jl:32, bbox.jl:41); Any for a type that does not define it
+volume_float(::Type{V}) where {V} = V <: Union{BSphere, BBox} ? eltype(V) : Any
 
-ibvh_types(::Type{L}, ::Type{N}, ::Type{I}, ::Type{M}) where {L, N, I, M} =
-    IbvhTypes(kind(L), fltcode(eltype(L)), kind(N), fltcode(eltype(N)), idxcode(I), morcode(M))
+# The library's type descriptor of (leaf volume L, node N, index I, Morton M) — or `nothing` when any of the four has no
+# code: the caller then takes the reference's generic path.  (A combination of KNOWN codes the library does not instantiate
+# is reported by the library itself: IBVH_ERR_UNSUPPORTED from the *_scratch_bytes queries.)
+function native_types(::Type{L}, ::Type{N}, ::Type{I}, ::Type{M}) where {L, N, I, M}
+    codes = (kind(L), fltcode(volume_float(L)), kind(N), fltcode(volume_float(N)), idxcode(I), morcode(M))
+    any(c -> c < 0, codes) && return nothing
+    IbvhTypes(codes...)
+end
 
 const IBVH_ERR_UNSUPPORTED = Cint(3)
 const IBVH_ERR_CAPACITY = Cint(4)
@@ -116,10 +129,14 @@ tree_of(t::ImplicitTree) = IbvhTree(t.levels, t.real_leaves, t.real_nodes, t.vir
 
 const RocBVH{I} = BVH{I, <:ROCVector, <:ROCVector, <:ROCVector}
 
+# The library's view of a built BVH, or `nothing` when its types have no code (-> generic path, as native_types).
 function bvh_desc(bvh::BVH{I, <:ROCVector, <:ROCVector{N}, <:ROCVector{BoundingVolume{L, I, M}}}) where {I, N, L, M}
-    IbvhBvh(ibvh_types(L, N, I, M), tree_of(bvh.tree), Int64(bvh.built_level),
+    types = native_types(L, N, I, M)
+    isnothing(types) && return nothing
+    IbvhBvh(types, tree_of(bvh.tree), Int64(bvh.built_level),
             devptr(bvh.leaves), devptr(bvh.nodes), devptr(bvh.skips))
 end
+bvh_desc(bvh::BVH) = nothing   # (leaves that are not BoundingVolume records of the BVH's own index type)
 
 # ---- narrow --------------------------------------------------------------------------------------------
 const DEFAULT_NARROW = (bv1, bv2) -> true          # the default of every method below (=== comparable)
@@ -173,17 +190,27 @@ end
 # allocated once per process and never freed (a kernel still in flight can only ever write into memory this module owns).
 # The scan kernel stores the total there with a system-scope release; the host polls the word instead of synchronising
 # the stream and copying 8 bytes back (the reference's blocking `@allowscalar`, lvt/traverse_single.jl:60).
-const HOST_WORDS = 4096
+const HOST_WORDS = 4096      # totals: words [0, HOST_WORDS)
+const HINT_WORDS = 1024      # skew hints of build chains: words [HOST_WORDS, HOST_WORDS + HINT_WORDS) — a ring of their own, so a
+                             # build still in flight can at worst overwrite another chain's HINT (speed only), never a total
 const HOST_PENDING = typemin(Int64) >> 1
 const host_block = Ref{Ptr{Int64}}(C_NULL)
 const host_next = Threads.Atomic{Int}(0)
-function next_host_word()
+const host_lock = ReentrantLock()
+function host_words()
     if host_block[] == C_NULL
-        p = Ref{Ptr{Cvoid}}(C_NULL)
-        AMDGPU.HIP.hipHostMalloc(p, 8 * HOST_WORDS, 0) |> AMDGPU.HIP.check   # hipHostMallocDefault: mapped, coherent
-        host_block[] = Ptr{Int64}(p[])
+        lock(host_lock) do
+            if host_block[] == C_NULL
+                p = Ref{Ptr{Cvoid}}(C_NULL)
+                AMDGPU.HIP.hipHostMalloc(p, 8 * (HOST_WORDS + HINT_WORDS), 0) |> AMDGPU.HIP.check   # hipHostMallocDefault: mapped, coherent
+                host_block[] = Ptr{Int64}(p[])
+            end
+        end
     end
-    w = host_block[] + 8 * (Threads.atomic_add!(host_next, 1) % HOST_WORDS)
+    host_block[]
+end
+function next_host_word()
+    w = host_words() + 8 * (Threads.atomic_add!(host_next, 1) % HOST_WORDS)
     unsafe_store!(w, HOST_PENDING)
     w
 end
@@ -317,6 +344,93 @@ c_traverse_rays_bfs(bvh, points, dirs, num_rays, sl, narrow, bvtt1, bvtt2, capac
           (Ref{IbvhBvh}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ref{IbvhBfsResult}, Ptr{Cvoid}),
           bvh, points, dirs, num_rays, sl, narrow, bvtt1, bvtt2, capacity, counters, result, stream)
 
+# ---- host policies of a rebuild chain (the same rules as the Python mirror, implicitbvh.jl_amd/api.py) -----------------
+# What a `cache=` rebuild asks the sort for is decided on the host from ONE word the previous build of the chain left in
+# mapped pinned memory (include/ibvh.h, ibvh_build_desc.skew_flag: low byte = extra partition levels that build would have
+# used, second byte = its fullest cell in 1/128 of what a finish workgroup sorts, bit 16 = it ran with equalised cells and
+# the plain grid would still have been crowded, bit 17 = equalising did not help).  tests/test_host_cpu.py parses the
+# constants and the two rule functions below and evaluates them against api.sort_hint_rule / api._cache_slots on a table
+# of inputs: the two hosts cannot drift apart.  (Both functions are written in the small subset that test understands:
+# integer arithmetic, comparisons, `ifelse`, if / elseif / else, `min` / `max` / `cld` / `nextpow`.)
+const COLD_SORT_LEVELS = 2      # extra partition levels a build without cache= launches (include/ibvh.h, sort_levels)
+const SPARE_OCCUPANCY = 96      # (of 128) fullest coarse cell from which a cached build launches a spare extra level
+const EQ_SPARE_OCCUPANCY = 120  # the same for a chain that builds with equalised cells (they re-fit the cells every time)
+const EQ_HOLDOFF = 32           # rebuilds a chain stays with the plain grid after an equalised build reported no gain (bit 17)
+const SPARE_ALWAYS_FROM = 16777216   # leaves from which a cached build always launches the spare level
+const EQUALIZE = 1              # 0: never ask for equalised cells
+const MAX_SORT_LEVELS = 4       # IBVH_MAX_SORT_LEVELS
+
+# (sort_levels, sort_equalize, holdoff') of a rebuild of n leaves — api.sort_hint_rule
+function sort_hint_rule(word::Int64, n::Int64, holdoff::Int64)
+    used = word & 0xff
+    occupancy = (word >> 8) & 0xff
+    eq = (word >> 16) & 1
+    nohelp = (word >> 17) & 1
+    if nohelp == 1 && holdoff == 0
+        holdoff = EQ_HOLDOFF
+    elseif holdoff > 0
+        holdoff = holdoff - 1
+    end
+    equalize = ifelse((used > 0 || eq == 1) && EQUALIZE == 1 && holdoff == 0, 1, 0)
+    threshold = ifelse(eq == 1 && equalize == 1, EQ_SPARE_OCCUPANCY, SPARE_OCCUPANCY)
+    spare = ifelse(used > 0 || occupancy >= threshold || n >= SPARE_ALWAYS_FROM, 1, 0)
+    return (min(used + spare, MAX_SORT_LEVELS), equalize, holdoff)
+end
+
+# contact-cache slots per work item: the default, or — when a previous traversal's contact buffer is reused — about four
+# times the contacts per item that buffer was sized for (a power of two, at most 64) — api._cache_slots
+function cache_slots_rule(capacity::Int64, n_items::Int64, default::Int64)
+    if capacity <= 0 || n_items <= 0
+        return default
+    end
+    per_item = cld(capacity, n_items)
+    want = nextpow(2, max(4 * per_item, 1))
+    return max(default, min(64, want))
+end
+cache_slots(cache, n_items, default) =
+    Int32(cache_slots_rule(isnothing(cache) ? Int64(0) : Int64(length(cache.cache1)), Int64(n_items), Int64(default)))
+
+# The chain's state lives beside the reference's BVH struct (build.jl:155-166 has no spare field): keyed by the node array,
+# which a `cache=` rebuild keeps (resize! preserves identity) and which dies with the chain.
+mutable struct ChainState
+    slot::Int          # index of the chain's word in the hint ring
+    generation::Int    # of that slot when the chain took it: a recycled slot is another chain's
+    holdoff::Int64
+end
+const hint_generation = zeros(Int, HINT_WORDS)
+const hint_next = Ref(0)
+const chains = WeakKeyDict{Any, ChainState}()
+hint_ptr(st::ChainState) = host_words() + 8 * (HOST_WORDS + st.slot)
+function new_chain()
+    lock(host_lock) do
+        slot = hint_next[]
+        hint_next[] = (slot + 1) % HINT_WORDS
+        hint_generation[slot + 1] += 1
+        st = ChainState(slot, hint_generation[slot + 1], 0)
+        unsafe_store!(hint_ptr(st), Int64(COLD_SORT_LEVELS))
+        st
+    end
+end
+# the state of the chain `cache` belongs to, if its word has not been recycled since
+function chain_of(cache)
+    isnothing(cache) && return nothing
+    st = lock(() -> get(chains, cache.nodes, nothing), host_lock)
+    (isnothing(st) || hint_generation[st.slot + 1] != st.generation) ? nothing : st
+end
+# (sort_levels, sort_equalize, skew_flag, state) of this build: cold builds launch COLD_SORT_LEVELS levels on the plain grid
+# and start a chain; a rebuild applies sort_hint_rule to the word (read ONCE, without synchronising: the latest value that
+# has arrived is good enough for a hint)
+function build_policy(cache, n)
+    st = chain_of(cache)
+    if isnothing(st)
+        st = new_chain()
+        return (Int32(COLD_SORT_LEVELS), Int32(0), Ptr{Cvoid}(hint_ptr(st)), st)
+    end
+    levels, equalize, holdoff = sort_hint_rule(unsafe_load(hint_ptr(st), :monotonic), Int64(n), st.holdoff)
+    st.holdoff = holdoff
+    (Int32(levels), Int32(equalize), Ptr{Cvoid}(hint_ptr(st)), st)
+end
+
 # ---- BVH(...) — build.jl:198-271 ------------------------------------------------------------------------
 function ImplicitBVH.BVH(
     bounding_volumes::ROCVector{L},
@@ -326,9 +440,19 @@ function ImplicitBVH.BVH(
     options=BVHOptions(),
 ) where {L, N}
     I = get_index_type(options)
-    M = eltype(options.morton)
     wrapped = L <: BoundingVolume
     V = wrapped ? fieldtype(L, :volume) : L
+    # What the library cannot serve goes to the reference's own method, unchanged: a Morton algorithm other than the default
+    # one, or any type without a code (Float16 volumes, index=UInt32, user volumes) — native_types; and a combination of
+    # known codes the library has no instantiation for — IBVH_ERR_UNSUPPORTED from the scratch query.  This is decided
+    # BEFORE anything is allocated or checked: the generic method does its own checks.
+    types = options.morton isa DefaultMortonAlgorithm ? native_types(V, N, I, eltype(options.morton)) : nothing
+    need = Ref{Csize_t}(0)
+    if isnothing(types) || c_build_scratch_bytes(types, length(bounding_volumes), need) == IBVH_ERR_UNSUPPORTED
+        return invoke(ImplicitBVH.BVH, Tuple{AbstractVector, Type}, bounding_volumes, node_type;
+                      built_level=built_level, cache=cache, options=options)
+    end
+    M = eltype(options.morton)
     if wrapped   # check_bounding_volume_types, build.jl:355-361
         fieldtype(L, :index) === I || throw(ArgumentError("BoundingVolume index type does not match BVHOptions"))
         fieldtype(L, :morton) === M || throw(ArgumentError("BoundingVolume morton type does not match BVHOptions"))
@@ -346,28 +470,18 @@ function ImplicitBVH.BVH(
         eltype(cache.nodes) === N || throw(ArgumentError("eltype(cache.nodes) === N must hold"))
         length(cache.nodes) == num_nodes || resize!(cache.nodes, num_nodes); cache.nodes end
 
-    types = ibvh_types(V, N, I, M)
-    need = Ref{Csize_t}(0)
-    st = c_build_scratch_bytes(types, numbv, need)
-    if st == IBVH_ERR_UNSUPPORTED   # e.g. Float16 volumes: the reference's own path
-        return invoke(ImplicitBVH.BVH, Tuple{AbstractVector, Type}, bounding_volumes, node_type;
-                      built_level=built_level, cache=cache, options=options)
-    end
-    check(st, "ibvh_build_scratch_bytes")
+    check(c_build_scratch_bytes(types, numbv, need), "ibvh_build_scratch_bytes")
     scratch = scratch!(:build, need[])
 
     alg = options.morton
+    # sort_levels / sort_equalize / skew_flag: the chain's policy (build_policy above; include/ibvh.h)
+    sort_levels, sort_equalize, skew_flag, chain = build_policy(cache, numbv)
     desc = IbvhBuildDesc(types, numbv, Int64(built_ilevel), wrapped ? 1 : 0, alg.compute_extrema ? 1 : 0,
                          Float64.(alg.mins), Float64.(alg.maxs),   # NB alg.mins/maxs, not options.mins (default.jl:55-56)
-                         # sort_levels = 2: always launch two extra partition levels (robust against clustered clouds; a
-                         # few per cent of a uniform 1e6-leaf build).  A shim that rebuilds every time step can hand the
-                         # library a mapped pinned host word as skew_flag and pass the level count the previous build left
-                         # in its low byte, plus a spare one when that is not 0 or the second byte (fullest cell, in 1/128 of
-                         # a workgroup's capacity) is close to 128 (include/ibvh.h) — and sort_equalize = 1 (cells = key ranges
-                         # of equal population: surface meshes, clustered clouds) when that low byte was not 0 or bit 16 is set.
-                         Int32(2), Int32(0), Ptr{Cvoid}(C_NULL))
+                         sort_levels, sort_equalize, skew_flag)
     check(c_build(desc, wrapped ? C_NULL : devptr(bounding_volumes), devptr(leaves), devptr(nodes), devptr(skips),
                   C_NULL, devptr(scratch), need[], stream_ptr()), "ibvh_build")
+    lock(() -> (chains[nodes] = chain), host_lock)
     BVH(I(built_ilevel), tree, skips, nodes, leaves)
 end
 
@@ -393,7 +507,8 @@ function dist_BVH(comm::IbvhComm, local_volumes::ROCVector{V}, node_type::Type{N
                   tolerance::Float64=0.005, cache::Union{Nothing, BVH}=nothing, options=BVHOptions()) where {V, N}
     I = get_index_type(options)
     M = eltype(options.morton)
-    types = ibvh_types(V, N, I, M)
+    types = native_types(V, N, I, M)
+    isnothing(types) && throw(ArgumentError("dist_BVH: no libibvh instantiation for $V leaves, $N nodes, $I indices, $M codes"))
     n_local = length(local_volumes)
     need = Ref{Csize_t}(0)
     check(c_dist_scratch_bytes(types, n_local, comm.size, need), "ibvh_dist_scratch_bytes")
@@ -425,6 +540,7 @@ contact set of the whole cloud, every pair once (include/ibvh.h "Cross-shard con
 """
 function dist_cross_contacts(comm::IbvhComm, bvh::RocBVH{I}; cache_slots::Integer=LVT_CACHE_SLOTS) where {I}
     desc = bvh_desc(bvh)
+    isnothing(desc) && throw(ArgumentError("dist_cross_contacts: no libibvh instantiation for this BVH's types"))
     nsmall = (16 * 48 + 16) * (Int(comm.size) + 1) + 16 * Int(comm.size) + 512    # IBVH_DIST_CROSS_SCRATCH
     small = scratch!(:dist_cross_plan, nsmall)
     plan = IbvhDistCrossPlan()
@@ -444,8 +560,8 @@ function dist_cross_contacts(comm::IbvhComm, bvh::RocBVH{I}; cache_slots::Intege
 end
 
 # ---- leaf-vs-tree: count -> (cache) -> write, or enqueue against a cached contact buffer ------------------------
-const LVT_CACHE_SLOTS = Int32(8)
-const RAY_CACHE_SLOTS = Int32(32)
+const LVT_CACHE_SLOTS = 8    # contacts per work item kept from the counting pass (include/ibvh.h); cache_slots() widens it
+const RAY_CACHE_SLOTS = 32   # hits per ray
 
 cached(cache, field::Symbol, ::Type{T}, n, like) where {T} =
     if isnothing(cache)
@@ -499,7 +615,9 @@ function ImplicitBVH.traverse(
     options=BVHOptions(),
 ) where {I}
     code = narrow_code(narrow)
-    if isnothing(code)   # an arbitrary closure: the reference's generic (KernelAbstractions) method evaluates it
+    d = bvh_desc(bvh)
+    # an arbitrary closure, or types without a libibvh instantiation: the reference's generic (KernelAbstractions) method
+    if isnothing(code) || isnothing(d)
         return invoke(ImplicitBVH.traverse, Tuple{BVH, LVTTraversal}, bvh, alg;
                       start_level=start_level, narrow=narrow, cache=cache, options=options)
     end
@@ -508,9 +626,9 @@ function ImplicitBVH.traverse(
     if bvh.tree.real_nodes <= 1   # :17-21
         return BVHTraversal(Int(start_level), 0, 0, similar(bvh.nodes, IndexPair{I}, 0), similar(bvh.nodes, I, 0))
     end
-    d = bvh_desc(bvh)
     s = stream_ptr()
-    total, contacts, counts = lvt_two_pass(I, bvh.nodes, length(bvh.leaves), d.types, LVT_CACHE_SLOTS, cache,
+    n_items = length(bvh.leaves)
+    total, contacts, counts = lvt_two_pass(I, bvh.nodes, n_items, d.types, cache_slots(cache, n_items, LVT_CACHE_SLOTS), cache,
         (cn, tot, sc, sb) -> c_traverse_lvt_count(d, start_level, code, devptr(cn), tot, devptr(sc), sb, s),
         (cn, ct, sc, sb) -> c_traverse_lvt_write(d, start_level, code, devptr(cn), devptr(ct), devptr(sc), sb, s),
         (cn, ct, cap, td, th, sc, sb) -> c_traverse_lvt_enqueue(d, start_level, code, devptr(cn), devptr(ct), cap, td, th, devptr(sc), sb, s))
@@ -529,7 +647,8 @@ function ImplicitBVH.traverse(
 ) where {I}
     code = narrow_code(narrow)
     d1, d2 = bvh_desc(bvh1), bvh_desc(bvh2)
-    if isnothing(code) || d1.types != d2.types   # closures, and pairs of different leaf / node types: generic method
+    # closures, types without an instantiation, and pairs of different leaf / node types: generic method
+    if isnothing(code) || isnothing(d1) || isnothing(d2) || d1.types != d2.types
         return invoke(ImplicitBVH.traverse, Tuple{BVH, BVH, LVTTraversal}, bvh1, bvh2, alg;
                       start_level1=start_level1, start_level2=start_level2, narrow=narrow, cache=cache, options=options)
     end
@@ -540,7 +659,7 @@ function ImplicitBVH.traverse(
     get_index_type(bvh2) === I || throw(ArgumentError("get_index_type(bvh2) === I must hold"))   # :50-52
     s = stream_ptr()
     n_items = max(length(bvh1.leaves), length(bvh2.leaves))
-    total, contacts, counts = lvt_two_pass(I, bvh1.nodes, n_items, d1.types, LVT_CACHE_SLOTS, cache,
+    total, contacts, counts = lvt_two_pass(I, bvh1.nodes, n_items, d1.types, cache_slots(cache, n_items, LVT_CACHE_SLOTS), cache,
         (cn, tot, sc, sb) -> c_traverse_pair_lvt_count(d1, d2, start_level1, start_level2, code, devptr(cn), tot, devptr(sc), sb, s),
         (cn, ct, sc, sb) -> c_traverse_pair_lvt_write(d1, d2, start_level1, start_level2, code, devptr(cn), devptr(ct), devptr(sc), sb, s),
         (cn, ct, cap, td, th, sc, sb) -> c_traverse_pair_lvt_enqueue(d1, d2, start_level1, start_level2, code, devptr(cn), devptr(ct), cap, td, th, devptr(sc), sb, s))
@@ -570,7 +689,7 @@ function ImplicitBVH.traverse_rays(
 ) where {I}
     d = bvh_desc(bvh)
     code = ray_narrow_code(narrow)
-    if isnothing(code) || d.types.leaf_float != d.types.node_float   # (isintersection needs one T)
+    if isnothing(code) || isnothing(d) || d.types.leaf_float != d.types.node_float   # (isintersection needs one T)
         return invoke(ImplicitBVH.traverse_rays, Tuple{BVH, AbstractMatrix, AbstractMatrix, LVTTraversal},
                       bvh, points, directions, alg; start_level=start_level, narrow=narrow, cache=cache, options=options)
     end
@@ -582,7 +701,7 @@ function ImplicitBVH.traverse_rays(
         return BVHTraversal(start_level, 0, 0, similar(bvh.nodes, IndexPair{I}, 0), similar(bvh.nodes, IndexPair{I}, 0))
     end
     s = stream_ptr()
-    total, contacts, counts = lvt_two_pass(I, bvh.nodes, nr, d.types, RAY_CACHE_SLOTS, cache,
+    total, contacts, counts = lvt_two_pass(I, bvh.nodes, nr, d.types, cache_slots(cache, nr, RAY_CACHE_SLOTS), cache,
         (cn, tot, sc, sb) -> c_traverse_rays_lvt_count(d, devptr(p), devptr(dr), nr, start_level, code, devptr(cn), tot, devptr(sc), sb, s),
         (cn, ct, sc, sb) -> c_traverse_rays_lvt_write(d, devptr(p), devptr(dr), nr, start_level, code, devptr(cn), devptr(ct), devptr(sc), sb, s),
         (cn, ct, cap, td, th, sc, sb) -> c_traverse_rays_lvt_enqueue(d, devptr(p), devptr(dr), nr, start_level, code, devptr(cn), devptr(ct), cap, td, th, devptr(sc), sb, s);
@@ -625,7 +744,8 @@ function ImplicitBVH.traverse(
     options=BVHOptions(),
 ) where {I}
     code = narrow_code(narrow)
-    if isnothing(code)
+    d = bvh_desc(bvh)
+    if isnothing(code) || isnothing(d)
         return invoke(ImplicitBVH.traverse, Tuple{BVH, BFSTraversal}, bvh, alg;
                       start_level=start_level, narrow=narrow, cache=cache, options=options)
     end
@@ -634,7 +754,6 @@ function ImplicitBVH.traverse(
     if bvh.tree.real_nodes <= 1
         return BVHTraversal(start_level, 0, 0, similar(bvh.nodes, IndexPair{I}, 0), similar(bvh.nodes, IndexPair{I}, 0))
     end
-    d = bvh_desc(bvh)
     s = stream_ptr()
     cap = Ref{Int64}(0)
     check(c_bfs_initial_capacity(d, start_level, cap), "ibvh_bfs_initial_capacity")
@@ -655,7 +774,7 @@ function ImplicitBVH.traverse(
 ) where {I}
     code = narrow_code(narrow)
     d1, d2 = bvh_desc(bvh1), bvh_desc(bvh2)
-    if isnothing(code) || d1.types != d2.types
+    if isnothing(code) || isnothing(d1) || isnothing(d2) || d1.types != d2.types
         return invoke(ImplicitBVH.traverse, Tuple{BVH, BVH, BFSTraversal}, bvh1, bvh2, alg;
                       start_level1=start_level1, start_level2=start_level2, narrow=narrow, cache=cache, options=options)
     end
@@ -684,7 +803,7 @@ function ImplicitBVH.traverse_rays(
 ) where {I}
     d = bvh_desc(bvh)
     code = ray_narrow_code(narrow)
-    if isnothing(code) || d.types.leaf_float != d.types.node_float
+    if isnothing(code) || isnothing(d) || d.types.leaf_float != d.types.node_float
         return invoke(ImplicitBVH.traverse_rays, Tuple{BVH, AbstractMatrix, AbstractMatrix, BFSTraversal},
                       bvh, points, directions, alg; start_level=start_level, narrow=narrow, cache=cache, options=options)
     end

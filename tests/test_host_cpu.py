@@ -404,3 +404,184 @@ def test_header_lists_exactly_the_knobs_the_library_has():
         assert L.ibvh_get_tuning(name.encode(), C.byref(v)) == 0, name
     for name in ("lvt_dual", "rays_shadow", "nope"):
         assert L.ibvh_get_tuning(name.encode(), C.byref(v)) != 0
+
+
+# ---- the Julia extension as a faithful boundary (round 6) --------------------------------------------------------------
+def _julia_methods(src):
+    """{(generic function, first 120 chars of the signature): body} of every `function ImplicitBVH.x(` in the extension."""
+    import re
+    out = {}
+    for m in re.finditer(r"\nfunction ImplicitBVH\.(\w+)\((.*?)\n\) where \{[^}]*\}\n(.*?)\nend\n", src, re.S):
+        out[(m.group(1), " ".join(m.group(2).split())[:120])] = m.group(3)
+    return out
+
+
+def test_julia_unsupported_types_reach_the_generic_methods():
+    """The extension's methods are more specific than the reference's, so every input the library has no instantiation for
+    must be handed to the reference's generic method, not raise: BSphere{Float16} leaves (runtests.jl:480,510-538), an index
+    type other than Int32 / Int64 (utils.jl:54-71 takes any Integer), a user-defined volume type, a Morton algorithm other
+    than the default.  Checked statically (no Julia here): (1) every type-code table ends in a catch-all returning -1 and
+    `native_types` turns any -1 into `nothing`; (2) in every method, each value obtained from `native_types(` / `bvh_desc(`
+    is tested with `isnothing(...)` in an `if` that returns `invoke(<generic method>)` BEFORE its first use."""
+    import re
+    src = _julia_ext()
+    assert "ibvh_types(" not in src  # (the old constructor that raised MethodError)
+    # (1) the code tables, emulated: specific entries + catch-all
+    tables = {}
+    for fn in ("kind", "fltcode", "idxcode", "morcode"):
+        entries = re.findall(fn + r"\(::Type(\{[^}]*\}+)?\)\s*=\s*Int32\((-?\d+)\)", src)
+        tables[fn] = {(e[0] or "").strip("{}"): int(e[1]) for e in entries}
+        assert tables[fn].get("") == -1, f"{fn} has no catch-all method returning -1"
+
+    def code(fn, t):
+        tab = tables[fn]
+        if fn == "kind":
+            return tab["<:BSphere"] if t.startswith("BSphere") else tab["<:BBox"] if t.startswith("BBox") else tab[""]
+        return tab.get(t, tab[""])
+
+    def native(leaf, node, index, morton):
+        flt = lambda v: re.search(r"\{(\w+)\}", v).group(1) if re.match(r"(BSphere|BBox)\{", v) else "Any"
+        codes = (code("kind", leaf), code("fltcode", flt(leaf)), code("kind", node), code("fltcode", flt(node)),
+                 code("idxcode", index), code("morcode", morton))
+        return None if any(c < 0 for c in codes) else codes
+    nt = re.search(r"function native_types\(.*?\nend\n", src, re.S).group(0)
+    assert "any(c -> c < 0, codes) && return nothing" in nt and "volume_float(L)" in nt and "volume_float(N)" in nt
+    assert native("BSphere{Float32}", "BBox{Float32}", "Int32", "UInt32") == (0, 0, 1, 0, 0, 1)
+    assert native("BBox{Float64}", "BSphere{Float64}", "Int64", "UInt64") == (1, 1, 0, 1, 1, 2)
+    for bad in (("BSphere{Float16}", "BBox{Float32}", "Int32", "UInt32"), ("BSphere{Float32}", "BBox{Float16}", "Int32", "UInt32"),
+                ("BSphere{Float32}", "BBox{Float32}", "UInt32", "UInt32"), ("BSphere{Float32}", "BBox{Float32}", "Int16", "UInt32"),
+                ("MyCapsule", "BBox{Float32}", "Int32", "UInt32"), ("BSphere{Float32}", "BBox{Float32}", "Int32", "UInt128")):
+        assert native(*bad) is None, bad
+    # every supported combination of the Python mirror has codes here too (and the same ones)
+    for k in (0, 1):
+        for f, fname in ((0, "Float32"), (1, "Float64")):
+            assert native(("BSphere", "BBox")[k] + "{" + fname + "}", "BBox{Float32}", "Int32", "UInt32")[:2] == (k, f)
+    bd = re.search(r"function bvh_desc\(bvh::BVH\{I.*?\nend\n", src, re.S).group(0)
+    assert "isnothing(types) && return nothing" in bd and "bvh_desc(bvh::BVH) = nothing" in src
+    # (2) dominance in every method
+    methods = _julia_methods(src)
+    assert len(methods) == 7, sorted(methods)  # BVH + 2 x (single, pair, rays)
+    generic = {"BVH": "invoke(ImplicitBVH.BVH, Tuple{AbstractVector, Type}", "traverse": "invoke(ImplicitBVH.traverse, Tuple{BVH",
+               "traverse_rays": "invoke(ImplicitBVH.traverse_rays, Tuple{BVH, AbstractMatrix, AbstractMatrix"}
+    for (fn, sig), body in methods.items():
+        lines = [l for l in body.split("\n") if l.strip() and not l.strip().startswith("#")]
+        text = "\n".join(lines)
+        got = re.findall(r"^\s*([\w, ]+?)\s*=\s*(?:options\.morton isa DefaultMortonAlgorithm \? )?((?:bvh_desc|native_types)\(.*)$", text, re.M)
+        assert got, (fn, sig)
+        variables = []
+        for lhs, rhs in got:
+            variables += [v.strip() for v in lhs.split(",")]
+        assert len(variables) == (2 if "bvh2" in sig else 1), (fn, sig, variables)
+        if fn == "BVH":
+            assert ": nothing" in got[0][1]  # a non-default Morton algorithm -> nothing -> generic
+        for v in variables:
+            guard = re.search(r"^\s*if [^\n]*isnothing\(" + v + r"\)[^\n]*\n\s*return " + re.escape(generic[fn]), text, re.M)
+            assert guard, (fn, sig, v)
+            before = text[:guard.start()]
+            # before the guard the value is only assigned, never dereferenced or passed on
+            uses = re.sub(r"(bvh_desc|native_types)\([^\n]*", "", before)   # (minus the assignments themselves)
+            assert not re.search(r"\b" + v + r"\.", uses) and not re.search(r"[(,]\s*" + v + r"\s*[,)]", uses), (fn, sig, v)
+        # the fallback carries every keyword over
+        call = text[text.index(generic[fn]):]
+        call = call[:call.index(")\n")]
+        kws = ("built_level", "cache", "options") if fn == "BVH" else \
+            ("start_level1", "start_level2", "narrow", "cache", "options") if "bvh2" in sig else ("start_level", "narrow", "cache", "options")
+        for kw in kws:
+            assert f"{kw}={kw}" in call, (fn, sig, kw)
+    # BVH: the library's own verdict on a combination of known codes is a fallback too, and comes before any allocation / check
+    body = methods[[k for k in methods if k[0] == "BVH"][0]]
+    head = body[:body.index("return invoke(")]
+    assert "== IBVH_ERR_UNSUPPORTED" in head and "similar(" not in head and "throw(" not in head and "ImplicitTree" not in head
+
+
+def _julia_to_python(fn_src):
+    """Transliterate one of the extension's two rule functions (written in a small subset on purpose) into Python."""
+    import re
+    lines = fn_src.strip("\n").split("\n")
+    name, args = re.match(r"function (\w+)\((.*)\)$", lines[0]).groups()
+    args = [a.split("::")[0].strip() for a in args.split(",")]
+    out = [f"def {name}({', '.join(args)}):"]
+    for l in lines[1:]:
+        ind = len(l) - len(l.lstrip())
+        t = l.strip()
+        if t == "end" or not t or t.startswith("#"):
+            continue
+        t = t.replace("||", " or ").replace("&&", " and ")
+        if t.startswith("if "):
+            t = t + ":"
+        elif t.startswith("elseif "):
+            t = "elif " + t[len("elseif "):] + ":"
+        elif t == "else":
+            t = "else:"
+        out.append(" " * ind + t)
+    return "\n".join(out) + "\n"
+
+
+def _julia_rules():
+    import re
+    src = _julia_ext()
+    env = {"ifelse": lambda c, a, b: a if c else b, "cld": lambda a, b: -(-a // b), "min": min, "max": max,
+           "nextpow": lambda base, x: 1 << max(0, (int(x) - 1).bit_length())}
+    consts = dict(re.findall(r"^const ([A-Z_]+) = (\d+)\b", src, re.M))
+    env.update({k: int(v) for k, v in consts.items()})
+    for fn in ("sort_hint_rule", "cache_slots_rule"):
+        code = re.search(r"^function " + fn + r"\(.*?^end$", src, re.S | re.M).group(0)
+        exec(_julia_to_python(code), env)
+    return env
+
+
+def test_julia_build_policy_equals_the_python_mirror():
+    """The host policies every BENCH number was measured with (api.sort_hint_rule: extra partition levels, equalised cells,
+    the spare level, the hold-off; api._cache_slots: adaptive contact-cache slots) exist in the Julia extension and compute
+    the same values: constants equal, the two rule functions transliterated and evaluated on a table of hint words /
+    buffer sizes, and the build descriptor takes sort_levels / sort_equalize / skew_flag from them."""
+    import itertools
+    import re
+    from implicitbvh_amd import abi, api
+    env = _julia_rules()
+    for name, want in (("COLD_SORT_LEVELS", api.COLD_SORT_LEVELS), ("SPARE_OCCUPANCY", api.SPARE_OCCUPANCY),
+                       ("EQ_SPARE_OCCUPANCY", api.EQ_SPARE_OCCUPANCY), ("EQ_HOLDOFF", api.EQ_HOLDOFF),
+                       ("SPARE_ALWAYS_FROM", api.SPARE_ALWAYS_FROM), ("EQUALIZE", int(api.EQUALIZE)),
+                       ("MAX_SORT_LEVELS", abi.MAX_SORT_LEVELS), ("LVT_CACHE_SLOTS", api.LVT_CACHE_SLOTS),
+                       ("RAY_CACHE_SLOTS", api.RAY_CACHE_SLOTS), ("HINT_WORDS", api._HostWords.HINT_SLOTS)):
+        assert env[name] == want, name
+    # every field of the hint word x sizes either side of SPARE_ALWAYS_FROM x hold-off states
+    words = [u | o << 8 | e << 16 | h << 17 for u, o, e, h in
+             itertools.product((0, 1, 2, 3, 4, 7), (0, 50, 95, 96, 119, 120, 128, 255), (0, 1), (0, 1))]
+    for w, n, hold in itertools.product(words, (1, 250_000, 1_000_000, 10_000_000, (1 << 24) - 1, 1 << 24, 100_000_000),
+                                        (0, 1, 2, api.EQ_HOLDOFF)):
+        assert tuple(env["sort_hint_rule"](w, n, hold)) == tuple(api.sort_hint_rule(w, n, hold)), (hex(w), n, hold)
+    # a chain, step by step, as the bench's rebuild loops drive it (the word each build leaves -> what the next one asks for)
+    for chain in ([60 << 8] * 6,                                                  # uniform cloud
+                  [2 | 255 << 8, 1 | 1 << 16 | 130 << 8, 1 << 16 | 100 << 8, 1 << 16 | 100 << 8],   # surface mesh
+                  [3 | 1 << 16 | 1 << 17 | 255 << 8] + [1 | 255 << 8] * 40):      # runs of equal keys: hold-off and back
+        hj = hp = 0
+        for w in chain:
+            lj, ej, hj = env["sort_hint_rule"](w, 1_000_000, hj)
+            lp, ep, hp = api.sort_hint_rule(w, 1_000_000, hp)
+            assert (lj, ej, hj) == (lp, ep, hp)
+
+    class _Trav(api.BVHTraversal):
+        def __init__(self, cap):
+            self.cap = cap
+
+        def _capacity(self):
+            return self.cap
+    for cap, n, default in itertools.product((0, 1, 7, 8, 9, 1000, 1_763_600, 7_000_000, 82_000_000, 10**9),
+                                             (1, 1000, 1_000_000, 7_200_000), (api.LVT_CACHE_SLOTS, api.RAY_CACHE_SLOTS)):
+        assert env["cache_slots_rule"](cap, n, default) == api._cache_slots(_Trav(cap), n, default), (cap, n, default)
+    assert env["cache_slots_rule"](0, 1000, 8) == api._cache_slots(None, 1000, 8) == 8
+    # the descriptor: its last three fields come from build_policy(cache, n), a cold build is (COLD_SORT_LEVELS, 0, own word)
+    src = _julia_ext()
+    body = _julia_methods(src)[[k for k in _julia_methods(src) if k[0] == "BVH"][0]]
+    assert re.search(r"sort_levels, sort_equalize, skew_flag, chain = build_policy\(cache, numbv\)", body)
+    desc = re.search(r"desc = IbvhBuildDesc\((.*?)\)\n\s*check\(c_build\(", body, re.S).group(1)
+    assert desc.rstrip().endswith("sort_levels, sort_equalize, skew_flag")
+    assert "chains[nodes] = chain" in body
+    pol = re.search(r"^function build_policy\(cache, n\).*?^end$", src, re.S | re.M).group(0)
+    assert "return (Int32(COLD_SORT_LEVELS), Int32(0), Ptr{Cvoid}(hint_ptr(st)), st)" in pol
+    assert "sort_hint_rule(unsafe_load(hint_ptr(st), :monotonic), Int64(n), st.holdoff)" in pol
+    # the traversal methods size the contact cache with the rule, not with the constant
+    for k, b in _julia_methods(src).items():
+        if "lvt_two_pass(" in b:
+            assert re.search(r"lvt_two_pass\(I, [\w.]+, \w+, \w+\.types, cache_slots\(cache, \w+, (LVT|RAY)_CACHE_SLOTS\), cache,", b), k
