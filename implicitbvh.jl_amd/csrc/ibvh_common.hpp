@@ -505,6 +505,7 @@ IBVH_HD int64_t ceil_div_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
 struct Tuning {
     int ray_block = 0;      // rays per wave of lvt_rays_kernel (0 = chosen from the batch size; a power of two, 64 .. 1024)
     int lvt_wide = 0;       // 1 = 64-bit queue entries for every tree (otherwise only for 29 .. 31 levels)
+    int msd_rescue = 1;     // 0 = ranges too large for one finish workgroup take the one-workgroup slow path of rounds 2 - 5 instead of the rescue workgroups (ibvh_msd_finish.hip)
     int lvt_dual = 0;       // -DIBVH_VARIANTS builds only (variants/lvt_dual.inc): 1 = BBox-node leaf queries take the dual descent (7 - 25 % slower than lvt_queue_kernel, round 4)
     int lvt_blocks = 1;     // walker 2: 1 = the descent is shared per block of leaves (lvt_block_frontier_kernel), 0 = every wave descends on its own
     int lvt_block_shift = 0; // log2 of the leaves per block (0 = 11; 9 .. 12)

@@ -795,7 +795,12 @@ ibvh_status ibvh_dist_cross_write(const ibvh_bvh *bvh, const ibvh_dist_cross_pla
                                   size_t scratch_bytes, const int64_t *totals, void *contacts_out, void *stream) {
     if (!bvh || !plan) return IBVH_ERR_INVALID_ARG;
     if (plan->n_recv == 0) return IBVH_OK;
-    if (!import_buf || !scratch || scratch_bytes < (size_t)plan->scratch_bytes || !totals || !contacts_out) return IBVH_ERR_INVALID_ARG;
+    if (!import_buf || !scratch || scratch_bytes < (size_t)plan->scratch_bytes || !totals) return IBVH_ERR_INVALID_ARG;
+    // (a rank that imported boundary leaves and found no contact among them has nothing to write: NULL is fine then)
+    bool any = false;
+    for (int k = 0; k < plan->n_recv; ++k) any = any || totals[k] > 0;
+    if (!any) return IBVH_OK;
+    if (!contacts_out) return IBVH_ERR_INVALID_ARG;
     ibvh_layout lay;
     if (!layout_of(bvh->types, lay)) return IBVH_ERR_UNSUPPORTED;
     int64_t at = 0;

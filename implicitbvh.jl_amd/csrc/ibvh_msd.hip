@@ -358,6 +358,7 @@ __global__ __launch_bounds__(PLAN_TPB) void plan_kernel(Tables tb, int radix, ui
         tb.cell_start[radix] = total_n;
         s_tbase[total_over] = total_tiles;
         *tb.needed = total_over > 0 ? 1u : 0u;
+        tb.needed[4] = tb.needed[5] = tb.needed[6] = tb.needed[7] = 0u; // (the finish kernel's rescue counters)
         {
             const uint64_t occ = ((uint64_t)s_biggest * 128u + cap - 1) / cap;
             tb.needed[1] = (uint32_t)(occ > 255 ? 255 : occ);
@@ -812,6 +813,7 @@ __global__ __launch_bounds__(TPB, partition_min_waves(TPB, IPT)) void partition_
                 tb.cell_start[radix] = (uint32_t)n;
                 tb.needed[0] = biggest > cap ? 1u : 0u;
                 tb.needed[1] = (uint32_t)(occ > 255 ? 255 : occ);
+                tb.needed[4] = tb.needed[5] = tb.needed[6] = tb.needed[7] = 0u; // (the finish kernel's rescue counters)
             }
             lds_barrier(); // (wave_tot is reused)
         }
@@ -937,7 +939,7 @@ template <class K, int TPB, int IPT> inline size_t partition_smem(int bits, int 
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
-static size_t carve_tables(Tables *tb, char *base, int radix, int num_tiles, int max_seg, int max_tiles2, int64_t n) {
+static size_t carve_tables(Tables *tb, char *base, int radix, int num_tiles, int max_seg, int max_tiles2, int64_t n, int rescuers, int cap) {
     size_t off = 0;
     auto take = [&](size_t bytes) {
         uint32_t *p = base ? (uint32_t *)(base + off) : nullptr;
@@ -956,6 +958,8 @@ static size_t carve_tables(Tables *tb, char *base, int radix, int num_tiles, int
     t.tile_or = (uint64_t *)take((size_t)max_tiles2 * 8);
     t.splitters = take(((size_t)(radix + 1) * 2 + 32768) * 8); // splitters, candidates, the sorted sample lists
     t.dig = (uint16_t *)take((size_t)n * 2);
+    t.rescue = take((size_t)max_seg * 64);
+    t.rescue_priv = take((size_t)rescuers * 2 * (size_t)cap * 4);
     for (int l = 0; l < MAX_LEVELS; ++l) {
         Level &L = t.lvl[l];
         L.hdr = take(64);
@@ -1032,7 +1036,10 @@ Plan make_plan(int64_t n, int key_bits, int key_bytes, int leaf_bytes, void *sor
     // segments of an extra level hold more than cap records each; a segment's last tile may be partial
     p.max_seg = (int)(n / cap + 1);
     p.max_tiles2 = p.num_tiles + p.max_seg;
-    carve_tables(&p.tb, (char *)sort_scratch, 1 << bits, p.num_tiles, p.max_seg, p.max_tiles2, n);
+    // rescue workgroups of the finish kernel (ibvh_msd_finish.inc): no more than there can be windows to sort (the launch
+    // clamps them to half of what the device holds at once)
+    p.rescuers = g_tuning.msd_rescue ? (p.max_seg < kRescuers ? p.max_seg : kRescuers) : 0;
+    carve_tables(&p.tb, (char *)sort_scratch, 1 << bits, p.num_tiles, p.max_seg, p.max_tiles2, n, p.rescuers, cap);
     return p;
 }
 
@@ -1040,7 +1047,7 @@ Plan make_plan(int64_t n, int key_bits, int key_bytes, int leaf_bytes, void *sor
 size_t scratch_bytes(int64_t n, int key_bits, int key_bytes, int leaf_bytes) {
     const Plan p = make_plan(n, key_bits, key_bytes, leaf_bytes, nullptr);
     if (!p.bits) return 0;
-    return carve_tables(nullptr, nullptr, 1 << p.bits, p.num_tiles, p.max_seg, p.max_tiles2, n) + 4096;
+    return carve_tables(nullptr, nullptr, 1 << p.bits, p.num_tiles, p.max_seg, p.max_tiles2, n, p.rescuers, p.ftpb * p.fipt) + 4096;
 }
 
 template <class K, int PT, int PI>
@@ -1162,6 +1169,8 @@ int sort_records(const Plan &p, int key_bytes, int key_bits, const void *keys, i
     fa.kpri = kpri;
     fa.valt = valt;
     fa.vpri = vpri;
+    fa.rescuers = (uint32_t)p.rescuers;
+    fa.rescue_priv = p.tb.rescue_priv;
     rc = run_finish(p, key_bytes, fa, st);
     if (rc) return rc;
     IBVH_LAUNCH_CHECK();

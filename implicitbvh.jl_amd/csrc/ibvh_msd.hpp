@@ -29,13 +29,16 @@ struct Tables {
     uint32_t *tile_scan;  // [num_tiles][R]   exclusive prefix over the tiles (scan)
     uint32_t *cell_total; // [R]
     uint32_t *cell_start; // [R + 1]          exclusive prefix of cell_total (plan)
-    uint32_t *needed;     // [3]              extra levels this input would have used, fullest cell, equalised route's verdict (the caller's hint)
+    uint32_t *needed;     // [16]             [0..3] extra levels this input would have used, fullest cell, equalised route's verdicts (the caller's
+                          //                  hint); [4..7] the finish kernel's rescue counters (ibvh_msd_finish.hip), zeroed with [0]
     uint32_t *tile_hist2; // [T2][256]        per-tile sub-cell counts of the level being run (shared by the levels)
     uint32_t *tile_scan2; // [T2][256]
     uint64_t *tile_and;   // [T2]             AND / OR of the keys of every tile of the first extra level (range_kernel)
     uint64_t *tile_or;    // [T2]
     void *splitters;      // [R + 1] keys     equalised route: cell d holds the keys in [splitters[d], splitters[d + 1])
     uint16_t *dig;        // [n]              equalised route: every source leaf's cell
+    uint32_t *rescue;     // [S] x 64 bytes   ranges the finish found too large for one workgroup (RescueEntry)
+    uint32_t *rescue_priv; // [H][2 * cap]    private scratch of the H rescue workgroups
     Level lvl[MAX_LEVELS];
 };
 
@@ -48,6 +51,7 @@ struct Plan {
     bool resident;       // the finish keeps a cell's records in LDS (ibvh_msd.hip, finish_range)
     int max_seg;         // S
     int max_tiles2;      // T2
+    int rescuers;        // H: rescue workgroups at the end of the finish grid (scratch is carved for them)
     Tables tb;
 };
 

@@ -82,6 +82,7 @@ template <class K> IBVH_D void cell_range(const Tables &tb, uint32_t d, int radi
 }
 
 constexpr int kMaxLds = 160 * 1024; // LDS of a gfx950 CU
+constexpr int kRescuers = 512;       // rescue workgroups of the finish kernel that scratch is carved for; a launch uses at most half of what the device holds at once (they WAIT for the ordinary workgroups)
 
 
 struct FinishArgs {
@@ -102,6 +103,10 @@ struct FinishArgs {
     // resident path (32-bit keys): 8-byte words of LDS behind the sort's arrays that hold a range's RECORDS (0: off), and
     // where they start (bytes from the base of the dynamic LDS)
     uint32_t resident_words, resident_off;
+    // rescue path (ranges too large for one workgroup that no partition level is left to split): the grid's first normal_wgs
+    // workgroups are the ordinary ones, the `rescuers` behind them share those ranges (0: off — the one-workgroup slow path)
+    uint32_t normal_wgs, rescuers;
+    uint32_t *rescue_priv;
 };
 
 

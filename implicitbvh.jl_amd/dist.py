@@ -257,8 +257,9 @@ class DistributedBuilder:
         vt.check("ibvh_dist_cross_count", L.ibvh_dist_cross_count(C.byref(s), C.byref(plan), api._ptr(imp), api._ptr(scratch), scratch.numel(), totals,
                                                                   C.byref(total), api._stream()))
         out = torch.empty((int(total.value), 2), dtype=api._torch_index(bvh.types.index_type), device="cuda")
-        vt.check("ibvh_dist_cross_write", L.ibvh_dist_cross_write(C.byref(s), C.byref(plan), api._ptr(imp), api._ptr(scratch), scratch.numel(), totals,
-                                                                  api._ptr(out) if out.numel() else None, api._stream()))
+        if total.value > 0:  # (imported leaves without a single contact among them: nothing to write — as the Julia binding)
+            vt.check("ibvh_dist_cross_write", L.ibvh_dist_cross_write(C.byref(s), C.byref(plan), api._ptr(imp), api._ptr(scratch), scratch.numel(),
+                                                                      totals, api._ptr(out), api._stream()))
         lay = abi.Layout()
         lib.call("ibvh_layout_of", C.byref(bvh.types), C.byref(lay))
         self.last_cross = {"partners": [int(plan.recv_rank[i]) for i in range(plan.n_recv)],

@@ -222,8 +222,8 @@ def test_ten_million_leaves_changing_under_a_cache_chain_time_bounds(monkeypatch
     inputs become clustered in a simulation — never meets a slow step, also without the always-on spare level of large
     builds: the build reports its fullest cell and the level comes on before a cell overflows.  (2) The policy of builds
     of api.SPARE_ALWAYS_FROM leaves and more (the spare level is always launched), forced here: an ABRUPT change from
-    uniform to one tight cluster stays within a few normal steps.  (3) Occupancy policy alone: that one step takes the one-workgroup path
-    (correct, slow) and the step after is normal again.  Generous bounds: the measured figures are 0.86 ms (1), 0.64 ms
+    uniform to one tight cluster stays within a few normal steps.  (3) Occupancy policy alone: that one step's crowded cell is sorted by the
+    finish kernel's rescue workgroups (round 6; one workgroup before: 118 ms) and the step after is normal again.  Generous bounds: the measured figures are 0.86 ms (1), 0.64 ms
     (2), 118 ms then 0.78 ms (3) against a uniform step of 0.6 ms."""
     from implicitbvh_amd import api
     n = 10_000_000
@@ -268,8 +268,12 @@ def test_ten_million_leaves_changing_under_a_cache_chain_time_bounds(monkeypatch
     b, t_slow = _timed_build(one, b)
     m = b.leaves.morton
     assert bool((m[1:] >= m[:-1]).all()) and int(b._skew[0]) >= 1
+    # (round 6: the crowded cell is shared by the finish kernel's rescue workgroups — 118 ms with one workgroup)
+    assert t_slow < 8 * t_uniform + 2.0, (t_slow, t_uniform)
     b, t_next = _timed_build(one, b)
     assert t_next < 8 * t_uniform + 2.0, (t_next, t_slow, t_uniform)
+    print(f"uniform {t_uniform:.3f} ms, gradual worst {worst:.3f} ms, abrupt with spare level {t_change:.3f} ms, "
+          f"abrupt without {t_slow:.3f} ms, step after {t_next:.3f} ms")
 
 
 @pytest.mark.parametrize("n", [12_500_000, 13_500_000])
