@@ -447,7 +447,92 @@ def run_configs(args, ibvh, lib, torch, cpu):
 
     # ---- time stepping: the reference's literal loop (build.jl:109-126, README.md:84-95) on a moving cloud -----------
     out["timestep"] = {str(nn): run_timestep(nn, ibvh, lib, torch, cpu) for nn in (1_000_000, 10_000_000)}
+    out["readme_250k"] = run_readme_250k(ibvh, lib, torch, cpu)
     return out
+
+
+README_TRIANGLES = 249_882  # xyzrgb_dragon.obj (README.md:228-231, benchmark/bvh_contact.jl:32)
+README_RAYS = 100_000       # benchmark/bvh_rays.jl:36
+# the reference's only published numbers (README.md:229-231), as CONTEXT: other hardware, the real mesh
+README_PUBLISHED = {"source": "/root/reference/README.md:229-231 (xyzrgb_dragon.obj, 249,882 triangles; 100,000 rays)",
+                    "a100_ms": {"build": 0.40958, "traverse": 1.14, "traverse_rays": 2.00},
+                    "m3max_1thread_ms": {"build": 7.11, "traverse": 67.14, "traverse_rays": 369.7},
+                    "m3max_4threads_ms": {"build": 2.631, "traverse": 19.7, "traverse_rays": 113.8}}
+
+
+def readme_mesh_volumes(ibvh, torch):
+    """The published workload's input: IBVH_MESH (the real xyzrgb_dragon.obj) when present and of that size, else the torus
+    generator cut to exactly 249,882 triangles; -> (BSphere{Float32} volumes on the GPU, name)."""
+    from implicitbvh_amd.synthetic import torus_mesh
+    mesh_path = os.environ.get("IBVH_MESH", "")
+    if mesh_path and os.path.exists(mesh_path):
+        tris = ibvh.load_obj_triangles(mesh_path)
+        if int(tris.shape[0]) == README_TRIANGLES:
+            return ibvh.bounding_volumes_from_triangles(tris), mesh_path
+    tris = torch.from_numpy(torus_mesh(354, 353)[:README_TRIANGLES].copy()).cuda()
+    return ibvh.bounding_volumes_from_triangles(tris), "torus surrogate cut to 249,882 triangles (xyzrgb_dragon.obj is not in the reference repo; set IBVH_MESH)"
+
+
+def run_readme_250k(ibvh, lib, torch, cpu):
+    """The reference's only PUBLISHED workload (README.md:226-231; benchmark/bvh_build.jl, bvh_contact.jl, bvh_rays.jl): 249,882
+    triangle spheres, BBox{Float32} nodes, UInt32 / Int32: build (cache= chain, as :38-45), LVT self-traverse on the built BVH,
+    traverse_rays with 100,000 random rays — at this size a step is a chain of dependent launches, not bandwidth."""
+    from implicitbvh_amd.synthetic import random_rays
+    orc, native, threads = cpu if cpu else (None, None, 0)
+    vols, name = readme_mesh_volumes(ibvh, torch)
+    n = int(vols.shape[0])
+    st = {"b": None, "t": None, "r": None}
+
+    def build():
+        st["b"] = ibvh.BVH(vols, cache=st["b"])
+        return st["b"]
+
+    def self_():
+        st["t"] = ibvh.traverse(st["b"], cache=st["t"])
+        return st["t"]
+    ms_b, _ = _timed(torch, build, 50)
+    _, _, ks_b = _dominant(lib, torch, build)
+    ms_s, t = _timed(torch, self_, 50)
+    dom_s, avg_s, ks_s = _dominant(lib, torch, self_)
+    hv = vols[:, :3]
+    lo, hi = hv.min(0).values.cpu().numpy(), hv.max(0).values.cpu().numpy()
+    p_host, d_host = random_rays(README_RAYS, lo, hi, seed=43)
+    p, d = torch.from_numpy(p_host).cuda().t(), torch.from_numpy(d_host).cuda().t()
+
+    def rays():
+        st["r"] = ibvh.traverse_rays(st["b"], p, d, cache=st["r"])
+        return st["r"]
+    ms_r, r = _timed(torch, rays, 30)
+    _, _, ks_r = _dominant(lib, torch, rays)
+
+    def step():  # build + self-traverse + the host's read of the count, chained: what a simulation step costs
+        build()
+        return self_().num_contacts
+    ms_step, _ = _timed(torch, step, 100)
+    res = {"workload": f"{name}: BSphere{{Float32}} leaves, BBox{{Float32}} nodes, UInt32, Int32; BVH(...; cache), traverse(bvh; cache), "
+                       f"traverse_rays with {README_RAYS} random rays (README.md:226-231, benchmark/bvh_contact.jl:21-45, bvh_rays.jl:36-58)",
+           "leaves": n,
+           "build": {"ms": round(ms_b, 4), "launches": len(ks_b), "kernels_ms": ks_b,
+                     "frac": _roof("whole build", ms_b, 216.0 * n, "216 B/leaf")["frac"]},
+           "self": {"ms": round(ms_s, 4), "contacts": t.num_contacts, "launches": len(ks_s), "kernels_ms": ks_s,
+                    "frac": _roof("whole traversal", ms_s, 60.0 * n + 8.0 * t.num_contacts, "60 B/leaf + 8 per contact")["frac"]},
+           "rays": {"ms": round(ms_r, 4), "hits": r.num_contacts, "launches": len(ks_r), "kernels_ms": ks_r,
+                    "frac": _roof("whole traversal", ms_r, 28.0 * README_RAYS + 48.0 * n + 8.0 * r.num_contacts,
+                                  "rays 24 + counts 4 per ray, tree 48 per leaf once, 8 per hit")["frac"]},
+           "build_plus_self_step_ms": round(ms_step, 4),
+           "published_for_context": README_PUBLISHED}
+    if orc is not None:
+        hv_all = vols.cpu().numpy()
+        best = None
+        for _ in range(3):
+            ob, cc, tb, tt = orc.bench_build_traverse_f32(hv_all, threads, native)
+            best = (tb, tt) if best is None or tb + tt < sum(best) else best
+        hits, ts = orc.bench_rays_lvt(ob, p_host, d_host, threads, native)
+        res["cpu_baseline"] = {"kind": "port", "cores": threads, "build_ms": round(best[0] * 1e3, 3), "self_ms": round(best[1] * 1e3, 3),
+                               "rays_ms": round(ts * 1e3, 3), "contacts_match_gpu": len(cc) == t.num_contacts,
+                               "hits_match_gpu": hits == r.num_contacts,
+                               "sample": f"the same {n} leaves and {README_RAYS} rays, oracle build + two-pass LVT (best of 3) and LVT ray walk (one run)"}
+    return res
 
 
 def run_timestep(n, ibvh, lib, torch, cpu, steps=40, cells=1.0):
@@ -619,6 +704,15 @@ def compact_line(line, detail_path):
         sk = line["configs"].get("skew_1e6_build")
         if isinstance(sk, dict) and out["configs"] is not None:
             out["configs"]["skew_1e6_build"] = {"uniform_ms": sk["uniform"]["ms"], "clusters8_ms": sk["clusters8"]["ms"], "ratio": sk["clusters_over_uniform"]}
+        rd = line["configs"].get("readme_250k")
+        if isinstance(rd, dict) and out["configs"] is not None:  # the reference's published workload (README.md:226-231)
+            c = {k: {"ms": rd[k]["ms"], "frac": rd[k]["frac"]} for k in ("build", "self", "rays")}
+            c["build_plus_self_step_ms"] = rd["build_plus_self_step_ms"]
+            c["leaves"] = rd["leaves"]
+            if isinstance(rd.get("cpu_baseline"), dict):
+                c["cpu_ms"] = _pick(rd["cpu_baseline"], ("build_ms", "self_ms", "rays_ms", "cores", "contacts_match_gpu", "hits_match_gpu"))
+            c["published_a100_ms"] = rd["published_for_context"]["a100_ms"]
+            out["configs"]["readme_250k"] = c
     if isinstance(line.get("exchange"), dict):
         out["exchange"] = _pick(line["exchange"], ("max_exchange_ms", "bytes_sent_max", "xgmi_frac_per_link"))
     if isinstance(line.get("work"), dict):

@@ -433,17 +433,41 @@ def sort_hint_rule(word, n, holdoff):
     """(sort_levels, sort_equalize, holdoff') of a rebuild of n leaves from the hint word the previous build of its chain left
     (include/ibvh.h, ibvh_build_desc.skew_flag: low byte = extra partition levels that build would have used, second byte =
     its fullest cell in 1/128 of what a finish workgroup sorts, bit 16 = it ran with equalised cells and the plain grid would
-    still have been crowded, bit 17 = equalising did not help) and the chain's hold-off counter.  Pure host logic."""
-    used, occupancy, eq = word & 0xff, (word >> 8) & 0xff, (word >> 16) & 1
-    # (bit 17: an equalised build found most of its records in crowded cells all the same — runs of equal keys — so the chain
-    # stays with the plain grid for EQ_HOLDOFF rebuilds before it tries again)
-    if (word >> 17) & 1 and holdoff == 0:
+    still have been crowded, bit 17 = equalising did not help, bit 18 = it ran with equalised cells) and the chain's counter
+    `holdoff`: > 0 = rebuilds left on the plain grid after bit 17; -1 = PROBATION: the previous request went back to the plain
+    grid on an equalised build's estimate (bit 16 = 0), with a spare level as insurance; <= -2 = STICKY: the probation build was
+    crowded after all, so the chain stays with equalised cells for EQ_STICKY rebuilds whatever bit 16 says (round 6: a mesh
+    whose fullest grid cell sits just above one workgroup's share went plain / equalised / plain ... every other build).
+    Pure host logic; the Julia extension carries the same function (tests/test_host_cpu.py evaluates both)."""
+    used, occupancy, eq, nohelp, ran_eq = word & 0xff, (word >> 8) & 0xff, (word >> 16) & 1, (word >> 17) & 1, (word >> 18) & 1
+    sticky = 0
+    if holdoff <= -2:
+        if nohelp == 1:
+            holdoff = EQ_HOLDOFF
+        else:
+            sticky = 1
+            holdoff = holdoff + 1
+            if holdoff == -1:
+                holdoff = 0
+    elif holdoff == -1:
+        if used > 0:
+            sticky = 1
+            holdoff = -2 - EQ_STICKY
+        else:
+            holdoff = 0
+    elif nohelp == 1 and holdoff == 0:
+        # (bit 17: an equalised build found most of its records in crowded cells all the same — runs of equal keys — so the chain
+        # stays with the plain grid for EQ_HOLDOFF rebuilds before it tries again)
         holdoff = EQ_HOLDOFF
     elif holdoff > 0:
-        holdoff -= 1
-    equalize = 1 if (used > 0 or eq) and EQUALIZE and holdoff == 0 else 0
-    spare = used > 0 or occupancy >= (EQ_SPARE_OCCUPANCY if eq and equalize else SPARE_OCCUPANCY) or n >= SPARE_ALWAYS_FROM
-    return min(used + (1 if spare else 0), abi.MAX_SORT_LEVELS), equalize, holdoff
+        holdoff = holdoff - 1
+    equalize = 1 if (used > 0 or eq == 1 or sticky == 1) and EQUALIZE and holdoff <= 0 else 0
+    probation = 1 if ran_eq == 1 and equalize == 0 and holdoff == 0 and EQUALIZE else 0
+    if probation == 1:
+        holdoff = -1
+    threshold = EQ_SPARE_OCCUPANCY if eq == 1 and equalize == 1 else SPARE_OCCUPANCY
+    spare = 1 if used > 0 or occupancy >= threshold or n >= SPARE_ALWAYS_FROM or probation == 1 else 0
+    return min(used + spare, abi.MAX_SORT_LEVELS), equalize, holdoff
 
 
 _host_words_singleton = None
@@ -814,6 +838,7 @@ def _cache_tensor(cache_t, need_rows, cols, dtype, what):
 # idle spare level (plan + four launches) costs EVERY step.  So they launch a spare level only when the fullest cell was about full.
 EQ_SPARE_OCCUPANCY = 120
 EQ_HOLDOFF = 32  # rebuilds a chain stays with the plain grid after an equalised build reported that it did not help (hint bit 17)
+EQ_STICKY = 32   # rebuilds a chain stays with equalised cells after a return to the plain grid turned out crowded (sort_hint_rule)
 EQUALIZE = True  # rebuilds of a chain whose input is skewed ask for equalised cells (False: the regular grid + extra levels, always)
 COLD_SORT_LEVELS = 2  # extra partition levels a build without cache= launches (include/ibvh.h, sort_levels)
 SPARE_OCCUPANCY = 96  # (of 128) fullest coarse cell from which a cached build launches a spare extra level (BVH.__init__)

@@ -215,14 +215,17 @@ __global__ __launch_bounds__(512) void bucket_hist_kernel(const K *__restrict__ 
         eyt[k] = spl[(2 * j + 1) * (radix >> (L + 1))];
     }
     if (blockIdx.x == 0) {
-        // the verdict: would the plain grid (cell = top `bits` bits) have had a crowded cell?  Crowded = clearly more samples in one
-        // cell than a full finish workgroup's share (lambda + 4 sqrt(lambda), in whole candidates: a cloud that fills its box stays
-        // below).  While it would, the caller keeps asking for equalised cells; the plain route is cheaper for an input that fits.
+        // the verdict: would the plain grid (cell = top `bits` bits) have had a crowded cell?  Crowded = a full finish workgroup's share
+        // of the samples (lambda) in one grid cell, in whole candidates (m consecutive candidates in one cell = m * per .. (m + 1) *
+        // per samples there): the threshold sits AT the capacity, not above it — rounds 5's lambda + 4 sqrt(lambda) + one candidate
+        // said "fits" for a fullest cell of 1.0 .. 1.4 (250 k leaves) or .. 2 (1e6) workgroup shares, the chain went back to the plain
+        // grid, met the crowded cell, came back, and so on every other build.  A cloud that fills its box holds <= 5/8 lambda per
+        // cell (make_plan) and stays clear.  While the grid would be crowded the caller keeps asking for equalised cells.
         constexpr int S = SampleGeom<K>::S;
         const int shift = key_bits - bits, per = S >> bits;
         const float lambda = (float)cap * (float)S / (float)(n > 0 ? n : 1);
-        const float kf = (lambda + 4.0f * __builtin_sqrtf(lambda)) / (float)per + 1.0f;
-        const int m = kf >= (float)radix ? radix : (int)kf;
+        const float kf = lambda / (float)per;
+        const int m = kf >= (float)radix ? radix : (kf < 1.0f ? 1 : (int)kf);
         int crowded = 0;
         for (int d = threadIdx.x + 1; d + m < radix; d += 512) crowded |= (int)((cand[d] >> shift) == (cand[d + m] >> shift));
         crowded = __syncthreads_or(crowded);

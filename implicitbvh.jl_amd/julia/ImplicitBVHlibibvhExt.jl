@@ -356,24 +356,51 @@ const COLD_SORT_LEVELS = 2      # extra partition levels a build without cache= 
 const SPARE_OCCUPANCY = 96      # (of 128) fullest coarse cell from which a cached build launches a spare extra level
 const EQ_SPARE_OCCUPANCY = 120  # the same for a chain that builds with equalised cells (they re-fit the cells every time)
 const EQ_HOLDOFF = 32           # rebuilds a chain stays with the plain grid after an equalised build reported no gain (bit 17)
+const EQ_STICKY = 32            # rebuilds a chain stays with equalised cells after a return to the plain grid turned out crowded
 const SPARE_ALWAYS_FROM = 16777216   # leaves from which a cached build always launches the spare level
 const EQUALIZE = 1              # 0: never ask for equalised cells
 const MAX_SORT_LEVELS = 4       # IBVH_MAX_SORT_LEVELS
 
-# (sort_levels, sort_equalize, holdoff') of a rebuild of n leaves — api.sort_hint_rule
+# (sort_levels, sort_equalize, holdoff') of a rebuild of n leaves — api.sort_hint_rule.  holdoff > 0: rebuilds left on the plain
+# grid after bit 17; -1: probation (the previous request went back to the plain grid on an equalised build's ESTIMATE, with a
+# spare level as insurance); <= -2: sticky (the probation build was crowded after all: equalised cells for EQ_STICKY rebuilds
+# whatever bit 16 says)
 function sort_hint_rule(word::Int64, n::Int64, holdoff::Int64)
     used = word & 0xff
     occupancy = (word >> 8) & 0xff
     eq = (word >> 16) & 1
     nohelp = (word >> 17) & 1
-    if nohelp == 1 && holdoff == 0
+    ran_eq = (word >> 18) & 1
+    sticky = 0
+    if holdoff <= -2
+        if nohelp == 1
+            holdoff = EQ_HOLDOFF
+        else
+            sticky = 1
+            holdoff = holdoff + 1
+            if holdoff == -1
+                holdoff = 0
+            end
+        end
+    elseif holdoff == -1
+        if used > 0
+            sticky = 1
+            holdoff = -2 - EQ_STICKY
+        else
+            holdoff = 0
+        end
+    elseif nohelp == 1 && holdoff == 0
         holdoff = EQ_HOLDOFF
     elseif holdoff > 0
         holdoff = holdoff - 1
     end
-    equalize = ifelse((used > 0 || eq == 1) && EQUALIZE == 1 && holdoff == 0, 1, 0)
+    equalize = ifelse((used > 0 || eq == 1 || sticky == 1) && EQUALIZE == 1 && holdoff <= 0, 1, 0)
+    probation = ifelse(ran_eq == 1 && equalize == 0 && holdoff == 0 && EQUALIZE == 1, 1, 0)
+    if probation == 1
+        holdoff = -1
+    end
     threshold = ifelse(eq == 1 && equalize == 1, EQ_SPARE_OCCUPANCY, SPARE_OCCUPANCY)
-    spare = ifelse(used > 0 || occupancy >= threshold || n >= SPARE_ALWAYS_FROM, 1, 0)
+    spare = ifelse(used > 0 || occupancy >= threshold || n >= SPARE_ALWAYS_FROM || probation == 1, 1, 0)
     return (min(used + spare, MAX_SORT_LEVELS), equalize, holdoff)
 end
 

@@ -160,7 +160,9 @@ typedef struct ibvh_build_desc {
      * of skew_flag = 1 while the plain grid would have had a crowded cell: a caller that rebuilds every step asks for
      * equalised cells when the previous build reported extra levels (low byte != 0) or that bit.  Bit 17 (equalised builds
      * with sort_levels > 0): more than half of the records sat in crowded cells all the same — runs of equal keys, which
-     * no choice of cells can split; such a chain is better off with the plain grid (the sample's launches buy nothing). */
+     * no choice of cells can split; such a chain is better off with the plain grid (the sample's launches buy nothing).
+     * Bit 18: this build ran with equalised cells (so a caller that goes back to the plain grid on the strength of bit 16 = 0
+     * knows it is doing so on an ESTIMATE, and can give that one build a spare level). */
     int32_t sort_equalize;
     void *skew_flag;
 } ibvh_build_desc;

@@ -286,3 +286,33 @@ def test_build_properties_where_the_sort_changes_geometry(n):
     torch.cuda.synchronize()
     assert int(g._skew[0]) == 0  # a uniform cloud crowds no cell of either geometry
     check_build_properties(vols, g)
+
+
+def test_reference_published_workload_size_matches_the_oracle():
+    """The reference's only published workload (README.md:226-231; benchmark/bvh_contact.jl:21-45, bvh_rays.jl:36-58): 249,882
+    triangle spheres (the torus generator cut to that size; the real mesh is not in the reference repo), build, LVT
+    self-traverse, traverse_rays with 100,000 rays — the size `bench.py` reports as configs.readme_250k.  Whole lists, in order,
+    against the oracle."""
+    import bench
+    vols, _ = bench.readme_mesh_volumes(ibvh, torch)
+    n = int(vols.shape[0])
+    assert n == bench.README_TRIANGLES
+    host = vols.cpu().numpy()
+    o = orc.build(host, abi.make_types())
+    g = ibvh.BVH(vols)
+    assert g.leaves.to_numpy().tobytes() == o.leaves.tobytes()
+    assert g.nodes.cpu().numpy().tobytes() == o.nodes.tobytes()
+    for cached in (None, "again"):  # (the counting pass + write, then the enqueue path against the cached buffer)
+        trav = ibvh.traverse(g, cache=None if cached is None else trav)
+        exp, _ = orc.traverse_lvt(o)
+        got = trav.contacts.cpu().numpy()
+        assert got.shape[0] == len(exp) and (got[:, 0] == exp["a"]).all() and (got[:, 1] == exp["b"]).all()
+    from implicitbvh_amd.synthetic import random_rays
+    hv = host[:, :3]
+    p, d = random_rays(bench.README_RAYS, hv.min(0), hv.max(0), seed=43)
+    rays = ibvh.traverse_rays(g, torch.from_numpy(p).cuda().t(), torch.from_numpy(d).cuda().t())
+    rexp, _ = orc.traverse_rays_lvt(o, p, d)
+    rgot = rays.contacts.cpu().numpy()
+    assert rgot.shape[0] == len(rexp) and (rgot[:, 0] == rexp["a"]).all() and (rgot[:, 1] == rexp["b"]).all()
+    bfs = ibvh.traverse(g, ibvh.BFSTraversal())
+    assert sorted(map(tuple, bfs.contacts.cpu().numpy().tolist())) == sorted(zip(exp["a"].tolist(), exp["b"].tolist()))

@@ -336,6 +336,23 @@ def test_sort_hint_rule_of_a_rebuild_chain():
         lv, eq, hold = rule(1 | 255 << 8, n, hold)
         asked.append(eq)
     assert asked == [0] * (api.EQ_HOLDOFF - 1) + [1] and hold == 0
+    # round 6: an equalised build (bit 18) whose estimate says "the plain grid fits" (bit 16 = 0): back to the plain grid ON PROBATION,
+    # with a spare level as insurance ...
+    ran = 1 << 18
+    assert rule(ran | 66 << 8, n, 0) == (1, 0, -1)
+    # ... which fits: an ordinary plain chain again
+    assert rule(60 << 8, n, -1) == (0, 0, 0)
+    # ... or was crowded after all (the level caught it): equalised cells, sticky for EQ_STICKY rebuilds whatever bit 16 says
+    lv, eq, hold = rule(1 | 170 << 8, n, -1)
+    assert (lv, eq, hold) == (2, 1, -2 - api.EQ_STICKY)
+    seen = []
+    for _ in range(api.EQ_STICKY + 1):
+        lv, eq, hold = rule(ran | 66 << 8, n, hold)
+        seen.append((lv, eq))
+    assert seen == [(0, 1)] * (api.EQ_STICKY + 1) and hold == 0
+    assert rule(ran | 66 << 8, n, hold) == (1, 0, -1)  # then the estimate is tried again
+    # a sticky chain whose equalised builds report that equalising does not help (bit 17) goes to the plain hold-off instead
+    assert rule(ran | 1 << 17 | 2 | 255 << 8, n, -10) == (3, 0, api.EQ_HOLDOFF)
     # switched off as a whole
     try:
         api.EQUALIZE = False
@@ -540,21 +557,22 @@ def test_julia_build_policy_equals_the_python_mirror():
     from implicitbvh_amd import abi, api
     env = _julia_rules()
     for name, want in (("COLD_SORT_LEVELS", api.COLD_SORT_LEVELS), ("SPARE_OCCUPANCY", api.SPARE_OCCUPANCY),
-                       ("EQ_SPARE_OCCUPANCY", api.EQ_SPARE_OCCUPANCY), ("EQ_HOLDOFF", api.EQ_HOLDOFF),
+                       ("EQ_SPARE_OCCUPANCY", api.EQ_SPARE_OCCUPANCY), ("EQ_HOLDOFF", api.EQ_HOLDOFF), ("EQ_STICKY", api.EQ_STICKY),
                        ("SPARE_ALWAYS_FROM", api.SPARE_ALWAYS_FROM), ("EQUALIZE", int(api.EQUALIZE)),
                        ("MAX_SORT_LEVELS", abi.MAX_SORT_LEVELS), ("LVT_CACHE_SLOTS", api.LVT_CACHE_SLOTS),
                        ("RAY_CACHE_SLOTS", api.RAY_CACHE_SLOTS), ("HINT_WORDS", api._HostWords.HINT_SLOTS)):
         assert env[name] == want, name
     # every field of the hint word x sizes either side of SPARE_ALWAYS_FROM x hold-off states
-    words = [u | o << 8 | e << 16 | h << 17 for u, o, e, h in
-             itertools.product((0, 1, 2, 3, 4, 7), (0, 50, 95, 96, 119, 120, 128, 255), (0, 1), (0, 1))]
+    words = [u | o << 8 | e << 16 | h << 17 | r << 18 for u, o, e, h, r in
+             itertools.product((0, 1, 2, 3, 4, 7), (0, 50, 95, 96, 119, 120, 128, 255), (0, 1), (0, 1), (0, 1))]
     for w, n, hold in itertools.product(words, (1, 250_000, 1_000_000, 10_000_000, (1 << 24) - 1, 1 << 24, 100_000_000),
-                                        (0, 1, 2, api.EQ_HOLDOFF)):
+                                        (0, 1, 2, api.EQ_HOLDOFF, -1, -2, -3, -2 - api.EQ_STICKY)):
         assert tuple(env["sort_hint_rule"](w, n, hold)) == tuple(api.sort_hint_rule(w, n, hold)), (hex(w), n, hold)
     # a chain, step by step, as the bench's rebuild loops drive it (the word each build leaves -> what the next one asks for)
     for chain in ([60 << 8] * 6,                                                  # uniform cloud
                   [2 | 255 << 8, 1 | 1 << 16 | 130 << 8, 1 << 16 | 100 << 8, 1 << 16 | 100 << 8],   # surface mesh
-                  [3 | 1 << 16 | 1 << 17 | 255 << 8] + [1 | 255 << 8] * 40):      # runs of equal keys: hold-off and back
+                  [3 | 1 << 16 | 1 << 17 | 255 << 8] + [1 | 255 << 8] * 40,       # runs of equal keys: hold-off and back
+                  [1 | 170 << 8] + [1 << 18 | 66 << 8, 1 | 170 << 8] + [1 << 18 | 66 << 8] * 40):   # a mesh at the edge: probation, sticky
         hj = hp = 0
         for w in chain:
             lj, ej, hj = env["sort_hint_rule"](w, 1_000_000, hj)
