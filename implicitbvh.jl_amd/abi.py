@@ -18,7 +18,7 @@ U16, U32, U64 = 0, 1, 2
 NARROW_NONE, NARROW_MORTON_LT, NARROW_INDEX_LT, NARROW_RAY_ORIGIN_OUTSIDE = 0, 1, 2, 3
 NARROW_MASK, OUTPUT_POSITIONS = 0xff, 0x100  # IBVH_NARROW_MASK, IBVH_OUTPUT_POSITIONS
 
-OK, ERR_INVALID_ARG, ERR_DOMAIN, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_OVERFLOW, ERR_HIP, ERR_SCRATCH = range(8)
+OK, ERR_INVALID_ARG, ERR_DOMAIN, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_OVERFLOW, ERR_HIP, ERR_SCRATCH, ERR_PEER = range(9)
 
 FLOAT_DTYPES = {F32: np.float32, F64: np.float64}
 INDEX_DTYPES = {I32: np.int32, I64: np.int64}
@@ -178,6 +178,7 @@ _STATUS_TEXT = {
     ERR_OVERFLOW: "count does not fit the index type",
     ERR_HIP: "HIP runtime error",
     ERR_SCRATCH: "scratch buffer too small",
+    ERR_PEER: "another rank's arguments were not acceptable (every rank returned together; that rank reports its own error)",
 }
 
 

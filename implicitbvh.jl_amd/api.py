@@ -367,6 +367,7 @@ class _HostWords:
         self.generation = [0] * (self.SLOTS + self.HINT_SLOTS)
         self.next = 0
         self.next_hint = 0
+        self.devices_this_lap = set()  # devices whose streams may hold a scan kernel that writes a total slot of this lap
         import threading
         self.lock = threading.Lock()
 
@@ -385,9 +386,13 @@ class _HostWords:
                     # r4: a traversal queued on another device is otherwise not retired), and under the lock on purpose:
                     # a thread that took a slot of the new lap meanwhile could launch behind a stale kernel of the old lap
                     # on its own stream and read that kernel's total as its own.  Cost: one device drain per 8,192 traversals.
+                    # Only the devices that were handed a slot during the lap that just ended (in a one-process-per-GPU
+                    # job every GPU is visible, and synchronising all of them creates a context — hundreds of MB — on each).
                     torch = _torch()
-                    for d in range(torch.cuda.device_count()):
+                    for d in sorted(self.devices_this_lap):
                         torch.cuda.synchronize(d)
+                    self.devices_this_lap = set()
+                self.devices_this_lap.add(_torch().cuda.current_device())
             self.generation[slot] += 1
             gen = self.generation[slot]
         self.words[slot] = initial

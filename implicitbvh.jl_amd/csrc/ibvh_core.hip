@@ -198,6 +198,7 @@ const char *ibvh_status_string(int32_t status) {
     case IBVH_ERR_OVERFLOW: return "count overflows the index type";
     case IBVH_ERR_HIP: return "HIP runtime error";
     case IBVH_ERR_SCRATCH: return "scratch buffer too small";
+    case IBVH_ERR_PEER: return "another rank's arguments were not acceptable";
     }
     return "unknown status";
 }

@@ -19,6 +19,7 @@
 #include <dlfcn.h>
 
 #include <cmath>
+#include <limits>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -58,7 +59,7 @@ Layout make_layout(const ibvh_types &t, int64_t n, int size) {
         return at;
     };
     L.ext_local = take(64);
-    L.vec = take((size_t)(6 + size) * 8);
+    L.vec = take((size_t)(7 + size) * 8); // (-mins, maxs, one-hot leaf counts, the largest status of all ranks)
     L.ext = take(64);
     L.hist = take((size_t)16 * (1 << DIGIT_BITS) * 4);
     L.hist64 = take((size_t)16 * (1 << DIGIT_BITS) * 8);
@@ -270,15 +271,43 @@ ibvh_status ibvh_dist_scratch_bytes(const ibvh_types *types, int64_t n_local, in
 
 ibvh_status ibvh_dist_plan(const ibvh_types *types, const ibvh_comm *comm, const void *volumes, int64_t n_local, double tolerance,
                            void *scratch, size_t scratch_bytes, ibvh_dist_plan_t *plan, void *stream) {
-    if (!types || !comm || !plan || n_local < 0 || (n_local > 0 && !volumes)) return IBVH_ERR_INVALID_ARG;
+    // what cannot be agreed on: no communicator, no plan to fill
+    if (!comm || !plan) return IBVH_ERR_INVALID_ARG;
     const int P = comm->size, me = comm->rank;
-    if (P < 1 || P > MAX_RANKS || me < 0 || me >= P || !(tolerance >= 0.0)) return IBVH_ERR_INVALID_ARG;
+    if (P < 1 || P > MAX_RANKS || me < 0 || me >= P) return IBVH_ERR_INVALID_ARG;
     if (P > 1 && (!comm->all_reduce || !comm->all_gather || !comm->all_to_all_v)) return IBVH_ERR_INVALID_ARG;
-    ibvh_layout lay;
-    if (!layout_of(*types, lay) || !combo_ok(*types)) return IBVH_ERR_UNSUPPORTED;
-    const Layout L = make_layout(*types, n_local, P);
-    if (!scratch || scratch_bytes < L.total) return IBVH_ERR_SCRATCH;
+    // everything else is this rank's STATUS (round 6): a rank whose arguments are not acceptable still takes part in the first
+    // all-reduce — which carries the largest status of all ranks in an element of its own — and every rank returns before the next
+    // collective: its own error, or IBVH_ERR_PEER.  (It needs room for its parts of the two collectives that run before the host
+    // looks at anything — the all-reduce's vector and the all-gather of the first histogram, ~150 KB at 8 ranks; a rank without
+    // that returns at once and its peers wait: abort the communicator.)
+    const size_t width0_bytes = (size_t)4 << DIGIT_BITS;
+    const size_t room_to_take_part = (size_t)8 * (7 + (size_t)P) + ((size_t)P + 1) * width0_bytes + 1024;
+    if (!scratch || scratch_bytes < room_to_take_part) return IBVH_ERR_SCRATCH;
     hipStream_t st = (hipStream_t)stream;
+    int status = IBVH_OK;
+    ibvh_layout lay{};
+    if (!types || n_local < 0 || (n_local > 0 && !volumes) || !(tolerance >= 0.0)) status = IBVH_ERR_INVALID_ARG;
+    else if (!layout_of(*types, lay) || !combo_ok(*types)) status = IBVH_ERR_UNSUPPORTED;
+    else if (scratch_bytes < make_layout(*types, n_local, P).total) status = IBVH_ERR_SCRATCH;
+    if (status != IBVH_OK) {
+        if (P > 1) { // neutral values + the status: [0, 6 + P) as ibvh_dist_pack_extrema lays them out, [6 + P] the status
+            std::vector<double> v(7 + (size_t)P, 0.0);
+            for (int k = 0; k < 6; ++k) v[k] = -std::numeric_limits<double>::infinity();
+            v[6 + (size_t)P] = (double)status;
+            char *tmp = (char *)align_up((int64_t)(uintptr_t)scratch, 256);
+            DIST_HIP_CHECK(hipMemcpyAsync(tmp, v.data(), v.size() * 8, hipMemcpyHostToDevice, st));
+            DIST_HIP_CHECK(hipStreamSynchronize(st));
+            if (int e = comm->all_reduce(comm->ctx, tmp, 7 + P, IBVH_COMM_F64, IBVH_COMM_MAX, stream)) return (ibvh_status)e;
+            // (the peers gather the first histogram before their host looks at the reduced vector: an empty one from here)
+            char *hist = tmp + align_up((int64_t)8 * (7 + P), 256);
+            DIST_HIP_CHECK(hipMemsetAsync(hist, 0, width0_bytes, st));
+            if (int e = comm->all_gather(comm->ctx, hist, hist + width0_bytes, (int64_t)width0_bytes, stream)) return (ibvh_status)e;
+            DIST_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        return (ibvh_status)status;
+    }
+    const Layout L = make_layout(*types, n_local, P);
     char *base = (char *)scratch;
     const int flt = types->leaf_float, fb = float_bytes(flt);
     const int kb = key_bytes_of(*types), key_bits = key_bits_of(*types);
@@ -295,7 +324,10 @@ ibvh_status ibvh_dist_plan(const ibvh_types *types, const ibvh_comm *comm, const
     if (n_local > 0)
         IBVH_TRY(ibvh_extrema(types, volumes, 0, n_local, 0, base + L.ext_local, base + L.ext_scratch, (size_t)1 << 17, stream));
     IBVH_TRY(ibvh_dist_pack_extrema(flt, base + L.ext_local, n_local > 0 ? 1 : 0, me, P, n_local, base + L.vec, stream));
-    if (P > 1) IBVH_TRY(comm->all_reduce(comm->ctx, base + L.vec, 6 + P, IBVH_COMM_F64, IBVH_COMM_MAX, stream));
+    if (P > 1) {
+        DIST_HIP_CHECK(hipMemsetAsync(base + L.vec + (size_t)8 * (6 + P), 0, 8, st)); // element 6 + P: the largest status of all ranks (0.0: fine)
+        IBVH_TRY(comm->all_reduce(comm->ctx, base + L.vec, 7 + P, IBVH_COMM_F64, IBVH_COMM_MAX, stream));
+    }
     IBVH_TRY(ibvh_dist_unpack_extrema(flt, base + L.vec, base + L.ext, stream));
     // 2. keys, first digit histogram (all-gathered: every rank then knows the whole send matrix when one level suffices)
     const int bits0 = key_bits < DIGIT_BITS ? key_bits : DIGIT_BITS, shift0 = key_bits - bits0, width0 = 1 << bits0;
@@ -308,13 +340,14 @@ ibvh_status ibvh_dist_plan(const ibvh_types *types, const ibvh_comm *comm, const
     if (P > 1) IBVH_TRY(comm->all_gather(comm->ctx, base + L.hist, base + L.allh, (int64_t)width0 * 4, stream));
     else DIST_HIP_CHECK(hipMemcpyAsync(base + L.allh, base + L.hist, (size_t)width0 * 4, hipMemcpyDeviceToDevice, st));
     // ONE device -> host round trip: the reduced vector (leaf counts), the extrema, every rank's histogram
-    std::vector<double> vec(6 + P);
+    std::vector<double> vec(7 + P, 0.0);
     unsigned char ext_raw[48];
     std::vector<uint32_t> H((size_t)P * width0);
     IBVH_TRY(d2h(vec.data(), base + L.vec, vec.size() * 8, st));
     IBVH_TRY(d2h(ext_raw, base + L.ext, (size_t)6 * fb, st));
     IBVH_TRY(d2h(H.data(), base + L.allh, H.size() * 4, st));
     DIST_HIP_CHECK(hipStreamSynchronize(st));
+    if (P > 1 && vec[6 + (size_t)P] > 0.0) return IBVH_ERR_PEER; // (every healthy rank reads the same element: all of them stop here)
     int64_t n_global = 0, before = 0;
     for (int r = 0; r < P; ++r) {
         const int64_t c = (int64_t)std::llround(vec[6 + r]);
@@ -448,27 +481,21 @@ ibvh_status ibvh_dist_exchange(const ibvh_types *types, const ibvh_comm *comm, c
 // ordinary BVH over what it received (ibvh_build: extrema, Morton sort, merge) and runs the ordinary pair traversal
 // (ibvh_traverse_pair_lvt_*) of its own tree against it.  Per-slice self contacts and these pairs together are the contact set
 // of the whole cloud, every pair exactly once (tests/test_gpu_dist_procs.py, test_gpu_parity.py, test_gpu_dist.py).
-//   _plan     all-gather of the boxes; per lower touching rank a counting pass over the own leaves; the counts exchanged (8 bytes a
-//             peer, one all_to_all_v); TWO host synchronisations; fills the plan: who sends how many leaves to whom and how large
-//             the caller's three buffers are (export, import, traversal scratch)
-//   _exchange selected leaves -> export buffer (one compaction pass per receiver), then P - 1 rounds of all_to_all_v (round d: the
-//             pairs (s - d, s)), every rank in every round
+//   _plan     the slice's description (<= 16 boxes, refined greedily ON THE DEVICE: describe_kernel) + leaf count + this rank's
+//             status, all-gathered (ONE all-gather of ~800 bytes a rank); per lower rank a counting pass over the own leaves, which
+//             reads the receiver's boxes from the gathered records and leaves at once when the two slices do not touch; the counts
+//             exchanged (8 bytes a peer, one all_to_all_v); ONE host synchronisation for records and counts together; fills the
+//             plan: who sends how many leaves to whom and how large the caller's three buffers are (export, import, traversal
+//             scratch).  A rank whose arguments are not acceptable still takes part in both collectives (its status travels in
+//             its record) and EVERY rank returns an error together: IBVH_ERR_PEER on the ranks that were fine (round 6).
+//   _exchange selected leaves -> export buffer, contiguous by receiver (one compaction pass per receiver), then ONE all_to_all_v
+//             (round 6; P - 1 sequential rounds before): the import buffer holds the received leaf sets contiguously by sender
+//             (what all_to_all_v delivers), the room for their trees' nodes and skips behind them
 //   _count    per imported set: ibvh_build in place, pair-traversal counting pass;  _write: the writing passes.
+// The order in which a sender's selected leaves arrive is NOT deterministic (one atomic cursor per workgroup): the receiver's
+// stable Morton sort then orders leaves of EQUAL codes differently from run to run, and with them the order of their cross
+// contacts — cross contacts are a SET (include/ibvh.h); the per-slice lists keep the reference's order.
 namespace {
-void root_box_of(const ibvh_types &t, const unsigned char *raw, bool is_leaf, double out[6]) {
-    const int kind = is_leaf ? t.leaf_kind : t.node_kind, flt = is_leaf ? t.leaf_float : t.node_float;
-    double v[6];
-    const int w = kind == IBVH_BSPHERE ? 4 : 6;
-    for (int k = 0; k < w; ++k) v[k] = flt == IBVH_F64 ? ((const double *)raw)[k] : (double)((const float *)raw)[k];
-    if (kind == IBVH_BSPHERE) { // the sphere's box (in double precision: never smaller than the box any node type would hold)
-        for (int k = 0; k < 3; ++k) {
-            out[k] = v[k] - v[3];
-            out[3 + k] = v[k] + v[3];
-        }
-    } else {
-        for (int k = 0; k < 6; ++k) out[k] = v[k];
-    }
-}
 // the box a leaf is tested with, in double
 template <class T> IBVH_D void leaf_box(const BSphere<T> &s, double (&lo)[3], double (&up)[3]) {
 #pragma unroll
@@ -484,29 +511,115 @@ template <class T> IBVH_D void leaf_box(const BBox<T> &b, double (&lo)[3], doubl
         up[k] = (double)b.up[k];
     }
 }
-constexpr int CROSS_BOXES = IBVH_DIST_CROSS_BOXES; // boxes a slice is described by: the nodes of its tree's level 4 (Morton slices are not convex)
-struct BoxSet {
-    int n;
-    double lo[CROSS_BOXES][3], up[CROSS_BOXES][3];
+constexpr int CROSS_BOXES = IBVH_DIST_CROSS_BOXES; // boxes a slice is described by: nodes of its tree, refined greedily (Morton slices are not convex)
+// one rank's record in the all-gather: the boxes its slice is described by, its leaf count, n_boxes (or -status when the rank's
+// arguments were not acceptable: the others then stop with IBVH_ERR_PEER instead of waiting in a later collective)
+struct CrossRec {
+    double box[CROSS_BOXES][6];
+    int64_t leaves, n_boxes;
 };
-// leaves of a slice whose box touches one of `box` (a peer's boxes, widened by a few ulps of the narrower float type: the filter must
+static_assert(sizeof(CrossRec) == IBVH_DIST_CROSS_BOXES * 48 + 16, "record layout (IBVH_DIST_CROSS_SCRATCH)");
+
+template <class V> IBVH_D void box_of(const V &v, double out[6]) { // the volume's box in double: never smaller than the box any node type would hold
+    double lo[3], up[3];
+    leaf_box(v, lo, up);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[k] = lo[k], out[3 + k] = up[k];
+}
+// This rank's record.  A Morton slice is not convex — where it straddles a big jump of the Z-curve one node box spans the scene
+// and every leaf of every other slice "touches" it — so the description is refined greedily: start with the root, replace the box
+// of the largest volume by its two children, until CROSS_BOXES boxes (the straddling node is split again and again, one tight
+// child peeled off each time, down to the level where the jump sits).  One thread: ~15 dependent 48-byte reads (round 5 made
+// them from the host, one stream synchronisation each).
+template <class NV, class LV>
+__global__ void describe_kernel(const char *nodes, const char *leaves, int64_t node_bytes, TreeDev tree, bool from_leaf, int64_t n_leaves, int32_t status,
+                                CrossRec *out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    CrossRec r;
+    for (int i = 0; i < CROSS_BOXES; ++i)
+        for (int k = 0; k < 6; ++k) r.box[i][k] = 0.0;
+    r.leaves = n_leaves;
+    r.n_boxes = -(int64_t)status;
+    if (status == 0) {
+        if (from_leaf) box_of(load_vol<LV>(leaves), r.box[0]);
+        else box_of(load_vol<NV>(nodes), r.box[0]);
+        int64_t node[CROSS_BOXES], level[CROSS_BOXES]; // heap index and level of every box
+        node[0] = 1, level[0] = 1;
+        int nb = 1;
+        const int64_t levels = tree.levels, vl = tree.virtual_leaves;
+        while (!from_leaf && nb < CROSS_BOXES) {
+            int pick = -1;
+            double best = 0.0;
+            for (int i = 0; i < nb; ++i) {
+                if (level[i] + 1 > levels - 1) continue; // (its children are leaves: not node boxes)
+                double v = 1.0;
+                for (int k = 0; k < 3; ++k) {
+                    const double d = r.box[i][3 + k] - r.box[i][k];
+                    v *= d > 0 ? d : 0.0;
+                }
+                v = v == v ? v : 0.0; // (a NaN box touches nothing: nothing to refine)
+                if (pick < 0 || v > best) pick = i, best = v;
+            }
+            if (pick < 0 || best <= 0.0) break;
+            const int64_t cl = level[pick] + 1, c0 = 2 * node[pick], c1 = c0 + 1;
+            const bool real1 = (c1 - ((int64_t)1 << (cl - 1))) < level_num_real(levels, vl, cl);
+            const int64_t mem0 = level_start(levels, vl, cl) - 1 + (c0 - ((int64_t)1 << (cl - 1))); // 0-based memory index of the left child
+            box_of(load_vol<NV>(nodes + mem0 * node_bytes), r.box[pick]);
+            node[pick] = c0, level[pick] = cl;
+            if (real1) {
+                box_of(load_vol<NV>(nodes + (mem0 + 1) * node_bytes), r.box[nb]);
+                node[nb] = c1, level[nb] = cl;
+                ++nb;
+            }
+        }
+        r.n_boxes = nb;
+    }
+    *out = r;
+}
+IBVH_HD bool recs_touch(const CrossRec &a, const CrossRec &b) { // any box of a against any box of b (iscontact.jl:20-28; a NaN box touches nothing)
+    if (a.n_boxes <= 0 || b.n_boxes <= 0) return false;
+    for (int64_t i = 0; i < a.n_boxes; ++i)
+        for (int64_t j = 0; j < b.n_boxes; ++j) {
+            bool t = true;
+            for (int k = 0; k < 3; ++k) t = t && a.box[i][3 + k] >= b.box[j][k] && a.box[i][k] <= b.box[j][3 + k];
+            if (t) return true;
+        }
+    return false;
+}
+// leaves of a slice whose box touches one of the RECEIVER's boxes (widened by a few ulps of the narrower float type: the filter must
 // keep every leaf the pair traversal could report, and its own box tests round differently): counted (out == nullptr) or copied,
-// unordered (the receiver sorts them again when it builds its tree), behind one atomic per workgroup
-template <class V> __global__ __launch_bounds__(256) void cross_filter_kernel(const char *leaves, LeafLayout lay, int64_t n, BoxSet box,
-                                                                              unsigned long long *cursor, char *out) {
-    __shared__ uint32_t s_cnt, s_base;
-    if (threadIdx.x == 0) s_cnt = 0;
+// unordered (the receiver sorts them again when it builds its tree), behind one atomic per workgroup.  recs: the gathered
+// records on the device; nothing to do when the receiver's slice (rank `to`, lower) and this one (rank `me`) do not touch.
+template <class V> __global__ __launch_bounds__(256) void cross_filter_kernel(const char *leaves, LeafLayout lay, int64_t n, const CrossRec *recs, int to,
+                                                                              int me, double eps, unsigned long long *cursor, char *out) {
+    __shared__ uint32_t s_cnt, s_base, s_touch;
+    __shared__ double s_lo[CROSS_BOXES][3], s_up[CROSS_BOXES][3];
+    if (threadIdx.x == 0) {
+        s_cnt = 0;
+        s_touch = recs_touch(recs[to], recs[me]) ? 1u : 0u;
+    }
+    const int nb = (int)recs[to].n_boxes;
+    if ((int)threadIdx.x < 3 * CROSS_BOXES) {
+        const int b = threadIdx.x / 3, k = threadIdx.x % 3;
+        if (b < nb) {
+            const double lo = recs[to].box[b][k], up = recs[to].box[b][3 + k];
+            const double ext = fabs(up - lo) + fabs(lo) + fabs(up);
+            s_lo[b][k] = lo - eps * ext - 1e-300;
+            s_up[b][k] = up + eps * ext + 1e-300;
+        }
+    }
     __syncthreads();
+    if (!s_touch) return;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     bool keep = false;
     if (i < n) {
         const V v = load_vol<V>(leaves + i * lay.stride);
         double lo[3], up[3];
         leaf_box(v, lo, up);
-        for (int b = 0; b < box.n; ++b) {
+        for (int b = 0; b < nb; ++b) {
             bool t = true;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) t = t && lo[k] <= box.up[b][k] && up[k] >= box.lo[b][k];
+            for (int k = 0; k < 3; ++k) t = t && lo[k] <= s_up[b][k] && up[k] >= s_lo[b][k];
             keep = keep || t;
         }
     }
@@ -521,24 +634,17 @@ template <class V> __global__ __launch_bounds__(256) void cross_filter_kernel(co
         for (int w = 0; w < lay.stride / 8; ++w) dst[w] = src[w];
     }
 }
-int launch_cross_filter(const ibvh_types &t, const void *leaves, int64_t n, const double (*boxes)[6], int n_boxes, unsigned long long *cursor, void *out,
+int launch_cross_filter(const ibvh_types &t, const void *leaves, int64_t n, const CrossRec *recs, int to, int me, unsigned long long *cursor, void *out,
                         hipStream_t st) {
     ibvh_layout lay;
     LeafLayout dl;
     if (!layout_of(t, lay, &dl)) return IBVH_ERR_UNSUPPORTED;
-    BoxSet b{};
-    b.n = n_boxes;
     const double eps = (t.leaf_float == IBVH_F32 || t.node_float == IBVH_F32) ? 1e-5 : 1e-13;
-    for (int i = 0; i < n_boxes; ++i)
-        for (int k = 0; k < 3; ++k) {
-            const double ext = std::fabs(boxes[i][3 + k] - boxes[i][k]) + std::fabs(boxes[i][k]) + std::fabs(boxes[i][3 + k]);
-            b.lo[i][k] = boxes[i][k] - eps * ext - 1e-300;
-            b.up[i][k] = boxes[i][3 + k] + eps * ext + 1e-300;
-        }
     if (n <= 0) return IBVH_OK;
     return dispatch_volume(t.leaf_kind, t.leaf_float, [&](auto vt) -> int {
         using V = typename decltype(vt)::type;
-        hipLaunchKernelGGL((cross_filter_kernel<V>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, (const char *)leaves, dl, n, b, cursor, (char *)out);
+        hipLaunchKernelGGL((cross_filter_kernel<V>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, (const char *)leaves, dl, n, recs, to, me, eps, cursor,
+                           (char *)out);
         return hipGetLastError() == hipSuccess ? (int)IBVH_OK : (int)IBVH_ERR_HIP;
     });
 }
@@ -562,6 +668,23 @@ bool cross_sizes(const ibvh_types &t, int64_t n_other, int64_t n_mine, int32_t c
     if (ibvh_build_scratch_bytes(&t, n_other, &z.build_bytes) != IBVH_OK) return false;
     return true;
 }
+// import buffer: [leaf set 0 | leaf set 1 | ...] contiguous, by ascending sender (what ONE all_to_all_v delivers), then, from the
+// next 256-byte boundary, [nodes 0 | skips 0 | nodes 1 | skips 1 | ...] (each padded to 256 bytes): the trees ibvh_build makes in place
+int64_t import_aux_offset(const ibvh_types &t, const ibvh_dist_cross_plan_t &plan, int k, int64_t *total_out) {
+    ibvh_layout lay;
+    layout_of(t, lay);
+    int64_t leaves = 0;
+    for (int i = 0; i < plan.n_recv; ++i) leaves += plan.recv_leaves[i] * lay.leaf_bytes;
+    int64_t off = align_up(leaves, 256), mine = off;
+    for (int i = 0; i < plan.n_recv; ++i) {
+        if (i == k) mine = off;
+        ibvh_tree tree;
+        ibvh_tree_shape(plan.recv_leaves[i], &tree);
+        off += align_up((tree.real_nodes - tree.real_leaves) * lay.node_bytes, 256) + align_up(tree.levels * (t.index_type == IBVH_I64 ? 8 : 4), 256);
+    }
+    if (total_out) *total_out = off;
+    return mine;
+}
 ibvh_bvh imported_tree(const ibvh_bvh &mine, const ibvh_dist_cross_plan_t &plan, int k, const void *import_buf) {
     ibvh_bvh o{};
     o.types = mine.types;
@@ -569,9 +692,8 @@ ibvh_bvh imported_tree(const ibvh_bvh &mine, const ibvh_dist_cross_plan_t &plan,
     o.built_level = 1;
     ibvh_layout lay;
     layout_of(mine.types, lay);
-    const char *at = (const char *)import_buf + plan.recv_offset[k];
-    o.leaves = at;
-    o.nodes = at + align_up(plan.recv_leaves[k] * lay.leaf_bytes, 256);
+    o.leaves = (const char *)import_buf + plan.recv_offset[k];
+    o.nodes = (const char *)import_buf + import_aux_offset(mine.types, plan, k, nullptr);
     o.skips = (const char *)o.nodes + align_up((o.tree.real_nodes - o.tree.real_leaves) * lay.node_bytes, 256);
     return o;
 }
@@ -581,124 +703,96 @@ extern "C" {
 
 ibvh_status ibvh_dist_cross_plan(const ibvh_comm *comm, const ibvh_bvh *bvh, int32_t cache_slots, void *scratch, size_t scratch_bytes,
                                  ibvh_dist_cross_plan_t *plan, void *stream) {
-    if (!comm || !bvh || !plan || cache_slots < 0) return IBVH_ERR_INVALID_ARG;
+    // what cannot be agreed on: no communicator, no plan to fill, no scratch to take part in the collectives with
+    if (!comm || !plan) return IBVH_ERR_INVALID_ARG;
     const int P = comm->size, me = comm->rank;
     if (P < 1 || P > MAX_RANKS || me < 0 || me >= P) return IBVH_ERR_INVALID_ARG;
     if (P > 1 && (!comm->all_gather || !comm->all_to_all_v)) return IBVH_ERR_INVALID_ARG;
-    if (bvh->built_level > 1 && bvh->tree.real_nodes > bvh->tree.real_leaves) return IBVH_ERR_UNSUPPORTED; // (the root must exist)
-    ibvh_layout lay;
-    if (!layout_of(bvh->types, lay)) return IBVH_ERR_UNSUPPORTED;
     if (!scratch || scratch_bytes < IBVH_DIST_CROSS_SCRATCH(P)) return IBVH_ERR_SCRATCH;
+    // everything else is this rank's STATUS: it travels in the rank's record, the rank takes part in both collectives, and all
+    // ranks return together (a rank that returned here would leave its peers waiting in the all-gather)
+    ibvh_layout lay{};
+    int status = IBVH_OK;
+    if (!bvh || cache_slots < 0) status = IBVH_ERR_INVALID_ARG;
+    else if (!layout_of(bvh->types, lay)) status = IBVH_ERR_UNSUPPORTED;
+    else if (bvh->built_level > 1 && bvh->tree.real_nodes > bvh->tree.real_leaves) status = IBVH_ERR_UNSUPPORTED; // (the root must exist)
+    else if (!bvh->leaves || (bvh->tree.real_nodes > bvh->tree.real_leaves && !bvh->nodes)) status = IBVH_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     std::memset(plan, 0, sizeof(*plan));
     plan->size = P;
     plan->rank = me;
     plan->cache_slots = cache_slots;
-    const int64_t n_mine = bvh->tree.real_leaves;
-    // this rank's record: the boxes its slice is described by + its leaf count.  A Morton slice is not convex — where it
-    // straddles a big jump of the Z-curve one node box spans the scene and every leaf of every other slice "touches" it — so
-    // the description is refined greedily: start with the root, replace the box of the largest volume by its two children,
-    // until CROSS_BOXES boxes (the straddling node is split again and again, one tight child peeled off each time, down to the
-    // level where the jump sits).  A dozen 48-byte reads from the device, once per completion.
-    struct Rec {
-        double box[CROSS_BOXES][6];
-        int64_t leaves, n_boxes;
-    } mine_rec{};
-    static_assert(sizeof(Rec) == IBVH_DIST_CROSS_BOXES * 48 + 16, "record layout");
-    const bool from_leaf = bvh->tree.real_nodes <= bvh->tree.real_leaves;
-    {
-        const size_t one = (size_t)(from_leaf ? lay.volume_bytes : lay.node_bytes);
-        unsigned char raw[2 * 48];
-        DIST_HIP_CHECK(hipMemcpyAsync(raw, from_leaf ? bvh->leaves : bvh->nodes, one, hipMemcpyDeviceToHost, st));
-        DIST_HIP_CHECK(hipStreamSynchronize(st));
-        root_box_of(bvh->types, raw, from_leaf, mine_rec.box[0]);
-        int64_t node[CROSS_BOXES], level[CROSS_BOXES]; // heap index and level of every box
-        node[0] = 1, level[0] = 1;
-        int nb = 1;
-        const int64_t levels = bvh->tree.levels, vl = bvh->tree.virtual_leaves;
-        auto volume = [&](const double *b) {
-            double v = 1.0;
-            for (int k = 0; k < 3; ++k) {
-                const double d = b[3 + k] - b[k];
-                v *= d > 0 ? d : 0.0;
-            }
-            return v == v ? v : 0.0; // (a NaN box touches nothing: nothing to refine)
-        };
-        while (!from_leaf && nb < CROSS_BOXES) {
-            int pick = -1;
-            double best = 0.0;
-            for (int i = 0; i < nb; ++i) {
-                if (level[i] + 1 > levels - 1) continue; // (its children are leaves: not node boxes)
-                const double v = volume(mine_rec.box[i]);
-                if (pick < 0 || v > best) pick = i, best = v;
-            }
-            if (pick < 0 || best <= 0.0) break;
-            const int64_t cl = level[pick] + 1, c0 = 2 * node[pick], c1 = c0 + 1;
-            const bool real1 = (c1 - ((int64_t)1 << (cl - 1))) < level_num_real(levels, vl, cl);
-            const int64_t mem0 = level_start(levels, vl, cl) - 1 + (c0 - ((int64_t)1 << (cl - 1))); // 0-based memory index of the left child
-            DIST_HIP_CHECK(hipMemcpyAsync(raw, (const char *)bvh->nodes + (size_t)mem0 * one, one * (real1 ? 2 : 1), hipMemcpyDeviceToHost, st));
-            DIST_HIP_CHECK(hipStreamSynchronize(st));
-            root_box_of(bvh->types, raw, false, mine_rec.box[pick]);
-            node[pick] = c0, level[pick] = cl;
-            if (real1) {
-                root_box_of(bvh->types, raw + one, false, mine_rec.box[nb]);
-                node[nb] = c1, level[nb] = cl;
-                ++nb;
-            }
-        }
-        mine_rec.n_boxes = nb;
-    }
-    mine_rec.leaves = n_mine;
-    std::vector<Rec> all(P);
-    all[me] = mine_rec;
+    const int64_t n_mine = status == IBVH_OK ? bvh->tree.real_leaves : 0;
     char *base = (char *)scratch;
-    const size_t gather_bytes = sizeof(Rec) * (size_t)(P + 1);
-    if (P > 1) {
-        DIST_HIP_CHECK(hipMemcpyAsync(base, &mine_rec, sizeof(Rec), hipMemcpyHostToDevice, st));
-        if (int e = comm->all_gather(comm->ctx, base, base + sizeof(Rec), (int64_t)sizeof(Rec), stream)) return (ibvh_status)e;
-        DIST_HIP_CHECK(hipMemcpyAsync(all.data(), base + sizeof(Rec), sizeof(Rec) * (size_t)P, hipMemcpyDeviceToHost, st));
-        DIST_HIP_CHECK(hipStreamSynchronize(st));
+    CrossRec *recs = (CrossRec *)(base + sizeof(CrossRec)); // [P] the gathered records; base[0]: this rank's own
+    const size_t gather_bytes = sizeof(CrossRec) * (size_t)(P + 1);
+    unsigned long long *cnt_send = (unsigned long long *)(base + align_up((int64_t)gather_bytes, 256)), *cnt_recv = cnt_send + P;
+    // 1. this rank's record, on the device
+    if (status == IBVH_OK) {
+        const bool from_leaf = bvh->tree.real_nodes <= bvh->tree.real_leaves;
+        const TreeDev td{bvh->tree.levels, bvh->tree.real_leaves, bvh->tree.virtual_leaves};
+        const int e = dispatch_volume(bvh->types.node_kind, bvh->types.node_float, [&](auto nt) -> int {
+            using NV = typename decltype(nt)::type;
+            return dispatch_volume(bvh->types.leaf_kind, bvh->types.leaf_float, [&](auto lt) -> int {
+                using LV = typename decltype(lt)::type;
+                hipLaunchKernelGGL((describe_kernel<NV, LV>), dim3(1), dim3(64), 0, st, (const char *)bvh->nodes, (const char *)bvh->leaves, (int64_t)lay.node_bytes, td,
+                                   from_leaf, n_mine, (int32_t)0, (CrossRec *)base);
+                return hipGetLastError() == hipSuccess ? (int)IBVH_OK : (int)IBVH_ERR_HIP;
+            });
+        });
+        if (e != IBVH_OK) status = e;
     }
-    auto touch = [&](int a, int b) { // any box of a against any box of b (iscontact.jl:20-28; a NaN box touches nothing)
-        for (int64_t i = 0; i < all[a].n_boxes; ++i)
-            for (int64_t j = 0; j < all[b].n_boxes; ++j) {
-                bool t = true;
-                for (int k = 0; k < 3; ++k) t = t && all[a].box[i][3 + k] >= all[b].box[j][k] && all[a].box[i][k] <= all[b].box[j][3 + k];
-                if (t) return true;
-            }
-        return false;
-    };
+    if (status != IBVH_OK) { // (the record of a rank that cannot take part in the completion: no boxes, its status)
+        CrossRec bad{};
+        bad.n_boxes = -(int64_t)status;
+        DIST_HIP_CHECK(hipMemcpyAsync(base, &bad, sizeof(bad), hipMemcpyHostToDevice, st));
+        DIST_HIP_CHECK(hipStreamSynchronize(st)); // (`bad` is a stack object)
+    }
+    // 2. every rank's record
+    if (P > 1) {
+        if (int e = comm->all_gather(comm->ctx, base, recs, (int64_t)sizeof(CrossRec), stream)) return (ibvh_status)e;
+    } else {
+        DIST_HIP_CHECK(hipMemcpyAsync(recs, base, sizeof(CrossRec), hipMemcpyDeviceToDevice, st));
+    }
+    // 3. how many of the own leaves every LOWER rank gets: a counting pass per lower rank (it leaves at once when the slices do
+    //    not touch), then the counts change hands
+    DIST_HIP_CHECK(hipMemsetAsync(cnt_send, 0, (size_t)16 * P, st));
+    if (P > 1) {
+        if (status == IBVH_OK)
+            for (int r = 0; r < me; ++r)
+                if (int e = launch_cross_filter(bvh->types, bvh->leaves, n_mine, recs, r, me, cnt_send + r, nullptr, st)) status = e;
+        std::vector<int64_t> eight(P, 8);
+        if (int e = comm->all_to_all_v(comm->ctx, cnt_send, eight.data(), cnt_recv, eight.data(), stream)) return (ibvh_status)e;
+    }
+    // 4. ONE device -> host round trip: the records, the counts
+    std::vector<CrossRec> all(P);
+    std::vector<unsigned long long> host(2 * (size_t)P);
+    DIST_HIP_CHECK(hipMemcpyAsync(all.data(), recs, sizeof(CrossRec) * (size_t)P, hipMemcpyDeviceToHost, st));
+    DIST_HIP_CHECK(hipMemcpyAsync(host.data(), cnt_send, (size_t)16 * P, hipMemcpyDeviceToHost, st));
+    DIST_HIP_CHECK(hipStreamSynchronize(st));
+    if (status != IBVH_OK) return (ibvh_status)status;
+    for (int r = 0; r < P; ++r)
+        if (all[r].n_boxes < 0) return IBVH_ERR_PEER; // (every rank sees the same records: all of them stop here)
     for (int r = 0; r < P; ++r) {
         plan->slice_leaves[r] = all[r].leaves;
-        plan->touches[r] = (r != me && touch(me < r ? me : r, me < r ? r : me)) ? 1 : 0;
+        plan->touches[r] = (r != me && recs_touch(all[me < r ? me : r], all[me < r ? r : me])) ? 1 : 0;
         plan->n_boxes[r] = (int32_t)all[r].n_boxes;
         for (int i = 0; i < CROSS_BOXES; ++i)
             for (int k = 0; k < 6; ++k) plan->boxes[r][i][k] = all[r].box[i][k];
     }
-    // how many of the own leaves every LOWER touching rank gets: a counting pass per such rank, then the counts change hands
-    unsigned long long *cnt_send = (unsigned long long *)(base + align_up((int64_t)gather_bytes, 256)), *cnt_recv = cnt_send + P;
     if (P > 1) {
-        DIST_HIP_CHECK(hipMemsetAsync(cnt_send, 0, (size_t)16 * P, st));
-        for (int r = 0; r < me; ++r)
-            if (plan->touches[r])
-                if (int e = launch_cross_filter(bvh->types, bvh->leaves, n_mine, plan->boxes[r], plan->n_boxes[r], cnt_send + r, nullptr, st)) return (ibvh_status)e;
-        std::vector<int64_t> eight(P, 8);
-        if (int e = comm->all_to_all_v(comm->ctx, cnt_send, eight.data(), cnt_recv, eight.data(), stream)) return (ibvh_status)e;
-        std::vector<unsigned long long> host(2 * (size_t)P);
-        DIST_HIP_CHECK(hipMemcpyAsync(host.data(), cnt_send, (size_t)16 * P, hipMemcpyDeviceToHost, st));
-        DIST_HIP_CHECK(hipStreamSynchronize(st));
         int64_t eo = 0;
-        for (int r = 0; r < P; ++r) {
+        for (int r = 0; r < P; ++r) { // the export buffer: contiguous by receiver, ascending (all_to_all_v's send layout)
             plan->send_leaves[r] = (int64_t)host[r];
             plan->send_offset[r] = eo;
-            eo += align_up((int64_t)host[r] * lay.leaf_bytes, 256);
+            eo += (int64_t)host[r] * lay.leaf_bytes;
         }
         plan->export_bytes = eo;
         int64_t off = 0, scr = 0;
         size_t build_max = 0;
-        for (int r = me + 1; r < P; ++r) { // leaf sets this rank imports, by ascending rank
+        for (int r = me + 1; r < P; ++r) { // leaf sets this rank imports, by ascending rank: contiguous (all_to_all_v's receive layout)
             const int64_t got = (int64_t)host[(size_t)P + r];
-            if (!plan->touches[r] || got <= 0) continue;
+            if (got <= 0) continue;
             CrossSizes z;
             if (!cross_sizes(bvh->types, got, n_mine, cache_slots, z)) return IBVH_ERR_UNSUPPORTED;
             const int k = plan->n_recv++;
@@ -706,11 +800,13 @@ ibvh_status ibvh_dist_cross_plan(const ibvh_comm *comm, const ibvh_bvh *bvh, int
             plan->recv_leaves[k] = got;
             plan->recv_offset[k] = off;
             plan->scratch_offset[k] = scr;
-            off += z.tree_bytes;
+            off += z.leaf_bytes;
             scr += (int64_t)(z.counts_bytes + z.lvt_bytes);
             build_max = z.build_bytes > build_max ? z.build_bytes : build_max;
         }
-        plan->import_bytes = off;
+        int64_t total = 0;
+        import_aux_offset(bvh->types, *plan, 0, &total);
+        plan->import_bytes = plan->n_recv ? total : 0;
         plan->build_offset = scr;
         plan->scratch_bytes = scr + (int64_t)align_up((int64_t)build_max, 256);
     }
@@ -728,32 +824,35 @@ ibvh_status ibvh_dist_cross_exchange(const ibvh_comm *comm, const ibvh_bvh *bvh,
     ibvh_layout lay;
     if (!layout_of(bvh->types, lay)) return IBVH_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    // the selected leaves of every receiver, compacted into the export buffer (the counting pass of _plan, now copying)
-    unsigned long long *cursor = (unsigned long long *)((char *)scratch + align_up((int64_t)((IBVH_DIST_CROSS_BOXES * 48 + 16) * (size_t)(P + 1)), 256));
+    // the records again (from the plan: the scratch need not be the one _plan was given), then the selected leaves of every
+    // receiver, compacted into the export buffer (the counting pass of _plan, now copying)
+    char *base = (char *)scratch;
+    CrossRec *recs = (CrossRec *)(base + sizeof(CrossRec));
+    {
+        std::vector<CrossRec> all(P);
+        for (int r = 0; r < P; ++r) {
+            all[r].leaves = plan->slice_leaves[r];
+            all[r].n_boxes = plan->n_boxes[r];
+            for (int i = 0; i < CROSS_BOXES; ++i)
+                for (int k = 0; k < 6; ++k) all[r].box[i][k] = plan->boxes[r][i][k];
+        }
+        DIST_HIP_CHECK(hipMemcpyAsync(recs, all.data(), sizeof(CrossRec) * (size_t)P, hipMemcpyHostToDevice, st));
+        DIST_HIP_CHECK(hipStreamSynchronize(st)); // (`all` is freed on return)
+    }
+    unsigned long long *cursor = (unsigned long long *)(base + align_up((int64_t)(sizeof(CrossRec) * (size_t)(P + 1)), 256));
     DIST_HIP_CHECK(hipMemsetAsync(cursor, 0, (size_t)8 * P, st));
     for (int r = 0; r < me; ++r)
         if (plan->touches[r] && plan->send_leaves[r] > 0)
-            if (int e = launch_cross_filter(bvh->types, bvh->leaves, bvh->tree.real_leaves, plan->boxes[r], plan->n_boxes[r], cursor + r, (char *)export_buf + plan->send_offset[r], st))
+            if (int e = launch_cross_filter(bvh->types, bvh->leaves, bvh->tree.real_leaves, recs, r, me, cursor + r, (char *)export_buf + plan->send_offset[r], st))
                 return (ibvh_status)e;
-    int k_of[MAX_RANKS];
-    for (int r = 0; r < P; ++r) k_of[r] = -1;
-    for (int k = 0; k < plan->n_recv; ++k) k_of[plan->recv_rank[k]] = k;
+    // ONE all_to_all_v: rank s sends every lower touching rank its share; both buffers are laid out the way it wants them
     int64_t sb[MAX_RANKS], rbts[MAX_RANKS];
-    for (int d = 1; d < P; ++d) { // round d: rank s sends to rank s - d — EVERY rank takes part in every round
-        const int dst = me - d, src = me + d;
-        for (int r = 0; r < P; ++r) sb[r] = rbts[r] = 0;
-        const void *send = export_buf ? export_buf : (const void *)scratch;
-        void *recv = import_buf ? import_buf : scratch;
-        if (dst >= 0 && plan->touches[dst] && plan->send_leaves[dst] > 0) {
-            sb[dst] = plan->send_leaves[dst] * lay.leaf_bytes;
-            send = (const char *)export_buf + plan->send_offset[dst];
-        }
-        if (src < P && k_of[src] >= 0) {
-            rbts[src] = plan->recv_leaves[k_of[src]] * lay.leaf_bytes;
-            recv = (char *)import_buf + plan->recv_offset[k_of[src]];
-        }
-        if (int e = comm->all_to_all_v(comm->ctx, send, sb, recv, rbts, stream)) return (ibvh_status)e;
-    }
+    for (int r = 0; r < P; ++r) sb[r] = rbts[r] = 0;
+    for (int r = 0; r < me; ++r) sb[r] = plan->send_leaves[r] * lay.leaf_bytes;
+    for (int k = 0; k < plan->n_recv; ++k) rbts[plan->recv_rank[k]] = plan->recv_leaves[k] * lay.leaf_bytes;
+    const void *send = export_buf ? export_buf : (const void *)scratch;
+    void *recv = import_buf ? import_buf : scratch;
+    if (int e = comm->all_to_all_v(comm->ctx, send, sb, recv, rbts, stream)) return (ibvh_status)e;
     return IBVH_OK;
 }
 

@@ -68,8 +68,9 @@ template <class L, class N, class I> struct Args {
     // pass — which needs nothing else of a leaf to put a cached pair together, and would otherwise pull every line of the leaf
     // records through the memory system for it (24-byte records: 240 MB at 1e7 leaves).  nullptr: read the leaf.
     I *q_index_dense;
-    // walker 2, counting pass: the tile aggregates of the single-kernel scan that follows it (scan_fused_kernel) — its first
-    // scan_nparts waves zero one word each (the scratch is the caller's, uninitialised).  nullptr: nothing to zero.
+    // walker 2, counting pass: the tile aggregates of the single-kernel scan that follows it (scan_fused_kernel) and, behind
+    // them, its ticket counter — the first scan_nparts + 1 waves zero one word each (the scratch is the caller's, uninitialised).
+    // nullptr: nothing to zero.
     unsigned long long *scan_agg;
     int32_t scan_nparts;
 };
@@ -548,15 +549,26 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_apply_kernel(I *c, int64_t n, c
 // The same scan in ONE kernel (round 5), for counts whose producer zeroed the tile aggregates (walker 2's counting pass): every
 // workgroup sums its tile, PUBLISHES the sum (bit 63 = "there"; one 64-bit agent-scope atomic store: value and flag travel together,
 // no fence — an agent-scope fence on this part writes back and invalidates an XCD's whole L2), adds up the aggregates of the tiles
-// before it (polling those that are not there yet: they belong to workgroups with smaller ids, which were dispatched earlier
-// and are resident or done) and scans its tile.  One launch and one dependent round trip less than reduce + apply: they are
-// launch- and latency-bound (245 workgroups at 1e6 leaves).
-template <class I>
+// before it (polling those that are not there yet) and scans its tile.  One launch and one dependent round trip less than reduce +
+// apply: they are launch- and latency-bound (245 workgroups at 1e6 leaves).
+// Whom a workgroup may wait for: TICKET = false — the grid is small enough for ALL its workgroups to be resident at once
+// (scan_counts checks), so every tile it polls belongs to a workgroup that is running or done, whatever order they started in;
+// TICKET = true (larger grids) — the tile is not blockIdx.x but a ticket from an atomic counter (agg[nparts], zeroed with the
+// aggregates): tiles before mine were taken by workgroups that started before me.  No assumption about dispatch order either way.
+constexpr int64_t SCAN_FUSED_RESIDENT = 1024; // workgroups of SCAN_TPB threads one MI355X holds at once: 256 CUs x 8, halved for margin
+template <class I, bool TICKET>
 __global__ __launch_bounds__(SCAN_TPB) void scan_fused_kernel(I *c, int64_t n, unsigned long long *agg, int64_t *totals, int64_t *total_host) {
     __shared__ int64_t s_w[SCAN_TPB / 64], s_p[SCAN_TPB / 64];
+    __shared__ uint32_t s_tile;
     constexpr unsigned long long THERE = 1ull << 63;
+    uint32_t tile = blockIdx.x;
+    if constexpr (TICKET) {
+        if (threadIdx.x == 0) s_tile = (uint32_t)__hip_atomic_fetch_add(&agg[gridDim.x], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        tile = s_tile;
+    }
     // thread owns SCAN_IPT consecutive items so the in-thread running sum is in memory order
-    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_IPT;
+    const int64_t base = (int64_t)tile * SCAN_TILE + (int64_t)threadIdx.x * SCAN_IPT;
     int64_t v[SCAN_IPT], sum = 0;
     constexpr int NV = SCAN_IPT * (int)sizeof(I) / 16;
     const bool vec = base + SCAN_IPT <= n && ((uintptr_t)c & 15) == 0;
@@ -593,9 +605,9 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_fused_kernel(I *c, int64_t n, u
         if (k < w) wb += s_w[k];
         tile_total += s_w[k];
     }
-    if (threadIdx.x == 0) __hip_atomic_store(&agg[blockIdx.x], THERE | (unsigned long long)tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(&agg[tile], THERE | (unsigned long long)tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int64_t before = 0;
-    for (int64_t j = threadIdx.x; j < (int64_t)blockIdx.x; j += SCAN_TPB) {
+    for (int64_t j = threadIdx.x; j < (int64_t)tile; j += SCAN_TPB) {
         unsigned long long a = __hip_atomic_load(&agg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (!(a & THERE)) {
             __builtin_amdgcn_s_sleep(1);
@@ -604,7 +616,7 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_fused_kernel(I *c, int64_t n, u
         before += (int64_t)(a & ~THERE);
     }
     const int64_t tile_offset = block_sum(before, s_p);
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    if (tile == gridDim.x - 1 && threadIdx.x == 0) {
         const int64_t total = tile_offset + tile_total;
         totals[0] = total;
         if (total_host) __hip_atomic_store(total_host, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -635,7 +647,7 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_fused_kernel(I *c, int64_t n, u
 //   [64, scan_bytes)   scan tile sums
 //   [scan_bytes, ...)  contact cache: K * n_items IndexPair{I}, slot-major
 inline size_t scan_scratch_bytes(int64_t n) {
-    return (size_t)align_up((ceil_div(n > 0 ? n : 1, SCAN_TILE) + 8) * 8, 256);
+    return (size_t)align_up((ceil_div(n > 0 ? n : 1, SCAN_TILE) + 9) * 8, 256); // header, one aggregate per tile, the fused scan's ticket
 }
 constexpr int MAX_CACHE_SLOTS = 64;
 inline int cache_slots_for(size_t scratch_bytes, int64_t n_items, int64_t pair_bytes) {
@@ -653,7 +665,10 @@ int scan_counts(I *counts, int64_t n, int64_t *total_out, void *scratch, hipStre
     int64_t *totals = total_dev ? total_dev : (int64_t *)scratch; // where the device-side total goes
     int64_t *partials = (int64_t *)scratch + 8;
     if (aggregates_zeroed && limit == nullptr && g_tuning.lvt_scan_fused != 0) {
-        IBVH_LAUNCH((scan_fused_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, (unsigned long long *)partials, totals, total_host);
+        if (nparts > SCAN_FUSED_RESIDENT)
+            IBVH_LAUNCH((scan_fused_kernel<I, true>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, (unsigned long long *)partials, totals, total_host);
+        else
+            IBVH_LAUNCH((scan_fused_kernel<I, false>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, (unsigned long long *)partials, totals, total_host);
     } else {
         IBVH_LAUNCH((scan_reduce_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, partials, limit);
         IBVH_LAUNCH((scan_apply_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, partials, totals, total_host, limit);

@@ -118,6 +118,7 @@ function check(status::Cint, what)
     status == 2 && throw(DomainError(0, "must have at least one geometry!"))       # implicit_tree.jl:78-80
     status == 3 && throw(ArgumentError("$what: type combination not instantiated in libibvh"))
     status == 5 && throw(OverflowError("$what: count does not fit the index type"))
+    status == 8 && error("$what: another rank's arguments were not acceptable (every rank returned together)")
     error("$what: libibvh status $status")
 end
 

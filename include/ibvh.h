@@ -54,7 +54,9 @@ typedef enum ibvh_status {
     IBVH_ERR_CAPACITY = 4,    /* caller buffer too small; the required size is reported                      */
     IBVH_ERR_OVERFLOW = 5,    /* a count does not fit the index type I                                       */
     IBVH_ERR_HIP = 6,         /* a HIP runtime call failed                                                    */
-    IBVH_ERR_SCRATCH = 7      /* scratch buffer smaller than ibvh_build_scratch_bytes()                      */
+    IBVH_ERR_SCRATCH = 7,     /* scratch buffer smaller than ibvh_build_scratch_bytes()                      */
+    IBVH_ERR_PEER = 8         /* multi-GPU calls: another rank's arguments were not acceptable — every rank returns
+                                 together instead of waiting for it in a collective (that rank reports its own error) */
 } ibvh_status;
 
 /* ----------------------------------------------------------------------------------- */
@@ -522,10 +524,13 @@ ibvh_status ibvh_dist_exchange(const ibvh_types *types, const ibvh_comm *comm, c
 /* Cross-shard contact completion: the contacts between leaves of DIFFERENT slices, which the
  * per-slice self-traversals cannot see.  Root boxes and leaf counts of all slices are all-gathered; for every pair of slices
  * r < s whose boxes touch, rank s sends rank r the leaves whose own box touches one of r's boxes (a slice is described by
- * <= 16 node boxes of its tree, refined from the root by always splitting the largest: a Morton slice is not convex) — a thin shell of its slice, not its tree — in P - 1 rounds of all_to_all_v over the same vtable; rank r builds an ordinary BVH over each set it received
+ * <= 16 node boxes of its tree, refined from the root by always splitting the largest: a Morton slice is not convex) — a thin
+ * shell of its slice, not its tree — in ONE all_to_all_v over the same vtable; rank r builds an ordinary BVH over each set it received
  * (ibvh_build, in place) and runs the ordinary pair traversal (traverse(bvh_r, bvh_s), lvt/traverse_pair.jl) against it.
  * Per-slice self contacts + these pairs = the contact set of the whole cloud, every pair once.  Count -> size -> write:
- *   _plan     collective; TWO host synchronisations (the boxes; how many leaves every peer gets); fills the plan:
+ *   _plan     collective (one all-gather, one 8-bytes-a-peer all_to_all_v); ONE host synchronisation (every slice's boxes and how
+ *             many leaves every peer gets, together); a rank with unacceptable arguments still takes part — its status travels in
+ *             its record — and EVERY rank returns an error: its own, or IBVH_ERR_PEER; fills the plan:
  *             export_bytes / import_bytes (the two buffers the caller hands to _exchange) and scratch_bytes (the scratch of
  *             _count / _write: traversal scratch per imported set, cache_slots as in ibvh_lvt_scratch_bytes, + the build's).
  *             `scratch` here and in _exchange: IBVH_DIST_CROSS_SCRATCH(size) bytes of device memory.
@@ -533,20 +538,23 @@ ibvh_status ibvh_dist_exchange(const ibvh_types *types, const ibvh_comm *comm, c
  *   _count    per imported set: ibvh_build + the pair traversal's counting pass; totals_out[k] (may be NULL), *total_out: pairs.
  *   _write    contacts_out: *total_out IndexPair{I}, the pairs against imported set 0 first: (index in THIS slice, index in
  *             the other slice), both GLOBAL 1-based leaf numbers (the records carry them).  `totals`: what _count returned.
- * The BVH must be fully built (built_level = 1).  Errors inside a collective sequence: the caller must abort the communicator
- * (a rank that returns early leaves its peers waiting). */
+ * The BVH must be fully built (built_level = 1).  The pairs are a SET: the order in which a sender's boundary leaves arrive is
+ * not deterministic, so leaves of equal Morton codes — and their cross contacts — may change places from run to run (the per-slice
+ * lists keep the reference's order).  Errors inside a collective sequence that are not argument errors (a failed HIP call, a
+ * failed collective; a rank without a communicator or scratch): the caller must abort the communicator — a rank that returns
+ * early leaves its peers waiting. */
 #define IBVH_DIST_CROSS_BOXES 16
 typedef struct ibvh_dist_cross_plan_t {
     int32_t size, rank, n_recv /* leaf sets this rank imports */, cache_slots;
     int64_t import_bytes, scratch_bytes, export_bytes, build_offset /* where the build's scratch starts in the scratch */;
     int32_t recv_rank[IBVH_DIST_MAX_RANKS];      /* [n_recv] ascending: the ranks leaves are imported from                   */
     int64_t recv_leaves[IBVH_DIST_MAX_RANKS];    /* [n_recv] how many                                                        */
-    int64_t recv_offset[IBVH_DIST_MAX_RANKS];    /* [n_recv] byte offset of that set in the import buffer (leaves | nodes | skips) */
+    int64_t recv_offset[IBVH_DIST_MAX_RANKS];    /* [n_recv] byte offset of that set's leaves in the import buffer (the sets are contiguous; the room for their trees' nodes and skips follows the last set) */
     int64_t scratch_offset[IBVH_DIST_MAX_RANKS]; /* [n_recv] byte offset of its counts + traversal scratch                   */
     int64_t slice_leaves[IBVH_DIST_MAX_RANKS];   /* [size] leaves of every rank's slice                                      */
     int32_t touches[IBVH_DIST_MAX_RANKS];        /* [size] 1: this rank's root box touches rank r's (r != rank)              */
     int64_t send_leaves[IBVH_DIST_MAX_RANKS];    /* [size] own leaves rank r gets (r < rank, boxes touching r's root box)    */
-    int64_t send_offset[IBVH_DIST_MAX_RANKS];    /* [size] where they are compacted in the export buffer                     */
+    int64_t send_offset[IBVH_DIST_MAX_RANKS];    /* [size] where they are compacted in the export buffer (contiguous, by rank) */
     int32_t n_boxes[IBVH_DIST_MAX_RANKS];        /* [size] boxes that describe rank r's slice (1 .. IBVH_DIST_CROSS_BOXES)   */
     double boxes[IBVH_DIST_MAX_RANKS][IBVH_DIST_CROSS_BOXES][6]; /* [size] ... node boxes of its tree, refined greedily (lo, up) */
 } ibvh_dist_cross_plan_t;

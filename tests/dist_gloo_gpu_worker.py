@@ -6,7 +6,8 @@ device).  RCCL cannot put two ranks on one device; the driver does not care what
   mode "build N TOL": N leaves per rank; the concatenation of the ranks' slices == the single-device build of all leaves, byte for
                       byte; per-slice self contacts + cross-shard contacts == the single-device contact list as a set
                       (TOL = 0 forces the splitter refinement and the count-exchange branch of ibvh_dist_plan)
-  mode "starved"    : every leaf has the same Morton code: one rank would receive nothing — EVERY rank must raise DomainError."""
+  mode "starved"    : every leaf has the same Morton code: one rank would receive nothing — EVERY rank must raise DomainError.
+  mode "bad_args"   : one rank's arguments are not acceptable: it raises its own error, the others IBVH_ERR_PEER, nobody hangs."""
 import datetime
 import math
 import os
@@ -68,6 +69,37 @@ if mode == "starved":
     print(f"rank {rank}: the build did not stop", flush=True)
     sys.exit(1)
 
+if mode == "bad_args":
+    # round 6: ONE rank's arguments are not acceptable (a negative tolerance for the build; a negative cache_slots for the
+    # completion): that rank reports its own error, every other rank IBVH_ERR_PEER — together, nobody is left in a collective
+    n_rank = 20_000
+    vols = ibvh.generate_spheres(n_rank, 46, first_index=rank * n_rank, r0=0.01)
+    culprit = world - 1
+    builder = ibd.DistributedBuilder(comm, tolerance=-1.0 if rank == culprit else 0.005)
+    try:
+        builder.build(vols)
+        print(f"rank {rank}: the build did not stop", flush=True)
+        sys.exit(1)
+    except ValueError as e:
+        assert rank == culprit, e
+    except RuntimeError as e:
+        assert rank != culprit and "another rank" in str(e), e
+    builder = ibd.DistributedBuilder(comm)
+    bvh = builder.build(vols)
+    try:
+        builder.cross_contacts(bvh, cache_slots=-1 if rank == culprit else None)
+        print(f"rank {rank}: the completion did not stop", flush=True)
+        sys.exit(1)
+    except ValueError as e:
+        assert rank == culprit, e
+    except RuntimeError as e:
+        assert rank != culprit and "another rank" in str(e), e
+    cross = builder.cross_contacts(bvh)  # ... and the communicator is still usable
+    torch.cuda.synchronize()
+    print(f"ok rank {rank}: both calls stopped on every rank, then worked ({cross.shape[0]} cross contacts)", flush=True)
+    dist.barrier()
+    sys.exit(0)
+
 n_rank, tol = int(sys.argv[2]), float(sys.argv[3])
 n = n_rank * world
 r0 = 0.5 * (3 * 8 / (4 * math.pi * n)) ** (1 / 3)
@@ -78,8 +110,10 @@ bvh2 = builder.build(vols, cache=bvh)  # the time-stepping shape: buffers reused
 own = ibvh.traverse(bvh).contacts
 cross = builder.cross_contacts(bvh)
 torch.cuda.synchronize()
-# two builds (one record exchange each) + the cross-shard completion (the counts, then world - 1 rounds of selected leaves)
-assert comm.calls["all_to_all"] >= 2 + 1 + (world - 1) and comm.calls["all_gather"] >= 2, comm.calls
+# two builds (one record exchange each) + the cross-shard completion: the counts, then ONE exchange of the selected leaves
+# (round 6; world - 1 sequential rounds before); with tolerance 0 each build exchanges its counts as well
+expect = 2 + 2 + (2 if tol == 0.0 else 0)
+assert comm.calls["all_to_all"] == expect and comm.calls["all_gather"] >= 3, (comm.calls, expect)
 lb = builder.last_cross
 assert all(0 < c <= int(sizes_hint) for c in lb["leaves_received"]) if (sizes_hint := n) else True
 if tol == 0.0:
