@@ -715,6 +715,9 @@ def compact_line(line, detail_path):
             out["configs"]["readme_250k"] = c
     if isinstance(line.get("exchange"), dict):
         out["exchange"] = _pick(line["exchange"], ("max_exchange_ms", "bytes_sent_max", "xgmi_frac_per_link"))
+    if isinstance(line.get("dist"), dict):
+        out["dist"] = _pick(line["dist"], ("cross_ms", "contacts_cross_total", "contacts_total_with_cross", "phases_ms_max_over_ranks",
+                                           "cross_bytes_received_max", "self_check"))
     if isinstance(line.get("work"), dict):
         out["work"] = _pick(line["work"], ("tests_hip_over_reference",))
     out["detail"] = detail_path
@@ -1088,6 +1091,62 @@ def main():
                         "note": "all-to-all of 24-byte records, timed with HIP events around the collective on every rank; "
                                 "xgmi_frac_per_link = bytes one GPU ships to ONE peer / time / 153 GB/s"}
 
+    # ---- what makes the result GLOBAL: the contacts between leaves of different slices, which the
+    # per-slice self-traversals of the timed step cannot see — timed on their own, every rank, max over
+    # ranks; the phases of one step with a synchronisation between them; and, while the whole cloud fits one GPU, a self-check:
+    # own + cross contacts of all ranks == the single-device contact count --------------------------------------------
+    dist_detail = None
+    if builder is not None:
+        import torch.distributed as tdist
+        cross = builder.cross_contacts(state[0])  # (untimed: sizes the buffers)
+        barrier()
+        reps_c = 3
+        t0 = time.perf_counter()
+        for _ in range(reps_c):
+            cross = builder.cross_contacts(state[0])
+        barrier()
+        cross_s = max_over_ranks(time.perf_counter() - t0) / reps_c
+        c = torch.tensor([int(cross.shape[0])], dtype=torch.int64, device="cuda")
+        tdist.all_reduce(c)
+        cross_total = int(c[0])
+        builder.time_phases = True
+        barrier()
+        t0 = time.perf_counter()
+        b_ph = builder.build(vols, cache=state[0])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        tr_ph = ibvh.traverse(b_ph, cache=state[1])
+        _ = tr_ph.num_contacts
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        builder.time_phases = False
+        phases = dict(builder.last.get("phases_ms", {}))
+        phases["traverse (per-slice LVT self-traverse + count read)"] = round((t2 - t1) * 1e3, 4)
+        phases["cross-shard completion (plan + exchange + build + pair traverse, its own call)"] = round(cross_s * 1e3, 4)
+        rows = [None] * world
+        tdist.all_gather_object(rows, {"rank": rank, "phases_ms": phases, "cross": builder.last_cross})
+        state = (b_ph, tr_ph)
+        check = None
+        if n_global <= 20_000_000:
+            if rank == 0:
+                single = ibvh.BVH(ibvh.generate_spheres(n_global, args.seed, r0=r0))
+                want = int(ibvh.traverse(single).num_contacts)
+                check = {"single_device_contacts": want, "own_plus_cross": contacts_total + cross_total,
+                         "match": want == contacts_total + cross_total}
+                del single
+                torch.cuda.empty_cache()
+            barrier()
+        if rank == 0:
+            keys = list(rows[0]["phases_ms"])
+            dist_detail = {"cross_ms": round(cross_s * 1e3, 4), "contacts_cross_total": cross_total,
+                           "contacts_total_with_cross": contacts_total + cross_total,
+                           "phases_ms_max_over_ranks": {k: max(r["phases_ms"].get(k, 0.0) for r in rows) for k in keys},
+                           "cross_bytes_received_max": max(r["cross"]["bytes_received"] for r in rows),
+                           "per_rank": rows, "self_check": check,
+                           "note": "the timed step (value) is distributed build + per-slice traversal, as BASELINE.json configs[4] words it; "
+                                   "cross_ms is what completing the contact set costs on top"
+                                   + ("" if world > 1 else "; ONE rank: no peers, nothing crosses")}
+
     # ---- CPU baseline: the oracle's multi-threaded restatement, rank 0 only, bounded sample --------
     cpu_baseline, cpu = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -1188,7 +1247,7 @@ def main():
             "mcontacts_per_s": round(contacts_total * args.steps / elapsed / 1e6, 3),
             "mcontacts_per_s_traverse_only": round(contacts / (t_trav * 1e-3) / 1e6, 3) if t_trav else None,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "work": work, "north_star_1e7": north_star, "configs": configs,
-            "exchange": exchange, "kernels": kernels, "profiled_ms_per_step": round(tp / prof_steps * 1e3, 4),
+            "exchange": exchange, "dist": dist_detail, "kernels": kernels, "profiled_ms_per_step": round(tp / prof_steps * 1e3, 4),
         }
         # full detail beside the script (gitignored; tools/profile_round.sh copies it under profiles/), ONE compact line on stdout
         detail_path = args.detail

@@ -17,6 +17,7 @@ I32, I64 = 0, 1
 U16, U32, U64 = 0, 1, 2
 NARROW_NONE, NARROW_MORTON_LT, NARROW_INDEX_LT, NARROW_RAY_ORIGIN_OUTSIDE = 0, 1, 2, 3
 NARROW_MASK, OUTPUT_POSITIONS = 0xff, 0x100  # IBVH_NARROW_MASK, IBVH_OUTPUT_POSITIONS
+PAIR_SMALLER_DRIVES = 0x200  # IBVH_PAIR_SMALLER_DRIVES: pair LVT traversals, the BVH with fewer leaves supplies the work items (a set, not the reference's order)
 
 OK, ERR_INVALID_ARG, ERR_DOMAIN, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_OVERFLOW, ERR_HIP, ERR_SCRATCH, ERR_PEER = range(9)
 

@@ -592,13 +592,19 @@ IBVH_HD bool recs_touch(const CrossRec &a, const CrossRec &b) { // any box of a 
 // records on the device; nothing to do when the receiver's slice (rank `to`, lower) and this one (rank `me`) do not touch.
 template <class V> __global__ __launch_bounds__(256) void cross_filter_kernel(const char *leaves, LeafLayout lay, int64_t n, const CrossRec *recs, int to,
                                                                               int me, double eps, unsigned long long *cursor, char *out) {
-    __shared__ uint32_t s_cnt, s_base, s_touch;
+    __shared__ uint32_t s_cnt, s_base;
     __shared__ double s_lo[CROSS_BOXES][3], s_up[CROSS_BOXES][3];
-    if (threadIdx.x == 0) {
-        s_cnt = 0;
-        s_touch = recs_touch(recs[to], recs[me]) ? 1u : 0u;
+    // do the two slices touch at all?  One (box of `to`, box of `me`) pair per thread: 16 x 16 = 256
+    const int nb = (int)recs[to].n_boxes, nm = (int)recs[me].n_boxes;
+    bool t = false;
+    {
+        const int i = threadIdx.x / CROSS_BOXES, j = threadIdx.x % CROSS_BOXES;
+        if (i < nb && j < nm) {
+            t = true;
+            for (int k = 0; k < 3; ++k) t = t && recs[to].box[i][3 + k] >= recs[me].box[j][k] && recs[to].box[i][k] <= recs[me].box[j][3 + k];
+        }
     }
-    const int nb = (int)recs[to].n_boxes;
+    if (!__syncthreads_or(t ? 1 : 0)) return;
     if ((int)threadIdx.x < 3 * CROSS_BOXES) {
         const int b = threadIdx.x / 3, k = threadIdx.x % 3;
         if (b < nb) {
@@ -608,30 +614,32 @@ template <class V> __global__ __launch_bounds__(256) void cross_filter_kernel(co
             s_up[b][k] = up + eps * ext + 1e-300;
         }
     }
-    __syncthreads();
-    if (!s_touch) return;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    bool keep = false;
-    if (i < n) {
-        const V v = load_vol<V>(leaves + i * lay.stride);
-        double lo[3], up[3];
-        leaf_box(v, lo, up);
-        for (int b = 0; b < nb; ++b) {
-            bool t = true;
+    for (int64_t c0 = (int64_t)blockIdx.x * 256; c0 < n; c0 += (int64_t)gridDim.x * 256) { // (a bounded grid: an idle launch costs microseconds)
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        const int64_t i = c0 + threadIdx.x;
+        bool keep = false;
+        if (i < n) {
+            const V v = load_vol<V>(leaves + i * lay.stride);
+            double lo[3], up[3];
+            leaf_box(v, lo, up);
+            for (int b = 0; b < nb; ++b) {
+                bool in = true;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) t = t && lo[k] <= s_up[b][k] && up[k] >= s_lo[b][k];
-            keep = keep || t;
+                for (int k = 0; k < 3; ++k) in = in && lo[k] <= s_up[b][k] && up[k] >= s_lo[b][k];
+                keep = keep || in;
+            }
         }
-    }
-    uint32_t at = 0;
-    if (keep) at = atomicAdd(&s_cnt, 1u);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_cnt != 0) s_base = (uint32_t)atomicAdd(cursor, (unsigned long long)s_cnt);
-    __syncthreads();
-    if (keep && out != nullptr) {
-        const uint64_t *src = (const uint64_t *)(leaves + i * lay.stride);
-        uint64_t *dst = (uint64_t *)(out + ((int64_t)s_base + at) * lay.stride);
-        for (int w = 0; w < lay.stride / 8; ++w) dst[w] = src[w];
+        uint32_t at = 0;
+        if (keep) at = atomicAdd(&s_cnt, 1u);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_cnt != 0) s_base = (uint32_t)atomicAdd(cursor, (unsigned long long)s_cnt);
+        __syncthreads();
+        if (keep && out != nullptr) {
+            const uint64_t *src = (const uint64_t *)(leaves + i * lay.stride);
+            uint64_t *dst = (uint64_t *)(out + ((int64_t)s_base + at) * lay.stride);
+            for (int w = 0; w < lay.stride / 8; ++w) dst[w] = src[w];
+        }
     }
 }
 int launch_cross_filter(const ibvh_types &t, const void *leaves, int64_t n, const CrossRec *recs, int to, int me, unsigned long long *cursor, void *out,
@@ -643,7 +651,8 @@ int launch_cross_filter(const ibvh_types &t, const void *leaves, int64_t n, cons
     if (n <= 0) return IBVH_OK;
     return dispatch_volume(t.leaf_kind, t.leaf_float, [&](auto vt) -> int {
         using V = typename decltype(vt)::type;
-        hipLaunchKernelGGL((cross_filter_kernel<V>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, (const char *)leaves, dl, n, recs, to, me, eps, cursor,
+        const int64_t wgs = ceil_div(n, 256);
+        hipLaunchKernelGGL((cross_filter_kernel<V>), dim3((unsigned)(wgs < 8192 ? wgs : 8192)), dim3(256), 0, st, (const char *)leaves, dl, n, recs, to, me, eps, cursor,
                            (char *)out);
         return hipGetLastError() == hipSuccess ? (int)IBVH_OK : (int)IBVH_ERR_HIP;
     });
@@ -661,7 +670,7 @@ bool cross_sizes(const ibvh_types &t, int64_t n_other, int64_t n_mine, int32_t c
     z.node_bytes = (tree.real_nodes - tree.real_leaves) * lay.node_bytes;
     z.skip_bytes = tree.levels * (t.index_type == IBVH_I64 ? 8 : 4);
     z.tree_bytes = align_up(z.leaf_bytes, 256) + align_up(z.node_bytes, 256) + align_up(z.skip_bytes, 256);
-    const int64_t items = n_other > n_mine ? n_other : n_mine; // the BVH with more leaves supplies the work items (traverse_pair.jl:15-36)
+    const int64_t items = n_other < n_mine ? n_other : n_mine; // IBVH_PAIR_SMALLER_DRIVES: the thin boundary shell walks the whole slice's tree
     z.counts_bytes = (size_t)align_up(items * (t.index_type == IBVH_I64 ? 8 : 4), 256);
     if (ibvh_lvt_scratch_bytes(&t, items, cache_slots, &z.lvt_bytes) != IBVH_OK) return false;
     z.lvt_bytes = (size_t)align_up((int64_t)z.lvt_bytes, 256);
@@ -879,13 +888,25 @@ ibvh_status ibvh_dist_cross_count(const ibvh_bvh *bvh, const ibvh_dist_cross_pla
         if (ibvh_status e = ibvh_build(&desc, nullptr, (void *)other.leaves, (void *)other.nodes, (void *)other.skips, nullptr,
                                        (char *)scratch + plan->build_offset, build_room, stream)) return e;
         char *counts = (char *)scratch + plan->scratch_offset[k];
-        int64_t total = 0;
-        // (own slice first: the pairs come out as (index in this slice, index in the other slice), both GLOBAL 1-based numbers)
-        const ibvh_status e = ibvh_traverse_pair_lvt_count(bvh, &other, bvh->built_level > 1 ? bvh->built_level : 1, 1, IBVH_NARROW_NONE, counts, &total,
-                                                           counts + z.counts_bytes, z.lvt_bytes, stream);
+        // (own slice first: the pairs come out as (index in this slice, index in the other slice), both GLOBAL 1-based numbers.)
+        // Enqueued with NO contact buffer: counting pass + scan, the total stays in the first 8 bytes of this set's traversal
+        // scratch — the host reads all sets' totals in ONE round trip below instead of synchronising per set (round 6)
+        const ibvh_status e = ibvh_traverse_pair_lvt_enqueue(bvh, &other, bvh->built_level > 1 ? bvh->built_level : 1, 1, IBVH_NARROW_NONE | IBVH_PAIR_SMALLER_DRIVES, counts,
+                                                             nullptr, 0, nullptr, nullptr, counts + z.counts_bytes, z.lvt_bytes, stream);
         if (e != IBVH_OK) return e;
-        if (totals_out) totals_out[k] = total;
-        *total_out += total;
+    }
+    int64_t totals[MAX_RANKS];
+    for (int k = 0; k < plan->n_recv; ++k) {
+        CrossSizes z;
+        cross_sizes(bvh->types, plan->recv_leaves[k], bvh->tree.real_leaves, plan->cache_slots, z);
+        DIST_HIP_CHECK(hipMemcpyAsync(&totals[k], (char *)scratch + plan->scratch_offset[k] + z.counts_bytes, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    }
+    DIST_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    const bool i32 = bvh->types.index_type == IBVH_I32;
+    for (int k = 0; k < plan->n_recv; ++k) {
+        if (i32 && totals[k] > (int64_t)INT32_MAX) return IBVH_ERR_OVERFLOW;
+        if (totals_out) totals_out[k] = totals[k];
+        *total_out += totals[k];
     }
     return IBVH_OK;
 }
@@ -909,7 +930,7 @@ ibvh_status ibvh_dist_cross_write(const ibvh_bvh *bvh, const ibvh_dist_cross_pla
         const ibvh_bvh other = imported_tree(*bvh, *plan, k, import_buf);
         char *counts = (char *)scratch + plan->scratch_offset[k];
         if (totals[k] > 0) {
-            const ibvh_status e = ibvh_traverse_pair_lvt_write(bvh, &other, bvh->built_level > 1 ? bvh->built_level : 1, 1, IBVH_NARROW_NONE, counts,
+            const ibvh_status e = ibvh_traverse_pair_lvt_write(bvh, &other, bvh->built_level > 1 ? bvh->built_level : 1, 1, IBVH_NARROW_NONE | IBVH_PAIR_SMALLER_DRIVES, counts,
                                                                (char *)contacts_out + at * lay.pair_bytes, counts + z.counts_bytes, z.lvt_bytes, stream);
             if (e != IBVH_OK) return e;
         }

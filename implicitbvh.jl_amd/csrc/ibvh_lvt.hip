@@ -274,8 +274,11 @@ static ibvh_status pair_common(const ibvh_bvh *bvh1, const ibvh_bvh *bvh2, int64
     if (int e = check_levels(*bvh2, sl2)) return (ibvh_status)e;
     if (!same_types(bvh1->types, bvh2->types)) return IBVH_ERR_UNSUPPORTED;
     if (!counts) return IBVH_ERR_INVALID_ARG;
-    // the BVH with more leaves supplies the work items; flip restores (bvh1, bvh2) order (:15-36)
-    const bool flip = !(bvh1->tree.real_leaves >= bvh2->tree.real_leaves);
+    // the BVH with more leaves supplies the work items; flip restores (bvh1, bvh2) order (:15-36).  IBVH_PAIR_SMALLER_DRIVES: the
+    // other way round (the contact SET is the same; the list's order is the smaller BVH's leaf order)
+    const bool smaller = (narrow & IBVH_PAIR_SMALLER_DRIVES) != 0;
+    narrow &= ~IBVH_PAIR_SMALLER_DRIVES;
+    const bool flip = smaller ? bvh1->tree.real_leaves > bvh2->tree.real_leaves : !(bvh1->tree.real_leaves >= bvh2->tree.real_leaves);
     const ibvh_bvh *drv = flip ? bvh2 : bvh1, *oth = flip ? bvh1 : bvh2;
     return (ibvh_status)run<MODE_PAIR>(drv, oth, nullptr, nullptr, drv->tree.real_leaves, flip ? sl1 : sl2, narrow,
                                        flip ? 1 : 0, counts, total_out, contacts, scratch, scratch_bytes,

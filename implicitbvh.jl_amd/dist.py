@@ -162,6 +162,7 @@ class DistributedBuilder:
         self.tolerance = tolerance  # allowed imbalance per splitter, as a fraction of N/P (0 = exact)
         self.last = {}
         self.time_exchange = False  # exchange_stats(): bracket the all-to-all with HIP events
+        self.time_phases = False    # bench.py --gpus N: synchronise between the phases of build() and keep their wall times in last["phases_ms"]
         self._scratch = None
 
     def build(self, volumes, node_type=None, cache=None, options=None):
@@ -184,8 +185,21 @@ class DistributedBuilder:
         sp, sn = api._ptr(self._scratch), self._scratch.numel()
         plan = abi.DistPlan()
         vt.begin()
+        phases, clock = {}, None
+        if self.time_phases:
+            import time
+            torch.cuda.synchronize()
+            clock = time.perf_counter
+
+            def lap(name, t0):
+                torch.cuda.synchronize()
+                phases[name] = round((clock() - t0) * 1e3, 4)
+                return clock()
+            t_phase = clock()
         vt.check("ibvh_dist_plan", lib.load().ibvh_dist_plan(C.byref(types), C.byref(vt.struct), api._ptr(volumes), n_local,
                                                              float(self.tolerance), sp, sn, C.byref(plan), api._stream()))
+        if clock:
+            t_phase = lap("plan (extrema all-reduce, keys, histogram all-gather, splitters, partition)", t_phase)
         n_recv = int(plan.n_slice)
         lay = abi.Layout()
         lib.call("ibvh_layout_of", C.byref(types), C.byref(lay))
@@ -197,6 +211,8 @@ class DistributedBuilder:
                                                                      sp, sn, api._ptr(recv), api._stream()))
         if events:
             events[1].record()
+        if clock:
+            t_phase = lap("exchange (pack + all_to_all_v of the records)", t_phase)
         P = comm.size
         ext_host = np.array(list(plan.extrema), dtype=abi.FLOAT_DTYPES[flt])
         self.last = {"splitters": [int(plan.splitters[k]) for k in range(P - 1)], "send_counts": [int(plan.send_counts[r]) for r in range(P)],
@@ -208,7 +224,11 @@ class DistributedBuilder:
                                            mins=tuple(float(v) for v in ext_host[:3]), maxs=tuple(float(v) for v in ext_host[3:]))
         opts = api.BVHOptions(index=options.index, morton=fixed, block_size=options.block_size)
         bv = api.BoundingVolumes(types, n_recv, recv)
-        return api.BVH(bv, node_type, cache=cache, options=opts, _out_of_place=True)
+        out = api.BVH(bv, node_type, cache=cache, options=opts, _out_of_place=True)
+        if clock:
+            lap("local build over the received slice", t_phase)
+            self.last["phases_ms"] = phases
+        return out
 
     def exchange_stats(self, volumes, node_type=None, options=None, repeats=3):
         """What this rank's share of the distributed sort exchange costs: `repeats` builds with the exchange (pack +

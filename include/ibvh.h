@@ -86,7 +86,14 @@ enum {
      * so the caller can evaluate the predicate on the records itself and keep what passes: `narrow` is only ever
      * evaluated as `iscontact(...) && narrow(...)` at leaf level (lvt/traverse_single.jl:170,
      * bfs/traverse_single_gpu.jl:187, raytrace/leaf_vs_tree/leaf_vs_tree.jl:194), i.e. a post-filter. */
-    IBVH_OUTPUT_POSITIONS = 0x100
+    IBVH_OUTPUT_POSITIONS = 0x100,
+    /* Pair LVT traversals only: let the BVH with FEWER leaves supply the work items (the reference lets the larger one,
+     * lvt/traverse_pair.jl:15-36 — and so does the library without this flag).  Same pairs, still (bvh1, bvh2) order inside a
+     * pair, but the LIST is ordered by the smaller BVH's leaves, so it is not the reference's order: for callers that want the
+     * contact SET.  A handful of leaves against a large tree then costs (few leaves) x (tree depth) instead of one work item —
+     * and 8 cached contacts of scratch — per leaf of the large tree; the cross-shard completion uses it (a slice's thin boundary
+     * shell against the neighbour's whole slice).  Size the scratch and `counts` for min(n1, n2) items then. */
+    IBVH_PAIR_SMALLER_DRIVES = 0x200
 };
 
 typedef struct ibvh_types {

@@ -58,6 +58,12 @@ def test_bench_self_launches_its_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["leaves_total"] == 200000 and line["value"] > 0
+    # round 6: the N > 1 schema — what completing the contact set costs, the phases of a step, the self-check against one device
+    d = line["dist"]
+    assert d["cross_ms"] >= 0 and d["contacts_cross_total"] == 0  # (one rank: nothing crosses)
+    assert d["contacts_total_with_cross"] == line["config"]["contacts_total"]
+    assert d["self_check"]["match"] is True
+    assert {k.split(" ")[0] for k in d["phases_ms_max_over_ranks"]} == {"plan", "exchange", "local", "traverse", "cross-shard"}
 
 
 def test_config5_at_its_stated_size_with_eight_virtual_ranks():

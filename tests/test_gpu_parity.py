@@ -1308,3 +1308,30 @@ def test_concurrent_builds_and_traversals_on_two_streams_from_two_threads():
         lib.call("ibvh_profile_enable", 0)
     assert not errors, errors
     assert cnt.value > 0
+
+
+def test_pair_lvt_smaller_bvh_drives_option():
+    """IBVH_PAIR_SMALLER_DRIVES (round 6; the cross-shard completion uses it): the BVH with FEWER leaves supplies the work items.
+    Same pairs in (bvh1, bvh2) order as the reference's rule gives (lvt/traverse_pair.jl:15-36: the larger one drives), listed
+    in the smaller BVH's leaf order; both argument orders."""
+    from implicitbvh_amd import api
+    rng = np.random.default_rng(5)
+    big = np.concatenate([rng.random((30_000, 3)), 0.02 * rng.random((30_000, 1))], axis=1).astype(np.float32)
+    small = np.concatenate([0.4 + 0.2 * rng.random((700, 3)), 0.03 * rng.random((700, 1))], axis=1).astype(np.float32)
+    b_big, b_small = ibvh.BVH(cuda(big)), ibvh.BVH(cuda(small))
+    for b1, b2 in ((b_big, b_small), (b_small, b_big)):
+        sl1, sl2 = ibvh.default_start_level(b1), ibvh.default_start_level(b2)
+        ref = ibvh.traverse(b1, b2).contacts.cpu().numpy()
+        got = api._traverse_lvt_pair(b1, b2, sl1, sl2, abi.PAIR_SMALLER_DRIVES, None).contacts.cpu().numpy()
+        assert len(ref) > 1000 and got.shape == ref.shape
+        assert sorted(map(tuple, got.tolist())) == sorted(map(tuple, ref.tolist()))
+        # ordered by the smaller BVH's leaves: its side of the pairs follows its sorted leaf order
+        col = 1 if b1 is b_big else 0
+        pos = np.empty(len(b_small.leaves) + 1, dtype=np.int64)
+        pos[b_small.leaves.index.cpu().numpy()] = np.arange(len(b_small.leaves))
+        p = pos[got[:, col]]
+        assert (p[1:] >= p[:-1]).all()
+        # the cached (enqueue) path too
+        t0 = api._traverse_lvt_pair(b1, b2, sl1, sl2, abi.PAIR_SMALLER_DRIVES, None)
+        again = api._traverse_lvt_pair(b1, b2, sl1, sl2, abi.PAIR_SMALLER_DRIVES, t0).contacts.cpu().numpy()
+        assert again.tobytes() == got.tobytes()
