@@ -723,7 +723,7 @@ def compact_line(line, detail_path):
     out["detail"] = detail_path
     return out
 
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def _host_cpu():
@@ -753,7 +753,7 @@ def _attach_counters(roofline, tag, avg_s):
     """roofline.traffic / roofline.issue from the committed counter profiles of the dominant kernel — only while the kernel
     sources still hash to the state the profile was taken at."""
     sha = csrc_sha()
-    for rnd in (PROFILE_ROUND, "r04", "r03"):
+    for rnd in (PROFILE_ROUND, "r05", "r04", "r03"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_fetch_write_{tag}.json")
         if not os.path.exists(path):
             continue
@@ -772,7 +772,7 @@ def _attach_counters(roofline, tag, avg_s):
         break
     else:
         roofline["traffic_note"] = "no counter profile for this state of the kernels"
-    for rnd in (PROFILE_ROUND, "r04", "r03"):
+    for rnd in (PROFILE_ROUND, "r05", "r04", "r03"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_sq_counters_{tag}.json")
         if not os.path.exists(path):
             continue
