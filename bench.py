@@ -40,7 +40,7 @@ MORTON_SORT_KERNELS = ("extrema_partial_kernel", "extrema_final_kernel", "encode
                        "hist_wide_kernel", "scan_kernel", "bucket_start_kernel", "scatter_kernel", "scatter_wide_kernel",
                        "scatter_records_kernel", "bucket_sort_kernel", "gather_kernel", "scan_tiles_kernel", "plan_kernel",
                        "partition_kernel", "finish_kernel", "finish_resident_kernel", "range_kernel", "hist_level_kernel", "scan_level_kernel")
-TRAVERSE_PREFIXES = ("lvt_", "scan_reduce", "scan_apply", "level_kernel", "fill_")
+TRAVERSE_PREFIXES = ("lvt_", "scan_reduce", "scan_apply", "scan_fused", "rays_", "level_kernel", "fill_")
 
 
 # Algorithmic bytes per LEAF and launch for the kernels of one step, for

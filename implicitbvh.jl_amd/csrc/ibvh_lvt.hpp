@@ -68,9 +68,8 @@ template <class L, class N, class I> struct Args {
     // pass — which needs nothing else of a leaf to put a cached pair together, and would otherwise pull every line of the leaf
     // records through the memory system for it (24-byte records: 240 MB at 1e7 leaves).  nullptr: read the leaf.
     I *q_index_dense;
-    // walker 2, counting pass: the tile aggregates of the single-kernel scan that follows it (scan_fused_kernel) and, behind
-    // them, its ticket counter — the first scan_nparts + 1 waves zero one word each (the scratch is the caller's, uninitialised).
-    // nullptr: nothing to zero.
+    // walker 2, counting pass: the tile aggregates of the single-kernel scan that follows it (scan_fused_kernel) — its first
+    // scan_nparts waves zero one word each (the scratch is the caller's, uninitialised).  nullptr: nothing to zero.
     unsigned long long *scan_agg;
     int32_t scan_nparts;
 };
@@ -551,22 +550,16 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_apply_kernel(I *c, int64_t n, c
 // no fence — an agent-scope fence on this part writes back and invalidates an XCD's whole L2), adds up the aggregates of the tiles
 // before it (polling those that are not there yet) and scans its tile.  One launch and one dependent round trip less than reduce +
 // apply: they are launch- and latency-bound (245 workgroups at 1e6 leaves).
-// Whom a workgroup may wait for: TICKET = false — the grid is small enough for ALL its workgroups to be resident at once
-// (scan_counts checks), so every tile it polls belongs to a workgroup that is running or done, whatever order they started in;
-// TICKET = true (larger grids) — the tile is not blockIdx.x but a ticket from an atomic counter (agg[nparts], zeroed with the
-// aggregates): tiles before mine were taken by workgroups that started before me.  No assumption about dispatch order either way.
-constexpr int64_t SCAN_FUSED_RESIDENT = 1024; // workgroups of SCAN_TPB threads one MI355X holds at once: 256 CUs x 8, halved for margin
-template <class I, bool TICKET>
+// Whom a workgroup may wait for: only workgroups that are RUNNING OR DONE, whatever order the hardware starts them
+// in — the grid never exceeds what the device holds at once (scan_counts: resident_scan_workgroups()).  Larger inputs go through
+// scan_fused_grouped_kernel, whose workgroups own several consecutive tiles each: one aggregate and one look-back per group.
+// (Round 6 first took the tile from an atomic ticket instead: 2,442 returning atomics on one word serialise at ~11 ns each —
+// the 1e7-item scan 25 -> 56 us.)
+template <class I>
 __global__ __launch_bounds__(SCAN_TPB) void scan_fused_kernel(I *c, int64_t n, unsigned long long *agg, int64_t *totals, int64_t *total_host) {
     __shared__ int64_t s_w[SCAN_TPB / 64], s_p[SCAN_TPB / 64];
-    __shared__ uint32_t s_tile;
     constexpr unsigned long long THERE = 1ull << 63;
-    uint32_t tile = blockIdx.x;
-    if constexpr (TICKET) {
-        if (threadIdx.x == 0) s_tile = (uint32_t)__hip_atomic_fetch_add(&agg[gridDim.x], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        tile = s_tile;
-    }
+    const uint32_t tile = blockIdx.x;
     // thread owns SCAN_IPT consecutive items so the in-thread running sum is in memory order
     const int64_t base = (int64_t)tile * SCAN_TILE + (int64_t)threadIdx.x * SCAN_IPT;
     int64_t v[SCAN_IPT], sum = 0;
@@ -642,6 +635,117 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_fused_kernel(I *c, int64_t n, u
     }
 }
 
+// The same scan for grids that would not be resident: a workgroup owns `tiles_per_group` CONSECUTIVE tiles.  Phase 1 sums them
+// (one pass over its items), publishes ONE aggregate and looks back over the groups before it; phase 2 reads the items again
+// (L2-hot) and scans tile by tile with a running base.  Grid = ceil(tiles / tiles_per_group) <= what the device holds at once.
+template <class I>
+__global__ __launch_bounds__(SCAN_TPB) void scan_fused_grouped_kernel(I *c, int64_t n, unsigned long long *agg, int64_t *totals, int64_t *total_host,
+                                                                      int tiles_per_group) {
+    __shared__ int64_t s_w[SCAN_TPB / 64], s_p[SCAN_TPB / 64];
+    constexpr unsigned long long THERE = 1ull << 63;
+    const int64_t nparts = (n + SCAN_TILE - 1) / SCAN_TILE;
+    const int64_t t0 = (int64_t)blockIdx.x * tiles_per_group, t1 = t0 + tiles_per_group < nparts ? t0 + tiles_per_group : nparts;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    auto load16 = [&](int64_t base, int64_t (&v)[SCAN_IPT]) { // a thread's SCAN_IPT consecutive items of a tile
+        constexpr int NV = SCAN_IPT * (int)sizeof(I) / 16;
+        if (base + SCAN_IPT <= n && ((uintptr_t)c & 15) == 0) {
+            I raw[SCAN_IPT];
+            const uint4 *src = (const uint4 *)(c + base);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) ((uint4 *)raw)[k] = src[k];
+#pragma unroll
+            for (int j = 0; j < SCAN_IPT; ++j) v[j] = (int64_t)raw[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < SCAN_IPT; ++j) v[j] = base + j < n ? (int64_t)c[base + j] : 0;
+        }
+    };
+    int64_t sum = 0;
+    for (int64_t t = t0; t < t1; ++t) {
+        int64_t v[SCAN_IPT];
+        load16(t * SCAN_TILE + (int64_t)threadIdx.x * SCAN_IPT, v);
+#pragma unroll
+        for (int j = 0; j < SCAN_IPT; ++j) sum += v[j];
+    }
+    const int64_t group_total = block_sum(sum, s_p);
+    if (threadIdx.x == 0) __hip_atomic_store(&agg[blockIdx.x], THERE | (unsigned long long)group_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int64_t before = 0;
+    for (int64_t j = threadIdx.x; j < (int64_t)blockIdx.x; j += SCAN_TPB) {
+        unsigned long long a = __hip_atomic_load(&agg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (!(a & THERE)) {
+            __builtin_amdgcn_s_sleep(1);
+            a = __hip_atomic_load(&agg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        before += (int64_t)(a & ~THERE);
+    }
+    __syncthreads(); // (s_p is reused)
+    int64_t run_base = block_sum(before, s_p);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        const int64_t total = run_base + group_total;
+        totals[0] = total;
+        if (total_host) __hip_atomic_store(total_host, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    for (int64_t t = t0; t < t1; ++t) {
+        const int64_t base = t * SCAN_TILE + (int64_t)threadIdx.x * SCAN_IPT;
+        int64_t v[SCAN_IPT], mine = 0;
+        load16(base, v);
+#pragma unroll
+        for (int j = 0; j < SCAN_IPT; ++j) mine += v[j];
+        int64_t inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int64_t u = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += u;
+        }
+        __syncthreads(); // (s_w is reused)
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        int64_t wb = 0, tile_total = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_TPB / 64; ++k) {
+            if (k < w) wb += s_w[k];
+            tile_total += s_w[k];
+        }
+        int64_t run = run_base + wb + inc - mine;
+        const bool vec = base + SCAN_IPT <= n && ((uintptr_t)c & 15) == 0;
+        if (vec) {
+            constexpr int NV = SCAN_IPT * (int)sizeof(I) / 16;
+            I raw[SCAN_IPT];
+#pragma unroll
+            for (int j = 0; j < SCAN_IPT; ++j) {
+                run += v[j];
+                raw[j] = (I)run;
+            }
+            uint4 *dst = (uint4 *)(c + base);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) dst[k] = ((const uint4 *)raw)[k];
+        } else {
+#pragma unroll
+            for (int j = 0; j < SCAN_IPT; ++j) {
+                run += v[j];
+                if (base + j < n) c[base + j] = (I)run;
+            }
+        }
+        run_base += tile_total;
+    }
+}
+// workgroups of SCAN_TPB threads the current device holds at once, halved (the margin for anything else that is running)
+template <class I> inline int64_t resident_scan_workgroups() {
+    static thread_local int memo_dev = -1;
+    static thread_local int64_t memo = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != memo_dev) {
+        int ncu = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 64;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)scan_fused_grouped_kernel<I>, SCAN_TPB, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
+        memo = (int64_t)ncu * per_cu / 2;
+        if (memo < 16) memo = 16;
+        memo_dev = dev;
+    }
+    return memo;
+}
+
 // scratch layout of the *_count / *_write calls:
 //   [0, 64)            int64 header: [0] total contacts, [1] contact-cache slots K in use
 //   [64, scan_bytes)   scan tile sums
@@ -665,10 +769,14 @@ int scan_counts(I *counts, int64_t n, int64_t *total_out, void *scratch, hipStre
     int64_t *totals = total_dev ? total_dev : (int64_t *)scratch; // where the device-side total goes
     int64_t *partials = (int64_t *)scratch + 8;
     if (aggregates_zeroed && limit == nullptr && g_tuning.lvt_scan_fused != 0) {
-        if (nparts > SCAN_FUSED_RESIDENT)
-            IBVH_LAUNCH((scan_fused_kernel<I, true>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, (unsigned long long *)partials, totals, total_host);
-        else
-            IBVH_LAUNCH((scan_fused_kernel<I, false>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, (unsigned long long *)partials, totals, total_host);
+        const int64_t room = resident_scan_workgroups<I>();
+        if (nparts > room) {
+            const int64_t per = ceil_div(nparts, room);
+            IBVH_LAUNCH((scan_fused_grouped_kernel<I>), dim3((unsigned)ceil_div(nparts, per)), dim3(SCAN_TPB), 0, st, counts, n, (unsigned long long *)partials, totals,
+                        total_host, (int)per);
+        } else {
+            IBVH_LAUNCH((scan_fused_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, (unsigned long long *)partials, totals, total_host);
+        }
     } else {
         IBVH_LAUNCH((scan_reduce_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, partials, limit);
         IBVH_LAUNCH((scan_apply_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, partials, totals, total_host, limit);
