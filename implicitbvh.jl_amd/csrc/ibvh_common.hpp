@@ -520,7 +520,7 @@ struct Tuning {
     int msd_bits = 0, msd_cap = 0, msd_tile = 0, msd_ftpb = 0; // forced partition geometry (0 = chosen from n)
     int msd_avg = 1024;     // largest average cell before another first-level bit is taken
     int msd_range = 1;      // 0 = first extra level on the next 8 bits, unmeasured
-    int lvt_scan_fused = 1; // the scan behind walker 2's counting pass in one kernel (scan_fused_kernel); 0 = reduce + apply
+    int lvt_scan_fused = 1; // the scan behind walker 2's counting pass in one kernel (scan_fused_kernel / scan_fused_grouped_kernel); 0 = reduce + apply; N > 1 = at most N workgroups (development: the default is half of what the device holds at once)
     int msd_equalize = 0;   // equalised cells (ibvh_msd.hip): 0 = when the build asks (ibvh_build_desc.sort_equalize), 1 = always, -1 = never
     int msd_finish_pad_kb = 0; // LDS (KiB) a finish workgroup asks for at least: limits the workgroups per CU (0 = what it needs)
     int msd_resident_kb = 0; // LDS budget (KiB) of a finish workgroup that keeps its range's RECORDS in LDS: 0 = the plan decides

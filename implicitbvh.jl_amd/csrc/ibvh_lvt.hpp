@@ -769,7 +769,8 @@ int scan_counts(I *counts, int64_t n, int64_t *total_out, void *scratch, hipStre
     int64_t *totals = total_dev ? total_dev : (int64_t *)scratch; // where the device-side total goes
     int64_t *partials = (int64_t *)scratch + 8;
     if (aggregates_zeroed && limit == nullptr && g_tuning.lvt_scan_fused != 0) {
-        const int64_t room = resident_scan_workgroups<I>();
+        int64_t room = resident_scan_workgroups<I>();
+        if (g_tuning.lvt_scan_fused > 1 && g_tuning.lvt_scan_fused < room) room = g_tuning.lvt_scan_fused; // (development knob: a smaller grid)
         if (nparts > room) {
             const int64_t per = ceil_div(nparts, room);
             IBVH_LAUNCH((scan_fused_grouped_kernel<I>), dim3((unsigned)ceil_div(nparts, per)), dim3(SCAN_TPB), 0, st, counts, n, (unsigned long long *)partials, totals,
