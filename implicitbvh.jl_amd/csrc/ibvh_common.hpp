@@ -533,6 +533,7 @@ struct Tuning {
                             // rays), 2 = wherever the tree allows it, 0 = never
     int rays_subtree_depth = 0; // levels of such a subtree below its root (0 = 9: 512 leaves; at most 11)
     int rays_fast_slab = 1;     // 0 = the binned path tests every box with isintersection_inv (A/B of the packed / v_min3 slab test)
+    int rays_tail = 8;          // binned rays, subtree pass: walks a wave parks for the workgroup's unit rounds once its chunk is dry (0 = never: every walk is finished by its lane)
     int rays_items_per_ray = 0; // capacity of the (ray, subtree) item list per ray (0 = 16); a call that overflows it is served by the binary walker
 };
 extern Tuning g_tuning;

@@ -70,7 +70,7 @@ const Knob kKnobs[] = {
     {"msd_avg", &Tuning::msd_avg},       {"msd_range", &Tuning::msd_range},   {"msd_equalize", &Tuning::msd_equalize}, {"msd_rescue", &Tuning::msd_rescue}, {"lvt_scan_fused", &Tuning::lvt_scan_fused}, {"bfs_wg_per_cu", &Tuning::bfs_wg_per_cu},
     {"lvt_blocks", &Tuning::lvt_blocks}, {"lvt_block_shift", &Tuning::lvt_block_shift}, {"lvt_blocks_min_items", &Tuning::lvt_blocks_min_items}, {"lvt_blocks_paired_below", &Tuning::lvt_blocks_paired_below},
     {"rays_binned", &Tuning::rays_binned}, {"rays_fast_slab", &Tuning::rays_fast_slab}, {"rays_subtree_depth", &Tuning::rays_subtree_depth},
-    {"rays_items_per_ray", &Tuning::rays_items_per_ray}, {"msd_resident_kb", &Tuning::msd_resident_kb}, {"msd_finish_pad_kb", &Tuning::msd_finish_pad_kb},
+    {"rays_items_per_ray", &Tuning::rays_items_per_ray}, {"rays_tail", &Tuning::rays_tail}, {"msd_resident_kb", &Tuning::msd_resident_kb}, {"msd_finish_pad_kb", &Tuning::msd_finish_pad_kb},
 #ifdef IBVH_VARIANTS // (development builds only: the kernels behind these knobs are not in libibvh.so, variants/*.inc)
     {"rays_shadow", &Tuning::rays_shadow}, {"lvt_dual", &Tuning::lvt_dual},
 #endif

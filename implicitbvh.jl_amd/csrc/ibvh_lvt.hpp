@@ -412,6 +412,7 @@ struct RayBins {
     int32_t cut_level;          // K
     int32_t depth;              // D = levels - K: a subtree holds 2^D leaves
     int32_t subtrees;           // real nodes on level K
+    int32_t tail_lanes;         // rays_subtree_kernel (counting pass): a wave whose chunk ran dry hands its last <= tail_lanes walks to the workgroup's unit rounds (0: off)
 };
 constexpr int RAYTILE_IPT = 16;
 constexpr int RAYSUB_CHUNK = 4096; // items of one rays_subtree_kernel workgroup: busy subtrees are shared by several (1,024: 2 % slower on config 3)
@@ -422,6 +423,12 @@ constexpr int RAYSUB_TPB = 256;
 // per 512 items, 2.47 ms with one)
 constexpr int RAYSUB_WALKERS = 4;
 constexpr int RAYSUB_STAGE = 64;  // hit records a wave stages in LDS (a step adds at most 64 left and 64 right hits: two appends)
+// The tail of a workgroup (round 6): walks still alive when their wave's chunk has run dry and <= tail_lanes lanes are busy are
+// PARKED — at most RAYSUB_TAIL_MAX a wave — and finished by the whole workgroup as UNITS (item, node whose children are to be
+// tested): a walk's pending right siblings are independent subtrees, so a long walk is no longer one chain of dependent steps.
+constexpr int RAYSUB_TAIL_MAX = 8;                                    // parked walks per wave
+constexpr int RAYSUB_TAIL_ITEMS = RAYSUB_TAIL_MAX * RAYSUB_WALKERS;   // per workgroup
+constexpr int RAYSUB_TAIL_UNITS = 208;                                // units per round (two lists in the flushed hit stages, beside masks and item table)
 constexpr int RAY_REGIONS = 256;  // the hit list is RAY_REGIONS lists with a cursor each: same-address atomics serialise
 // a hit of the counting pass: the pair as it will be reported, the item it belongs to and its rank within the item; the
 // writing pass puts it at scan[g - 1] + k (rays_place_kernel) instead of walking again
@@ -907,6 +914,7 @@ inline RayBins rays_bins_at(const RayBinPlan &p, char *base) {
     rb.cap = (int32_t)p.cap;
     rb.cut_level = p.cut_level;
     rb.depth = p.depth;
+    rb.tail_lanes = (p.depth <= 9 && g_tuning.rays_tail > 0) ? (g_tuning.rays_tail < RAYSUB_TAIL_MAX ? g_tuning.rays_tail : RAYSUB_TAIL_MAX) : 0;
     rb.subtrees = p.subtrees;
     return rb;
 }

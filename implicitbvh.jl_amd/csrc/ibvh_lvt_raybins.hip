@@ -349,11 +349,193 @@ template <int RAYTILE_TPB> __global__ __launch_bounds__(RAYTILE_TPB) void rays_s
                         // after the wave's chunk ran dry with < 8 / >= 8 lanes busy)
 __device__ unsigned long long g_raysub_hist[16];
 #endif
+// ---- the tail of a rays_subtree_kernel workgroup (counting pass, round 6) -----------------------------------------------------
+// Walks still alive when their wave's chunk has run dry and <= tail_lanes lanes are busy are PARKED (<= RAYSUB_TAIL_MAX a wave) and
+// finished by the WHOLE workgroup as units (item, node whose two children are still to be tested): the walk's current node and
+// every pending right sibling are independent subtrees, so a long walk is no longer one chain of dependent steps that three
+// quarters of the wave-steps of the pass waited for with < 8 lanes busy (profiles/r05_variants.txt).  Rounds: every unit goes down
+// one level, children that hit become the next round's units (two lists in LDS, <= D rounds); a hit leaf sets its bit in the
+// item's mask (one bit per leaf of the subtree: pre-order = leaf order); when the rounds are through, an item's hits are its
+// mask's bits in order, with ranks that go on from the hits the walk had made before it was parked.  A unit that finds the next
+// list full is finished depth-first by its lane on the spot.  All of it lives in the four waves' flushed hit stages (4 KB): two
+// unit lists, the masks, the parked items' (ray, g, hits so far).  A function of its own on purpose: inlined behind the walking
+// loop its address arithmetic and uniform values were kept live across that loop (68 -> 106 SGPRs, the hot loop +12 %).
+template <class L, class N, class I>
+IBVH_D void rays_tail_phase(const Args<L, N, I> &a, const RayBins &rb, unsigned char *stage, const N *s_nodes, const L *s_leaves,
+                                                     const I *s_index, uint32_t *s_npark, uint32_t *s_nunits, bool busy, uint32_t ray, uint32_t g,
+                                                     uint32_t tn, int dl, uint32_t pend, uint32_t cnt, uint32_t j, uint32_t region) {
+    using T = typename L::elt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int levels = (int)a.tree.levels, K = rb.cut_level, D = rb.depth;
+    const uint32_t S = 1u << D;
+    const uint32_t vl = (uint32_t)a.tree.virtual_leaves, real_leaves = (uint32_t)a.tree.real_leaves;
+    constexpr int UNITS = RAYSUB_TAIL_UNITS;
+    uint32_t *units = (uint32_t *)stage;                     // [2][UNITS]: item | depth << 6 | node << 10 | pending siblings << 20 (a parked walk's first unit only)
+    uint32_t *masks = units + 2 * UNITS;                     // [RAYSUB_TAIL_ITEMS][S / 32]
+    const int mask_words = (int)(S >> 5) > 0 ? (int)(S >> 5) : 1;
+    uint32_t *p_ray = masks + RAYSUB_TAIL_ITEMS * 16, *p_g = p_ray + RAYSUB_TAIL_ITEMS, *p_cnt = p_g + RAYSUB_TAIL_ITEMS;
+    static_assert((2 * RAYSUB_TAIL_UNITS + RAYSUB_TAIL_ITEMS * 19) * 4 <= RAYSUB_WALKERS * RAYSUB_STAGE * 16, "the tail lives in the hit stages");
+    // one unit down one level; returns the children that hit (node tests) or marks the leaves that hit (cd == D)
+    auto expand = [&](uint32_t pid, uint32_t t, int cd, const T (&up)[3], const T (&ud)[3], const T (&uinv)[3], bool &n0, bool &n1) {
+        const uint32_t c0 = 2u * t, c1 = c0 + 1u;
+        n0 = n1 = false;
+        if (cd == D) { // the two leaves under t
+            const uint32_t li = c0 - S;
+            const bool real1 = (j << D) + li + 1u < real_leaves;
+            const L la = s_leaves[li], lb = s_leaves[li + 1];
+            bool h0 = isintersection(la, up, ud), h1 = real1 && isintersection(lb, up, ud);
+            if (a.narrow == IBVH_NARROW_RAY_ORIGIN_OUTSIDE) {
+                h0 = h0 && origin_outside(la, up);
+                h1 = h1 && origin_outside(lb, up);
+            }
+            const uint32_t bits = (h0 ? 1u << (li & 31u) : 0u) | (h1 ? 1u << ((li + 1u) & 31u) : 0u); // (li is even: one word)
+            if (bits != 0) atomicOr(&masks[pid * mask_words + (li >> 5)], bits);
+        } else {
+            const int level = K + cd;
+            const uint32_t nreal = (1u << (level - 1)) - (uint32_t)((uint64_t)vl >> (levels - level));
+            const bool real1 = (j << cd) + (c1 - (1u << cd)) < nreal;
+            const N na = s_nodes[c0], nb = s_nodes[c1];
+            if constexpr (N::kind == IBVH_BBOX) {
+                n0 = isintersection_inv(na, up, uinv);
+                n1 = real1 && isintersection_inv(nb, up, uinv);
+            } else {
+                n0 = isintersection(na, up, ud);
+                n1 = real1 && isintersection(nb, up, ud);
+            }
+        }
+    };
+    __syncthreads(); // every wave has left the walking loop and flushed: the stages are free
+    if (busy) {
+        const uint32_t pid = atomicAdd(s_npark, 1u);
+        p_ray[pid] = ray;
+        p_g[pid] = g;
+        p_cnt[pid] = cnt;
+        for (int k = 0; k < mask_words; ++k) masks[pid * mask_words + k] = 0u;
+        // ONE unit per parked walk: it stands at tn (its children are next) and carries the walk's pending right siblings, which the
+        // lane that takes the unit turns into units of their own
+        const uint32_t slot = atomicAdd(&s_nunits[0], 1u); // (< RAYSUB_TAIL_ITEMS <= UNITS)
+        units[slot] = pid | ((uint32_t)dl << 6) | (tn << 10) | (pend << 20);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int round = 0; round <= D; ++round) {
+        uint32_t n_units = s_nunits[cur];
+        if (n_units == 0) break;
+        n_units = n_units < (uint32_t)UNITS ? n_units : (uint32_t)UNITS;
+        __syncthreads(); // (everybody has read the count)
+        if (tid == 0) s_nunits[cur ^ 1] = 0;
+        __syncthreads();
+        const uint32_t *in = units + cur * UNITS;
+        uint32_t *out = units + (cur ^ 1) * UNITS;
+        for (uint32_t u = tid; u < n_units; u += RAYSUB_TPB) {
+            const uint32_t unit = in[u];
+            const uint32_t pid = unit & 63u;
+            const int64_t r = (int64_t)p_ray[pid];
+            T up[3], ud[3], uinv[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                up[k] = a.points[3 * r + k];
+                ud[k] = a.dirs[3 * r + k];
+                uinv[k] = T(1) / ud[k];
+            }
+            // this unit one level down; a child that finds the next list full is walked depth-first, here and now
+            uint32_t t = (unit >> 10) & 1023u, spill_pend = 0;
+            int d = (int)((unit >> 6) & 15u);
+            for (uint32_t up_pend = unit >> 20; up_pend != 0;) { // a parked walk's pending right siblings: units of their own
+                const int pl = 31 - __builtin_clz(up_pend);
+                up_pend &= ~(1u << pl);
+                const uint32_t slot = atomicAdd(&s_nunits[cur ^ 1], 1u);
+                if (slot < (uint32_t)UNITS) out[slot] = pid | ((uint32_t)pl << 6) | (((t >> (d - pl)) | 1u) << 10);
+                else spill_pend |= 1u << pl; // (no room: this lane's depth-first walk below takes it)
+            }
+            bool first = true;
+            for (;;) {
+                bool n0, n1;
+                expand(pid, t, d + 1, up, ud, uinv, n0, n1);
+                bool descended = false;
+                if (first) {
+                    first = false;
+                    uint32_t keep = 0; // children that did not fit the next list
+                    if (n0) {
+                        const uint32_t slot = atomicAdd(&s_nunits[cur ^ 1], 1u);
+                        if (slot < (uint32_t)UNITS) out[slot] = pid | ((uint32_t)(d + 1) << 6) | ((2u * t) << 10);
+                        else keep |= 1u;
+                    }
+                    if (n1) {
+                        const uint32_t slot = atomicAdd(&s_nunits[cur ^ 1], 1u);
+                        if (slot < (uint32_t)UNITS) out[slot] = pid | ((uint32_t)(d + 1) << 6) | ((2u * t + 1u) << 10);
+                        else keep |= 2u;
+                    }
+                    n0 = (keep & 1u) != 0;
+                    n1 = (keep & 2u) != 0;
+                }
+                if (n0) { // (the walking loop's step, hits marked instead of staged)
+                    if (n1) spill_pend |= 1u << (d + 1);
+                    t = 2u * t;
+                    d += 1;
+                    descended = true;
+                } else if (n1) {
+                    t = 2u * t + 1u;
+                    d += 1;
+                    descended = true;
+                }
+                if (!descended) {
+                    if (spill_pend == 0) break;
+                    const int pl = 31 - __builtin_clz(spill_pend);
+                    spill_pend &= ~(1u << pl);
+                    t = (t >> (d - pl)) | 1u;
+                    d = pl;
+                }
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    __syncthreads();
+    // ranked records: item pid's hits are its mask's bits in leaf order, ranks go on from the hits its walk had made
+    const uint32_t n_park = *s_npark;
+    if (wave == 0) {
+        uint32_t total = 0;
+        if ((uint32_t)lane < n_park)
+            for (int k = 0; k < mask_words; ++k) total += (uint32_t)__popc(masks[lane * mask_words + k]);
+        uint32_t inc = total;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)inc, off, 64);
+            if (lane >= off) inc += v;
+        }
+        const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        if ((uint32_t)lane < n_park) ((I *)rb.hits)[p_g[lane]] = (I)(p_cnt[lane] + total);
+        if (all != 0) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&rb.region_cursor[region], all);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if ((uint64_t)base + all > (uint64_t)rb.region_cap) {
+                if (lane == 0) *rb.reflag = 1;
+            } else if ((uint32_t)lane < n_park && total != 0) {
+                RayHit<I> *dst = (RayHit<I> *)rb.hit_list + (size_t)region * rb.region_cap + base + (inc - total);
+                uint32_t k = p_cnt[lane];
+                const I ray1 = (I)((int64_t)p_ray[lane] + 1);
+                for (int wd = 0; wd < mask_words; ++wd) {
+                    uint32_t m = masks[lane * mask_words + wd];
+                    while (m != 0) {
+                        const int b = __builtin_ctz(m);
+                        m &= m - 1u;
+                        *dst++ = RayHit<I>{IndexPair<I>{s_index[wd * 32 + b], ray1}, p_g[lane], k++};
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <class L, class N, class I, bool WRITE>
 __global__ __launch_bounds__(RAYSUB_TPB) void rays_subtree_kernel(Args<L, N, I> a, RayBins rb) {
     using T = typename L::elt;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     __shared__ uint32_t s_next;
+    // the workgroup's tail (counting pass; RAYSUB_TAIL_*): parked walks and the counters of the unit rounds
+    __shared__ uint32_t s_npark, s_nunits[2];
     if (*rb.flag != 0) return;
     if constexpr (WRITE) {
         if (*rb.reflag == 0) return; // the counting pass kept every hit: rays_place_kernel writes them
@@ -401,9 +583,13 @@ __global__ __launch_bounds__(RAYSUB_TPB) void rays_subtree_kernel(Args<L, N, I> 
             s_index[t] = a.positions ? (I)(g0 + t + 1u) : load_index<I>(rec, a.lay);
         }
     }
-    if (tid == 0) s_next = 0;
+    if (tid == 0) {
+        s_next = 0;
+        s_npark = 0;
+        s_nunits[0] = s_nunits[1] = 0;
+    }
     __syncthreads();
-    if (wave >= RAYSUB_WALKERS) return;
+    static_assert(RAYSUB_WALKERS * 64 == RAYSUB_TPB, "every wave walks: the tail's barriers count on all of them");
 
     const I *hits = (const I *)rb.hits;
     const uint32_t region = blockIdx.x & (RAY_REGIONS - 1);
@@ -431,6 +617,8 @@ __global__ __launch_bounds__(RAYSUB_TPB) void rays_subtree_kernel(Args<L, N, I> 
         }
         fill = 0;
     };
+    // tail_lanes > 0 (counting pass): the loop is left with <= tail_lanes walks alive once the chunk is dry; they are parked below
+    const int tail_lanes = WRITE ? 0 : rb.tail_lanes;
     for (;;) {
         const uint64_t idle = __builtin_amdgcn_ballot_w64(!busy);
         if (idle != 0 && more) {
@@ -545,9 +733,14 @@ __global__ __launch_bounds__(RAYSUB_TPB) void rays_subtree_kernel(Args<L, N, I> 
 #endif
             if (idle_now == ~(uint64_t)0) break;
             if (more && __popcll(idle_now) >= 16) break;
+            if (!more && 64 - __popcll(idle_now) <= tail_lanes) break;
         }
+        if (!more && tail_lanes > 0 && 64 - __popcll(__builtin_amdgcn_ballot_w64(!busy)) <= tail_lanes) break;
     }
-    if constexpr (!WRITE) flush();
+    if constexpr (!WRITE) {
+        flush();
+        if (tail_lanes > 0) rays_tail_phase<L, N, I>(a, rb, s_raw + o, s_nodes, s_leaves, s_index, &s_npark, s_nunits, busy, ray, g, tn, dl, pend, cnt, j, region);
+    }
 }
 
 // the writing pass when the counting pass kept every hit: records -> their places in the contact list

@@ -622,7 +622,7 @@ ibvh_status ibvh_lvt_work_counters(const ibvh_bvh *bvh, const ibvh_bvh *bvh2, co
  * "sort_lsd", "sort_msd_avg", "bucket_tpb", "msd", "msd_bits", "msd_cap", "msd_tile", "msd_ftpb", "msd_avg",
  * "msd_range", "msd_equalize", "msd_rescue", "lvt_scan_fused", "bfs_wg_per_cu", "lvt_blocks", "lvt_block_shift",
  * "lvt_blocks_min_items", "lvt_blocks_paired_below", "rays_binned" (1 = the binned ray path where it pays, 2 =
- * wherever the tree allows it, 0 = never), "rays_fast_slab", "rays_subtree_depth", "rays_items_per_ray",
+ * wherever the tree allows it, 0 = never), "rays_fast_slab", "rays_subtree_depth", "rays_items_per_ray", "rays_tail",
  * "msd_resident_kb", "msd_finish_pad_kb".  Unknown name: IBVH_ERR_INVALID_ARG — that includes the names of
  * development variants whose kernels are not in libibvh.so (variants/ builds with -DIBVH_VARIANTS add their own). */
 ibvh_status ibvh_set_tuning(const char *name, int32_t value);
