@@ -833,11 +833,19 @@ def emulate_config5(args):
         rb = last["record_bytes"]
         # cross-shard completion (ibvh_dist_cross_*: trees of touching slices exchanged, pair traversals): a JOINT call of all
         # ranks (collectives served in process), wall time of this rank's call
+        # — the FIRST call (buffers allocated, code paged in) and, like the rebuild above, a second one
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         cross = builder.cross_contacts(bvh)
         torch.cuda.synchronize()
+        t_cross_first = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        cross = builder.cross_contacts(bvh)
+        torch.cuda.synchronize()
         t_cross = time.perf_counter() - t0
+        builder.time_phases = True
+        builder.cross_contacts(bvh)
+        builder.time_phases = False
         return {"rank": comm.rank, "leaves_in": n, "leaves_slice": last["n_slice"], "contacts": int(trav.num_contacts),
                 "bytes_sent_to_peers": int(sum(c for r, c in enumerate(last["send_counts"]) if r != comm.rank) * rb),
                 "bytes_received_from_peers": int(sum(c for r, c in enumerate(last["recv_counts"]) if r != comm.rank) * rb),
@@ -845,6 +853,7 @@ def emulate_config5(args):
                 "joint_build_wall_ms": round(t_build * 1e3, 3), "traverse_alone_ms": round(t_trav * 1e3, 3),
                 "cross_contacts": int(cross.shape[0]), "cross_partners": builder.last_cross["partners"],
                 "cross_import_bytes": builder.last_cross["import_bytes"], "joint_cross_wall_ms": round(t_cross * 1e3, 3),
+                "joint_cross_first_call_ms": round(t_cross_first * 1e3, 3), "joint_cross_phases_ms": builder.last_cross.get("phases_ms"),
                 "splitter_key_bits": last["levels_used"]}
     rows = run_virtual_ranks(P, fn)
     slices = [r["leaves_slice"] for r in rows]
@@ -1119,6 +1128,7 @@ def main():
         _ = tr_ph.num_contacts
         torch.cuda.synchronize()
         t2 = time.perf_counter()
+        builder.cross_contacts(b_ph)  # (once more, synchronised between its four calls: last_cross["phases_ms"])
         builder.time_phases = False
         phases = dict(builder.last.get("phases_ms", {}))
         phases["traverse (per-slice LVT self-traverse + count read)"] = round((t2 - t1) * 1e3, 4)

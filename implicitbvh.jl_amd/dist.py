@@ -265,21 +265,38 @@ class DistributedBuilder:
         small = torch.empty(abi.dist_cross_scratch(comm.size), dtype=torch.uint8, device="cuda")
         plan = abi.DistCrossPlan()
         vt.begin()
+        phases, t_phase = {}, None
+        if self.time_phases:  # (bench.py: synchronise between the four calls and keep their wall times in last_cross["phases_ms"])
+            import time
+            torch.cuda.synchronize()
+            t_phase = time.perf_counter()
+
+        def lap(name):
+            nonlocal t_phase
+            if t_phase is not None:
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                phases[name] = round((now - t_phase) * 1e3, 4)
+                t_phase = now
         vt.check("ibvh_dist_cross_plan", L.ibvh_dist_cross_plan(C.byref(vt.struct), C.byref(s), k, api._ptr(small), small.numel(), C.byref(plan),
                                                                 api._stream()))
+        lap("cross plan (describe, all-gather, filter, all_to_all of the counts)")
         exp = torch.empty(max(int(plan.export_bytes), 1), dtype=torch.uint8, device="cuda")
         imp = torch.empty(max(int(plan.import_bytes), 1), dtype=torch.uint8, device="cuda")
         vt.check("ibvh_dist_cross_exchange", L.ibvh_dist_cross_exchange(C.byref(vt.struct), C.byref(s), C.byref(plan), api._ptr(exp), api._ptr(imp),
                                                                         api._ptr(small), small.numel(), api._stream()))
+        lap("cross exchange (pack + all_to_all_v of the touching leaves)")
         scratch = torch.empty(max(int(plan.scratch_bytes), 1), dtype=torch.uint8, device="cuda")
         totals = (C.c_int64 * abi.DIST_MAX_RANKS)()
         total = C.c_int64()
         vt.check("ibvh_dist_cross_count", L.ibvh_dist_cross_count(C.byref(s), C.byref(plan), api._ptr(imp), api._ptr(scratch), scratch.numel(), totals,
                                                                   C.byref(total), api._stream()))
+        lap("cross count (trees over the imported sets + pair traversals, counting)")
         out = torch.empty((int(total.value), 2), dtype=api._torch_index(bvh.types.index_type), device="cuda")
         if total.value > 0:  # (imported leaves without a single contact among them: nothing to write — as the Julia binding)
             vt.check("ibvh_dist_cross_write", L.ibvh_dist_cross_write(C.byref(s), C.byref(plan), api._ptr(imp), api._ptr(scratch), scratch.numel(),
                                                                       totals, api._ptr(out), api._stream()))
+        lap("cross write")
         lay = abi.Layout()
         lib.call("ibvh_layout_of", C.byref(bvh.types), C.byref(lay))
         self.last_cross = {"partners": [int(plan.recv_rank[i]) for i in range(plan.n_recv)],
@@ -287,4 +304,6 @@ class DistributedBuilder:
                            "bytes_received": int(sum(plan.recv_leaves[i] for i in range(plan.n_recv)) * lay.leaf_bytes),
                            "bytes_sent": int(sum(plan.send_leaves[r] for r in range(comm.size)) * lay.leaf_bytes),
                            "import_bytes": int(plan.import_bytes), "pairs": [int(totals[i]) for i in range(plan.n_recv)]}
+        if phases:
+            self.last_cross["phases_ms"] = phases
         return out
