@@ -11,6 +11,13 @@ def test_random_configurations_match_the_oracle(seed):
     assert fuzz_gpu.main(seconds=8.0, seed=seed, verbose=False, light=True) >= 1
 
 
+def test_large_random_chains_match_the_oracle():
+    """A seeded slice of tests/fuzz_gpu_large.py: 1.3e5 .. 5e5 leaves (the sizes at which the MSD sort, its equalised cells and
+    rescue workgroups, the shared descent and the binned rays are chosen), `cache=` chains through abrupt changes of the input."""
+    import fuzz_gpu_large
+    assert fuzz_gpu_large.main(seconds=15.0, seed=5, verbose=False, sizes=(131_072, 200_000, 524_289)) >= 1
+
+
 def test_64_bit_queue_entries_match_the_oracle():
     """The BBox-node walker's 64-bit queue entries (trees of 29 .. 31 levels, > 134 M leaves) cannot be reached with an
     oracle-sized input; the development knob lvt_wide = 1 (ibvh_set_tuning, applied by the binding from IBVH_TUNING when the
