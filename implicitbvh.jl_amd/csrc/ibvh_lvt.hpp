@@ -405,8 +405,9 @@ struct RayBins {
     uint32_t *bin_cursor;       // [subtrees]
     uint2 *bucket;              // [cap] {ray, g} grouped by subtree
     uint2 *chunk_tab;           // [subtrees + cap / RAYSUB_CHUNK] {subtree, chunk of its bucket}: one workgroup each
-    void *hit_list;             // [RAY_REGIONS][region_cap] RayHit<I>: the hits of the counting pass
+    void *hit_list;             // [regions][region_cap] RayHit<I>: the hits of the counting pass
     int32_t region_cap;
+    int32_t regions;            // lists in use (a power of two <= RAY_REGIONS): a workgroup moves on to another one after every flush
     void *hits;                 // [cap] of I: hits of item g; after the scan: inclusive prefix
     int32_t cap;                // 0: the path is not in use
     int32_t cut_level;          // K
@@ -429,13 +430,14 @@ constexpr int RAYSUB_STAGE = 64;  // hit records a wave stages in LDS (a step ad
 constexpr int RAYSUB_TAIL_MAX = 8;                                    // parked walks per wave
 constexpr int RAYSUB_TAIL_ITEMS = RAYSUB_TAIL_MAX * RAYSUB_WALKERS;   // per workgroup
 constexpr int RAYSUB_TAIL_UNITS = 208;                                // units per round (two lists in the flushed hit stages, beside masks and item table)
-constexpr int RAY_REGIONS = 256;  // the hit list is RAY_REGIONS lists with a cursor each: same-address atomics serialise
+constexpr int RAY_REGIONS = 256;  // the hit list is at most RAY_REGIONS lists with a cursor each: same-address atomics serialise
 // a hit of the counting pass: the pair as it will be reported, the item it belongs to and its rank within the item; the
 // writing pass puts it at scan[g - 1] + k (rays_place_kernel) instead of walking again
 template <class I> struct RayHit {
     IndexPair<I> pair;
     uint32_t g, k;
 };
+constexpr uint32_t RAY_HIT_NONE = 0xffffffffu; // RayHit::g of a slot nobody filled (the unused end of a full list: rays_place_kernel skips it)
 IBVH_HD size_t rays_subtree_lds(int depth, size_t node_bytes, size_t leaf_bytes, size_t index_bytes, size_t hit_bytes, bool write) {
     const size_t S = (size_t)1 << depth;
     size_t o = (S * node_bytes + 15) & ~(size_t)15;
@@ -563,9 +565,12 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_apply_kernel(I *c, int64_t n, c
 // (Round 6 first took the tile from an atomic ticket instead: 2,442 returning atomics on one word serialise at ~11 ns each —
 // the 1e7-item scan 25 -> 56 us.)
 template <class I>
-__global__ __launch_bounds__(SCAN_TPB) void scan_fused_kernel(I *c, int64_t n, unsigned long long *agg, int64_t *totals, int64_t *total_host) {
+__global__ __launch_bounds__(SCAN_TPB) void scan_fused_kernel(I *c, int64_t n, unsigned long long *agg, int64_t *totals, int64_t *total_host,
+                                                              const int32_t *limit) {
     __shared__ int64_t s_w[SCAN_TPB / 64], s_p[SCAN_TPB / 64];
     constexpr unsigned long long THERE = 1ull << 63;
+    // (limit: the array's length is min(n, *limit), known only on the device — tiles beyond it hold zeros and store nothing)
+    if (limit != nullptr) n = (int64_t)*limit < n ? (int64_t)*limit : n;
     const uint32_t tile = blockIdx.x;
     // thread owns SCAN_IPT consecutive items so the in-thread running sum is in memory order
     const int64_t base = (int64_t)tile * SCAN_TILE + (int64_t)threadIdx.x * SCAN_IPT;
@@ -647,10 +652,11 @@ __global__ __launch_bounds__(SCAN_TPB) void scan_fused_kernel(I *c, int64_t n, u
 // (L2-hot) and scans tile by tile with a running base.  Grid = ceil(tiles / tiles_per_group) <= what the device holds at once.
 template <class I>
 __global__ __launch_bounds__(SCAN_TPB) void scan_fused_grouped_kernel(I *c, int64_t n, unsigned long long *agg, int64_t *totals, int64_t *total_host,
-                                                                      int tiles_per_group) {
+                                                                      int tiles_per_group, const int32_t *limit) {
     __shared__ int64_t s_w[SCAN_TPB / 64], s_p[SCAN_TPB / 64];
     constexpr unsigned long long THERE = 1ull << 63;
-    const int64_t nparts = (n + SCAN_TILE - 1) / SCAN_TILE;
+    const int64_t nparts = (n + SCAN_TILE - 1) / SCAN_TILE; // (of the launch: the grid was sized for it)
+    if (limit != nullptr) n = (int64_t)*limit < n ? (int64_t)*limit : n;
     const int64_t t0 = (int64_t)blockIdx.x * tiles_per_group, t1 = t0 + tiles_per_group < nparts ? t0 + tiles_per_group : nparts;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     auto load16 = [&](int64_t base, int64_t (&v)[SCAN_IPT]) { // a thread's SCAN_IPT consecutive items of a tile
@@ -775,15 +781,16 @@ int scan_counts(I *counts, int64_t n, int64_t *total_out, void *scratch, hipStre
     int64_t nparts = ceil_div(n, SCAN_TILE);
     int64_t *totals = total_dev ? total_dev : (int64_t *)scratch; // where the device-side total goes
     int64_t *partials = (int64_t *)scratch + 8;
-    if (aggregates_zeroed && limit == nullptr && g_tuning.lvt_scan_fused != 0) {
+    if (aggregates_zeroed && g_tuning.lvt_scan_fused != 0) {
         int64_t room = resident_scan_workgroups<I>();
         if (g_tuning.lvt_scan_fused > 1 && g_tuning.lvt_scan_fused < room) room = g_tuning.lvt_scan_fused; // (development knob: a smaller grid)
         if (nparts > room) {
             const int64_t per = ceil_div(nparts, room);
             IBVH_LAUNCH((scan_fused_grouped_kernel<I>), dim3((unsigned)ceil_div(nparts, per)), dim3(SCAN_TPB), 0, st, counts, n, (unsigned long long *)partials, totals,
-                        total_host, (int)per);
+                        total_host, (int)per, limit);
         } else {
-            IBVH_LAUNCH((scan_fused_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, (unsigned long long *)partials, totals, total_host);
+            IBVH_LAUNCH((scan_fused_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, (unsigned long long *)partials, totals, total_host,
+                        limit);
         }
     } else {
         IBVH_LAUNCH((scan_reduce_kernel<I>), dim3((unsigned)nparts), dim3(SCAN_TPB), 0, st, counts, n, partials, limit);
@@ -822,6 +829,7 @@ struct RayBinPlan {
     size_t bytes = 0, off_scan = 0, off_ray_items = 0, off_bin_count = 0, off_bin_start = 0, off_bin_cursor = 0, off_items = 0,
            off_bucket = 0, off_hits = 0, off_chunks = 0, off_hit_list = 0;
     int64_t region_cap = 0;
+    int regions = RAY_REGIONS;
 };
 inline RayBinPlan rays_bin_plan(const ibvh_bvh &bvh, int64_t num_rays) {
     RayBinPlan p;
@@ -885,8 +893,13 @@ inline RayBinPlan rays_bin_plan(const ibvh_bvh &bvh, int64_t num_rays) {
     p.off_bucket = o, o += (size_t)cap * 8;
     p.off_hits = o, o += (size_t)cap * 8;
     p.off_chunks = o, o += (size_t)align_up(8 * (subtrees + cap / RAYSUB_CHUNK + 1), 256);
-    p.region_cap = (cap + 255) / 256; // (RAY_REGIONS lists, as many records as items all together)
-    p.off_hit_list = o, o += (size_t)p.region_cap * 256 * (bvh.types.index_type == IBVH_I64 ? 24 : 16);
+    // As many records as items all together, in `regions` lists with a cursor each (same-address atomics serialise).  A list
+    // should take at least 8,192 records — a workgroup's flush is a few hundred — so small batches get fewer lists (round 6: with
+    // 256 lists for every batch, 1e5 rays left 6,250 records a list, one list overflowed and the writing pass walked every
+    // subtree again; a 1,000-ray batch had 63 records a list and ALWAYS walked twice).
+    while (p.regions > 1 && cap / p.regions < 8192) p.regions >>= 1;
+    p.region_cap = (cap + p.regions - 1) / p.regions;
+    p.off_hit_list = o, o += (size_t)p.region_cap * (size_t)p.regions * (bvh.types.index_type == IBVH_I64 ? 24 : 16);
     p.bytes = o;
     return p;
 }
@@ -911,6 +924,7 @@ inline RayBins rays_bins_at(const RayBinPlan &p, char *base) {
     rb.chunk_tab = (uint2 *)(base + p.off_chunks);
     rb.hit_list = base + p.off_hit_list;
     rb.region_cap = (int32_t)p.region_cap;
+    rb.regions = p.regions;
     rb.cap = (int32_t)p.cap;
     rb.cut_level = p.cut_level;
     rb.depth = p.depth;

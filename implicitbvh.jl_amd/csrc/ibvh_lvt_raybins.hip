@@ -271,6 +271,11 @@ __global__ __launch_bounds__(1024) void rays_binscan_kernel(RayBins rb) {
     __shared__ unsigned long long s_w[16];
     const unsigned long long cur = *rb.cursor;
     if (threadIdx.x == 0) *rb.n_items = (int32_t)(cur < (unsigned long long)rb.cap ? cur : (unsigned long long)rb.cap);
+    { // the tile aggregates of the scan over the items' hits (scan_counts, one-kernel route): the scan over the rays' items has used them
+        unsigned long long *agg = (unsigned long long *)rb.scan_scratch + 8;
+        const int words = (rb.cap + SCAN_TILE - 1) / SCAN_TILE + 1;
+        for (int k = (int)threadIdx.x; k < words; k += 1024) agg[k] = 0ull;
+    }
     if (*rb.flag != 0) {
         if (threadIdx.x == 0) *rb.n_chunks = 0;
         return;
@@ -343,6 +348,31 @@ template <int RAYTILE_TPB> __global__ __launch_bounds__(RAYTILE_TPB) void rays_s
             rb.bucket[s_hist[j] + rank[k]] = make_uint2(ray, g);
         }
     }
+}
+
+// Room for `count` hit records of this wave in the hit list: the list `region` points at, or — when that one is full — one of the
+// next few (what was left of a full list is marked unused; a wave moves on to another list after every reservation, so the lists
+// fill evenly whatever a subtree's share of the hits).  false: no room found, the writing pass walks the subtrees again (*reflag).
+template <class I> IBVH_D bool reserve_hits(const RayBins &rb, uint32_t &region, uint32_t count, int lane, RayHit<I> *&dst) {
+    const uint32_t mask = (uint32_t)(rb.regions - 1);
+    const int tries = rb.regions < 8 ? rb.regions : 8;
+    uint32_t r = region;
+    for (int attempt = 0; attempt < tries; ++attempt) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&rb.region_cursor[r], count);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        RayHit<I> *list = (RayHit<I> *)rb.hit_list + (size_t)r * rb.region_cap;
+        r = (r + 61u) & mask;
+        if ((uint64_t)base + count <= (uint64_t)rb.region_cap) {
+            dst = list + base;
+            region = r;
+            return true;
+        }
+        for (uint64_t t = (uint64_t)base + (uint32_t)lane; t < (uint64_t)rb.region_cap; t += 64) list[t].g = RAY_HIT_NONE;
+    }
+    region = r;
+    if (lane == 0) *rb.reflag = 1;
+    return false;
 }
 
 #ifdef IBVH_RAYSUB_HIST // (diagnostic build, tools/dbg_raysub_hist.py: wave-steps of the counting pass by number of busy lanes; [8], [9]: steps
@@ -507,13 +537,9 @@ IBVH_D void rays_tail_phase(const Args<L, N, I> &a, const RayBins &rb, unsigned 
         const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         if ((uint32_t)lane < n_park) ((I *)rb.hits)[p_g[lane]] = (I)(p_cnt[lane] + total);
         if (all != 0) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&rb.region_cursor[region], all);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if ((uint64_t)base + all > (uint64_t)rb.region_cap) {
-                if (lane == 0) *rb.reflag = 1;
-            } else if ((uint32_t)lane < n_park && total != 0) {
-                RayHit<I> *dst = (RayHit<I> *)rb.hit_list + (size_t)region * rb.region_cap + base + (inc - total);
+            RayHit<I> *room = nullptr;
+            if (reserve_hits<I>(rb, region, all, lane, room) && (uint32_t)lane < n_park && total != 0) {
+                RayHit<I> *dst = room + (inc - total);
                 uint32_t k = p_cnt[lane];
                 const I ray1 = (I)((int64_t)p_ray[lane] + 1);
                 for (int wd = 0; wd < mask_words; ++wd) {
@@ -592,7 +618,8 @@ __global__ __launch_bounds__(RAYSUB_TPB) void rays_subtree_kernel(Args<L, N, I> 
     static_assert(RAYSUB_WALKERS * 64 == RAYSUB_TPB, "every wave walks: the tail's barriers count on all of them");
 
     const I *hits = (const I *)rb.hits;
-    const uint32_t region = blockIdx.x & (RAY_REGIONS - 1);
+    // (the list this wave appends to next — the records carry their place, any list serves: reserve_hits)
+    uint32_t region = blockIdx.x & (uint32_t)(rb.regions - 1);
     T p[3] = {0, 0, 0}, d[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
     bool busy = false, more = true; // more: wave-uniform, the chunk may still hold items
     uint32_t ray = 0, g = 0, tn = 1, pend = 0;
@@ -606,15 +633,9 @@ __global__ __launch_bounds__(RAYSUB_TPB) void rays_subtree_kernel(Args<L, N, I> 
     };
     auto flush = [&]() {
         if (fill == 0) return;
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&rb.region_cursor[region], (uint32_t)fill);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if ((uint64_t)base + (uint32_t)fill > (uint64_t)rb.region_cap) {
-            if (lane == 0) *rb.reflag = 1;
-        } else {
-            RayHit<I> *dst = (RayHit<I> *)rb.hit_list + (size_t)region * rb.region_cap + base;
+        RayHit<I> *dst = nullptr;
+        if (reserve_hits<I>(rb, region, (uint32_t)fill, lane, dst))
             for (int t = lane; t < fill; t += 64) dst[t] = s_stage[t];
-        }
         fill = 0;
     };
     // tail_lanes > 0 (counting pass): the loop is left with <= tail_lanes walks alive once the chunk is dry; they are parked below
@@ -753,6 +774,7 @@ template <class I> __global__ __launch_bounds__(256) void rays_place_kernel(RayB
     const I *h = (const I *)rb.hits;
     for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
         const RayHit<I> r = src[t];
+        if (r.g == RAY_HIT_NONE) continue; // (the unused end of a list that filled up: reserve_hits)
         const int64_t at = (r.g > 0 ? (int64_t)h[r.g - 1] : 0) + (int64_t)r.k;
         contacts[at] = r.pair;
     }
@@ -772,14 +794,16 @@ template <class I> __global__ __launch_bounds__(256) void rays_counts_kernel(Ray
 template <class L, class N, class I>
 int launch_rays_binned(const Args<L, N, I> &a, bool write, hipStream_t st, const RayBins &rb, int ray_block, unsigned rblocks) {
     // the binned path (3c); the binary walker stands by behind it, gated on the overflow flag
-    static_assert(RAY_REGIONS == 256, "rays_bin_plan sizes the hit list for 256 regions");
     const size_t lds = rays_subtree_lds(rb.depth, sizeof(N), sizeof(L), sizeof(I), sizeof(RayHit<I>), write);
     Args<L, N, I> standby = a;
     standby.gate = rb.flag;
     standby.shadow = nullptr;
     const PairCache<I> none{nullptr, 0};
     if (!write) {
-        IBVH_HIP_CHECK(hipMemsetAsync(rb.cursor, 0, 2048, st));
+        // (header + the helper scans' header and tile aggregates right behind it: both scans take the one-kernel route, the second
+        // one's aggregates are zeroed again by rays_binscan_kernel)
+        const int64_t scan_words = 8 + ceil_div((int64_t)rb.cap > a.n_items ? (int64_t)rb.cap : a.n_items, (int64_t)SCAN_TILE) + 1;
+        IBVH_HIP_CHECK(hipMemsetAsync(rb.cursor, 0, 2048 + (size_t)scan_words * 8, st));
         IBVH_HIP_CHECK(hipMemsetAsync(rb.bin_count, 0, (size_t)((char *)rb.items - (char *)rb.bin_count), st)); // counts, starts, cursors
         if (!g_tuning.rays_fast_slab) IBVH_HIP_CHECK(hipMemsetAsync(rb.top_nan, 0xff, 4, st)); // (-1: no fast slab test anywhere)
         if constexpr (N::kind == IBVH_BBOX && std::is_same<typename N::elt, float>::value) {
@@ -789,7 +813,7 @@ int launch_rays_binned(const Args<L, N, I> &a, bool write, hipStream_t st, const
                         st, a.nodes + top_first, top_count, rb);
         }
         IBVH_LAUNCH((rays_top_kernel<L, N, I>), dim3(rblocks), dim3(64), 0, st, a, rb, ray_block);
-        if (int e = scan_counts<int32_t>(rb.ray_items, a.n_items, nullptr, rb.scan_scratch, st, rb.dummy_total)) return e;
+        if (int e = scan_counts<int32_t>(rb.ray_items, a.n_items, nullptr, rb.scan_scratch, st, rb.dummy_total, nullptr, nullptr, true)) return e;
         const bool big_tiles = rb.cap >= (1 << 22);
         const unsigned tiles = (unsigned)ceil_div((int64_t)rb.cap, (big_tiles ? 1024 : 256) * RAYTILE_IPT);
         const size_t hist_lds = (size_t)rb.subtrees * 4;
@@ -802,11 +826,11 @@ int launch_rays_binned(const Args<L, N, I> &a, bool write, hipStream_t st, const
         if (lds > 64 * 1024)
             IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)rays_subtree_kernel<L, N, I, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         IBVH_LAUNCH((rays_subtree_kernel<L, N, I, false>), dim3(chunks), dim3(RAYSUB_TPB), lds, st, a, rb);
-        if (int e = scan_counts<I>((I *)rb.hits, (int64_t)rb.cap, nullptr, rb.scan_scratch, st, rb.dummy_total, nullptr, rb.n_items)) return e;
+        if (int e = scan_counts<I>((I *)rb.hits, (int64_t)rb.cap, nullptr, rb.scan_scratch, st, rb.dummy_total, nullptr, rb.n_items, true)) return e;
         IBVH_LAUNCH((rays_counts_kernel<I>), dim3((unsigned)ceil_div(a.n_items, 256)), dim3(256), 0, st, rb, a.counts, a.n_items);
         if (int e = launch_rays_standby<L, N, I>(standby, false, st, ray_block, rblocks)) return e;
     } else {
-        IBVH_LAUNCH((rays_place_kernel<I>), dim3((unsigned)ceil_div((int64_t)rb.region_cap, 1024), RAY_REGIONS), dim3(256), 0, st, rb, a.contacts,
+        IBVH_LAUNCH((rays_place_kernel<I>), dim3((unsigned)ceil_div((int64_t)rb.region_cap, 1024), (unsigned)rb.regions), dim3(256), 0, st, rb, a.contacts,
                     a.guard_total, a.guard_capacity);
         if (lds > 64 * 1024)
             IBVH_HIP_CHECK(hipFuncSetAttribute((const void *)rays_subtree_kernel<L, N, I, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

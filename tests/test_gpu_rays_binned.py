@@ -232,3 +232,50 @@ def test_the_shipped_rule_really_takes_the_path_it_names():
     with knobs(rays_binned=0):
         k = _kernels_of(lambda: ibvh.traverse_rays(g, P, D))
         assert "rays_top_kernel" not in k and "lvt_rays_kernel" in k
+
+
+def _subtree_passes_ms(fn):
+    """(counting pass, writing pass) durations of rays_subtree_kernel in one call of fn, in launch order"""
+    import ctypes as C
+    lib.call("ibvh_profile_enable", 1)
+    try:
+        fn()
+        torch.cuda.synchronize()
+        cnt = C.c_int64()
+        lib.call("ibvh_profile_count", C.byref(cnt))
+        out = []
+        for i in range(cnt.value):
+            name, ms = C.c_char_p(), C.c_float()
+            lib.call("ibvh_profile_get", i, C.byref(name), C.byref(ms))
+            if "rays_subtree_kernel" in name.value.decode():
+                out.append(ms.value)
+        return out
+    finally:
+        lib.call("ibvh_profile_enable", 0)
+
+
+@pytest.mark.parametrize("n_leaves,n_rays", [(249_882, 100_000), (70_000, 1_000), (70_000, 64)])
+def test_the_counting_pass_keeps_its_hits_for_the_writing_pass(n_leaves, n_rays):
+    """The hit list of the counting pass (records placed by rays_place_kernel) must serve batches of every size: with 256 lists
+    whatever the batch (rounds 4 - 5), 1e5 rays on the reference's published mesh size overflowed one list and a 1,000-ray batch
+    had 63 records a list — the writing pass then walked every subtree again, silently (same list, twice the time).  Seen in the
+    library's launch profile: the writing pass of rays_subtree_kernel returns at once when the list holds everything."""
+    from implicitbvh_amd.synthetic import random_rays, torus_mesh
+    u = int(np.sqrt(n_leaves / 2)) + 2
+    tris = torus_mesh(u, u)[:n_leaves].reshape(-1, 3, 3)
+    c = tris.mean(1)
+    r = np.linalg.norm(tris - c[:, None, :], axis=2).max(1, keepdims=True)
+    vols = np.concatenate([c, r], axis=1).astype(np.float32)
+    g = ibvh.BVH(cuda(vols))
+    o = orc.build(vols, abi.make_types(abi.BSPHERE, abi.F32, abi.BBOX, abi.F32))
+    p, d = random_rays(n_rays, vols[:, :3].min(0), vols[:, :3].max(0), seed=5)
+    P, D = cuda(p).t(), cuda(d).t()
+    t = ibvh.traverse_rays(g, P, D)  # (warm: sizes the cache)
+    exp = oracle_pairs(orc.traverse_rays_lvt(o, p, d, 1)[0])
+    assert (contacts_np(t).reshape(-1, 2) == exp).all()
+    best = None
+    for _ in range(3):
+        ms = _subtree_passes_ms(lambda: ibvh.traverse_rays(g, P, D, cache=t))
+        assert len(ms) == 2, ms
+        best = ms if best is None or ms[1] / ms[0] < best[1] / best[0] else best
+    assert best[1] < 0.3 * best[0] + 0.01, f"the writing pass walked again: count {best[0]:.3f} ms, write {best[1]:.3f} ms"
